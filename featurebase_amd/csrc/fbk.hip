@@ -1,0 +1,772 @@
+// fbk.hip — C ABI (include/fbk.h) over the CDNA4 kernels in fbk_kernels.hip.h.
+// Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC
+// No torch, no CPU fallback: every compute entry point launches a HIP kernel.
+#include "../../include/fbk.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fbk_kernels.hip.h"
+
+using fbk::Slot;
+using fbk::u64;
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int32_t fail(int32_t code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      (void)hipGetLastError();                                                                 \
+      return fail(e_ == hipErrorOutOfMemory ? FBK_E_NOMEM : FBK_E_HIP,                         \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+    }                                                                                          \
+  } while (0)
+
+inline uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
+
+}  // namespace
+
+struct fbk_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+};
+
+// Host mirror of one device-resident batch.
+struct fbk_batch {
+  fbk_ctx* ctx = nullptr;
+  uint32_t n_rows = 0;
+  uint64_t arena_bytes = 0;
+  uint8_t* d_arena = nullptr;  // payloads, each 16-byte aligned and padded
+  Slot* d_slots = nullptr;     // n_rows * 16
+  bool dense = false;          // every slot a bitmap at (row*16+slot)*8192
+  bool slots_stale = false;    // host copy must be refreshed from device before use
+  std::vector<Slot> h_slots;   // host copy of the descriptors (types, n, offsets)
+  std::vector<uint64_t> h_keys;  // container key per slot (carried through to download)
+};
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  template <class T>
+  T* as() {
+    return static_cast<T*>(p);
+  }
+};
+
+int32_t set_device(fbk_ctx* ctx) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  return FBK_OK;
+}
+
+int32_t refresh_slots(fbk_batch* b) {
+  if (!b->slots_stale) return FBK_OK;
+  HIP_TRY(hipMemcpyAsync(b->h_slots.data(), b->d_slots, b->h_slots.size() * sizeof(Slot),
+                         hipMemcpyDeviceToHost, b->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+  b->slots_stale = false;
+  return FBK_OK;
+}
+
+int32_t upload_rows(fbk_ctx* ctx, const uint32_t* rows, uint64_t n, uint32_t n_rows_limit, DevBuf& out) {
+  for (uint64_t i = 0; i < n; ++i)
+    if (rows[i] >= n_rows_limit)
+      return fail(FBK_E_INVALID, "row index " + std::to_string(rows[i]) + " out of range (batch has " +
+                                     std::to_string(n_rows_limit) + " rows)");
+  HIP_TRY(hipMalloc(&out.p, std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+  if (n) HIP_TRY(hipMemcpyAsync(out.p, rows, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  return FBK_OK;
+}
+
+bool is_gfx950(const hipDeviceProp_t& p) { return std::strncmp(p.gcnArchName, "gfx950", 6) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int32_t fbk_abi_version(void) { return FBK_ABI_VERSION; }
+
+const char* fbk_last_error(fbk_ctx*) { return g_err.c_str(); }
+
+int32_t fbk_device_count(int32_t* out_n) {
+  if (!out_n) return fail(FBK_E_INVALID, "out_n is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *out_n = 0;
+    return fail(FBK_E_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *out_n = n;
+  return FBK_OK;
+}
+
+int32_t fbk_open(int32_t device, uint32_t /*flags*/, fbk_ctx** out_ctx) {
+  if (!out_ctx) return fail(FBK_E_INVALID, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(FBK_E_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+  }
+  if (device < 0 || device >= n) return fail(FBK_E_INVALID, "device ordinal out of range");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (!is_gfx950(prop))
+    return fail(FBK_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  fbk_ctx* ctx = new (std::nothrow) fbk_ctx();
+  if (!ctx) return fail(FBK_E_NOMEM, "host allocation failed");
+  ctx->device = device;
+  hipError_t e2 = hipSetDevice(device);
+  if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e2 != hipSuccess) {
+    delete ctx;
+    return fail(FBK_E_HIP, std::string("stream create: ") + hipGetErrorString(e2));
+  }
+  ctx->stream = ctx->own_stream;
+  *out_ctx = ctx;
+  return FBK_OK;
+}
+
+int32_t fbk_close(fbk_ctx* ctx) {
+  if (!ctx) return FBK_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return FBK_OK;
+}
+
+int32_t fbk_set_stream(fbk_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(FBK_E_INVALID, "ctx is NULL");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return FBK_OK;
+}
+
+int32_t fbk_synchronize(fbk_ctx* ctx) {
+  if (!ctx) return fail(FBK_E_INVALID, "ctx is NULL");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return FBK_OK;
+}
+
+int32_t fbk_batch_free(fbk_ctx* ctx, fbk_batch* b) {
+  if (!b) return FBK_OK;
+  if (!ctx) ctx = b->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (b->d_arena) (void)hipFree(b->d_arena);
+  if (b->d_slots) (void)hipFree(b->d_slots);
+  delete b;
+  return FBK_OK;
+}
+
+static int32_t validate_container(const fbk_container_desc& d, const uint8_t* payload, uint64_t payload_len,
+                                  uint64_t* bytes) {
+  uint64_t need;
+  switch (d.type) {
+    case FBK_TYPE_ARRAY:
+      if (d.len > 65536) return fail(FBK_E_INVALID, "array container longer than 65536");
+      need = uint64_t(d.len) * 2;
+      break;
+    case FBK_TYPE_BITMAP:
+      if (d.len != FBK_BITMAP_WORDS) return fail(FBK_E_INVALID, "bitmap container must have len 1024");
+      need = 8192;
+      break;
+    case FBK_TYPE_RUN:
+      if (d.len > 32768) return fail(FBK_E_INVALID, "run container with more than 32768 intervals");
+      need = uint64_t(d.len) * 4;
+      break;
+    default:
+      return fail(FBK_E_INVALID, "unknown container type " + std::to_string(d.type));
+  }
+  if (d.off > payload_len || need > payload_len - d.off) return fail(FBK_E_INVALID, "container payload out of bounds");
+  if (d.n < -1 || d.n > 65536) return fail(FBK_E_INVALID, "container n out of range");
+  const uint8_t* p = payload + d.off;
+  if (d.type == FBK_TYPE_ARRAY) {
+    // must be strictly ascending (sorted []uint16, roaring.go:53-58)
+    uint16_t prev = 0;
+    for (uint32_t i = 0; i < d.len; ++i) {
+      uint16_t v;
+      std::memcpy(&v, p + 2 * i, 2);
+      if (i && v <= prev) return fail(FBK_E_INVALID, "array container not strictly ascending");
+      prev = v;
+    }
+    if (d.n >= 0 && uint32_t(d.n) != d.len) return fail(FBK_E_INVALID, "array container n != len");
+  } else if (d.type == FBK_TYPE_RUN) {
+    int64_t prev_last = -1;
+    for (uint32_t i = 0; i < d.len; ++i) {
+      uint16_t s, l;
+      std::memcpy(&s, p + 4 * i, 2);
+      std::memcpy(&l, p + 4 * i + 2, 2);
+      if (l < s || int64_t(s) <= prev_last) return fail(FBK_E_INVALID, "run container intervals overlap or are unordered");
+      prev_last = l;
+    }
+  }
+  *bytes = need;
+  return FBK_OK;
+}
+
+int32_t fbk_batch_upload(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t n_desc, uint32_t n_rows,
+                         const void* payload, uint64_t payload_len, fbk_batch** out_batch) {
+  if (!ctx || !out_batch || (n_desc && (!descs || !payload))) return fail(FBK_E_INVALID, "NULL argument");
+  *out_batch = nullptr;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  const uint8_t* pay = static_cast<const uint8_t*>(payload);
+  const uint64_t n_slots = uint64_t(n_rows) * fbk::kSlots;
+
+  fbk_batch* b = new (std::nothrow) fbk_batch();
+  if (!b) return fail(FBK_E_NOMEM, "host allocation failed");
+  b->ctx = ctx;
+  b->n_rows = n_rows;
+  b->h_slots.assign(n_slots, Slot{0, 0, 0});
+  b->h_keys.assign(n_slots, 0);
+  std::vector<int64_t> src(n_slots, -1);
+  std::vector<uint64_t> nbytes(n_slots, 0);
+  bool need_recount = false;
+  for (uint64_t i = 0; i < n_desc; ++i) {
+    const fbk_container_desc& d = descs[i];
+    if (d.row >= n_rows) {
+      delete b;
+      return fail(FBK_E_INVALID, "container row ordinal out of range");
+    }
+    const uint64_t s = uint64_t(d.row) * fbk::kSlots + (d.key & 15);
+    if (src[s] >= 0) {
+      delete b;
+      return fail(FBK_E_INVALID, "duplicate container for (row, key&15)");
+    }
+    uint64_t bytes = 0;
+    if (int32_t rc = validate_container(d, pay, payload_len, &bytes)) {
+      delete b;
+      return rc;
+    }
+    src[s] = int64_t(i);
+    nbytes[s] = bytes;
+    b->h_keys[s] = d.key;
+  }
+  // Lay the arena out in (row, slot) order, 16-byte aligned and padded, so that a dense
+  // row is one contiguous 128 KiB block and consecutive wavefronts read consecutive KiBs.
+  uint64_t off = 0;
+  bool dense = n_slots > 0;
+  for (uint64_t s = 0; s < n_slots; ++s) {
+    if (src[s] < 0) {
+      dense = false;
+      continue;
+    }
+    const fbk_container_desc& d = descs[src[s]];
+    if (d.n == 0 || d.len == 0) {  // empty containers are stored as nil (roaring.go:751-752)
+      src[s] = -1;
+      dense = false;
+      continue;
+    }
+    Slot& hs = b->h_slots[s];
+    hs.off = off;
+    hs.len = d.len;
+    hs.tn = fbk::make_tn(d.type, d.n < 0 ? 0x00FFFFFFu : uint32_t(d.n));
+    if (d.n < 0) need_recount = true;
+    if (d.type != FBK_TYPE_BITMAP || off != s * 8192ull) dense = false;
+    off += align16(nbytes[s]);
+  }
+  b->arena_bytes = off;
+  b->dense = dense;
+  std::vector<uint8_t> stage;
+  const uint8_t* h_src = nullptr;
+  try {
+    stage.assign(std::max<uint64_t>(off, 16), 0);
+  } catch (...) {
+    delete b;
+    return fail(FBK_E_NOMEM, "host staging allocation failed");
+  }
+  for (uint64_t s = 0; s < n_slots; ++s)
+    if (src[s] >= 0) std::memcpy(stage.data() + b->h_slots[s].off, pay + descs[src[s]].off, nbytes[s]);
+  h_src = stage.data();
+
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_arena), std::max<uint64_t>(off, 16));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_slots), std::max<uint64_t>(n_slots, 1) * sizeof(Slot));
+  if (e == hipSuccess && off) e = hipMemcpyAsync(b->d_arena, h_src, off, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n_slots)
+    e = hipMemcpyAsync(b->d_slots, b->h_slots.data(), n_slots * sizeof(Slot), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && need_recount) {
+    const uint32_t blocks = uint32_t((n_slots + 3) / 4);
+    hipLaunchKernelGGL(fbk::k_recount, dim3(blocks), dim3(256), 0, ctx->stream, b->d_slots, b->d_arena, n_slots);
+    e = hipGetLastError();
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(b->h_slots.data(), b->d_slots, n_slots * sizeof(Slot), hipMemcpyDeviceToHost, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (b->d_arena) (void)hipFree(b->d_arena);
+    if (b->d_slots) (void)hipFree(b->d_slots);
+    delete b;
+    return fail(e == hipErrorOutOfMemory ? FBK_E_NOMEM : FBK_E_HIP, std::string("batch upload: ") + hipGetErrorString(e));
+  }
+  if (need_recount) {
+    // containers that turned out empty become nil on both sides
+    bool changed = false;
+    for (uint64_t s = 0; s < n_slots; ++s) {
+      Slot& hs = b->h_slots[s];
+      if (fbk::slot_type(hs) != fbk::kTypeNil && fbk::slot_n(hs) == 0) {
+        hs = Slot{0, 0, 0};
+        b->dense = false;
+        changed = true;
+      }
+    }
+    if (changed) {
+      e = hipMemcpy(b->d_slots, b->h_slots.data(), n_slots * sizeof(Slot), hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        (void)hipFree(b->d_arena);
+        (void)hipFree(b->d_slots);
+        delete b;
+        return fail(FBK_E_HIP, std::string("batch upload: ") + hipGetErrorString(e));
+      }
+    }
+  }
+  *out_batch = b;
+  return FBK_OK;
+}
+
+int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_rows, fbk_batch** out_batch) {
+  if (!ctx || !out_batch || (n_rows && !words)) return fail(FBK_E_INVALID, "NULL argument");
+  *out_batch = nullptr;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  const uint64_t n_slots = uint64_t(n_rows) * fbk::kSlots;
+  const uint64_t bytes = n_slots * 8192ull;
+  fbk_batch* b = new (std::nothrow) fbk_batch();
+  if (!b) return fail(FBK_E_NOMEM, "host allocation failed");
+  b->ctx = ctx;
+  b->n_rows = n_rows;
+  b->arena_bytes = bytes;
+  b->dense = n_rows > 0;
+  b->h_slots.resize(n_slots);
+  b->h_keys.resize(n_slots);
+  for (uint64_t s = 0; s < n_slots; ++s) {
+    b->h_slots[s] = Slot{s * 8192ull, FBK_BITMAP_WORDS, fbk::make_tn(fbk::kTypeBitmap, 0)};
+    b->h_keys[s] = s;
+  }
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_arena), std::max<uint64_t>(bytes, 16));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_slots), std::max<uint64_t>(n_slots, 1) * sizeof(Slot));
+  if (e == hipSuccess && bytes) e = hipMemcpyAsync(b->d_arena, words, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n_slots) {
+    e = hipMemcpyAsync(b->d_slots, b->h_slots.data(), n_slots * sizeof(Slot), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(fbk::k_recount, dim3(uint32_t((n_slots + 3) / 4)), dim3(256), 0, ctx->stream, b->d_slots,
+                         b->d_arena, n_slots);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(b->h_slots.data(), b->d_slots, n_slots * sizeof(Slot), hipMemcpyDeviceToHost, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (b->d_arena) (void)hipFree(b->d_arena);
+    if (b->d_slots) (void)hipFree(b->d_slots);
+    delete b;
+    return fail(e == hipErrorOutOfMemory ? FBK_E_NOMEM : FBK_E_HIP, std::string("dense upload: ") + hipGetErrorString(e));
+  }
+  // NOTE: an all-zero bitmap keeps type bitmap with n == 0 here (the batch stays
+  // `dense`); every kernel treats n == 0 as empty, and download skips it.
+  *out_batch = b;
+  return FBK_OK;
+}
+
+int32_t fbk_batch_info(fbk_ctx* ctx, const fbk_batch* batch, uint32_t* n_rows, uint64_t* n_containers,
+                       uint64_t* payload_bytes) {
+  if (!batch) return fail(FBK_E_INVALID, "batch is NULL");
+  fbk_batch* b = const_cast<fbk_batch*>(batch);
+  if (!ctx) ctx = b->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  if (int32_t rc = refresh_slots(b)) return rc;
+  uint64_t nc = 0, pb = 0;
+  for (const Slot& s : b->h_slots) {
+    const uint32_t t = fbk::slot_type(s);
+    if (t == fbk::kTypeNil || fbk::slot_n(s) == 0) continue;
+    ++nc;
+    pb += t == fbk::kTypeArray ? uint64_t(s.len) * 2 : t == fbk::kTypeRun ? uint64_t(s.len) * 4 : 8192ull;
+  }
+  if (n_rows) *n_rows = b->n_rows;
+  if (n_containers) *n_containers = nc;
+  if (payload_bytes) *payload_bytes = pb;
+  return FBK_OK;
+}
+
+int32_t fbk_batch_download(fbk_ctx* ctx, const fbk_batch* batch, fbk_container_desc* descs_out, uint64_t descs_cap,
+                           void* payload_out, uint64_t payload_cap) {
+  if (!batch) return fail(FBK_E_INVALID, "batch is NULL");
+  fbk_batch* b = const_cast<fbk_batch*>(batch);
+  if (!ctx) ctx = b->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  if (int32_t rc = refresh_slots(b)) return rc;
+  uint64_t nc = 0, pb = 0;
+  uint8_t* out = static_cast<uint8_t*>(payload_out);
+  for (uint64_t s = 0; s < b->h_slots.size(); ++s) {
+    const Slot& hs = b->h_slots[s];
+    const uint32_t t = fbk::slot_type(hs);
+    if (t == fbk::kTypeNil || fbk::slot_n(hs) == 0) continue;
+    const uint64_t bytes = t == fbk::kTypeArray ? uint64_t(hs.len) * 2 : t == fbk::kTypeRun ? uint64_t(hs.len) * 4 : 8192ull;
+    if (nc >= descs_cap || pb + bytes > payload_cap || !descs_out || !out)
+      return fail(FBK_E_CAPACITY, "download buffers too small (use fbk_batch_info)");
+    fbk_container_desc& d = descs_out[nc];
+    std::memset(&d, 0, sizeof(d));
+    d.key = b->h_keys[s];
+    d.off = pb;
+    d.row = uint32_t(s / fbk::kSlots);
+    d.len = hs.len;
+    d.n = int32_t(fbk::slot_n(hs));
+    d.type = uint8_t(t);
+    HIP_TRY(hipMemcpyAsync(out + pb, b->d_arena + hs.off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ++nc;
+    pb += bytes;
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return FBK_OK;
+}
+
+int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n, uint64_t* out_counts) {
+  if (!batch || (n && (!rows || !out_counts))) return fail(FBK_E_INVALID, "NULL argument");
+  fbk_batch* b = const_cast<fbk_batch*>(batch);
+  if (!ctx) ctx = b->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  if (int32_t rc = refresh_slots(b)) return rc;
+  // Container.N is a stored field (container_stash.go:430-440); Bitmap.Count sums it
+  // (containers_slice.go:120-126).  The device produced every n (k_recount / fused in
+  // the set-op kernels), so Count itself is the same 16 adds the reference does.
+  for (uint64_t i = 0; i < n; ++i) {
+    if (rows[i] >= b->n_rows) return fail(FBK_E_INVALID, "row index out of range");
+    uint64_t c = 0;
+    for (int s = 0; s < fbk::kSlots; ++s) c += fbk::slot_n(b->h_slots[uint64_t(rows[i]) * fbk::kSlots + s]);
+    out_counts[i] = c;
+  }
+  return FBK_OK;
+}
+
+
+// ---- plans ---------------------------------------------------------------------------
+// A plan is a prepared list of row pairs (A.rows_a[i], B.rows_b[i]) whose index arrays and
+// output buffers live on the device, so that the hot path is launch-only: no host
+// allocation, no H2D copy, no synchronisation between steps.  It is the unit one
+// (query, node) batch call from mapperLocal (executor.go:6742) becomes.
+
+}  // extern "C"
+
+struct fbk_plan {
+  fbk_ctx* ctx = nullptr;
+  const fbk_batch* a = nullptr;
+  const fbk_batch* b = nullptr;
+  uint64_t n_pairs = 0;
+  uint32_t* d_rows_a = nullptr;
+  uint32_t* d_rows_b = nullptr;
+  u64* d_counts = nullptr;     // n_pairs (owned unless ext_counts)
+  u64* d_total = nullptr;      // 1
+  bool ext_counts = false;
+  fbk_batch* out = nullptr;    // lazily created by the first set-op enqueue
+  uint32_t* d_runs = nullptr;  // per output slot run count (optimize pass)
+  std::vector<uint32_t> h_rows_a, h_rows_b;
+};
+
+namespace {
+
+template <int OP>
+void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
+  const uint32_t blocks = uint32_t(p->n_pairs * fbk::kSlots / 4);
+  if (dense)
+    hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
+                       p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, p->d_counts);
+  else
+    hipLaunchKernelGGL(fbk::k_setop<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
+                       p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
+                       want_runs ? p->d_runs : nullptr, p->d_counts);
+}
+
+void free_batch_storage(fbk_batch* b) {
+  if (!b) return;
+  if (b->d_arena) (void)hipFree(b->d_arena);
+  if (b->d_slots) (void)hipFree(b->d_slots);
+  delete b;
+}
+
+void free_plan_storage(fbk_plan* p) {
+  if (!p) return;
+  if (p->d_rows_a) (void)hipFree(p->d_rows_a);
+  if (p->d_rows_b) (void)hipFree(p->d_rows_b);
+  if (p->d_counts && !p->ext_counts) (void)hipFree(p->d_counts);
+  if (p->d_total) (void)hipFree(p->d_total);
+  if (p->d_runs) (void)hipFree(p->d_runs);
+  free_batch_storage(p->out);
+  delete p;
+}
+
+int32_t plan_create_locked(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
+                           const uint32_t* rows_b, uint64_t n_pairs, void* ext_counts, fbk_plan** out_plan) {
+  if (n_pairs > (1ull << 27)) return fail(FBK_E_INVALID, "too many pairs in one plan");
+  for (uint64_t i = 0; i < n_pairs; ++i)
+    if (rows_a[i] >= a->n_rows || rows_b[i] >= b->n_rows) return fail(FBK_E_INVALID, "row index out of range");
+  fbk_plan* p = new (std::nothrow) fbk_plan();
+  if (!p) return fail(FBK_E_NOMEM, "host allocation failed");
+  p->ctx = ctx;
+  p->a = a;
+  p->b = b;
+  p->n_pairs = n_pairs;
+  p->h_rows_a.assign(rows_a, rows_a + n_pairs);
+  p->h_rows_b.assign(rows_b, rows_b + n_pairs);
+  const uint64_t rb = std::max<uint64_t>(n_pairs, 1) * sizeof(uint32_t);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_rows_a), rb);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_rows_b), rb);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_total), sizeof(u64));
+  if (e == hipSuccess) {
+    if (ext_counts) {
+      p->d_counts = static_cast<u64*>(ext_counts);
+      p->ext_counts = true;
+    } else {
+      e = hipMalloc(reinterpret_cast<void**>(&p->d_counts), std::max<uint64_t>(n_pairs, 1) * sizeof(u64));
+    }
+  }
+  if (e == hipSuccess && n_pairs) {
+    e = hipMemcpyAsync(p->d_rows_a, rows_a, n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->d_rows_b, rows_b, n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    free_plan_storage(p);
+    return fail(e == hipErrorOutOfMemory ? FBK_E_NOMEM : FBK_E_HIP, std::string("plan: ") + hipGetErrorString(e));
+  }
+  *out_plan = p;
+  return FBK_OK;
+}
+
+int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p) {
+  if (p->n_pairs == 0) return FBK_OK;
+  const uint32_t np = uint32_t(p->n_pairs);
+  if (p->a->dense && p->b->dense) {
+    // all-bitmap rows: pure streaming kernel.  slots-per-block 16 = one block per row
+    // pair, plain store; smaller groups = more blocks + one atomicAdd per block.
+    static const int spb = [] {
+      const char* e = getenv("FBK_DENSE_SPB");
+      int v = e ? atoi(e) : 16;
+      return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 16;
+    }();
+    if (spb != 16) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
+#define FBK_LAUNCH_DENSE(S)                                                                                       \
+  hipLaunchKernelGGL(fbk::k_icount_dense<S>, dim3(np*(16 / S)), dim3(256), 0, ctx->stream, p->a->d_arena,         \
+                     p->d_rows_a, p->b->d_arena, p->d_rows_b, p->d_counts)
+    switch (spb) {
+      case 1: FBK_LAUNCH_DENSE(1); break;
+      case 2: FBK_LAUNCH_DENSE(2); break;
+      case 4: FBK_LAUNCH_DENSE(4); break;
+      case 8: FBK_LAUNCH_DENSE(8); break;
+      default: FBK_LAUNCH_DENSE(16); break;
+    }
+#undef FBK_LAUNCH_DENSE
+  } else {
+    HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
+    hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,
+                       p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts);
+  }
+  HIP_TRY(hipGetLastError());
+  return FBK_OK;
+}
+
+int32_t plan_setop_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, int32_t op, bool want_runs) {
+  const uint64_t n_slots = p->n_pairs * fbk::kSlots;
+  if (!p->out) {
+    fbk_batch* o = new (std::nothrow) fbk_batch();
+    if (!o) return fail(FBK_E_NOMEM, "host allocation failed");
+    o->ctx = ctx;
+    o->n_rows = uint32_t(p->n_pairs);
+    o->arena_bytes = n_slots * 8192ull;
+    o->h_slots.assign(n_slots, Slot{0, 0, 0});
+    o->h_keys.assign(n_slots, 0);
+    for (uint64_t i = 0; i < p->n_pairs; ++i)
+      for (int s = 0; s < fbk::kSlots; ++s) {
+        const uint64_t ia = uint64_t(p->h_rows_a[i]) * fbk::kSlots + s, ib = uint64_t(p->h_rows_b[i]) * fbk::kSlots + s;
+        // a nil/nil slot pair yields nil and its key is never reported
+        const bool has_a = fbk::slot_type(p->a->h_slots[ia]) != fbk::kTypeNil;
+        o->h_keys[i * fbk::kSlots + s] = has_a ? p->a->h_keys[ia] : p->b->h_keys[ib];
+      }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&o->d_arena), std::max<uint64_t>(o->arena_bytes, 16));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&o->d_slots), std::max<uint64_t>(n_slots, 1) * sizeof(Slot));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      free_batch_storage(o);
+      return fail(e == hipErrorOutOfMemory ? FBK_E_NOMEM : FBK_E_HIP, std::string("setop output: ") + hipGetErrorString(e));
+    }
+    p->out = o;
+  }
+  if (want_runs && !p->d_runs) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_runs), std::max<uint64_t>(n_slots, 1) * 4));
+  if (p->n_pairs == 0) return FBK_OK;
+  const bool dense = p->a->dense && p->b->dense && !want_runs;
+  HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
+  switch (op) {
+    case FBK_OP_AND: launch_setop<0>(dense, p, ctx->stream, want_runs); break;
+    case FBK_OP_OR: launch_setop<1>(dense, p, ctx->stream, want_runs); break;
+    case FBK_OP_XOR: launch_setop<2>(dense, p, ctx->stream, want_runs); break;
+    default: launch_setop<3>(dense, p, ctx->stream, want_runs); break;
+  }
+  HIP_TRY(hipGetLastError());
+  // dense kernels write the dense layout (an all-zero result cell stays an all-zero
+  // bitmap in the arena, its slot says nil): the output can feed the dense kernels again
+  p->out->dense = dense;
+  p->out->slots_stale = true;
+  return FBK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t fbk_plan_create(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
+                        const uint32_t* rows_b, uint64_t n_pairs, void* device_counts_or_null, fbk_plan** out_plan) {
+  if (!ctx || !a || !b || !out_plan || (n_pairs && (!rows_a || !rows_b))) return fail(FBK_E_INVALID, "NULL argument");
+  *out_plan = nullptr;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  return plan_create_locked(ctx, a, rows_a, b, rows_b, n_pairs, device_counts_or_null, out_plan);
+}
+
+int32_t fbk_plan_free(fbk_ctx* ctx, fbk_plan* plan) {
+  if (!plan) return FBK_OK;
+  if (!ctx) ctx = plan->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_plan_storage(plan);
+  return FBK_OK;
+}
+
+int32_t fbk_plan_intersection_count(fbk_ctx* ctx, fbk_plan* plan) {
+  if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  return plan_icount_enqueue_locked(ctx, plan);
+}
+
+int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags) {
+  if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
+  if (op < 0 || op > 3) return fail(FBK_E_INVALID, "unknown set operation");
+  if (flags & ~FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "unknown flags");
+  if (flags & FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "FBK_SETOP_OPTIMIZE not available in this build");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  return plan_setop_enqueue_locked(ctx, plan, op, false);
+}
+
+int32_t fbk_plan_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null) {
+  if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  u64* dst = device_total_or_null ? static_cast<u64*>(device_total_or_null) : plan->d_total;
+  hipLaunchKernelGGL(fbk::k_sum_u64, dim3(1), dim3(256), 0, ctx->stream, plan->d_counts, plan->n_pairs, dst);
+  HIP_TRY(hipGetLastError());
+  return FBK_OK;
+}
+
+int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64_t* out_total) {
+  if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  if (out_counts && plan->n_pairs)
+    HIP_TRY(hipMemcpyAsync(out_counts, plan->d_counts, plan->n_pairs * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_total) HIP_TRY(hipMemcpyAsync(out_total, plan->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return FBK_OK;
+}
+
+int32_t fbk_plan_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch) {
+  if (!plan || !out_batch) return fail(FBK_E_INVALID, "NULL argument");
+  (void)ctx;
+  *out_batch = plan->out;
+  if (!plan->out) return fail(FBK_E_INVALID, "plan has no set-op output yet");
+  return FBK_OK;
+}
+
+int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch) {
+  if (!plan || !out_batch) return fail(FBK_E_INVALID, "NULL argument");
+  if (!ctx) ctx = plan->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (!plan->out) return fail(FBK_E_INVALID, "plan has no set-op output yet");
+  *out_batch = plan->out;
+  plan->out = nullptr;
+  return FBK_OK;
+}
+
+// ---- one-shot calls (plan + enqueue + read) --------------------------------------------
+
+int32_t fbk_intersection_count(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
+                               const uint32_t* rows_b, uint64_t n_pairs, uint64_t* out_counts) {
+  if (!ctx || !a || !b || (n_pairs && (!rows_a || !rows_b || !out_counts))) return fail(FBK_E_INVALID, "NULL argument");
+  if (n_pairs == 0) return FBK_OK;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  fbk_plan* p = nullptr;
+  if (int32_t rc = plan_create_locked(ctx, a, rows_a, b, rows_b, n_pairs, nullptr, &p)) return rc;
+  int32_t rc = plan_icount_enqueue_locked(ctx, p);
+  if (!rc) {
+    hipError_t e = hipMemcpyAsync(out_counts, p->d_counts, n_pairs * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(FBK_E_HIP, std::string("intersection_count: ") + hipGetErrorString(e));
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  free_plan_storage(p);
+  return rc;
+}
+
+int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
+                  const uint32_t* rows_b, uint64_t n_pairs, uint32_t flags, fbk_batch** out_batch,
+                  uint64_t* out_counts) {
+  if (!ctx || !a || !b || !out_batch || (n_pairs && (!rows_a || !rows_b))) return fail(FBK_E_INVALID, "NULL argument");
+  if (op < 0 || op > 3) return fail(FBK_E_INVALID, "unknown set operation");
+  if (flags & ~FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "unknown flags");
+  if (flags & FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "FBK_SETOP_OPTIMIZE not available in this build");
+  *out_batch = nullptr;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  fbk_plan* p = nullptr;
+  if (int32_t rc = plan_create_locked(ctx, a, rows_a, b, rows_b, n_pairs, nullptr, &p)) return rc;
+  int32_t rc = plan_setop_enqueue_locked(ctx, p, op, false);
+  if (!rc && out_counts && n_pairs) {
+    hipError_t e = hipMemcpyAsync(out_counts, p->d_counts, n_pairs * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) rc = fail(FBK_E_HIP, std::string("setop: ") + hipGetErrorString(e));
+  }
+  if (!rc) rc = refresh_slots(p->out);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (!rc && e != hipSuccess) rc = fail(FBK_E_HIP, std::string("setop: ") + hipGetErrorString(e));
+  if (!rc) {
+    *out_batch = p->out;
+    p->out = nullptr;
+  }
+  free_plan_storage(p);
+  return rc;
+}
+
+}  // extern "C"

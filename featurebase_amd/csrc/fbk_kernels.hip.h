@@ -1,0 +1,427 @@
+// fbk_kernels.hip.h — hand-written CDNA4 (gfx950) kernels for the roaring set-op /
+// count hot path.  Integer bit-twiddling, HBM-bound: no MFMA.  Written for 64-lane
+// wavefronts: ONE WAVEFRONT OWNS ONE CONTAINER SLOT (2^16 bits) and holds it as
+// 16 x uint64 per lane (1024 words / 64 lanes), loaded with 8 coalesced 16-byte loads.
+//
+// Word <-> lane mapping used everywhere ("fragment layout"):
+//     register w[2*j + h] of lane l  holds container word  128*j + 2*l + h     (j=0..7, h=0..1)
+// so that load j of a wave covers one contiguous KiB of the 8 KiB bitmap container.
+//
+// Non-bitmap encodings are decoded on the fly into a per-wave 8 KiB LDS scratch:
+//   array: zero scratch, ds_or one bit per element           (arrayToBitmap, roaring.go:3756)
+//   run  : zero scratch, ds_xor a toggle bit at start and last+1, then a parity
+//          prefix-scan (in-word shifts + wave ballot carry) turns toggles into filled
+//          runs                                              (runToBitmap,  roaring.go:3792)
+// so HBM traffic is the *encoded* payload (2n / 4*runs / 8192 bytes), never more.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fbk {
+
+constexpr int kWave = 64;
+constexpr int kSlots = 16;          // containers per shard row (fragment.go:47)
+constexpr int kWords = 1024;        // bitmapN (roaring.go:44)
+constexpr int kWordsPerLane = 16;   // 1024 / 64
+constexpr uint32_t kTypeNil = 0, kTypeArray = 1, kTypeBitmap = 2, kTypeRun = 3;
+
+// Device-side container descriptor: one 16-byte record per (row, slot), loaded with a
+// single scalar dwordx4 load because it is wave-uniform.  type==0 means nil container.
+struct alignas(16) Slot {
+  uint64_t off;   // byte offset into the batch arena (16-byte aligned)
+  uint32_t len;   // array: #u16, bitmap: 1024, run: #intervals
+  uint32_t tn;    // type << 24 | n   (n <= 65536 needs 17 bits)
+};
+__host__ __device__ inline uint32_t slot_type(const Slot& s) { return s.tn >> 24; }
+__host__ __device__ inline uint32_t slot_n(const Slot& s) { return s.tn & 0xFFFFFFu; }
+__host__ __device__ inline uint32_t make_tn(uint32_t type, uint32_t n) { return (type << 24) | n; }
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS instructions of one wavefront are issued and retired in order; this only stops
+  // the compiler from moving LDS accesses of other lanes' data across the point.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+
+// ---- fragment loaders --------------------------------------------------------------
+
+__device__ __forceinline__ void frag_zero(u64 (&w)[kWordsPerLane]) {
+#pragma unroll
+  for (int i = 0; i < kWordsPerLane; ++i) w[i] = 0;
+}
+
+// bitmap container: 8 x global_load_dwordx4 per lane, each wave-load = 1 KiB contiguous.
+__device__ __forceinline__ void frag_load_bitmap(const uint8_t* __restrict__ p, int lane,
+                                                 u64 (&w)[kWordsPerLane]) {
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ulonglong2 v = q[j * kWave + lane];
+    w[2 * j] = v.x;
+    w[2 * j + 1] = v.y;
+  }
+}
+
+__device__ __forceinline__ void frag_store_bitmap(uint8_t* __restrict__ p, int lane,
+                                                  const u64 (&w)[kWordsPerLane]) {
+  ulonglong2* q = reinterpret_cast<ulonglong2*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ulonglong2 v;
+    v.x = w[2 * j];
+    v.y = w[2 * j + 1];
+    q[j * kWave + lane] = v;
+  }
+}
+
+__device__ __forceinline__ void lds_zero(u64* scratch, int lane) {
+  ulonglong2* q = reinterpret_cast<ulonglong2*>(scratch);
+  ulonglong2 z;
+  z.x = 0;
+  z.y = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) q[j * kWave + lane] = z;
+}
+
+__device__ __forceinline__ void lds_read_frag(const u64* scratch, int lane, u64 (&w)[kWordsPerLane]) {
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(scratch);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ulonglong2 v = q[j * kWave + lane];
+    w[2 * j] = v.x;
+    w[2 * j + 1] = v.y;
+  }
+}
+
+// array container -> fragment.  Elements are sorted and unique, but several lanes can
+// hit one dword, hence LDS atomics (ds_or_b32, no return).
+__device__ __forceinline__ void frag_load_array(const uint8_t* __restrict__ p, uint32_t len, int lane,
+                                                u64* scratch, u64 (&w)[kWordsPerLane]) {
+  lds_zero(scratch, lane);
+  wave_lds_sync();
+  uint32_t* s32 = reinterpret_cast<uint32_t*>(scratch);
+  // 4 elements (8 bytes) per lane per iteration; payloads are 16-byte aligned and the
+  // arena is padded, but we never *use* elements past len.
+  const uint2* q = reinterpret_cast<const uint2*>(p);
+  const uint32_t nquad = (len + 3) >> 2;
+  for (uint32_t i = lane; i < nquad; i += kWave) {
+    uint2 v = q[i];
+    uint32_t base = i << 2;
+    uint32_t e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
+    if (base + 0 < len) atomicOr(&s32[e0 >> 5], 1u << (e0 & 31));
+    if (base + 1 < len) atomicOr(&s32[e1 >> 5], 1u << (e1 & 31));
+    if (base + 2 < len) atomicOr(&s32[e2 >> 5], 1u << (e2 & 31));
+    if (base + 3 < len) atomicOr(&s32[e3 >> 5], 1u << (e3 & 31));
+  }
+  wave_lds_sync();
+  lds_read_frag(scratch, lane, w);
+  wave_lds_sync();
+}
+
+__device__ __forceinline__ u64 prefix_xor64(u64 x) {
+  x ^= x << 1;
+  x ^= x << 2;
+  x ^= x << 4;
+  x ^= x << 8;
+  x ^= x << 16;
+  x ^= x << 32;
+  return x;
+}
+
+// run container -> fragment.  Each interval [s,l] toggles bit s and bit l+1; the
+// inclusive parity prefix of the toggle bitmap is the filled bitmap.  Adjacent runs
+// ([0,5],[6,9]) toggle bit 6 twice and merge, as they should.
+__device__ __forceinline__ void frag_load_run(const uint8_t* __restrict__ p, uint32_t len, int lane,
+                                              u64* scratch, u64 (&w)[kWordsPerLane]) {
+  lds_zero(scratch, lane);
+  wave_lds_sync();
+  uint32_t* s32 = reinterpret_cast<uint32_t*>(scratch);
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+  for (uint32_t i = lane; i < len; i += kWave) {
+    uint32_t iv = q[i];
+    uint32_t s = iv & 0xFFFFu, e = (iv >> 16) + 1u;
+    atomicXor(&s32[s >> 5], 1u << (s & 31));
+    if (e < 65536u) atomicXor(&s32[e >> 5], 1u << (e & 31));
+  }
+  wave_lds_sync();
+  lds_read_frag(scratch, lane, w);
+  wave_lds_sync();
+  const u64 lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t carry = 0;  // parity of all toggles in earlier words
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u64 t0 = w[2 * j], t1 = w[2 * j + 1];
+    uint32_t p0 = __popcll(t0) & 1u, p1 = __popcll(t1) & 1u;
+    u64 m = __ballot((p0 ^ p1) != 0);
+    uint32_t in = carry ^ (__popcll(m & lane_lt) & 1u);
+    w[2 * j] = prefix_xor64(t0) ^ (in ? ~0ull : 0ull);
+    w[2 * j + 1] = prefix_xor64(t1) ^ ((in ^ p0) ? ~0ull : 0ull);
+    carry ^= __popcll(m) & 1u;
+  }
+}
+
+// Any container (wave-uniform dispatch on type; no divergence inside a wave).
+__device__ __forceinline__ void frag_load(const Slot& s, const uint8_t* __restrict__ arena, int lane,
+                                          u64* scratch, u64 (&w)[kWordsPerLane]) {
+  const uint32_t t = slot_type(s);
+  const uint8_t* p = arena + s.off;
+  if (t == kTypeBitmap) {
+    frag_load_bitmap(p, lane, w);
+  } else if (t == kTypeArray) {
+    frag_load_array(p, s.len, lane, scratch, w);
+  } else if (t == kTypeRun) {
+    frag_load_run(p, s.len, lane, scratch, w);
+  } else {
+    frag_zero(w);
+  }
+}
+
+template <int OP>
+__device__ __forceinline__ u64 apply_op(u64 a, u64 b) {
+  if (OP == 0) return a & b;   // intersect  (roaring.go:4971)
+  if (OP == 1) return a | b;   // union      (roaring.go:5463)
+  if (OP == 2) return a ^ b;   // xor        (roaring.go:6170)
+  return a & ~b;               // difference (roaring.go:6040)
+}
+
+__device__ __forceinline__ uint32_t frag_popcount(const u64 (&w)[kWordsPerLane]) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < kWordsPerLane; ++i) c += __popcll(w[i]);
+  return c;
+}
+
+// Number of runs in a fragment (bitmapCountRuns, roaring.go:3372-3380): a run starts at
+// every 1-bit whose predecessor bit is 0.  The predecessor of a word's bit 0 is bit 63
+// of the previous container word, which lives in the neighbouring register / lane.
+__device__ __forceinline__ uint32_t frag_count_runs(const u64 (&w)[kWordsPerLane], int lane) {
+  uint32_t r = 0;
+  uint32_t prev_iter_last = 0;  // top bit of word 128*j - 1 (lane 63's w[2j-1])
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u64 w0 = w[2 * j], w1 = w[2 * j + 1];
+    uint32_t top1 = (uint32_t)(w1 >> 63);
+    uint32_t left = __shfl_up(top1, 1, kWave);  // top bit of previous lane's w1
+    if (lane == 0) left = prev_iter_last;
+    r += __popcll(w0 & ~((w0 << 1) | (u64)left));
+    r += __popcll(w1 & ~((w1 << 1) | (w0 >> 63)));
+    prev_iter_last = __shfl(top1, 63, kWave);
+  }
+  return r;
+}
+
+// ---- kernels -------------------------------------------------------------------------
+
+// Cardinality of every container of a batch whose n is unknown (the analogue of
+// Container.count / bitmapRepair, roaring.go:3052,4193).  One wave per slot.
+__global__ void __launch_bounds__(256) k_recount(Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                                uint64_t n_slots) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= n_slots) return;
+  Slot s = slots[wid];
+  const uint32_t t = slot_type(s);
+  if (t == kTypeNil) return;
+  uint32_t c = 0;
+  const uint8_t* p = arena + s.off;
+  if (t == kTypeBitmap) {
+    u64 w[kWordsPerLane];
+    frag_load_bitmap(p, lane, w);
+    c = frag_popcount(w);
+  } else if (t == kTypeArray) {
+    c = (lane == 0) ? s.len : 0;
+  } else {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    for (uint32_t i = lane; i < s.len; i += kWave) {
+      uint32_t iv = q[i];
+      c += (iv >> 16) - (iv & 0xFFFFu) + 1u;  // Interval16.runlen, roaring.go:3047
+    }
+  }
+  c = wave_reduce_add(c);
+  if (lane == 0) slots[wid].tn = make_tn(t, c);
+}
+
+// |A ∩ B| for dense rows: every slot a bitmap container and each row one contiguous
+// 128 KiB block (config 2, the HBM-roofline case).  One 256-thread block per
+// (pair, group of SPB slots); thread t streams 16-byte chunks t, t+256, ... of its
+// group from both operands.  No LDS staging (nothing is reused), no descriptors read.
+template <int SPB>
+__global__ void __launch_bounds__(256) k_icount_dense(const uint8_t* __restrict__ arenaA,
+                                                     const uint32_t* __restrict__ rowsA,
+                                                     const uint8_t* __restrict__ arenaB,
+                                                     const uint32_t* __restrict__ rowsB,
+                                                     u64* __restrict__ out) {
+  constexpr int kGroups = kSlots / SPB;
+  const uint32_t pair = blockIdx.x / kGroups;
+  const uint32_t grp = blockIdx.x % kGroups;
+  const uint64_t rowBytes = (uint64_t)kSlots * 8192;
+  const ulonglong2* a = reinterpret_cast<const ulonglong2*>(arenaA + rowsA[pair] * rowBytes + (uint64_t)grp * SPB * 8192);
+  const ulonglong2* b = reinterpret_cast<const ulonglong2*>(arenaB + rowsB[pair] * rowBytes + (uint64_t)grp * SPB * 8192);
+  constexpr int kIters = SPB * 8192 / 16 / 256;  // 16-byte chunks per thread
+  constexpr int kUnroll = kIters < 8 ? kIters : 8;
+  uint32_t c = 0;
+  for (int i0 = 0; i0 < kIters; i0 += kUnroll) {
+    ulonglong2 va[kUnroll], vb[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) va[u] = a[(i0 + u) * 256 + threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) vb[u] = b[(i0 + u) * 256 + threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) c += __popcll(va[u].x & vb[u].x) + __popcll(va[u].y & vb[u].y);
+  }
+  c = wave_reduce_add(c);
+  __shared__ uint32_t part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 tot = (u64)part[0] + part[1] + part[2] + part[3];
+    if (kGroups == 1) out[pair] = tot;
+    else atomicAdd(&out[pair], tot);
+  }
+}
+
+// A <op> B for dense rows, materialised as dense rows, cardinality fused in the same
+// pass (roaring.go:4971-4974).  out row `pair` is written at out + pair*128 KiB and
+// per-slot cardinalities into outSlots.
+template <int OP>
+__global__ void __launch_bounds__(256) k_setop_dense(const uint8_t* __restrict__ arenaA,
+                                                    const uint32_t* __restrict__ rowsA,
+                                                    const uint8_t* __restrict__ arenaB,
+                                                    const uint32_t* __restrict__ rowsB,
+                                                    uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
+                                                    u64* __restrict__ out_counts) {
+  // one wave per container slot; 4 slots per block
+  const int lane = threadIdx.x & 63;
+  const uint32_t wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t pair = wslot >> 4, slot = wslot & 15;
+  const uint64_t rowBytes = (uint64_t)kSlots * 8192;
+  u64 wa[kWordsPerLane], wb[kWordsPerLane];
+  frag_load_bitmap(arenaA + rowsA[pair] * rowBytes + slot * 8192ull, lane, wa);
+  frag_load_bitmap(arenaB + rowsB[pair] * rowBytes + slot * 8192ull, lane, wb);
+#pragma unroll
+  for (int i = 0; i < kWordsPerLane; ++i) wa[i] = apply_op<OP>(wa[i], wb[i]);
+  const uint64_t ooff = (uint64_t)pair * rowBytes + slot * 8192ull;
+  frag_store_bitmap(arenaO + ooff, lane, wa);
+  uint32_t c = wave_reduce_add(frag_popcount(wa));
+  if (lane == 0) {
+    Slot s;
+    s.off = ooff;
+    s.len = kWords;
+    s.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
+    outSlots[wslot] = s;
+    if (out_counts) atomicAdd(&out_counts[pair], (u64)c);
+  }
+}
+
+// Generic |A ∩ B| over row pairs with any mix of array / bitmap / run / nil containers
+// (intersectionCount and its six kernels, roaring.go:4477-4614).  One wave per
+// (pair, slot).  Short-circuits mirror roaring.go:4478-4486.
+__global__ void __launch_bounds__(256) k_icount(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
+                                               const uint32_t* __restrict__ rowsA,
+                                               const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB,
+                                               const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
+                                               u64* __restrict__ out) {
+  __shared__ u64 lds[4][kWords];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
+  const uint64_t pair = wslot >> 4;
+  const uint32_t slot = wslot & 15;
+  if (pair >= n_pairs) return;
+  const Slot sa = slotsA[(uint64_t)rowsA[pair] * kSlots + slot];
+  const Slot sb = slotsB[(uint64_t)rowsB[pair] * kSlots + slot];
+  const uint32_t na = slot_n(sa), nb = slot_n(sb);
+  uint32_t c;
+  if (na == 0 || nb == 0) {
+    return;  // contributes 0
+  } else if (na == 65536u) {
+    c = nb;
+  } else if (nb == 65536u) {
+    c = na;
+  } else {
+    u64 wa[kWordsPerLane], wb[kWordsPerLane];
+    frag_load(sa, arenaA, lane, lds[wv], wa);
+    frag_load(sb, arenaB, lane, lds[wv], wb);
+    uint32_t part = 0;
+#pragma unroll
+    for (int i = 0; i < kWordsPerLane; ++i) part += __popcll(wa[i] & wb[i]);
+    c = wave_reduce_add(part);
+  }
+  if (lane == 0 && c) atomicAdd(&out[pair], (u64)c);
+}
+
+// Generic materialising A <op> B: result of every (pair, slot) is written as a bitmap
+// container at a fixed 8 KiB cell of the output arena, with its cardinality and run
+// count (for the optional optimize() re-encode pass).
+template <int OP>
+__global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
+                                              const uint32_t* __restrict__ rowsA,
+                                              const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB,
+                                              const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
+                                              uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
+                                              uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts) {
+  __shared__ u64 lds[4][kWords];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
+  const uint64_t pair = wslot >> 4;
+  const uint32_t slot = wslot & 15;
+  if (pair >= n_pairs) return;
+  const Slot sa = slotsA[(uint64_t)rowsA[pair] * kSlots + slot];
+  const Slot sb = slotsB[(uint64_t)rowsB[pair] * kSlots + slot];
+  const uint32_t na = slot_n(sa), nb = slot_n(sb);
+  Slot so;
+  so.off = wslot * 8192ull;
+  so.len = kWords;
+  so.tn = 0;
+  bool empty;
+  if (OP == 0) empty = (na == 0 || nb == 0);
+  else if (OP == 3) empty = (na == 0 || nb == 65536u);
+  else empty = (na == 0 && nb == 0);
+  if (empty) {
+    if (lane == 0) {
+      outSlots[wslot] = so;
+      if (outRuns) outRuns[wslot] = 0;
+    }
+    return;
+  }
+  u64 wa[kWordsPerLane], wb[kWordsPerLane];
+  frag_load(sa, arenaA, lane, lds[wv], wa);
+  frag_load(sb, arenaB, lane, lds[wv], wb);
+#pragma unroll
+  for (int i = 0; i < kWordsPerLane; ++i) wa[i] = apply_op<OP>(wa[i], wb[i]);
+  frag_store_bitmap(arenaO + so.off, lane, wa);
+  uint32_t c = wave_reduce_add(frag_popcount(wa));
+  uint32_t r = 0;
+  if (outRuns) r = wave_reduce_add(frag_count_runs(wa, lane));
+  if (lane == 0) {
+    so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
+    outSlots[wslot] = so;
+    if (outRuns) outRuns[wslot] = r;
+    if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
+  }
+}
+
+// total = sum(counts[0..n)): the per-node half of executeCount's reduceFn
+// (executor.go:5880): one block, deterministic order (integer adds anyway).
+__global__ void __launch_bounds__(256) k_sum_u64(const u64* __restrict__ counts, uint64_t n, u64* __restrict__ total) {
+  u64 acc = 0;
+  for (uint64_t i = threadIdx.x; i < n; i += 256) acc += counts[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+  __shared__ u64 part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *total = part[0] + part[1] + part[2] + part[3];
+}
+
+}  // namespace fbk

@@ -1,0 +1,108 @@
+"""ctypes binding of the C ABI declared in include/fbk.h (libfbk.so, built by hipcc).
+
+This module is plumbing: it declares argtypes/restypes for every exported symbol and
+turns negative status codes into exceptions.  There is no CPU fallback anywhere in this
+package: if libfbk.so is missing, or no gfx950 device is visible, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfbk.so")
+
+FBK_OK = 0
+FBK_E_INVALID, FBK_E_NODEVICE, FBK_E_HIP, FBK_E_NOMEM, FBK_E_CAPACITY = -1, -2, -3, -4, -5
+TYPE_NIL, TYPE_ARRAY, TYPE_BITMAP, TYPE_RUN = 0, 1, 2, 3
+OP_AND, OP_OR, OP_XOR, OP_ANDNOT = 0, 1, 2, 3
+SETOP_KEEP_BITMAP, SETOP_OPTIMIZE = 0, 1
+
+
+class FbkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"fbk error {code}: {msg}")
+        self.code = code
+
+
+class ContainerDesc(C.Structure):
+    """Mirror of fbk_container_desc (include/fbk.h)."""
+
+    _fields_ = [
+        ("key", C.c_uint64),
+        ("off", C.c_uint64),
+        ("row", C.c_uint32),
+        ("len", C.c_uint32),
+        ("n", C.c_int32),
+        ("type", C.c_uint8),
+        ("pad", C.c_uint8 * 3),
+    ]
+
+
+_vp, _u32p, _u64p, _i32p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+_vpp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes).  Must list every symbol include/fbk.h declares
+# (tests/test_abi.py cross-checks this table against the header).
+SIGNATURES = {
+    "fbk_abi_version": (C.c_int32, []),
+    "fbk_last_error": (C.c_char_p, [_vp]),
+    "fbk_device_count": (C.c_int32, [_i32p]),
+    "fbk_open": (C.c_int32, [C.c_int32, C.c_uint32, _vpp]),
+    "fbk_close": (C.c_int32, [_vp]),
+    "fbk_set_stream": (C.c_int32, [_vp, _vp]),
+    "fbk_synchronize": (C.c_int32, [_vp]),
+    "fbk_batch_upload": (C.c_int32, [_vp, C.POINTER(ContainerDesc), C.c_uint64, C.c_uint32, _vp, C.c_uint64, _vpp]),
+    "fbk_batch_upload_dense": (C.c_int32, [_vp, _vp, C.c_uint32, _vpp]),
+    "fbk_batch_free": (C.c_int32, [_vp, _vp]),
+    "fbk_batch_info": (C.c_int32, [_vp, _vp, _u32p, _u64p, _u64p]),
+    "fbk_batch_download": (C.c_int32, [_vp, _vp, C.POINTER(ContainerDesc), C.c_uint64, _vp, C.c_uint64]),
+    "fbk_count": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    "fbk_intersection_count": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
+    "fbk_setop": (C.c_int32, [_vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vpp, _vp]),
+    "fbk_plan_create": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vpp]),
+    "fbk_plan_free": (C.c_int32, [_vp, _vp]),
+    "fbk_plan_intersection_count": (C.c_int32, [_vp, _vp]),
+    "fbk_plan_setop": (C.c_int32, [_vp, _vp, C.c_int32, C.c_uint32]),
+    "fbk_plan_total": (C.c_int32, [_vp, _vp, _vp]),
+    "fbk_plan_read": (C.c_int32, [_vp, _vp, _vp, _vp]),
+    "fbk_plan_output": (C.c_int32, [_vp, _vp, _vpp]),
+    "fbk_plan_detach_output": (C.c_int32, [_vp, _vp, _vpp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libfbk.so (no GPU needed just to load it).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        # One HIP runtime per process: the torch wheel bundles its own libamdhip64.so.7
+        # (same SONAME as /opt/rocm's).  If libfbk.so pulled in /opt/rocm's copy first and
+        # torch were imported later, the process would hold two HSA runtimes and the
+        # second one finds no GPU.  Importing torch first makes libfbk.so bind to the
+        # already-loaded runtime.  (A Go host has no torch: /opt/rocm's runtime is used.)
+        if "torch" not in sys.modules and os.environ.get("FBK_STANDALONE_HIP") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != FBK_OK:
+        msg = load().fbk_last_error(None)
+        raise FbkError(rc, msg.decode() if msg else "?")

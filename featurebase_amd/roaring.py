@@ -1,0 +1,237 @@
+"""Host-side driver of the fbk C ABI, named after the reference types it stands in for.
+
+    Container  ~ roaring.Container          (roaring/container_stash.go:46-53)
+    Batch      ~ a set of fragment.row()s   (fragment.go:283-333), device resident
+    Plan       ~ one (query, node) batch of per-shard map calls (executor.go:6742)
+    Context    ~ one GPU
+
+This is test/bench plumbing over ctypes; all arithmetic happens in libfbk.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import lib as L
+
+SLOTS = 16
+BITMAP_WORDS = 1024
+
+
+@dataclass
+class Container:
+    """One roaring container in its wire encoding (roaring.go:53-58)."""
+
+    typ: int  # L.TYPE_ARRAY / TYPE_BITMAP / TYPE_RUN
+    data: np.ndarray  # array: uint16[n]; bitmap: uint64[1024]; run: uint16[runs, 2] (start, last)
+    n: int = -1  # cardinality, -1 = unknown (device recounts)
+
+    @staticmethod
+    def array(values: Iterable[int]) -> "Container":
+        a = np.asarray(list(values) if not isinstance(values, np.ndarray) else values, dtype=np.uint16)
+        return Container(L.TYPE_ARRAY, a, int(a.size))
+
+    @staticmethod
+    def bitmap(words: np.ndarray, n: int = -1) -> "Container":
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        if w.size < BITMAP_WORDS:  # tests write short literals, like the reference's do
+            w = np.concatenate([w, np.zeros(BITMAP_WORDS - w.size, dtype=np.uint64)])
+        assert w.size == BITMAP_WORDS
+        return Container(L.TYPE_BITMAP, w, n)
+
+    @staticmethod
+    def run(intervals: Iterable[Tuple[int, int]], n: int = -1) -> "Container":
+        r = np.asarray(list(intervals), dtype=np.uint16).reshape(-1, 2)
+        if n < 0:
+            n = int((r[:, 1].astype(np.int64) - r[:, 0].astype(np.int64) + 1).sum()) if r.size else 0
+        return Container(L.TYPE_RUN, r, n)
+
+    @property
+    def length(self) -> int:
+        if self.typ == L.TYPE_ARRAY:
+            return int(self.data.size)
+        if self.typ == L.TYPE_RUN:
+            return int(self.data.shape[0])
+        return BITMAP_WORDS
+
+    def payload(self) -> bytes:
+        return np.ascontiguousarray(self.data).tobytes()
+
+    def words(self) -> np.ndarray:
+        """Bit content as uint64[1024] (representation independent, cf. BitwiseEqual
+        roaring.go:6857-6922)."""
+        if self.typ == L.TYPE_BITMAP:
+            return self.data.copy()
+        bits = np.zeros(65536, dtype=np.uint8)
+        if self.typ == L.TYPE_ARRAY:
+            bits[self.data.astype(np.int64)] = 1
+        else:
+            for s, l in self.data.astype(np.int64):
+                bits[s : l + 1] = 1
+        return np.packbits(bits, bitorder="little").view(np.uint64)
+
+
+Row = Dict[int, Container]  # container key -> container; slot = key & 15
+
+
+class Batch:
+    def __init__(self, ctx: "Context", handle: int):
+        self.ctx = ctx
+        self.h = C.c_void_p(handle)
+
+    def info(self) -> Tuple[int, int, int]:
+        nr, nc, pb = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        L.check(self.ctx.lib.fbk_batch_info(self.ctx.h, self.h, C.byref(nr), C.byref(nc), C.byref(pb)))
+        return nr.value, nc.value, pb.value
+
+    @property
+    def n_rows(self) -> int:
+        return self.info()[0]
+
+    def count(self, rows: Sequence[int]) -> np.ndarray:
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.zeros(r.size, dtype=np.uint64)
+        L.check(self.ctx.lib.fbk_count(self.ctx.h, self.h, r.ctypes.data, r.size, out.ctypes.data))
+        return out
+
+    def download(self) -> List[Row]:
+        n_rows, nc, pb = self.info()
+        descs = (L.ContainerDesc * max(nc, 1))()
+        payload = np.zeros(max(pb, 1), dtype=np.uint8)
+        L.check(self.ctx.lib.fbk_batch_download(self.ctx.h, self.h, descs, nc, payload.ctypes.data, pb))
+        rows: List[Row] = [dict() for _ in range(n_rows)]
+        for i in range(nc):
+            d = descs[i]
+            if d.type == L.TYPE_ARRAY:
+                data = payload[d.off : d.off + 2 * d.len].view(np.uint16).copy()
+            elif d.type == L.TYPE_RUN:
+                data = payload[d.off : d.off + 4 * d.len].view(np.uint16).reshape(-1, 2).copy()
+            else:
+                data = payload[d.off : d.off + 8192].view(np.uint64).copy()
+            rows[d.row][int(d.key)] = Container(int(d.type), data, int(d.n))
+        return rows
+
+    def free(self) -> None:
+        if self.h:
+            L.check(self.ctx.lib.fbk_batch_free(self.ctx.h, self.h))
+            self.h = C.c_void_p(None)
+
+
+class Plan:
+    def __init__(self, ctx: "Context", handle: int, n_pairs: int):
+        self.ctx, self.h, self.n_pairs = ctx, C.c_void_p(handle), n_pairs
+
+    def intersection_count(self) -> None:
+        L.check(self.ctx.lib.fbk_plan_intersection_count(self.ctx.h, self.h))
+
+    def setop(self, op: int, flags: int = 0) -> None:
+        L.check(self.ctx.lib.fbk_plan_setop(self.ctx.h, self.h, op, flags))
+
+    def total(self, device_ptr: int = 0) -> None:
+        L.check(self.ctx.lib.fbk_plan_total(self.ctx.h, self.h, C.c_void_p(device_ptr or None)))
+
+    def read(self, want_total: bool = False):
+        counts = np.zeros(self.n_pairs, dtype=np.uint64)
+        tot = C.c_uint64()
+        L.check(
+            self.ctx.lib.fbk_plan_read(
+                self.ctx.h, self.h, counts.ctypes.data, C.cast(C.byref(tot), C.c_void_p) if want_total else None
+            )
+        )
+        return (counts, tot.value) if want_total else counts
+
+    def output(self) -> Batch:
+        """Borrowed handle of the plan's set-op output (do not free)."""
+        h = C.c_void_p()
+        L.check(self.ctx.lib.fbk_plan_output(self.ctx.h, self.h, C.byref(h)))
+        return Batch(self.ctx, h.value)
+
+    def free(self) -> None:
+        if self.h:
+            L.check(self.ctx.lib.fbk_plan_free(self.ctx.h, self.h))
+            self.h = C.c_void_p(None)
+
+
+class Context:
+    """One GPU.  Fails loudly when libfbk.so is missing or no gfx950 device is visible."""
+
+    def __init__(self, device: int = 0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        L.check(self.lib.fbk_open(device, 0, C.byref(h)))
+        self.h = h
+
+    def close(self) -> None:
+        if self.h:
+            L.check(self.lib.fbk_close(self.h))
+            self.h = C.c_void_p(None)
+
+    def set_stream(self, hip_stream: int) -> None:
+        L.check(self.lib.fbk_set_stream(self.h, C.c_void_p(hip_stream or None)))
+
+    def synchronize(self) -> None:
+        L.check(self.lib.fbk_synchronize(self.h))
+
+    # -- residency ------------------------------------------------------------------
+    def upload(self, rows: Sequence[Row]) -> Batch:
+        """rows[i] maps container key -> Container (what fragment.row() yields)."""
+        n_desc = sum(len(r) for r in rows)
+        descs = (L.ContainerDesc * max(n_desc, 1))()
+        chunks: List[bytes] = []
+        off = 0
+        i = 0
+        for ri, row in enumerate(rows):
+            for key, c in row.items():
+                d = descs[i]
+                d.key, d.off, d.row, d.len, d.n, d.type = key, off, ri, c.length, c.n, c.typ
+                b = c.payload()
+                chunks.append(b)
+                off += len(b)
+                i += 1
+        payload = b"".join(chunks) or b"\0"
+        h = C.c_void_p()
+        L.check(self.lib.fbk_batch_upload(self.h, descs, n_desc, len(rows), payload, off, C.byref(h)))
+        return Batch(self, h.value)
+
+    def upload_dense(self, words: np.ndarray) -> Batch:
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        assert w.size % (SLOTS * BITMAP_WORDS) == 0
+        n_rows = w.size // (SLOTS * BITMAP_WORDS)
+        h = C.c_void_p()
+        L.check(self.lib.fbk_batch_upload_dense(self.h, w.ctypes.data, n_rows, C.byref(h)))
+        return Batch(self, h.value)
+
+    # -- one-shot ops -----------------------------------------------------------------
+    def intersection_count(self, a: Batch, rows_a, b: Batch, rows_b) -> np.ndarray:
+        ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
+        rb = np.ascontiguousarray(rows_b, dtype=np.uint32)
+        assert ra.size == rb.size
+        out = np.zeros(ra.size, dtype=np.uint64)
+        L.check(self.lib.fbk_intersection_count(self.h, a.h, ra.ctypes.data, b.h, rb.ctypes.data, ra.size, out.ctypes.data))
+        return out
+
+    def setop(self, op: int, a: Batch, rows_a, b: Batch, rows_b, flags: int = 0) -> Tuple[Batch, np.ndarray]:
+        ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
+        rb = np.ascontiguousarray(rows_b, dtype=np.uint32)
+        assert ra.size == rb.size
+        out = np.zeros(ra.size, dtype=np.uint64)
+        h = C.c_void_p()
+        L.check(
+            self.lib.fbk_setop(self.h, op, a.h, ra.ctypes.data, b.h, rb.ctypes.data, ra.size, flags, C.byref(h), out.ctypes.data)
+        )
+        return Batch(self, h.value), out
+
+    def plan(self, a: Batch, rows_a, b: Batch, rows_b, device_counts_ptr: int = 0) -> Plan:
+        ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
+        rb = np.ascontiguousarray(rows_b, dtype=np.uint32)
+        assert ra.size == rb.size
+        h = C.c_void_p()
+        L.check(
+            self.lib.fbk_plan_create(
+                self.h, a.h, ra.ctypes.data, b.h, rb.ctypes.data, ra.size, C.c_void_p(device_counts_ptr or None), C.byref(h)
+            )
+        )
+        return Plan(self, h.value, int(ra.size))

@@ -1,0 +1,217 @@
+/*
+ * fbk.h — C ABI of the MI355X roaring-bitmap execution kernel ("fbk" = FeatureBase
+ * Kernel).  This is the drop-in boundary for ONE hot path of FeatureBase: the
+ * Intersect / Union / Difference / Xor / Count / IntersectionCount loop that the
+ * reference runs container-by-container on the CPU in Go.
+ *
+ * The reference has no FFI for this path (CGO_ENABLED=0, Makefile:34); the narrowest
+ * Go choke points each entry point replaces are cited per function below as
+ * <file>:<line> relative to the FeatureBase tree.  INTEGRATION.md shows the cgo stub a
+ * maintainer would add on the Go side.
+ *
+ * Conventions
+ *   - C linkage, plain pointers and sizes, no exceptions across the boundary.
+ *   - Every function returns an int32 status: FBK_OK (0) or a negative FBK_E_* code;
+ *     fbk_last_error(ctx) returns a thread-local human readable message.
+ *     (roaring set-ops never return errors in Go — invariant breaks panic,
+ *     roaring/roaring.go:976,3524 — so every error here is an argument/resource error.)
+ *   - The caller owns every input buffer for the duration of the call only: the
+ *     library copies/uploads before returning, which matches the lifetime rule of
+ *     mmapped containers ("must not retain", roaring/filter.go:179-181, tx.go:66-72).
+ *   - Handles (fbk_ctx, fbk_batch) are opaque; one fbk_ctx drives ONE GPU.  A process
+ *     that owns several GPUs opens one context per device (one process per GPU is the
+ *     deployment model; shards are partitioned over contexts by the caller exactly as
+ *     executor.go:6579 `mapper` partitions shards over nodes).
+ *   - Thread safety: calls on one context are serialised by an internal mutex (cgo pins
+ *     one OS thread per call; ~NumCPU goroutines may call concurrently,
+ *     executor.go:6723-6737).
+ *   - There is NO CPU fallback: if no gfx950 device is usable, fbk_open fails.
+ *
+ * Data model (modelled on roaring/containers_slice.go:5-10 — sorted keys + containers —
+ * flattened to SoA descriptors over one payload arena):
+ *   A *batch* is a set of *rows*.  A row is what fragment.row() returns
+ *   (fragment.go:283-333): the <=16 containers of one (fragment,rowID) in one shard,
+ *   ShardWidth = 2^20 columns = 16 containers of 2^16 bits (shardwidth/helper.go:14,
+ *   fragment.go:47).  Container `key & 15` is the slot inside the row; the library never
+ *   interprets the high key bits, it only carries them through to download.
+ *   Payload encodings are byte-identical to what arrayWriteTo / bitmapWriteTo /
+ *   runWriteTo emit (roaring/roaring.go:4068-4108) minus the 2-byte run-count prefix:
+ *     array : len x uint16 ascending
+ *     bitmap: 1024 x uint64 little endian, bit v at word v/64, bit v%64
+ *     run   : len x {uint16 start, uint16 last}, inclusive, ascending, non-overlapping
+ */
+#ifndef FBK_H
+#define FBK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FBK_ABI_VERSION 1
+
+/* status codes */
+#define FBK_OK 0
+#define FBK_E_INVALID (-1)   /* bad argument / malformed container */
+#define FBK_E_NODEVICE (-2)  /* no usable gfx950 device */
+#define FBK_E_HIP (-3)       /* HIP runtime error (message has hipGetErrorString) */
+#define FBK_E_NOMEM (-4)     /* host or device allocation failed */
+#define FBK_E_CAPACITY (-5)  /* caller-provided output buffer too small */
+
+/* container type codes — identical to roaring/roaring.go:53-58 */
+#define FBK_TYPE_NIL 0
+#define FBK_TYPE_ARRAY 1
+#define FBK_TYPE_BITMAP 2
+#define FBK_TYPE_RUN 3
+
+/* set operations: intersect (roaring.go:4753), union (:4980), xor (:6052),
+ * difference a\b (:5692) */
+#define FBK_OP_AND 0
+#define FBK_OP_OR 1
+#define FBK_OP_XOR 2
+#define FBK_OP_ANDNOT 3
+
+#define FBK_SLOTS_PER_ROW 16      /* containers per shard row, fragment.go:47 */
+#define FBK_BITMAP_WORDS 1024     /* bitmapN, roaring.go:44 */
+#define FBK_CONTAINER_BITS 65536
+
+/* fbk_setop flags */
+#define FBK_SETOP_KEEP_BITMAP 0u  /* every non-empty output container is a bitmap */
+#define FBK_SETOP_OPTIMIZE 1u     /* re-encode outputs with Container.optimize() rules
+                                     (roaring.go:3412-3461): run if runs<=2048 && runs<=n/2,
+                                     else array if n<4096, else bitmap */
+
+typedef struct fbk_ctx fbk_ctx;
+typedef struct fbk_batch fbk_batch;
+
+/* One container of a batch.  Replaces *roaring.Container (container_stash.go:46-53). */
+typedef struct fbk_container_desc {
+  uint64_t key;  /* roaring container key; slot = key & 15 */
+  uint64_t off;  /* byte offset of the payload inside `payload` */
+  uint32_t row;  /* batch-local row ordinal, 0 <= row < n_rows */
+  uint32_t len;  /* array: #uint16; bitmap: 1024; run: #intervals */
+  int32_t n;     /* cardinality (Container.N, container_stash.go:430); -1 = recount on device */
+  uint8_t type;  /* FBK_TYPE_* */
+  uint8_t pad[3];
+} fbk_container_desc;
+
+/* ---- lifetime ---------------------------------------------------------------- */
+
+/* Number of visible HIP devices. */
+int32_t fbk_device_count(int32_t* out_n);
+
+/* Open a context on HIP device `device`.  Replaces nothing in Go; called at server
+ * start (server/server.go Open). */
+int32_t fbk_open(int32_t device, uint32_t flags, fbk_ctx** out_ctx);
+int32_t fbk_close(fbk_ctx* ctx);
+
+/* Thread-local message of the last failing call (never NULL). ctx may be NULL. */
+const char* fbk_last_error(fbk_ctx* ctx);
+
+int32_t fbk_abi_version(void);
+
+/* Use an externally owned hipStream_t (e.g. the caller's framework stream) for all
+ * subsequent launches on this context; NULL restores the context's own stream. */
+int32_t fbk_set_stream(fbk_ctx* ctx, void* hip_stream);
+
+/* Block until everything enqueued on the context's stream has finished. */
+int32_t fbk_synchronize(fbk_ctx* ctx);
+
+/* ---- residency ----------------------------------------------------------------
+ * fbk_batch_upload makes the rows a query touches device resident.  Replaces the
+ * per-row materialisation fragment.row / rowFromStorage (fragment.go:283-333) ->
+ * Tx.OffsetRange (rbf/tx.go:1586-1638).  `descs` may be in any order; (row, key&15)
+ * must be unique.  Containers with n == 0 are legal and stored as nil (the reference
+ * stores empty results as nil, roaring.go:751-752). */
+int32_t fbk_batch_upload(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t n_desc,
+                         uint32_t n_rows, const void* payload, uint64_t payload_len,
+                         fbk_batch** out_batch);
+
+/* Dense upload: n_rows rows of 16 bitmap containers each, `words` = n_rows*16*1024
+ * uint64 (row-major).  Cardinalities are recounted on the device (the analogue of
+ * bitmapRepair, roaring.go:4193-4206).  Keys are assigned row*16+slot. */
+int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_rows,
+                               fbk_batch** out_batch);
+
+int32_t fbk_batch_free(fbk_ctx* ctx, fbk_batch* batch);
+
+/* Sizes needed to download a batch. */
+int32_t fbk_batch_info(fbk_ctx* ctx, const fbk_batch* batch, uint32_t* n_rows,
+                       uint64_t* n_containers, uint64_t* payload_bytes);
+
+/* Copy a batch back to the host in the same flattened layout (non-nil containers only,
+ * sorted by (row, slot)).  The Go side rebuilds containers with
+ * NewContainerArray/BitmapN/RunN (container_stash.go).  Replaces result Row
+ * construction (row.go:561-610). */
+int32_t fbk_batch_download(fbk_ctx* ctx, const fbk_batch* batch, fbk_container_desc* descs_out,
+                           uint64_t descs_cap, void* payload_out, uint64_t payload_cap);
+
+/* ---- counts -------------------------------------------------------------------- */
+
+/* out[i] = Row.Count of rows[i]: sum of stored container N (roaring.go:542,
+ * containers_slice.go:120-126, row.go:446). */
+int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n,
+                  uint64_t* out_counts);
+
+/* out[i] = |A.rows_a[i] ∩ B.rows_b[i]| without materialising.  Replaces
+ * RowSegment.IntersectionCount (row.go:556) -> Bitmap.IntersectionCount
+ * (roaring.go:711-733) -> intersectionCount (roaring.go:4477-4614), one call per
+ * (query,node) instead of one per container.  a and b may be the same batch. */
+int32_t fbk_intersection_count(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a,
+                               const fbk_batch* b, const uint32_t* rows_b, uint64_t n_pairs,
+                               uint64_t* out_counts);
+
+/* ---- materialising set operations ---------------------------------------------- */
+
+/* out row i = A.rows_a[i] <op> B.rows_b[i]; out_counts[i] (may be NULL) = its cardinality.
+ * Replaces RowSegment.{Intersect,Union,Difference,Xor} (row.go:561-610) ->
+ * Bitmap.{Intersect,Union,Difference,Xor} (roaring.go:736,1272,1564,1598).  The
+ * cardinality is produced in the same pass, as the reference fuses it
+ * (roaring.go:4971-4974).  Output keys are taken from operand A (or B where A's slot
+ * is nil). */
+int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* rows_a,
+                  const fbk_batch* b, const uint32_t* rows_b, uint64_t n_pairs, uint32_t flags,
+                  fbk_batch** out_batch, uint64_t* out_counts);
+
+/* ---- plans: launch-only hot path -------------------------------------------------
+ * A plan is a prepared list of row pairs whose index arrays and result buffers are
+ * device resident, so one step of the hot path is kernel launches only (no host
+ * allocation, copy or synchronisation).  It is what ONE batch call per (query, node)
+ * from mapperLocal (executor.go:6742-6790) becomes: the per-shard mapFn closure
+ * (executor.go:5871) is the pair list, the reduceFn (executor.go:5880) is
+ * fbk_plan_total.  `device_counts_or_null`, when given, is a caller-owned device buffer
+ * of n_pairs uint64 (e.g. the tensor a collective library will all-reduce). */
+typedef struct fbk_plan fbk_plan;
+
+int32_t fbk_plan_create(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
+                        const uint32_t* rows_b, uint64_t n_pairs, void* device_counts_or_null,
+                        fbk_plan** out_plan);
+int32_t fbk_plan_free(fbk_ctx* ctx, fbk_plan* plan);
+
+/* Enqueue counts[i] = |A.rows_a[i] ∩ B.rows_b[i]| (Bitmap.IntersectionCount,
+ * roaring.go:711-733).  Asynchronous. */
+int32_t fbk_plan_intersection_count(fbk_ctx* ctx, fbk_plan* plan);
+
+/* Enqueue out row i = A.rows_a[i] <op> B.rows_b[i] and counts[i] = its cardinality
+ * (Bitmap.Intersect/Union/Xor/Difference + Count, roaring.go:736,1272,1598,1564;
+ * executeCount's mapFn, executor.go:5871-5876).  The output batch is owned by the plan
+ * and overwritten by the next enqueue.  Asynchronous. */
+int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags);
+
+/* Enqueue total = sum_i counts[i] (executeCount reduceFn, executor.go:5880) into the
+ * plan's total cell or into a caller-owned device uint64.  Asynchronous. */
+int32_t fbk_plan_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null);
+
+/* Synchronise and copy counts (n_pairs, may be NULL) and total (may be NULL) to the host. */
+int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64_t* out_total);
+
+/* Borrow / take ownership of the plan's set-op output batch. */
+int32_t fbk_plan_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch);
+int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FBK_H */
