@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the roaring set-op hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): per GPU 1024 shards x 2 rows x 2^20 columns, density
+50 % => 32768 bitmap containers (256 MiB) resident in HBM; one *step* = one pass of
+Count(Intersect(Row a, Row b)) over every shard: |a_s ∩ b_s| for each shard s
+(Bitmap.IntersectionCount, roaring.go:711), the per-node sum (executeCount reduceFn,
+executor.go:5880) and, for N > 1, the cross-GPU sum of the partial counts by one RCCL
+all-reduce (the exchange step executor.go:6449 mapReduce does over HTTP).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `value` = container set-ops per second over all N GPUs
+(a set-op = one container pair with equal keys); weak scaling (1024 shards
+per GPU).  Also reported: bits-scanned GB/s, the roofline of the dominant kernel (HIP
+events around back-to-back launches), the materialising variant, and the CPU oracle timed
+on this box's host cores as `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: one HIP runtime per process, see featurebase_amd/lib.py)
+
+SHARDS_PER_GPU = 1024
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def cpu_baseline(wa: np.ndarray, wb: np.ndarray, budget_s: float = 12.0):
+    """The CPU restatement of the Go path (oracle/roaring_oracle.c) on this box's host
+    cores: same inputs, one worker thread per shard chunk (the reference runs one
+    goroutine per shard over NumCPU workers, executor.go:6723-6737)."""
+    import ctypes as C
+    import threading
+
+    src = [os.path.join(ROOT, "oracle", f) for f in ("roaring_oracle.c", "bsi_oracle.c")]
+    so = os.path.join(ROOT, "oracle", "libroaring_oracle.so")
+    build = "portable -O3 -mpopcnt"
+    try:  # a -march=native build for the box we are on (the committed .so is portable)
+        tmp = os.path.join(tempfile.mkdtemp(prefix="fbk_orc_"), "liborc_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c99", "-fPIC", "-shared", "-o", tmp] + src, stderr=subprocess.DEVNULL)
+        so, build = tmp, "gcc -O3 -march=native"
+    except Exception:
+        pass
+    lib = C.CDLL(so)
+    lib.orc_dense_intersection_count.restype = C.c_uint64
+    lib.orc_dense_intersection_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    n = wa.shape[0]
+    cores = os.cpu_count() or 1
+    chunks = np.array_split(np.arange(n), cores)
+    counts = np.zeros(n, dtype=np.uint64)
+    row_bytes = 16 * 1024 * 8
+
+    def work(ch):
+        if ch.size:
+            lib.orc_dense_intersection_count(
+                wa.ctypes.data + int(ch[0]) * row_bytes, wb.ctypes.data + int(ch[0]) * row_bytes, ch.size, counts.ctypes.data + int(ch[0]) * 8
+            )
+
+    def one_pass():
+        ts = [threading.Thread(target=work, args=(ch,)) for ch in chunks]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+
+    one_pass()  # warm
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        one_pass()
+        passes += 1
+        if time.perf_counter() - t0 > budget_s or passes >= 2000:
+            break
+    dt = (time.perf_counter() - t0) / passes
+    # single-thread reference point
+    t1 = time.perf_counter()
+    lib.orc_dense_intersection_count(wa.ctypes.data, wb.ctypes.data, n, counts.ctypes.data)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": n * 16 / dt,
+        "unit": "set-ops/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"full workload ({n} shards x 2 rows, 256 MiB) x {passes} passes, {cores} threads, C restatement of the Go path built with {build}",
+        "bits_scanned_GBps": 2 * n * 16 * 8192 / dt / 1e9,
+        "single_thread_set_ops_per_s": n * 16 / dt1,
+        "total_count": int(counts.sum()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--shards", type=int, default=SHARDS_PER_GPU, help="shards per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n_gpus = max(world, 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if n_gpus > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import datagen as D
+    from featurebase_amd import lib as L
+    from featurebase_amd.roaring import Context
+
+    ctx = Context(local_rank)
+    stream = torch.cuda.Stream(device=dev)  # non-default: its handle is what fbk launches on
+    ctx.set_stream(stream.cuda_stream)
+
+    n = args.shards
+    # synthetic shards of this rank: global shard id = rank*n + s seeds the generator
+    wa = D.dense_rows(n, 0.5, 1000 + 2 * rank)
+    wb = D.dense_rows(n, 0.5, 1001 + 2 * rank)
+    t_up0 = time.perf_counter()
+    A, B = ctx.upload_dense(wa), ctx.upload_dense(wb)
+    t_upload = time.perf_counter() - t_up0
+    rows = np.arange(n)
+
+    with torch.cuda.stream(stream):
+        counts = torch.zeros(n, dtype=torch.int64, device=dev)  # uint64 payload; int64 for RCCL
+        total = torch.zeros(1, dtype=torch.int64, device=dev)
+    plan = ctx.plan(A, rows, B, rows, device_counts_ptr=counts.data_ptr())
+
+    def step():
+        plan.intersection_count()  # per-shard |a ∩ b|
+        plan.total(total.data_ptr())  # per-node reduce
+        if n_gpus > 1:
+            dist.all_reduce(total)  # RCCL sum of the partial counts over xGMI
+
+    def barrier():
+        if n_gpus > 1:
+            dist.barrier()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+
+        # parity spot check of the timed result (numpy popcount of this rank's shards)
+        local_expected = int(np.bitwise_count(wa & wb).sum())
+        got_counts = counts.cpu().numpy().view(np.uint64)
+        assert int(got_counts.sum()) == local_expected, "GPU result differs from numpy popcount"
+        if n_gpus == 1:
+            assert int(total.item()) == local_expected
+
+        # ---- roofline of the dominant kernel: HIP events around back-to-back launches
+        # of k_icount_dense alone, on the stream it is launched on
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        kiters = max(args.steps, 50)
+        for _ in range(5):
+            plan.intersection_count()
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(kiters):
+            plan.intersection_count()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / kiters
+        alg_bytes = 2 * n * 16 * 8192 + n * 8  # both operands read once + one u64 count per shard
+        # ---- materialising variant: Intersect written out + Count fused (roaring.go:4960)
+        for _ in range(5):
+            plan.setop(L.OP_AND)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(kiters):
+            plan.setop(L.OP_AND)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        m_ms = e0.elapsed_time(e1) / kiters
+        m_bytes = 3 * n * 16 * 8192 + n * 16 * 16 + n * 8
+        plan.total(total.data_ptr())
+        torch.cuda.synchronize()
+        assert int(total.item()) == local_expected
+
+    # max over ranks
+    if n_gpus > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        set_ops = n_gpus * n * 16 * args.steps
+        ms_per_step = dt / args.steps * 1e3
+        out = {
+            "metric": "container set-ops/sec + bits-scanned GB/s, 1M-col Intersect+Count",
+            "value": set_ops / dt,
+            "unit": "set-ops/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: per GPU 1024 shards x 2 rows x 2^20 cols, bitmap x bitmap AND+popcount, density 50%",
+                "shards_per_gpu": n,
+                "containers_per_gpu": 2 * n * 16,
+                "op": "Count(Intersect(Row,Row)) as IntersectionCount + per-node sum" + (" + RCCL all-reduce" if n_gpus > 1 else ""),
+                "parallelism": f"shards/{n_gpus}gpu",
+            },
+            "bits_scanned_GBps": n_gpus * 2 * n * 16 * 8192 / (dt / args.steps) / 1e9,
+            "roofline": {
+                "kernel": "k_icount_dense<16>",
+                "bound": "hbm",
+                "achieved": alg_bytes / (k_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "traffic": None,
+                "kernel_us": k_ms * 1e3,
+                "algorithmic_bytes": alg_bytes,
+            },
+            "materialized": {
+                "kernel": "k_setop_dense<AND>",
+                "set_ops_per_s": n * 16 / (m_ms * 1e-3),
+                "achieved_GBps": m_bytes / (m_ms * 1e-3) / 1e9,
+                "frac": m_bytes / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "kernel_us": m_ms * 1e3,
+                "algorithmic_bytes": m_bytes,
+            },
+            "h2d_upload_s": t_upload,
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                out["roofline"]["traffic"] = json.load(open(traffic_file)).get("k_icount_dense_hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(wa, wb)
+            assert cb.pop("total_count") == local_expected, "oracle and GPU disagree"
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+
+    plan.free()
+    A.free()
+    B.free()
+    ctx.close()
+    if n_gpus > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

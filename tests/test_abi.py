@@ -1,0 +1,85 @@
+"""CPU-only checks of the drop-in boundary: libfbk.so loads without a GPU, exports every
+symbol include/fbk.h declares, the ctypes table covers exactly that set, and the
+library fails loudly (no CPU fallback) when no device is present."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "fbk.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(fbk_[a-z0-9_]+)\s*\(", src))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+
+    g.build()
+    from featurebase_amd import lib as L
+
+    return L
+
+
+def test_header_symbols_exported(lib):
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (fbk_[a-z0-9_]+)", out))
+    assert decl <= exported, f"declared but not exported: {sorted(decl - exported)}"
+    assert exported <= decl, f"exported but not declared in include/fbk.h: {sorted(exported - decl)}"
+
+
+def test_ctypes_table_matches_header(lib):
+    assert set(lib.SIGNATURES) == declared_symbols()
+    lib.load()
+
+
+def test_struct_layout_matches_header(lib):
+    # fbk_container_desc: u64 key, u64 off, u32 row, u32 len, i32 n, u8 type, u8 pad[3]
+    assert C.sizeof(lib.ContainerDesc) == 32
+    assert lib.ContainerDesc.off.offset == 8 and lib.ContainerDesc.row.offset == 16
+    assert lib.ContainerDesc.n.offset == 24 and lib.ContainerDesc.type.offset == 28
+
+
+def test_abi_version(lib):
+    assert lib.load().fbk_abi_version() == 1
+
+
+def test_no_device_fails_loudly(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from featurebase_amd.roaring import Context
+
+    with pytest.raises(lib.FbkError) as ei:
+        Context(0)
+    assert ei.value.code == lib.FBK_E_NODEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_null_arguments_are_errors_not_crashes(lib):
+    l = lib.load()
+    assert l.fbk_open(0, 0, None) == lib.FBK_E_INVALID
+    assert l.fbk_device_count(None) == lib.FBK_E_INVALID
+    assert l.fbk_batch_info(None, None, None, None, None) == lib.FBK_E_INVALID
+    assert l.fbk_close(None) == lib.FBK_OK
+    assert l.fbk_last_error(None) is not None
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "featurebase_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle" not in txt.lower(), f"{f} mentions the oracle"
