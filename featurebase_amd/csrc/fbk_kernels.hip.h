@@ -52,6 +52,22 @@ __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
   return v;
 }
 
+// Streaming (non-temporal) 16-byte global accesses.  Container payloads are read once
+// per kernel and never reused by the same launch, so they should not displace each other
+// in L2 / Infinity Cache: measured on MI355X with a 1 GiB working set, the dense
+// |A∩B| kernel goes from 5.69 TB/s (plain loads) to 6.54 TB/s with `nt` loads
+// (profiles/tune_dense_r01.txt).
+__device__ __forceinline__ ulonglong2 ld_stream(const ulonglong2* p) {
+  ulonglong2 v;
+  v.x = __builtin_nontemporal_load(&p->x);
+  v.y = __builtin_nontemporal_load(&p->y);
+  return v;
+}
+__device__ __forceinline__ void st_stream(ulonglong2* p, ulonglong2 v) {
+  __builtin_nontemporal_store(v.x, &p->x);
+  __builtin_nontemporal_store(v.y, &p->y);
+}
+
 // ---- fragment loaders --------------------------------------------------------------
 
 __device__ __forceinline__ void frag_zero(u64 (&w)[kWordsPerLane]) {
@@ -65,7 +81,7 @@ __device__ __forceinline__ void frag_load_bitmap(const uint8_t* __restrict__ p, 
   const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    ulonglong2 v = q[j * kWave + lane];
+    ulonglong2 v = ld_stream(&q[j * kWave + lane]);
     w[2 * j] = v.x;
     w[2 * j + 1] = v.y;
   }
@@ -79,7 +95,7 @@ __device__ __forceinline__ void frag_store_bitmap(uint8_t* __restrict__ p, int l
     ulonglong2 v;
     v.x = w[2 * j];
     v.y = w[2 * j + 1];
-    q[j * kWave + lane] = v;
+    st_stream(&q[j * kWave + lane], v);
   }
 }
 
@@ -272,9 +288,9 @@ __global__ void __launch_bounds__(256) k_icount_dense(const uint8_t* __restrict_
   for (int i0 = 0; i0 < kIters; i0 += kUnroll) {
     ulonglong2 va[kUnroll], vb[kUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) va[u] = a[(i0 + u) * 256 + threadIdx.x];
+    for (int u = 0; u < kUnroll; ++u) va[u] = ld_stream(&a[(i0 + u) * 256 + threadIdx.x]);
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) vb[u] = b[(i0 + u) * 256 + threadIdx.x];
+    for (int u = 0; u < kUnroll; ++u) vb[u] = ld_stream(&b[(i0 + u) * 256 + threadIdx.x]);
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) c += __popcll(va[u].x & vb[u].x) + __popcll(va[u].y & vb[u].y);
   }

@@ -1934,3 +1934,51 @@ int32_t orc_count_kernel(const char* name, const orc_container* a, const orc_con
 #undef K
   return -1;
 }
+
+/* ---- multi-threaded bulk baseline ------------------------------------------------------
+ * One worker per shard chunk, as the reference runs one goroutine per shard over
+ * runtime.NumCPU() pool workers (executor.go:128-147, 6723-6737).  Every worker makes
+ * `passes` passes over its own chunk, so thread start-up is paid once, not per pass. */
+#include <pthread.h>
+
+typedef struct {
+  const uint64_t *a, *b;
+  uint64_t n_pairs, passes;
+  uint64_t* out_counts;
+  uint64_t total;
+} mt_job;
+
+static void* mt_worker(void* p) {
+  mt_job* j = (mt_job*)p;
+  uint64_t t = 0;
+  for (uint64_t k = 0; k < j->passes; k++) t = orc_dense_intersection_count(j->a, j->b, j->n_pairs, j->out_counts);
+  j->total = t;
+  return NULL;
+}
+
+uint64_t orc_dense_intersection_count_mt(const uint64_t* a, const uint64_t* b, uint64_t n_pairs, uint64_t* out_counts,
+                                         int32_t n_threads, uint64_t passes) {
+  if (n_threads < 1) n_threads = 1;
+  if ((uint64_t)n_threads > n_pairs) n_threads = (int32_t)(n_pairs ? n_pairs : 1);
+  pthread_t* th = (pthread_t*)xmalloc((size_t)n_threads * sizeof(pthread_t));
+  mt_job* jobs = (mt_job*)xcalloc((size_t)n_threads, sizeof(mt_job));
+  uint64_t per = n_pairs / (uint64_t)n_threads, rem = n_pairs % (uint64_t)n_threads, at = 0;
+  for (int32_t t = 0; t < n_threads; t++) {
+    uint64_t cnt = per + ((uint64_t)t < rem ? 1 : 0);
+    jobs[t].a = a + at * 16 * BN;
+    jobs[t].b = b + at * 16 * BN;
+    jobs[t].n_pairs = cnt;
+    jobs[t].passes = passes;
+    jobs[t].out_counts = out_counts ? out_counts + at : NULL;
+    at += cnt;
+    pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+  }
+  uint64_t total = 0;
+  for (int32_t t = 0; t < n_threads; t++) {
+    pthread_join(th[t], NULL);
+    total += jobs[t].total;
+  }
+  free(th);
+  free(jobs);
+  return total;
+}

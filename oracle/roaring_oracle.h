@@ -127,6 +127,42 @@ uint64_t orc_dense_intersection_count(const uint64_t* a, const uint64_t* b, uint
 uint64_t orc_dense_intersect_count(const uint64_t* a, const uint64_t* b, uint64_t n_pairs, uint64_t* out_rows,
                                    uint64_t* out_counts);
 
+/* ---- BSI / TopK / GroupBy / UnionRows (bsi_oracle.c).  A fragment is an array of rows;
+ * row r is an orc_bitmap with container keys 0..15 (NULL = no containers).  BSI layout
+ * (fragment.go:62-65): row 0 exists, row 1 sign, row 2+i magnitude bit i. ---- */
+#define ORC_EQ 1
+#define ORC_NEQ 2
+#define ORC_LT 3
+#define ORC_LTE 4
+#define ORC_GT 5
+#define ORC_GTE 6
+/* fragment.sum (fragment.go:724) via BitmapBSICountFilter (roaring/filter.go:1097-1218) */
+void orc_bsi_sum(const orc_bitmap* const* rows, int32_t n_rows, const orc_bitmap* filter, int32_t has_filter,
+                 int64_t* out_sum, uint64_t* out_count);
+/* fragment.rangeOp (fragment.go:937) / rangeBetween (:1213) */
+orc_bitmap* orc_bsi_range(const orc_bitmap* const* rows, int32_t n_rows, int32_t op, uint64_t bit_depth,
+                          int64_t predicate);
+orc_bitmap* orc_bsi_range_between(const orc_bitmap* const* rows, int32_t n_rows, uint64_t bit_depth, int64_t pmin,
+                                  int64_t pmax);
+orc_bitmap* orc_bsi_range_lt_unsigned(const orc_bitmap* const* rows, int32_t n_rows, const orc_bitmap* filter,
+                                      uint64_t bit_depth, uint64_t predicate, int32_t allow_eq);
+orc_bitmap* orc_bsi_range_gt_unsigned(const orc_bitmap* const* rows, int32_t n_rows, const orc_bitmap* filter,
+                                      uint64_t bit_depth, uint64_t predicate, int32_t allow_eq);
+orc_bitmap* orc_bsi_range_between_unsigned(const orc_bitmap* const* rows, int32_t n_rows, const orc_bitmap* filter,
+                                           uint64_t bit_depth, uint64_t pmin, uint64_t pmax);
+/* doTopK (executor.go:2705): per-row |row ∩ filter| */
+void orc_topk_row_counts(const orc_bitmap* const* rows, int32_t n_rows, const orc_bitmap* filter, int32_t has_filter,
+                         uint64_t* out_counts);
+/* groupByIterator (executor.go:8880): out[i*nb+j] = |(A_i ∩ F) ∩ B_j| */
+void orc_groupby_counts(const orc_bitmap* const* a_rows, int32_t na, const orc_bitmap* const* b_rows, int32_t nb,
+                        const orc_bitmap* filter, int32_t has_filter, uint64_t* out);
+/* BitmapRowsUnion (roaring/filter.go:294) */
+orc_bitmap* orc_union_rows(const orc_bitmap* const* rows, int32_t n_rows);
+
+/* every worker thread makes `passes` passes over its own chunk of row pairs */
+uint64_t orc_dense_intersection_count_mt(const uint64_t* a, const uint64_t* b, uint64_t n_pairs, uint64_t* out_counts,
+                                         int32_t n_threads, uint64_t passes);
+
 /* ---- test hooks (the reference's per-kernel tests call the type-pair kernels directly) */
 void orc_set_n(orc_container* c, int32_t n);
 orc_container* orc_flip(const orc_container* a); /* roaring.go:4221 */
