@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "fbk_kernels.hip.h"
+#include "fbk_query_kernels.hip.h"
 
 using fbk::Slot;
 using fbk::u64;
@@ -496,6 +497,8 @@ struct fbk_plan {
 
 namespace {
 
+int32_t optimize_cells(fbk_ctx* ctx, fbk_batch* o, const uint32_t* d_runs);  // fbk_query_api.inc
+
 template <int OP>
 void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
   const uint32_t blocks = uint32_t(p->n_pairs * fbk::kSlots / 4);
@@ -675,7 +678,8 @@ int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags)
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   if (op < 0 || op > 3) return fail(FBK_E_INVALID, "unknown set operation");
   if (flags & ~FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "unknown flags");
-  if (flags & FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "FBK_SETOP_OPTIMIZE not available in this build");
+  if (flags & FBK_SETOP_OPTIMIZE)
+    return fail(FBK_E_INVALID, "FBK_SETOP_OPTIMIZE needs a synchronisation point: use fbk_setop or fbk_batch_optimize");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   return plan_setop_enqueue_locked(ctx, plan, op, false);
@@ -747,17 +751,18 @@ int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* 
   if (!ctx || !a || !b || !out_batch || (n_pairs && (!rows_a || !rows_b))) return fail(FBK_E_INVALID, "NULL argument");
   if (op < 0 || op > 3) return fail(FBK_E_INVALID, "unknown set operation");
   if (flags & ~FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "unknown flags");
-  if (flags & FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "FBK_SETOP_OPTIMIZE not available in this build");
   *out_batch = nullptr;
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   fbk_plan* p = nullptr;
   if (int32_t rc = plan_create_locked(ctx, a, rows_a, b, rows_b, n_pairs, nullptr, &p)) return rc;
-  int32_t rc = plan_setop_enqueue_locked(ctx, p, op, false);
+  const bool opt = (flags & FBK_SETOP_OPTIMIZE) != 0;
+  int32_t rc = plan_setop_enqueue_locked(ctx, p, op, opt);
   if (!rc && out_counts && n_pairs) {
     hipError_t e = hipMemcpyAsync(out_counts, p->d_counts, n_pairs * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
     if (e != hipSuccess) rc = fail(FBK_E_HIP, std::string("setop: ") + hipGetErrorString(e));
   }
+  if (!rc && opt) rc = optimize_cells(ctx, p->out, p->d_runs);
   if (!rc) rc = refresh_slots(p->out);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (!rc && e != hipSuccess) rc = fail(FBK_E_HIP, std::string("setop: ") + hipGetErrorString(e));
@@ -770,3 +775,5 @@ int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* 
 }
 
 }  // extern "C"
+
+#include "fbk_query_api.inc"

@@ -69,7 +69,16 @@ SIGNATURES = {
     "fbk_plan_read": (C.c_int32, [_vp, _vp, _vp, _vp]),
     "fbk_plan_output": (C.c_int32, [_vp, _vp, _vpp]),
     "fbk_plan_detach_output": (C.c_int32, [_vp, _vp, _vpp]),
+    "fbk_union_n": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vpp, _vp]),
+    "fbk_union_n_intersection_count": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp, _vp]),
+    "fbk_count_matrix": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp, _vp]),
+    "fbk_bsi_sum": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "fbk_bsi_range": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_uint32, C.c_int64, C.c_uint32, _vpp, _vp]),
+    "fbk_bsi_range_between": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_uint32, _vpp, _vp]),
 }
+
+BSI_EQ, BSI_NEQ, BSI_LT, BSI_LTE, BSI_GT, BSI_GTE = 1, 2, 3, 4, 5, 6
+BSI_OPS = {"EQ": BSI_EQ, "NEQ": BSI_NEQ, "LT": BSI_LT, "LTE": BSI_LTE, "GT": BSI_GT, "GTE": BSI_GTE}
 
 _lib = None
 

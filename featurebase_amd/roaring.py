@@ -224,6 +224,77 @@ class Context:
         )
         return Batch(self, h.value), out
 
+    # -- n-way union ------------------------------------------------------------------
+    def union_n(self, batch: Batch, groups, flags: int = 0) -> Tuple[Batch, np.ndarray]:
+        """groups: array [n_groups, k] of row ordinals; out row g = union of group g."""
+        g = np.ascontiguousarray(groups, dtype=np.uint32).reshape(len(groups), -1) if len(groups) else np.zeros((0, 0), np.uint32)
+        n_groups, k = g.shape
+        out = np.zeros(n_groups, dtype=np.uint64)
+        h = C.c_void_p()
+        L.check(self.lib.fbk_union_n(self.h, batch.h, g.ctypes.data, n_groups, k, flags, C.byref(h), out.ctypes.data))
+        return Batch(self, h.value), out
+
+    def union_n_intersection_count(self, batch: Batch, groups, filt: Optional[Batch] = None, rows_f=None) -> np.ndarray:
+        g = np.ascontiguousarray(groups, dtype=np.uint32).reshape(len(groups), -1)
+        n_groups, k = g.shape
+        out = np.zeros(n_groups, dtype=np.uint64)
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        L.check(
+            self.lib.fbk_union_n_intersection_count(
+                self.h, batch.h, g.ctypes.data, n_groups, k, filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None, out.ctypes.data
+            )
+        )
+        return out
+
+    # -- GroupBy / TopK count matrix -----------------------------------------------------
+    def count_matrix(self, a: Batch, rows_a, b: Batch, rows_b, filt: Optional[Batch] = None, rows_f=None, per_shard: bool = False):
+        """rows_a: [n_shards, n_a], rows_b: [n_shards, n_b], rows_f: [n_shards].
+        Returns total [n_a, n_b] (and the per-shard [n_shards, n_a, n_b] if asked)."""
+        ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
+        rb = np.ascontiguousarray(rows_b, dtype=np.uint32)
+        n_shards, n_a = ra.shape
+        n_b = rb.shape[1]
+        assert rb.shape[0] == n_shards
+        tot = np.zeros((n_a, n_b), dtype=np.uint64)
+        ps = np.zeros((n_shards, n_a, n_b), dtype=np.uint64) if per_shard else None
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        L.check(
+            self.lib.fbk_count_matrix(
+                self.h, a.h, ra.ctypes.data, n_a, b.h, rb.ctypes.data, n_b,
+                filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None,
+                n_shards, tot.ctypes.data, ps.ctypes.data if ps is not None else None,
+            )
+        )
+        return (tot, ps) if per_shard else tot
+
+    # -- BSI -----------------------------------------------------------------------------
+    def bsi_sum(self, batch: Batch, base_rows, bit_depth: int, filt: Optional[Batch] = None, rows_f=None):
+        base = np.ascontiguousarray(base_rows, dtype=np.uint32)
+        sums = np.zeros(base.size, dtype=np.int64)
+        counts = np.zeros(base.size, dtype=np.uint64)
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        L.check(
+            self.lib.fbk_bsi_sum(
+                self.h, batch.h, base.ctypes.data, base.size, bit_depth,
+                filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None, sums.ctypes.data, counts.ctypes.data,
+            )
+        )
+        return sums, counts
+
+    def bsi_range(self, batch: Batch, base_rows, op: int, bit_depth: int, predicate: int, flags: int = 0) -> Tuple[Batch, np.ndarray]:
+        base = np.ascontiguousarray(base_rows, dtype=np.uint32)
+        counts = np.zeros(base.size, dtype=np.uint64)
+        h = C.c_void_p()
+        L.check(self.lib.fbk_bsi_range(self.h, batch.h, base.ctypes.data, base.size, op, bit_depth, predicate, flags, C.byref(h), counts.ctypes.data))
+        return Batch(self, h.value), counts
+
+    def bsi_range_between(self, batch: Batch, base_rows, bit_depth: int, lo: int, hi: int, flags: int = 0) -> Tuple[Batch, np.ndarray]:
+        base = np.ascontiguousarray(base_rows, dtype=np.uint32)
+        counts = np.zeros(base.size, dtype=np.uint64)
+        h = C.c_void_p()
+        L.check(self.lib.fbk_bsi_range_between(self.h, batch.h, base.ctypes.data, base.size, bit_depth, lo, hi, flags, C.byref(h), counts.ctypes.data))
+        return Batch(self, h.value), counts
+
     def plan(self, a: Batch, rows_a, b: Batch, rows_b, device_counts_ptr: int = 0) -> Plan:
         ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
         rb = np.ascontiguousarray(rows_b, dtype=np.uint32)

@@ -211,6 +211,66 @@ int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64
 int32_t fbk_plan_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch);
 int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch);
 
+/* ---- n-way union ---------------------------------------------------------------------
+ * rows holds n_groups groups of k row ordinals (group g = rows[g*k .. g*k+k)); out row g
+ * is the union of the group's rows, out_counts[g] its cardinality.  Replaces
+ * Row.Union(others...) (row.go:288) -> RowSegment.Union (:572) -> the n-way
+ * Bitmap.unionInPlace (roaring.go:1410-1561) and the streaming BitmapRowsUnion used by
+ * UnionRows (roaring/filter.go:294-366, fragment.go:2489): the accumulation happens in
+ * registers, the union is written once. */
+int32_t fbk_union_n(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n_groups,
+                    uint32_t k, uint32_t flags, fbk_batch** out_batch, uint64_t* out_counts);
+
+/* Fused Union-of-k-rows then IntersectionCount against a filter row, without ever
+ * materialising the union: out_counts[g] = |(∪ group g) ∩ filter.rows_f[g]|
+ * (filter == NULL: |∪ group g|).  executor.go:5382 executeUnionShard followed by
+ * Row.intersectionCount (row.go:226). */
+int32_t fbk_union_n_intersection_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows,
+                                       uint64_t n_groups, uint32_t k, const fbk_batch* filter,
+                                       const uint32_t* rows_f, uint64_t* out_counts);
+
+/* ---- count matrix (GroupBy / TopN / TopK shape) --------------------------------------------
+ * For every shard s, out[s][i][j] = |A.rows_a[s*n_a+i] ∩ B.rows_b[s*n_b+j] ∩ F.rows_f[s]|
+ * (filter may be NULL).  out_total[i*n_b+j] is the sum over shards (mergeGroupCounts /
+ * Pairs.Add arithmetic, executor.go:3728, 2852); out_per_shard (n_shards*n_a*n_b, may be
+ * NULL) keeps the per-shard matrices.  Replaces groupByIterator.Next's
+ * rows[last].intersectionCount(rows[last-1]) (executor.go:8893) and, with n_b == 1 and
+ * B = the filter row, doTopK / fragment.top (executor.go:2705-2746, fragment.go:1317). */
+int32_t fbk_count_matrix(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a,
+                         const fbk_batch* b, const uint32_t* rows_b, uint32_t n_b, const fbk_batch* filter,
+                         const uint32_t* rows_f, uint32_t n_shards, uint64_t* out_total,
+                         uint64_t* out_per_shard);
+
+/* ---- BSI (bit-sliced integers) ----------------------------------------------------------------
+ * A BSI fragment of shard s occupies bit_depth+2 consecutive rows of `batch` starting at
+ * base_rows[s]: +0 exists, +1 sign, +2+i magnitude bit i (fragment.go:62-65). */
+#define FBK_BSI_EQ 1
+#define FBK_BSI_NEQ 2
+#define FBK_BSI_LT 3
+#define FBK_BSI_LTE 4
+#define FBK_BSI_GT 5
+#define FBK_BSI_GTE 6
+
+/* Per shard: out_counts[s] = |exists ∩ filter|, out_sums[s] = Σ_i 2^i (|pos ∩ bit_i| − |neg ∩ bit_i|)
+ * with uint64 wrap-around exactly as BitmapBSICountFilter (roaring/filter.go:1097-1218,
+ * fragment.sum fragment.go:724-750).  filter == NULL means "no filter"; a filter row with no
+ * container in a slot contributes nothing for that slot.  The caller adds count*Base
+ * (executor.go:2205). */
+int32_t fbk_bsi_sum(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards,
+                    uint32_t bit_depth, const fbk_batch* filter, const uint32_t* rows_f, int64_t* out_sums,
+                    uint64_t* out_counts);
+
+/* out row s = columns of shard s whose value satisfies `op predicate` (fragment.rangeOp,
+ * fragment.go:937-1208); container keys of the result are the slot numbers 0..15. */
+int32_t fbk_bsi_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards,
+                      int32_t op, uint32_t bit_depth, int64_t predicate, uint32_t flags, fbk_batch** out_batch,
+                      uint64_t* out_counts);
+
+/* lo <= value <= hi (fragment.rangeBetween, fragment.go:1213-1303). */
+int32_t fbk_bsi_range_between(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows,
+                              uint32_t n_shards, uint32_t bit_depth, int64_t lo, int64_t hi, uint32_t flags,
+                              fbk_batch** out_batch, uint64_t* out_counts);
+
 #ifdef __cplusplus
 }
 #endif

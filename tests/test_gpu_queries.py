@@ -1,0 +1,287 @@
+"""GPU parity for the query-level kernels (n-way union, GroupBy/TopK count matrix, BSI
+Sum/Range, optimize() re-encode) against the oracle, bit-exact, through the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import datagen as D
+from featurebase_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = json.load(open(os.path.join(HERE, "golden", "fragment_bsi_cases.json")))
+ZERO = np.zeros(1024, dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def B(oracle):
+    from oracle import pybsi
+
+    pybsi._lib()
+    return pybsi
+
+
+def fbk_row_of_bitmap(bm, key_base=0):
+    """oracle OBitmap (keys 0..15) -> {key: fbk Container}"""
+    return {key_base + k: D.to_fbk(c) for k, c in bm.items() if c.n} if bm is not None else {}
+
+
+def row_words(row):
+    """{key: fbk Container} -> [16, 1024] uint64"""
+    w = np.zeros((16, 1024), dtype=np.uint64)
+    for k, c in row.items():
+        w[k & 15] = c.words()
+    return w
+
+
+def bitmap_words(bm):
+    w = np.zeros((16, 1024), dtype=np.uint64)
+    if bm is not None:
+        for k, c in bm.items():
+            w[k & 15] = c.words()
+    return w
+
+
+def assert_optimized_like_oracle(O, got_row, exp_bm):
+    """With FBK_SETOP_OPTIMIZE every output container has the encoding Container.optimize()
+    (roaring.go:3412-3461) gives its content, byte for byte."""
+    exp = {k & 15: c for k, c in exp_bm.items() if c.n}
+    got = {k & 15: c for k, c in got_row.items()}
+    assert set(got) == set(exp)
+    for s, c in exp.items():
+        # optimize() of the bit content (via a bitmap container, so runs are maximal)
+        oc = O.optimize(O.OContainer.bitmap(c.words()))
+        g = got[s]
+        assert g.typ == oc.typ, (s, g.typ, oc)
+        assert g.n == oc.n
+        assert np.array_equal(np.asarray(g.data).reshape(-1), np.asarray(oc.data()).reshape(-1)), s
+
+
+# ---- set-ops with optimize() -------------------------------------------------------------------
+def test_setop_optimize_matches_oracle_encoding(gpu_ctx, oracle):
+    O = oracle
+    rng = D.rng_for(31)
+    n = 24
+    rows_a = [D.random_row(rng, r) for r in range(n)]
+    rows_b = [D.random_row(rng, r) for r in range(n)]
+    A, Bt = gpu_ctx.upload([D.to_fbk_row(r) for r in rows_a]), gpu_ctx.upload([D.to_fbk_row(r) for r in rows_b])
+    idx = np.arange(n)
+    for op, name in [(L.OP_AND, "intersect"), (L.OP_OR, "union"), (L.OP_XOR, "xor"), (L.OP_ANDNOT, "difference")]:
+        out, cnt = gpu_ctx.setop(op, A, idx, Bt, idx, flags=L.SETOP_OPTIMIZE)
+        res = out.download()
+        for r in range(n):
+            a = O.OBitmap.from_containers(list(rows_a[r].items()))
+            b = O.OBitmap.from_containers(list(rows_b[r].items()))
+            e = {"intersect": a.intersect, "xor": a.xor}[name](b) if name in ("intersect", "xor") else (a.union(b) if name == "union" else a.difference(b))
+            assert_optimized_like_oracle(O, res[r], e)
+            assert int(cnt[r]) == e.count()
+        out.free()
+    A.free()
+    Bt.free()
+
+
+# ---- n-way union (config 3 shape) ------------------------------------------------------------------
+def make_union_groups(rng, n_groups, k):
+    rows, groups = [], []
+    for g in range(n_groups):
+        ids = []
+        for i in range(k):
+            d = D.zipf_density(i)
+            row = {}
+            for s in range(16):
+                if rng.random() < 0.1:
+                    continue
+                c = D.mixed_container_for_density(rng, d, rng.random() < 0.25)
+                if c is not None and c.n:
+                    row[g * 16 + s] = c
+            ids.append(len(rows))
+            rows.append(row)
+        groups.append(ids)
+    return rows, np.array(groups, dtype=np.uint32)
+
+
+def test_union_n_vs_oracle(gpu_ctx, oracle):
+    O = oracle
+    rng = D.rng_for(41)
+    rows, groups = make_union_groups(rng, 6, 12)
+    # one group gets a full container to exercise the short-circuit (roaring.go:1465)
+    rows[groups[2][5]][2 * 16 + 3] = O.OContainer.run([(0, 65535)])
+    batch = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+    filt_rows = [D.random_row(rng, g) for g in range(len(groups))]
+    F = gpu_ctx.upload([D.to_fbk_row(r) for r in filt_rows])
+    for flags in (0, L.SETOP_OPTIMIZE):
+        out, cnt = gpu_ctx.union_n(batch, groups, flags)
+        res = out.download()
+        for g, ids in enumerate(groups):
+            bms = [O.OBitmap.from_containers(list(rows[i].items())) for i in ids]
+            exp = bms[0].union(*bms[1:])  # Bitmap.Union n-way (roaring.go:1272)
+            assert int(cnt[g]) == exp.count()
+            assert (row_words(res[g]) == bitmap_words(exp)).all(), g
+            if flags:
+                assert_optimized_like_oracle(O, res[g], exp)
+        out.free()
+    # fused Union-of-k then IntersectionCount
+    fidx = np.arange(len(groups))
+    got = gpu_ctx.union_n_intersection_count(batch, groups, F, fidx)
+    got_nf = gpu_ctx.union_n_intersection_count(batch, groups)
+    for g, ids in enumerate(groups):
+        bms = [O.OBitmap.from_containers(list(rows[i].items())) for i in ids]
+        u = bms[0].union(*bms[1:])
+        f = O.OBitmap.from_containers(list(filt_rows[g].items()))
+        assert int(got[g]) == u.intersection_count(f), g
+        assert int(got_nf[g]) == u.count()
+    # k == 1 and single-row groups behave like a copy
+    out, cnt = gpu_ctx.union_n(batch, groups[:, :1])
+    assert cnt.tolist() == [sum(c.n for c in rows[ids[0]].values()) for ids in groups]
+    out.free()
+    batch.free()
+    F.free()
+
+
+# ---- GroupBy / TopK count matrix (config 4 shape) ---------------------------------------------------------
+def test_count_matrix_vs_oracle(gpu_ctx, oracle, B):
+    O = oracle
+    rng = D.rng_for(51)
+    n_shards, n_a, n_b = 11, 6, 5  # n_shards not a multiple of 8, n_a not a multiple of the tile
+    a_rows, b_rows, f_rows = [], [], []
+    for s in range(n_shards):
+        a_rows.append([D.random_row(rng, 0, p_missing=0.3) for _ in range(n_a)])
+        b_rows.append([D.random_row(rng, 0, p_missing=0.3) for _ in range(n_b)])
+        f_rows.append(D.random_row(rng, 0, p_missing=0.2))
+    A = gpu_ctx.upload([D.to_fbk_row(r) for s in a_rows for r in s])
+    Bt = gpu_ctx.upload([D.to_fbk_row(r) for s in b_rows for r in s])
+    F = gpu_ctx.upload([D.to_fbk_row(r) for r in f_rows])
+    ra = np.arange(n_shards * n_a).reshape(n_shards, n_a)
+    rb = np.arange(n_shards * n_b).reshape(n_shards, n_b)
+    rf = np.arange(n_shards)
+
+    def obm(row):
+        return O.OBitmap.from_containers(list(row.items()))
+
+    for with_filter in (False, True):
+        if with_filter:
+            tot, ps = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf, per_shard=True)
+        else:
+            tot, ps = gpu_ctx.count_matrix(A, ra, Bt, rb, per_shard=True)
+        exp_tot = np.zeros((n_a, n_b), dtype=np.uint64)
+        for s in range(n_shards):
+            fa = B.Fragment([obm(r) for r in a_rows[s]])
+            fb = B.Fragment([obm(r) for r in b_rows[s]])
+            e = B.groupby_counts(fa, fb, obm(f_rows[s]) if with_filter else None)
+            assert (ps[s] == e).all(), (s, with_filter)
+            exp_tot += e
+        assert (tot == exp_tot).all()
+    # TopK shape (doTopK, executor.go:2705): every row of a fragment against one filter row
+    tot, ps = gpu_ctx.count_matrix(A, ra, F, rf.reshape(-1, 1), per_shard=True)
+    for s in range(n_shards):
+        e = B.topk_row_counts(B.Fragment([obm(r) for r in a_rows[s]]), obm(f_rows[s]))
+        assert ps[s, :, 0].tolist() == e.tolist()
+    for b in (A, Bt, F):
+        b.free()
+
+
+# ---- BSI ---------------------------------------------------------------------------------------
+def upload_bsi(gpu_ctx, frags):
+    """frags: list (one per shard) of pybsi.Fragment -> (batch, base_rows)"""
+    rows, base = [], []
+    for fr in frags:
+        base.append(len(rows))
+        for r, bm in enumerate(fr.rows):
+            rows.append(fbk_row_of_bitmap(bm, key_base=r * 16))
+    return gpu_ctx.upload(rows), np.array(base, dtype=np.uint32)
+
+
+def check_range(gpu_ctx, B, frags, depth, batch, base, op, pred, flags=0):
+    out, cnt = gpu_ctx.bsi_range(batch, base, L.BSI_OPS[op], depth, pred, flags)
+    res = out.download()
+    for s, fr in enumerate(frags):
+        e = B.bsi_range(fr, B.OPS[op], depth, pred)
+        assert (row_words(res[s]) == bitmap_words(e)).all(), (op, pred, s)
+        assert int(cnt[s]) == e.count()
+    out.free()
+
+
+@pytest.mark.parametrize("case", CASES["range_cases"], ids=lambda c: c["test"])
+def test_bsi_range_reference_cases_on_gpu(gpu_ctx, B, case):
+    """The reference's TestFragment_Range literals evaluated by the HIP plane-program kernel."""
+    depth = max(v[1] for v in case["values"])
+    fr = B.bsi_fragment_from_values({v[0]: v[2] for v in case["values"]}, depth)
+    batch, base = upload_bsi(gpu_ctx, [fr])
+    for q in case["queries"]:
+        if q["kind"] == "rangeOp":
+            out, cnt = gpu_ctx.bsi_range(batch, base, L.BSI_OPS[q["op"]], q["depth"], q["pred"])
+        elif q["kind"] == "rangeBetween":
+            out, cnt = gpu_ctx.bsi_range_between(batch, base, q["depth"], q["lo"], q["hi"])
+        else:
+            continue  # the *Unsigned kernels are not entry points of the boundary
+        got = []
+        for k, c in sorted(out.download()[0].items()):
+            bits = np.unpackbits(c.words().view(np.uint8), bitorder="little")
+            got.extend(((k & 15) << 16) + int(v) for v in np.nonzero(bits)[0])
+        assert got == q["exp"], (case["test"], q)
+        assert int(cnt[0]) == len(q["exp"])
+        out.free()
+    batch.free()
+
+
+def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B):
+    """TestFragmentBSIUnsigned / Signed (fragment_internal_test.go:3768-4275) on the GPU."""
+    k = 6
+    fu = B.bsi_fragment_from_values({i: i for i in range(1 << k)}, k)
+    mn, mx = 1 - (1 << k), (1 << k) - 1
+    fs = B.bsi_fragment_from_values({v - mn: v for v in range(mn, mx + 1)}, k)
+    frags = [fu, fs]
+    batch, base = upload_bsi(gpu_ctx, frags)
+    for p in list(range(-8, 12)) + list(range(55, 72)) + [-63, -64, -65, -126, 126, 127, 128]:
+        for op in ("LT", "LTE", "GT", "GTE", "EQ", "NEQ"):
+            check_range(gpu_ctx, B, frags, k, batch, base, op, p)
+    for lo, hi in [(-3, 5), (0, 63), (10, 10), (-63, -1), (-20, 20), (5, 200), (-200, -5), (7, 6), (0, 0), (1, 64)]:
+        out, cnt = gpu_ctx.bsi_range_between(batch, base, k, lo, hi)
+        res = out.download()
+        for s, fr in enumerate(frags):
+            e = B.bsi_range_between(fr, k, lo, hi)
+            assert (row_words(res[s]) == bitmap_words(e)).all(), (lo, hi, s)
+        out.free()
+    batch.free()
+
+
+def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle):
+    O = oracle
+    rng = D.rng_for(61)
+    depth = 64
+    frags, filts, vals_all = [], [], []
+    for s in range(5):
+        ncol = [40000, 3000, 200, 1 << 16, 7][s]
+        cols = rng.choice(1 << 20, size=ncol, replace=False)
+        mag = rng.integers(0, 1 << 62, size=ncol) * (1 if s != 3 else 0) + rng.integers(0, 1000, size=ncol)
+        sign = np.where(rng.random(ncol) < 0.4, -1, 1)
+        vals = {int(c): int(m) * int(g) for c, m, g in zip(cols, mag, sign)}
+        vals_all.append(vals)
+        frags.append(B.bsi_fragment_from_values(vals, depth))
+        fcols = [int(c) for c in cols[:: 2 + s]] + [5, 70000]
+        filts.append(B.row_from_columns(fcols))
+    batch, base = upload_bsi(gpu_ctx, frags)
+    F = gpu_ctx.upload([fbk_row_of_bitmap(f) for f in filts])
+    sums, counts = gpu_ctx.bsi_sum(batch, base, depth)
+    for s, fr in enumerate(frags):
+        assert (int(sums[s]), int(counts[s])) == B.bsi_sum(fr, None, False), s
+    sums, counts = gpu_ctx.bsi_sum(batch, base, depth, F, np.arange(5))
+    for s, fr in enumerate(frags):
+        assert (int(sums[s]), int(counts[s])) == B.bsi_sum(fr, filts[s], True), s
+    med = sorted(vals_all[0].values())[len(vals_all[0]) // 2]
+    for op, p in [("GT", med), ("LTE", med), ("GT", 0), ("LT", 0), ("GTE", -1), ("EQ", med), ("NEQ", med), ("GT", (1 << 63) - 1), ("LT", -(1 << 63)), ("GTE", -(1 << 63))]:
+        check_range(gpu_ctx, B, frags, depth, batch, base, op, p)
+    check_range(gpu_ctx, B, frags, depth, batch, base, "GT", med, flags=L.SETOP_OPTIMIZE)
+    # Range(>k) then Sum over the result (config 5's pipeline): filter = the range output batch
+    out, cnt = gpu_ctx.bsi_range(batch, base, L.BSI_GT, depth, med)
+    sums, counts = gpu_ctx.bsi_sum(batch, base, depth, out, np.arange(5))
+    for s, fr in enumerate(frags):
+        e = B.bsi_range(fr, B.GT, depth, med)
+        assert (int(sums[s]), int(counts[s])) == B.bsi_sum(fr, e, True), s
+        assert int(counts[s]) == int(cnt[s])
+    out.free()
+    batch.free()
+    F.free()
