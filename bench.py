@@ -114,8 +114,9 @@ def main():
     if n_gpus > 1:
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from featurebase_amd import dist as fdist
+
+        fdist.init("nccl", dev)  # backend "nccl" IS RCCL on ROCm
 
     import datagen as D
     from featurebase_amd import lib as L
@@ -143,7 +144,7 @@ def main():
         plan.intersection_count()  # per-shard |a ∩ b|
         plan.total(total.data_ptr())  # per-node reduce
         if n_gpus > 1:
-            dist.all_reduce(total)  # RCCL sum of the partial counts over xGMI
+            fdist.all_reduce_counts(total)  # RCCL sum of the partial counts over xGMI
 
     def barrier():
         if n_gpus > 1:

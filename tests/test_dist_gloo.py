@@ -1,0 +1,95 @@
+"""world_size-2 test of the multi-GPU path on CPU (gloo): shard partition + one all-reduce of
+the partial count vectors reproduces the single-process result.  The per-shard partial
+counts come from the oracle here (no GPU in this container); on the GPU box the same
+`featurebase_amd.dist` functions carry the counts the HIP kernels produce (bench.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank: int, world: int, port: int, n_shards: int, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    import datagen as D
+    from featurebase_amd import dist as fd
+    from oracle import pyoracle as O
+
+    fd.init("gloo")
+    mine = fd.shards_for_rank(n_shards, rank, world)
+    # Count(Intersect(a, b)): per-shard |a ∩ b| (scalar reduce) and a 2x2 GroupBy-style matrix
+    total = np.zeros(1, dtype=np.uint64)
+    mat = np.zeros(4, dtype=np.uint64)
+    for s in mine:
+        rng = D.rng_for(900 + s)
+        rows = [O.OBitmap.from_containers(list(D.random_row(rng, 0).items())) for _ in range(4)]
+        total[0] += rows[0].intersection_count(rows[1])
+        for i in range(2):
+            for j in range(2):
+                mat[i * 2 + j] += rows[i].intersection_count(rows[2 + j])
+    total = fd.reduce_count_vector(total)
+    mat = fd.reduce_count_vector(mat)
+    q.put((rank, mine, int(total[0]), mat.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_partition_is_a_partition():
+    sys.path.insert(0, ROOT)
+    from featurebase_amd import dist as fd
+
+    for world in (1, 2, 4, 8):
+        parts = [fd.shards_for_rank(8192, r, world) for r in range(world)]
+        flat = sorted(s for p in parts for s in p)
+        assert flat == list(range(8192))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_reduce_to_single_process_result():
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datagen as D
+    from oracle import pyoracle as O
+
+    O.build()
+    n_shards, world = 7, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_shards, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = [q.get(timeout=240) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    # single-process expectation
+    exp_total, exp_mat = 0, [0, 0, 0, 0]
+    for s in range(n_shards):
+        rng = D.rng_for(900 + s)
+        rows = [O.OBitmap.from_containers(list(D.random_row(rng, 0).items())) for _ in range(4)]
+        exp_total += rows[0].intersection_count(rows[1])
+        for i in range(2):
+            for j in range(2):
+                exp_mat[i * 2 + j] += rows[i].intersection_count(rows[2 + j])
+    seen = []
+    for rank, mine, total, mat in results:
+        assert total == exp_total and mat == exp_mat, (rank, total, exp_total)
+        seen += mine
+    assert sorted(seen) == list(range(n_shards))
