@@ -87,6 +87,19 @@ __device__ __forceinline__ void frag_load_bitmap(const uint8_t* __restrict__ p, 
   }
 }
 
+// Same, with the default cache policy: for operands that other workgroups of the same XCD
+// re-read soon (the B rows of the count matrix), so that they stay in L2.
+__device__ __forceinline__ void frag_load_bitmap_cached(const uint8_t* __restrict__ p, int lane,
+                                                        u64 (&w)[kWordsPerLane]) {
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ulonglong2 v = q[j * kWave + lane];
+    w[2 * j] = v.x;
+    w[2 * j + 1] = v.y;
+  }
+}
+
 __device__ __forceinline__ void frag_store_bitmap(uint8_t* __restrict__ p, int lane,
                                                   const u64 (&w)[kWordsPerLane]) {
   ulonglong2* q = reinterpret_cast<ulonglong2*>(p);
@@ -186,12 +199,15 @@ __device__ __forceinline__ void frag_load_run(const uint8_t* __restrict__ p, uin
 }
 
 // Any container (wave-uniform dispatch on type; no divergence inside a wave).
+// STREAM = true: non-temporal loads (payload read once); false: keep it in L2 for re-reads.
+template <bool STREAM = true>
 __device__ __forceinline__ void frag_load(const Slot& s, const uint8_t* __restrict__ arena, int lane,
                                           u64* scratch, u64 (&w)[kWordsPerLane]) {
   const uint32_t t = slot_type(s);
   const uint8_t* p = arena + s.off;
   if (t == kTypeBitmap) {
-    frag_load_bitmap(p, lane, w);
+    if (STREAM) frag_load_bitmap(p, lane, w);
+    else frag_load_bitmap_cached(p, lane, w);
   } else if (t == kTypeArray) {
     frag_load_array(p, s.len, lane, scratch, w);
   } else if (t == kTypeRun) {

@@ -16,12 +16,116 @@ __device__ __forceinline__ u64 wave_reduce_add64(u64 v) {
   return v;
 }
 
+__device__ __forceinline__ void lds_write_frag(u64* slot, int lane, const u64 (&w)[kWordsPerLane]) {
+  ulonglong2* q2 = reinterpret_cast<ulonglong2*>(slot);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    ulonglong2 v;
+    v.x = w[2 * jj];
+    v.y = w[2 * jj + 1];
+    q2[jj * kWave + lane] = v;
+  }
+}
+
+// ---- raw payload prefetch ----------------------------------------------------------------
+// A container payload of at most 8 KiB (every bitmap, arrays <= 4096 values, <= 2048 runs —
+// i.e. everything roaring policy produces, roaring.go:3036-3044) is fetched as eight 16-byte
+// chunks per lane *before* it is needed and decoded later from registers, so that a wave
+// walking a list of containers overlaps the HBM latency of container i+1 with the decode of
+// container i.  Chunk c = 64*j + lane covers payload bytes [16c, 16c+16).
+struct Raw {
+  ulonglong2 v[8];
+};
+__device__ __forceinline__ uint32_t payload_bytes(uint32_t type, uint32_t len) {
+  return type == kTypeBitmap ? 8192u : type == kTypeArray ? len * 2u : len * 4u;
+}
+__device__ __forceinline__ void raw_load(const uint8_t* __restrict__ p, uint32_t bytes, int lane, Raw& r) {
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t c = j * kWave + lane;
+    if (c * 16u < bytes) r.v[j] = ld_stream(&q[c]);  // payloads are padded to 16 bytes in the arena
+  }
+}
+// Decode a prefetched payload (bytes <= 8192) into a fragment.
+__device__ __forceinline__ void frag_from_raw(const Raw& r, uint32_t type, uint32_t len, int lane, u64* scratch,
+                                              u64 (&w)[kWordsPerLane]) {
+  if (type == kTypeBitmap) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      w[2 * j] = r.v[j].x;
+      w[2 * j + 1] = r.v[j].y;
+    }
+    return;
+  }
+  lds_zero(scratch, lane);
+  wave_lds_sync();
+  uint32_t* s32 = reinterpret_cast<uint32_t*>(scratch);
+  if (type == kTypeArray) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t e0 = (j * kWave + lane) * 8u;
+      if (e0 < len) {
+        const u64 lo = r.v[j].x, hi = r.v[j].y;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t a = (uint32_t)(lo >> (16 * t)) & 0xFFFFu, bb = (uint32_t)(hi >> (16 * t)) & 0xFFFFu;
+          if (e0 + t < len) atomicOr(&s32[a >> 5], 1u << (a & 31));
+          if (e0 + 4 + t < len) atomicOr(&s32[bb >> 5], 1u << (bb & 31));
+        }
+      }
+    }
+    wave_lds_sync();
+    lds_read_frag(scratch, lane, w);
+    wave_lds_sync();
+    return;
+  }
+  // run: toggles, then parity prefix scan (as frag_load_run)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t i0 = (j * kWave + lane) * 4u;
+    if (i0 < len) {
+      const u64 lo = r.v[j].x, hi = r.v[j].y;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t iv = (t < 2) ? (uint32_t)(lo >> (32 * t)) : (uint32_t)(hi >> (32 * (t - 2)));
+        if (i0 + t < len) {
+          const uint32_t st = iv & 0xFFFFu, e = (iv >> 16) + 1u;
+          atomicXor(&s32[st >> 5], 1u << (st & 31));
+          if (e < 65536u) atomicXor(&s32[e >> 5], 1u << (e & 31));
+        }
+      }
+    }
+  }
+  wave_lds_sync();
+  lds_read_frag(scratch, lane, w);
+  wave_lds_sync();
+  const u64 lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u64 t0 = w[2 * j], t1 = w[2 * j + 1];
+    uint32_t p0 = __popcll(t0) & 1u, p1 = __popcll(t1) & 1u;
+    u64 m = __ballot((p0 ^ p1) != 0);
+    uint32_t in = carry ^ (__popcll(m & lane_lt) & 1u);
+    w[2 * j] = prefix_xor64(t0) ^ (in ? ~0ull : 0ull);
+    w[2 * j + 1] = prefix_xor64(t1) ^ ((in ^ p0) ? ~0ull : 0ull);
+    carry ^= __popcll(m) & 1u;
+  }
+}
+
 // ---- n-way union ------------------------------------------------------------------------
-// One wave per (group, slot): OR-accumulates the k containers of the group's rows at that
-// slot in registers (the union never touches HBM unless WRITE), mirroring what
-// BitmapRowsUnion does with its 16 accumulators (filter.go:327-334) and what the n-way
-// Bitmap.unionInPlace does per key (roaring.go:1455-1560).  Short-circuit: any full
-// operand => full container (roaring.go:1465-1474).
+// One 256-thread block per (group, slot): the k containers of the group's rows at that
+// slot are split over the 4 wavefronts (wave w takes rows w, w+4, ...), each OR-accumulating
+// in registers (the union never touches HBM unless WRITE); the 4 partial unions are
+// combined through LDS.  Latency is what matters here (many small containers): all
+// descriptors of the group are fetched by one vector load (lane i reads row i's slot) and
+// handed out by readlane, and the payload of container i+1 is prefetched while container i
+// is decoded (raw_load / frag_from_raw).  A single wave walking 64 containers with dependent
+// descriptor -> payload loads measured 184 us for 64 shards x 64 rows; see profiles/.
+// Mirrors what BitmapRowsUnion does with its 16 accumulators (filter.go:327-334) and the
+// n-way Bitmap.unionInPlace per key (roaring.go:1455-1560).  Short-circuit: any full operand
+// => full container (roaring.go:1465-1474).
 // With a filter batch: counts[g] += |union ∩ F.rows_f[g]| (Bitmap.IntersectionCount of
 // the union against the filter row), else counts[g] += |union|.
 template <bool WRITE>
@@ -32,32 +136,91 @@ __global__ void __launch_bounds__(256) k_union_n(const Slot* __restrict__ slots,
                                                 Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
                                                 u64* __restrict__ out_counts) {
   __shared__ u64 lds[4][kWords];
+  __shared__ uint32_t s_full;
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
-  const uint64_t g = wslot >> 4;
-  const uint32_t slot = wslot & 15;
-  if (g >= n_groups) return;
+  const uint64_t cell = blockIdx.x;  // (group, slot)
+  const uint64_t g = cell >> 4;
+  const uint32_t slot = cell & 15;
+  if (threadIdx.x == 0) s_full = 0;
+  __syncthreads();
   u64 acc[kWordsPerLane];
   frag_zero(acc);
-  bool full = false;
   const uint32_t* grow = rows + g * k;
-  for (uint32_t i = 0; i < k; ++i) {
-    const Slot s = slots[(uint64_t)grow[i] * kSlots + slot];
-    const uint32_t n = slot_n(s);
-    if (n == 0) continue;
-    if (n == 65536u) {
+  bool full = false;
+  for (uint32_t base = 0; base < k && !full; base += 64) {
+    // lane l holds the descriptor of row base+l of the group
+    Slot mine;
+    mine.off = 0;
+    mine.len = 0;
+    mine.tn = 0;
+    if (base + lane < k) mine = slots[(uint64_t)grow[base + lane] * kSlots + slot];
+    const uint32_t cnt = min(64u, k - base);
+    // a full container anywhere => the union is full (checked for the whole group at once)
+    if (__ballot(slot_n(mine) == 65536u) != 0) {
       full = true;
       break;
     }
-    u64 w[kWordsPerLane];
-    frag_load(s, arena, lane, lds[wv], w);
+    Raw cur, nxt;
+    uint32_t i = wv;
+    // descriptor of this wave's first container
+    u64 off = __shfl(mine.off, (int)(i & 63), kWave);
+    uint32_t len = __shfl(mine.len, (int)(i & 63), kWave), tn = __shfl(mine.tn, (int)(i & 63), kWave);
+    bool have = i < cnt;
+    uint32_t bytes = have ? payload_bytes(tn >> 24, len) : 0;
+    if (have && (tn & 0xFFFFFFu) != 0 && bytes <= 8192u) raw_load(arena + off, bytes, lane, cur);
+    while (have) {
+      const uint32_t in = i + 4;
+      const bool have_n = in < cnt;
+      u64 off_n = 0;
+      uint32_t len_n = 0, tn_n = 0, bytes_n = 0;
+      if (have_n) {
+        off_n = __shfl(mine.off, (int)(in & 63), kWave);
+        len_n = __shfl(mine.len, (int)(in & 63), kWave);
+        tn_n = __shfl(mine.tn, (int)(in & 63), kWave);
+        bytes_n = payload_bytes(tn_n >> 24, len_n);
+        if ((tn_n & 0xFFFFFFu) != 0 && bytes_n <= 8192u) raw_load(arena + off_n, bytes_n, lane, nxt);
+      }
+      if ((tn & 0xFFFFFFu) != 0) {
+        u64 w[kWordsPerLane];
+        if (bytes <= 8192u) {
+          frag_from_raw(cur, tn >> 24, len, lane, lds[wv], w);
+        } else {  // arrays > 4096 values / > 2048 runs: legal but outside roaring policy
+          Slot s;
+          s.off = off;
+          s.len = len;
+          s.tn = tn;
+          frag_load(s, arena, lane, lds[wv], w);
+        }
 #pragma unroll
-    for (int q = 0; q < kWordsPerLane; ++q) acc[q] |= w[q];
+        for (int q = 0; q < kWordsPerLane; ++q) acc[q] |= w[q];
+      }
+      i = in;
+      have = have_n;
+      off = off_n;
+      len = len_n;
+      tn = tn_n;
+      bytes = bytes_n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cur.v[j] = nxt.v[j];
+    }
   }
-  if (full) {
+  if (full && lane == 0) s_full = 1;
+  // publish the partial union of this wave (its scratch is free again)
+  lds_write_frag(lds[wv], lane, acc);
+  __syncthreads();
+  if (wv != 0) return;
+  if (s_full) {
 #pragma unroll
     for (int q = 0; q < kWordsPerLane; ++q) acc[q] = ~0ull;
+  } else {
+#pragma unroll
+    for (int o = 1; o < 4; ++o) {
+      u64 w[kWordsPerLane];
+      lds_read_frag(lds[o], lane, w);
+#pragma unroll
+      for (int q = 0; q < kWordsPerLane; ++q) acc[q] |= w[q];
+    }
   }
   uint32_t c;
   if (fslots) {
@@ -66,7 +229,7 @@ __global__ void __launch_bounds__(256) k_union_n(const Slot* __restrict__ slots,
       c = 0;
     } else {
       u64 w[kWordsPerLane];
-      frag_load(sf, farena, lane, lds[wv], w);
+      frag_load(sf, farena, lane, lds[0], w);
       uint32_t part = 0;
 #pragma unroll
       for (int q = 0; q < kWordsPerLane; ++q) part += __popcll(acc[q] & w[q]);
@@ -78,61 +241,96 @@ __global__ void __launch_bounds__(256) k_union_n(const Slot* __restrict__ slots,
   if (WRITE) {
     const uint32_t cu = fslots ? wave_reduce_add(frag_popcount(acc)) : c;
     Slot so;
-    so.off = wslot * 8192ull;
+    so.off = cell * 8192ull;
     so.len = kWords;
     so.tn = make_tn(cu ? kTypeBitmap : kTypeNil, cu);
     if (cu) frag_store_bitmap(arenaO + so.off, lane, acc);
     uint32_t r = 0;
     if (outRuns) r = wave_reduce_add(frag_count_runs(acc, lane));
     if (lane == 0) {
-      outSlots[wslot] = so;
-      if (outRuns) outRuns[wslot] = r;
+      outSlots[cell] = so;
+      if (outRuns) outRuns[cell] = r;
     }
   }
   if (lane == 0 && c && out_counts) atomicAdd(&out_counts[g], (u64)c);
 }
 
 // ---- count matrix (GroupBy / TopK / TopN shape) -----------------------------------------------
-// out_shard[(shard*nA + i)*nB + j] = sum over the 16 slots of |A[shard][i] ∩ B[shard][j] ∩ F[shard]|.
-// One 256-thread block per (shard, tile of TA A-rows); wave w owns slots w, w+4, w+8, w+12.
-// Per slot the wave keeps TA A-fragments (already ANDed with the filter) in registers and
-// streams the nB B-containers past them, so every B container is read by nA/TA blocks
-// (they are scheduled on the same XCD so the re-reads hit its L2) and every A container
-// exactly once.  The block->work mapping keeps all blocks of one shard on one XCD
-// (block b runs on XCD b % 8 on MI355X; used for L2 affinity only, never for correctness).
+// out_shard[(shard*nA + i)*nBtot + j] (+)= sum over the block's slots of
+//     |A[shard][i] ∩ B[shard][j] ∩ F[shard]|.
+// One 512-thread block (8 wavefronts) per (shard, slot group, group of 8*TA A-rows).
+// Wave w keeps TA A-fragments (already ANDed with the filter: rows[0] ∩= filter,
+// executor.go:8830) in registers.  The B containers of the slot are fetched from HBM exactly
+// ONCE per block: in groups of 8, wave w brings B[8g+w] into slot w of a double-buffered LDS
+// ring — bitmap containers by direct global->LDS DMA (global_load_lds_dwordx4: lane l of
+// load j lands at 1024*j + 16*l, which IS the fragment layout), array/run containers by
+// decoding in place — and after one barrier every wave reads all 8 ring slots (ds_read_b128)
+// against its A tile while the next group's DMA is in flight.  A first version that re-read
+// B from global memory per A tile was bound by HBM re-reads (787 us for 128 shards x 32x32
+// rows: the per-XCD working set is far beyond the 4 MiB L2); keeping the prefetched B
+// fragment in registers instead of using the DMA spilled VGPRs.
+// Counts are wave-reduced and accumulated lane-distributed (lane j%64 owns column j), so no
+// atomics are needed inside the block.
+__device__ __forceinline__ void dma_bitmap_to_lds(const uint8_t* __restrict__ g, u64* lds_slot, int lane) {
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + j * 1024 + lane * 16),
+                                     (lptr_t)(reinterpret_cast<uint8_t*>(lds_slot) + j * 1024), 16, 0, 0);
+}
+
+// Bring one container into an LDS ring slot as a 1024-word bitmap (async for bitmaps).
+__device__ __forceinline__ void ring_fetch(const Slot& s, const uint8_t* __restrict__ arena, int lane, u64* slot) {
+  const uint32_t t = slot_type(s);
+  if (slot_n(s) == 0 || t == kTypeNil) {
+    lds_zero(slot, lane);
+  } else if (t == kTypeBitmap) {
+    dma_bitmap_to_lds(arena + s.off, slot, lane);
+  } else {
+    u64 w[kWordsPerLane];
+    frag_load(s, arena, lane, slot, w);  // decodes in `slot`, result in registers
+    lds_write_frag(slot, lane, w);
+  }
+}
+
 template <int TA>
-__global__ void __launch_bounds__(256) k_count_matrix(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
+__global__ void __launch_bounds__(512) k_count_matrix(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
                                                      const uint32_t* __restrict__ rowsA, uint32_t nA,
                                                      const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB,
-                                                     const uint32_t* __restrict__ rowsB, uint32_t nB,
-                                                     const Slot* __restrict__ slotsF, const uint8_t* __restrict__ arenaF,
-                                                     const uint32_t* __restrict__ rowsF, uint32_t n_shards,
-                                                     u64* __restrict__ out_shard) {
-  __shared__ u64 lds[4][kWords];
-  extern __shared__ uint32_t cnt[];  // TA * nB block-level counters
+                                                     const uint32_t* __restrict__ rowsB, uint32_t nBtot, uint32_t j0,
+                                                     uint32_t nB, const Slot* __restrict__ slotsF,
+                                                     const uint8_t* __restrict__ arenaF, const uint32_t* __restrict__ rowsF,
+                                                     uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard) {
+  constexpr int kWaves = 8;
+  constexpr int kNBC = 4;  // 64-column chunks per launch: nB <= 256
+  __shared__ u64 ring[2][kWaves][kWords];  // 128 KiB of the CU's 160 KiB LDS
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const uint32_t tiles = (nA + TA - 1) / TA;
-  // XCD-aware remap: x = b % 8 picks the shard residue class, so all tiles of a shard
-  // share b % 8.  Shards beyond the last full group of 8 are handled by the same formula.
-  const uint32_t b = blockIdx.x;
-  const uint32_t x = b & 7u, t = b >> 3;
-  const uint32_t shard = (t / tiles) * 8u + x;
-  const uint32_t tile = t % tiles;
+  const uint32_t agroups = (nA + kWaves * TA - 1) / (kWaves * TA);
+  const uint32_t sgroups = kSlots / spb;
+  uint32_t b = blockIdx.x;
+  const uint32_t ag = b % agroups;
+  b /= agroups;
+  const uint32_t sg = b % sgroups;
+  const uint32_t shard = b / sgroups;
   if (shard >= n_shards) return;
-  for (uint32_t q = threadIdx.x; q < TA * nB; q += 256) cnt[q] = 0;
-  __syncthreads();
-  const uint32_t i0 = tile * TA;
-  for (uint32_t slot = wv; slot < kSlots; slot += 4) {
+  const uint32_t i0 = ag * kWaves * TA + wv * TA;
+  uint32_t acc[TA][kNBC];
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int c = 0; c < kNBC; ++c) acc[a][c] = 0;
+  const uint32_t groups = (nB + kWaves - 1) / kWaves;
+  const uint32_t* brow = rowsB + (uint64_t)shard * nBtot + j0;
+  for (uint32_t slot = sg * spb; slot < (sg + 1) * spb; ++slot) {
+    // ---- A tile (and filter) of this wave; ring[0][wv] doubles as decode scratch ----
     u64 fa[TA][kWordsPerLane];
     bool any = false;
-    // filter fragment first (intersected into every A row: rows[0] ∩= filter, executor.go:8830)
-    bool have_f = slotsF != nullptr;
-    u64 wf[kWordsPerLane];
+    const bool have_f = slotsF != nullptr;
     if (have_f) {
       const Slot sf = slotsF[(uint64_t)rowsF[shard] * kSlots + slot];
-      if (slot_n(sf) == 0) continue;  // nothing can intersect at this slot
-      frag_load(sf, arenaF, lane, lds[wv], wf);
+      if (slot_n(sf) == 0) continue;  // block-uniform: nothing can intersect at this slot
     }
 #pragma unroll
     for (int a = 0; a < TA; ++a) {
@@ -140,53 +338,87 @@ __global__ void __launch_bounds__(256) k_count_matrix(const Slot* __restrict__ s
       if (i0 + a < nA) {
         const Slot sa = slotsA[(uint64_t)rowsA[(uint64_t)shard * nA + i0 + a] * kSlots + slot];
         if (slot_n(sa) != 0) {
-          frag_load(sa, arenaA, lane, lds[wv], fa[a]);
+          frag_load(sa, arenaA, lane, ring[0][wv], fa[a]);
           present = true;
         }
       }
       if (!present) frag_zero(fa[a]);
-      if (have_f) {
-#pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) fa[a][q] &= wf[q];
-      }
       any |= present;
     }
-    if (!any) continue;
-    for (uint32_t j = 0; j < nB; ++j) {
-      const Slot sb = slotsB[(uint64_t)rowsB[(uint64_t)shard * nB + j] * kSlots + slot];
-      if (slot_n(sb) == 0) continue;
-      u64 wb[kWordsPerLane];
-      frag_load(sb, arenaB, lane, lds[wv], wb);
-      uint32_t part[TA];
+    if (have_f) {
+      const Slot sf = slotsF[(uint64_t)rowsF[shard] * kSlots + slot];
+      u64 wf[kWordsPerLane];
+      frag_load<false>(sf, arenaF, lane, ring[0][wv], wf);
 #pragma unroll
-      for (int a = 0; a < TA; ++a) {
-        uint32_t p = 0;
+      for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) p += __popcll(fa[a][q] & wb[q]);
-        part[a] = p;
+        for (int q = 0; q < kWordsPerLane; ++q) fa[a][q] &= wf[q];
+    }
+    // ---- B pipeline: one barrier per group of 8 containers ----
+    if (wv < (int)nB) ring_fetch(slotsB[(uint64_t)brow[wv] * kSlots + slot], arenaB, lane, ring[0][wv]);
+    for (uint32_t g = 0; g < groups; ++g) {
+      const uint32_t cur = g & 1u;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA into ring[cur][wv] has landed
+      __syncthreads();
+      if (g + 1 < groups) {
+        const uint32_t j = (g + 1) * kWaves + wv;
+        if (j < nB) ring_fetch(slotsB[(uint64_t)brow[j] * kSlots + slot], arenaB, lane, ring[cur ^ 1u][wv]);
       }
+      if (any) {
+#pragma unroll 1
+        for (int r = 0; r < kWaves; ++r) {  // not unrolled: keeps only one 16-byte B chunk live
+          const uint32_t j = g * kWaves + r;
+          if (j >= nB) break;
+          const ulonglong2* qb = reinterpret_cast<const ulonglong2*>(ring[cur][r]);
+          uint32_t p[TA];
 #pragma unroll
-      for (int a = 0; a < TA; ++a) {
-        uint32_t c = wave_reduce_add(part[a]);
-        if (lane == 0 && c) atomicAdd(&cnt[a * nB + j], c);
+          for (int a = 0; a < TA; ++a) p[a] = 0;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const ulonglong2 v = qb[jj * kWave + lane];
+#pragma unroll
+            for (int a = 0; a < TA; ++a) p[a] += __popcll(fa[a][2 * jj] & v.x) + __popcll(fa[a][2 * jj + 1] & v.y);
+          }
+#pragma unroll
+          for (int a = 0; a < TA; ++a) {
+            const uint32_t c = wave_reduce_add(p[a]);
+            if (lane == (int)(j & 63u)) {
+#pragma unroll
+              for (int cc = 0; cc < kNBC; ++cc)
+                if ((j >> 6) == (uint32_t)cc) acc[a][cc] += c;
+            }
+          }
+        }
       }
     }
+    __syncthreads();  // everyone is done with the ring before the next slot reuses it as scratch
   }
-  __syncthreads();
-  for (uint32_t q = threadIdx.x; q < TA * nB; q += 256) {
-    const uint32_t a = q / nB, j = q % nB;
-    if (i0 + a < nA) out_shard[((uint64_t)shard * nA + i0 + a) * nB + j] = cnt[q];
+#pragma unroll
+  for (int a = 0; a < TA; ++a) {
+    if (i0 + a >= nA) continue;
+#pragma unroll
+    for (int cc = 0; cc < kNBC; ++cc) {
+      const uint32_t j = cc * 64 + lane;
+      if (j < nB && acc[a][cc]) {
+        u64* dst = &out_shard[((uint64_t)shard * nA + i0 + a) * nBtot + j0 + j];
+        if (spb == kSlots) *dst = acc[a][cc];
+        else atomicAdd(dst, (u64)acc[a][cc]);
+      }
+    }
   }
 }
 
-// out[c] = sum over shards of in[shard*width + c]   (mergeGroupCounts' arithmetic, executor.go:3728)
+// out[c] += sum over a chunk of shards of in[shard*width + c]   (mergeGroupCounts' arithmetic,
+// executor.go:3728).  grid = (width/256, shard chunks); out must be zeroed.
 __global__ void __launch_bounds__(256) k_reduce_shards(const u64* __restrict__ in, uint32_t n_shards, uint64_t width,
                                                       u64* __restrict__ out) {
   const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= width) return;
+  const uint32_t per = (n_shards + gridDim.y - 1) / gridDim.y;
+  const uint32_t s0 = blockIdx.y * per, s1 = min(n_shards, s0 + per);
   u64 acc = 0;
-  for (uint32_t s = 0; s < n_shards; ++s) acc += in[(uint64_t)s * width + c];
-  out[c] = acc;
+  for (uint32_t s = s0; s < s1; ++s) acc += in[(uint64_t)s * width + c];
+  if (acc) atomicAdd(&out[c], acc);
 }
 
 // ---- BSI Sum ---------------------------------------------------------------------------------

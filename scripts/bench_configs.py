@@ -1,0 +1,157 @@
+"""Secondary measurements: BASELINE.json configs 3, 4 (per-GPU slice) and 5 on one MI355X.
+Not the headline (bench.py is); prints one JSON line per config with the algorithmic bytes,
+GPU time (HIP events on the library's stream) and achieved GB/s.  Run it under
+`rocprofv3 --kernel-trace --stats` to get per-kernel durations.
+
+    python scripts/bench_configs.py [--shards3 64] [--shards4 128] [--iters 10]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import datagen as D  # noqa: E402
+from featurebase_amd import lib as L  # noqa: E402
+from featurebase_amd.roaring import Context  # noqa: E402
+
+
+def timed(stream, fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(iters):
+        e0.record(stream)
+        fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2] * 1e-3  # median, seconds
+
+
+def encoded_bytes(c):
+    return {1: 2 * c.length, 2: 8192, 3: 4 * c.length}[c.typ]
+
+
+def config3(ctx, stream, n_shards, iters):
+    """mixed array/run/bitmap containers, rank-law density 0.001..0.5, Union-of-64 rows then
+    IntersectionCount against a filter row (fused: the union never touches HBM)."""
+    k = 64
+    rows, groups, nbytes, ncont = [], [], 0, 0
+    t0 = time.time()
+    for s in range(n_shards):
+        rng = D.rng_for(3000 + s)
+        ids = []
+        for r in range(k):
+            d = D.zipf_density(r)
+            row = {}
+            for slot in range(16):
+                c = D.mixed_container_for_density(rng, d, rng.random() < 0.25)
+                if c is not None and c.n:
+                    row[s * 16 + slot] = D.to_fbk(c)
+                    nbytes += encoded_bytes(c)
+                    ncont += 1
+            ids.append(len(rows))
+            rows.append(row)
+        groups.append(ids)
+    frows = []
+    for s in range(n_shards):
+        rng = D.rng_for(3500 + s)
+        row = {}
+        for slot in range(16):
+            c = D.mixed_container_for_density(rng, 0.5, False)
+            row[s * 16 + slot] = D.to_fbk(c)
+            nbytes += encoded_bytes(c)
+            ncont += 1
+        frows.append(row)
+    gen_s = time.time() - t0
+    batch, F = ctx.upload(rows), ctx.upload(frows)
+    groups = np.array(groups, dtype=np.uint32)
+    fidx = np.arange(n_shards)
+    t = timed(stream, lambda: ctx.union_n_intersection_count(batch, groups, F, fidx), iters)
+    tm = timed(stream, lambda: ctx.union_n(batch, groups)[0].free(), max(2, iters // 2))
+    set_ops = n_shards * 16 * k  # (k-1) unions + 1 intersection count per slot
+    return {
+        "config": 3, "workload": f"{n_shards} shards x (64 rows + filter), mixed containers, Union-of-64 then IntersectionCount (fused)",
+        "containers": ncont, "algorithmic_bytes": nbytes, "gpu_s": t, "GBps": nbytes / t / 1e9, "set_ops_per_s": set_ops / t,
+        "materialised_union_gpu_s": tm, "host_gen_s": gen_s,
+    }
+
+
+def config4(ctx, stream, n_shards, iters, n_a=32, n_b=32):
+    """GroupBy/TopN-style many-row IntersectionCount matrix with a filter row, dense bitmaps
+    (upper bound on bytes per shard: 65 rows x 128 KiB)."""
+    wa = D.dense_rows(n_shards * n_a, 0.5, 4001)
+    wb = D.dense_rows(n_shards * n_b, 0.5, 4002)
+    wf = D.dense_rows(n_shards, 0.5, 4003)
+    A, B, F = ctx.upload_dense(wa), ctx.upload_dense(wb), ctx.upload_dense(wf)
+    ra = np.arange(n_shards * n_a).reshape(n_shards, n_a)
+    rb = np.arange(n_shards * n_b).reshape(n_shards, n_b)
+    rf = np.arange(n_shards)
+    t = timed(stream, lambda: ctx.count_matrix(A, ra, B, rb, F, rf), iters)
+    # spot check one cell against numpy
+    tot = ctx.count_matrix(A, ra, B, rb, F, rf)
+    exp = int(sum(np.bitwise_count(wa[s * n_a + 3] & wb[s * n_b + 5] & wf[s]).sum() for s in range(n_shards)))
+    assert int(tot[3, 5]) == exp
+    nbytes = n_shards * (n_a + n_b + 1) * 16 * 8192
+    return {
+        "config": 4, "workload": f"{n_shards} shards x ({n_a} x {n_b} rows + filter), dense bitmaps, count matrix",
+        "algorithmic_bytes_read_once": nbytes, "gpu_s": t, "GBps_vs_read_once": nbytes / t / 1e9,
+        "set_ops_per_s": n_shards * 16 * n_a * n_b / t, "pair_bits_scanned_GBps": n_shards * n_a * n_b * 2 * 16 * 8192 / t / 1e9,
+    }
+
+
+def config5(ctx, stream, iters, n_shards=96, depth=64):
+    """BSI Range(> k) + Sum over 64 bit planes + exists + sign (dense planes)."""
+    w = D.dense_rows(n_shards * (depth + 2), 0.5, 5001)
+    w = w.reshape(n_shards, depth + 2, 16, 1024)
+    w[:, 0] = np.uint64(0xFFFFFFFFFFFFFFFF)  # exists: every column has a value
+    w[-1, 0, 6:] = 0  # last shard partial (100M columns = 95 full shards + 385 280 columns)
+    batch = ctx.upload_dense(w.reshape(-1))
+    base = np.arange(n_shards, dtype=np.uint32) * (depth + 2)
+    k = 1 << 62
+    t_range = timed(stream, lambda: ctx.bsi_range(batch, base, L.BSI_GT, depth, k)[0].free(), iters)
+    out, cnt = ctx.bsi_range(batch, base, L.BSI_GT, depth, k)
+    t_sum_f = timed(stream, lambda: ctx.bsi_sum(batch, base, depth, out, np.arange(n_shards)), iters)
+    t_sum = timed(stream, lambda: ctx.bsi_sum(batch, base, depth), iters)
+    out.free()
+    plane_bytes = n_shards * 16 * 8192
+    return {
+        "config": 5, "workload": f"BSI {n_shards} shards x (64 planes + exists + sign), dense; Range(>2^62), Sum(filter=range), Sum",
+        "range_gpu_s": t_range, "range_GBps": plane_bytes * (depth + 2 + 1) / t_range / 1e9,
+        "range_note": "Range(> 2^62) reads exists, sign and all 64 planes once, writes 1 row",
+        "sum_filtered_gpu_s": t_sum_f, "sum_filtered_GBps": plane_bytes * (depth + 3) / t_sum_f / 1e9,
+        "sum_gpu_s": t_sum, "sum_GBps": plane_bytes * (depth + 2) / t_sum / 1e9,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shards3", type=int, default=64)
+    ap.add_argument("--shards4", type=int, default=128)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", type=int, default=0)
+    a = ap.parse_args()
+    ctx = Context(0)
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        if a.only in (0, 4):
+            print(json.dumps(config4(ctx, stream, a.shards4, a.iters)), flush=True)
+        if a.only in (0, 5):
+            print(json.dumps(config5(ctx, stream, a.iters)), flush=True)
+        if a.only in (0, 3):
+            print(json.dumps(config3(ctx, stream, a.shards3, a.iters)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
