@@ -37,7 +37,7 @@ SHARDS_PER_GPU = 1024
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
-def cpu_baseline(wa: np.ndarray, wb: np.ndarray, budget_s: float = 12.0):
+def cpu_baseline(wa: np.ndarray, wb: np.ndarray, budget_s: float = 15.0):
     """The CPU restatement of the Go path (oracle/roaring_oracle.c) on this box's host
     cores: same inputs, one pthread worker per shard chunk (the reference runs one
     goroutine per shard over NumCPU pool workers, executor.go:6723-6737)."""
@@ -71,15 +71,19 @@ def cpu_baseline(wa: np.ndarray, wb: np.ndarray, budget_s: float = 12.0):
         tot = f(wa.ctypes.data, wb.ctypes.data, n, counts.ctypes.data, threads, passes)
         return time.perf_counter() - t0, tot
 
-    # single thread: calibrate, then ~budget/3 seconds
-    t1, tot = run(1, 1)
-    p1 = max(1, int(budget_s / 3 / max(t1, 1e-6)))
-    t1, tot = run(1, p1)
+    def timed(threads, target_s):
+        """Grow the pass count until one call lasts >= target_s (thread start-up and the
+        first touch of the pages are then negligible); returns (seconds, passes, total)."""
+        passes = 1
+        while True:
+            t, tot = run(threads, passes)
+            if t >= target_s or passes >= 1 << 20:
+                return t, passes, tot
+            passes = max(passes * 2, int(passes * 1.2 * target_s / max(t, 1e-4)))
+
+    t1, p1, tot = timed(1, budget_s / 3)
     single = n * 16 * p1 / t1
-    # all cores: calibrate, then ~budget*2/3 seconds
-    tm, _ = run(cores, 4)
-    pm = max(4, int(budget_s * 2 / 3 / max(tm / 4, 1e-6)))
-    tm, tot = run(cores, pm)
+    tm, pm, tot = timed(cores, budget_s * 2 / 3)
     return {
         "value": n * 16 * pm / tm,
         "unit": "set-ops/s",

@@ -15,6 +15,7 @@
 
 #include "fbk_kernels.hip.h"
 #include "fbk_query_kernels.hip.h"
+#include "fbk_bsi_kernels.hip.h"
 
 using fbk::Slot;
 using fbk::u64;
@@ -468,6 +469,30 @@ int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, ui
     for (int s = 0; s < fbk::kSlots; ++s) c += fbk::slot_n(b->h_slots[uint64_t(rows[i]) * fbk::kSlots + s]);
     out_counts[i] = c;
   }
+  return FBK_OK;
+}
+
+
+int32_t fbk_count_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n, uint64_t start,
+                        uint64_t end, uint64_t* out_counts) {
+  if (!batch || (n && (!rows || !out_counts))) return fail(FBK_E_INVALID, "NULL argument");
+  const uint64_t width = uint64_t(fbk::kSlots) << 16;
+  if (start > end || end > width) return fail(FBK_E_INVALID, "count_range: need 0 <= start <= end <= 2^20");
+  if (n > (1ull << 27)) return fail(FBK_E_INVALID, "too many rows in one call");
+  if (n == 0) return FBK_OK;
+  fbk_batch* b = const_cast<fbk_batch*>(batch);
+  if (!ctx) ctx = b->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  DevBuf drows, dcnt;
+  if (int32_t rc = upload_rows(ctx, rows, n, b->n_rows, drows)) return rc;
+  HIP_TRY(hipMalloc(&dcnt.p, n * 8));
+  HIP_TRY(hipMemsetAsync(dcnt.p, 0, n * 8, ctx->stream));
+  hipLaunchKernelGGL(fbk::k_count_range, dim3(uint32_t(n * fbk::kSlots / 4)), dim3(256), 0, ctx->stream, b->d_slots,
+                     b->d_arena, drows.as<uint32_t>(), n, uint32_t(start), uint32_t(end), dcnt.as<u64>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_counts, dcnt.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return FBK_OK;
 }
 

@@ -282,6 +282,50 @@ __global__ void __launch_bounds__(256) k_recount(Slot* __restrict__ slots, const
   if (lane == 0) slots[wid].tn = make_tn(t, c);
 }
 
+// Bits of each row in [start, end) (Bitmap.CountRange, roaring.go:573-615): one wave per
+// (row, slot).  Containers wholly inside the range contribute their stored n (roaring.go:603),
+// the (at most two) boundary containers are loaded and masked (BitmapCountRange :3092,
+// ArrayCountRange :3074, RunCountRange :3200 — here all three are "decode, mask, popcount").
+__global__ void __launch_bounds__(256) k_count_range(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                                    const uint32_t* __restrict__ rows, uint64_t n_rows, uint32_t start,
+                                                    uint32_t end, u64* __restrict__ out) {
+  __shared__ u64 lds[4][kWords];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
+  const uint64_t r = wslot >> 4;
+  const uint32_t slot = wslot & 15;
+  if (r >= n_rows) return;
+  const uint32_t base = slot << 16;
+  const uint32_t lo = start > base ? min(start - base, 65536u) : 0u;
+  const uint32_t hi = end > base ? min(end - base, 65536u) : 0u;
+  if (lo >= hi) return;
+  const Slot s = slots[(uint64_t)rows[r] * kSlots + slot];
+  const uint32_t n = slot_n(s);
+  if (n == 0) return;
+  uint32_t c;
+  if (lo == 0 && hi == 65536u) {
+    c = n;
+  } else {
+    u64 w[kWordsPerLane];
+    frag_load(s, arena, lane, lds[wv], w);
+    uint32_t part = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t b0 = (128u * j + 2u * lane + h) * 64u;  // first bit of this word
+        // mask of the bits b0+i with lo <= b0+i < hi
+        u64 m = ~0ull;
+        if (lo > b0) m = (lo - b0 >= 64u) ? 0ull : (m << (lo - b0));
+        if (hi < b0 + 64u) m = (hi <= b0) ? 0ull : (m & (~0ull >> (b0 + 64u - hi)));
+        part += __popcll(w[2 * j + h] & m);
+      }
+    c = wave_reduce_add(part);
+  }
+  if (lane == 0 && c) atomicAdd(&out[r], (u64)c);
+}
+
 // |A ∩ B| for dense rows: every slot a bitmap container and each row one contiguous
 // 128 KiB block (config 2, the HBM-roofline case).  One 256-thread block per
 // (pair, group of SPB slots); thread t streams 16-byte chunks t, t+256, ... of its

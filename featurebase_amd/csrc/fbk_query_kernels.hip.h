@@ -114,53 +114,65 @@ __device__ __forceinline__ void frag_from_raw(const Raw& r, uint32_t type, uint3
   }
 }
 
-// ---- n-way union ------------------------------------------------------------------------
+// ---- n-way fold (union / intersect / xor / difference of k rows) ---------------------------
 // One 256-thread block per (group, slot): the k containers of the group's rows at that
-// slot are split over the 4 wavefronts (wave w takes rows w, w+4, ...), each OR-accumulating
-// in registers (the union never touches HBM unless WRITE); the 4 partial unions are
+// slot are split over the 4 wavefronts (wave w takes rows w, w+4, ...), each accumulating
+// in registers (the result never touches HBM unless WRITE); the 4 partial results are
 // combined through LDS.  Latency is what matters here (many small containers): all
 // descriptors of the group are fetched by one vector load (lane i reads row i's slot) and
 // handed out by readlane, and the payload of container i+1 is prefetched while container i
 // is decoded (raw_load / frag_from_raw).  A single wave walking 64 containers with dependent
 // descriptor -> payload loads measured 184 us for 64 shards x 64 rows; see profiles/.
-// Mirrors what BitmapRowsUnion does with its 16 accumulators (filter.go:327-334) and the
-// n-way Bitmap.unionInPlace per key (roaring.go:1455-1560).  Short-circuit: any full operand
-// => full container (roaring.go:1465-1474).
-// With a filter batch: counts[g] += |union ∩ F.rows_f[g]| (Bitmap.IntersectionCount of
-// the union against the filter row), else counts[g] += |union|.
-template <bool WRITE>
-__global__ void __launch_bounds__(256) k_union_n(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
-                                                const uint32_t* __restrict__ rows, uint64_t n_groups, uint32_t k,
-                                                const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,
-                                                const uint32_t* __restrict__ frows, uint8_t* __restrict__ arenaO,
-                                                Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
-                                                u64* __restrict__ out_counts) {
+//   OP 1 (OR):  r0 | r1 | ...   BitmapRowsUnion's 16 accumulators (filter.go:327-334) and the
+//               n-way Bitmap.unionInPlace per key (roaring.go:1455-1560); any full operand =>
+//               full container (roaring.go:1465-1474).
+//   OP 0 (AND): r0 & r1 & ...   executeIntersectShard's left fold (executor.go:5357-5380) /
+//               Bitmap.IntersectInPlace(others...) (roaring.go:855-925): any empty operand =>
+//               empty, full operands are the identity (roaring.go:929-942).
+//   OP 2 (XOR): r0 ^ r1 ^ ...   executeXorShard's left fold (executor.go:5513-5552).
+//   OP 3 (ANDNOT): r0 \ r1 \ r2 ... = r0 & ~(r1 | r2 | ...)   executeDifferenceShard
+//               (executor.go:2950-2983) / Bitmap.Difference(others...) (roaring.go:1564-1595).
+// With a filter batch: counts[g] += |result ∩ F.rows_f[g]| (Bitmap.IntersectionCount of
+// the result against the filter row), else counts[g] += |result|.
+template <int OP, bool WRITE>
+__global__ void __launch_bounds__(256) k_fold_n(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                               const uint32_t* __restrict__ rows, uint64_t n_groups, uint32_t k,
+                                               const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,
+                                               const uint32_t* __restrict__ frows, uint8_t* __restrict__ arenaO,
+                                               Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
+                                               u64* __restrict__ out_counts) {
   __shared__ u64 lds[4][kWords];
-  __shared__ uint32_t s_full;
+  __shared__ uint32_t s_short;
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const uint64_t cell = blockIdx.x;  // (group, slot)
   const uint64_t g = cell >> 4;
   const uint32_t slot = cell & 15;
-  if (threadIdx.x == 0) s_full = 0;
+  if (threadIdx.x == 0) s_short = 0;
   __syncthreads();
   u64 acc[kWordsPerLane];
-  frag_zero(acc);
+#pragma unroll
+  for (int q = 0; q < kWordsPerLane; ++q) acc[q] = (OP == 0) ? ~0ull : 0ull;
   const uint32_t* grow = rows + g * k;
-  bool full = false;
-  for (uint32_t base = 0; base < k && !full; base += 64) {
+  // a container that leaves the accumulator unchanged: empty for OR/XOR/ANDNOT, full for AND
+  auto is_identity = [](uint32_t tn) { return (OP == 0) ? (tn & 0xFFFFFFu) == 65536u : (tn & 0xFFFFFFu) == 0u; };
+  bool shortcut = false;  // OR/ANDNOT: a full operand saturates; AND: an empty operand annihilates
+  for (uint32_t base = 0; base < k && !shortcut; base += 64) {
     // lane l holds the descriptor of row base+l of the group
     Slot mine;
     mine.off = 0;
     mine.len = 0;
     mine.tn = 0;
-    if (base + lane < k) mine = slots[(uint64_t)grow[base + lane] * kSlots + slot];
+    const bool valid = base + lane < k;
+    if (valid) mine = slots[(uint64_t)grow[base + lane] * kSlots + slot];
+    if (OP == 3 && base + lane == 0) mine.tn = 0;  // r0 is not one of the subtrahends
     const uint32_t cnt = min(64u, k - base);
-    // a full container anywhere => the union is full (checked for the whole group at once)
-    if (__ballot(slot_n(mine) == 65536u) != 0) {
-      full = true;
-      break;
+    if (OP == 1 || OP == 3) {
+      if (__ballot(slot_n(mine) == 65536u) != 0) shortcut = true;
+    } else if (OP == 0) {
+      if (__ballot(valid && slot_n(mine) == 0u) != 0) shortcut = true;
     }
+    if (shortcut) break;
     Raw cur, nxt;
     uint32_t i = wv;
     // descriptor of this wave's first container
@@ -168,7 +180,7 @@ __global__ void __launch_bounds__(256) k_union_n(const Slot* __restrict__ slots,
     uint32_t len = __shfl(mine.len, (int)(i & 63), kWave), tn = __shfl(mine.tn, (int)(i & 63), kWave);
     bool have = i < cnt;
     uint32_t bytes = have ? payload_bytes(tn >> 24, len) : 0;
-    if (have && (tn & 0xFFFFFFu) != 0 && bytes <= 8192u) raw_load(arena + off, bytes, lane, cur);
+    if (have && !is_identity(tn) && bytes <= 8192u) raw_load(arena + off, bytes, lane, cur);
     while (have) {
       const uint32_t in = i + 4;
       const bool have_n = in < cnt;
@@ -179,9 +191,9 @@ __global__ void __launch_bounds__(256) k_union_n(const Slot* __restrict__ slots,
         len_n = __shfl(mine.len, (int)(in & 63), kWave);
         tn_n = __shfl(mine.tn, (int)(in & 63), kWave);
         bytes_n = payload_bytes(tn_n >> 24, len_n);
-        if ((tn_n & 0xFFFFFFu) != 0 && bytes_n <= 8192u) raw_load(arena + off_n, bytes_n, lane, nxt);
+        if (!is_identity(tn_n) && bytes_n <= 8192u) raw_load(arena + off_n, bytes_n, lane, nxt);
       }
-      if ((tn & 0xFFFFFFu) != 0) {
+      if (!is_identity(tn)) {
         u64 w[kWordsPerLane];
         if (bytes <= 8192u) {
           frag_from_raw(cur, tn >> 24, len, lane, lds[wv], w);
@@ -193,7 +205,11 @@ __global__ void __launch_bounds__(256) k_union_n(const Slot* __restrict__ slots,
           frag_load(s, arena, lane, lds[wv], w);
         }
 #pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) acc[q] |= w[q];
+        for (int q = 0; q < kWordsPerLane; ++q) {
+          if (OP == 0) acc[q] &= w[q];
+          else if (OP == 2) acc[q] ^= w[q];
+          else acc[q] |= w[q];
+        }
       }
       i = in;
       have = have_n;
@@ -205,22 +221,34 @@ __global__ void __launch_bounds__(256) k_union_n(const Slot* __restrict__ slots,
       for (int j = 0; j < 8; ++j) cur.v[j] = nxt.v[j];
     }
   }
-  if (full && lane == 0) s_full = 1;
-  // publish the partial union of this wave (its scratch is free again)
+  if (shortcut && lane == 0) s_short = 1;
+  // publish the partial result of this wave (its scratch is free again)
   lds_write_frag(lds[wv], lane, acc);
   __syncthreads();
   if (wv != 0) return;
-  if (s_full) {
+  if (s_short) {
 #pragma unroll
-    for (int q = 0; q < kWordsPerLane; ++q) acc[q] = ~0ull;
+    for (int q = 0; q < kWordsPerLane; ++q) acc[q] = (OP == 1 || OP == 3) ? ~0ull : 0ull;
   } else {
 #pragma unroll
     for (int o = 1; o < 4; ++o) {
       u64 w[kWordsPerLane];
       lds_read_frag(lds[o], lane, w);
 #pragma unroll
-      for (int q = 0; q < kWordsPerLane; ++q) acc[q] |= w[q];
+      for (int q = 0; q < kWordsPerLane; ++q) {
+        if (OP == 0) acc[q] &= w[q];
+        else if (OP == 2) acc[q] ^= w[q];
+        else acc[q] |= w[q];
+      }
     }
+  }
+  if (OP == 3) {  // r0 \ (r1 | r2 | ...)
+    const Slot s0 = slots[(uint64_t)grow[0] * kSlots + slot];
+    u64 w[kWordsPerLane];
+    if (slot_n(s0) == 0 || s_short) frag_zero(w);
+    else frag_load(s0, arena, lane, lds[0], w);
+#pragma unroll
+    for (int q = 0; q < kWordsPerLane; ++q) acc[q] = w[q] & ~acc[q];
   }
   uint32_t c;
   if (fslots) {
@@ -419,171 +447,6 @@ __global__ void __launch_bounds__(256) k_reduce_shards(const u64* __restrict__ i
   u64 acc = 0;
   for (uint32_t s = s0; s < s1; ++s) acc += in[(uint64_t)s * width + c];
   if (acc) atomicAdd(&out[c], acc);
-}
-
-// ---- BSI Sum ---------------------------------------------------------------------------------
-// One wave per (shard, slot).  positive = filter ∩ exists \ sign, negative = filter ∩ exists ∩ sign
-// stay in registers while the bit planes stream past once:
-//   psum += |positive ∩ plane_i| << i ; nsum += |negative ∩ plane_i| << i   (uint64 wrap-around,
-// roaring/filter.go:1157-1160).  Rows of the BSI fragment of shard s are base[s] + {0: exists,
-// 1: sign, 2+i: bit i} (fragment.go:62-65).  out3[shard] = {psum, nsum, count}.
-__global__ void __launch_bounds__(256) k_bsi_sum(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
-                                                const uint32_t* __restrict__ base, uint32_t n_shards,
-                                                uint32_t bit_depth, const Slot* __restrict__ fslots,
-                                                const uint8_t* __restrict__ farena, const uint32_t* __restrict__ frows,
-                                                u64* __restrict__ out3) {
-  __shared__ u64 lds[4][kWords];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
-  const uint64_t shard = wslot >> 4;
-  const uint32_t slot = wslot & 15;
-  if (shard >= n_shards) return;
-  const uint64_t r0 = base[shard];
-  const Slot se = slots[(r0 + 0) * kSlots + slot];
-  if (slot_n(se) == 0) return;  // no existence bits: positive stays nil (filter.go:1135)
-  u64 pos[kWordsPerLane], neg[kWordsPerLane], w[kWordsPerLane];
-  frag_load(se, arena, lane, lds[wv], pos);
-  if (fslots) {
-    const Slot sf = fslots[(uint64_t)frows[shard] * kSlots + slot];
-    if (slot_n(sf) == 0) return;  // ConsiderKey rejects: no filter container here (filter.go:1112)
-    frag_load(sf, farena, lane, lds[wv], w);
-#pragma unroll
-    for (int q = 0; q < kWordsPerLane; ++q) pos[q] &= w[q];
-  }
-  const uint32_t count = wave_reduce_add(frag_popcount(pos));
-  const Slot ss = slots[(r0 + 1) * kSlots + slot];
-  if (slot_n(ss) != 0) {
-    frag_load(ss, arena, lane, lds[wv], w);
-#pragma unroll
-    for (int q = 0; q < kWordsPerLane; ++q) {
-      neg[q] = pos[q] & w[q];
-      pos[q] &= ~w[q];
-    }
-  } else {
-    frag_zero(neg);
-  }
-  u64 psum = 0, nsum = 0;
-  for (uint32_t i = 0; i < bit_depth; ++i) {
-    const Slot sp = slots[(r0 + 2 + i) * kSlots + slot];
-    if (slot_n(sp) == 0) continue;
-    frag_load(sp, arena, lane, lds[wv], w);
-    uint32_t pc = 0, nc = 0;
-#pragma unroll
-    for (int q = 0; q < kWordsPerLane; ++q) {
-      pc += __popcll(pos[q] & w[q]);
-      nc += __popcll(neg[q] & w[q]);
-    }
-    psum += (u64)pc << i;
-    nsum += (u64)nc << i;
-  }
-  psum = wave_reduce_add64(psum);
-  nsum = wave_reduce_add64(nsum);
-  if (lane == 0) {
-    if (psum) atomicAdd(&out3[shard * 3 + 0], psum);
-    if (nsum) atomicAdd(&out3[shard * 3 + 1], nsum);
-    if (count) atomicAdd(&out3[shard * 3 + 2], (u64)count);
-  }
-}
-
-// ---- BSI Range: plane-program interpreter -----------------------------------------------------
-// The host walks the reference's control flow (rangeEQ/LT/GT/Between, fragment.go:963-1303)
-// ONCE per query and emits a short straight-line program over three fragment registers
-// X (remaining / result), M (matched), S (saved); every (shard, slot) wave then runs the
-// same program with its own containers, each bit plane read at most once per pass.
-enum BsiOp : uint32_t {
-  kLoadX = 0,   // X = row[r]
-  kAndX = 1,    // X &= row[r]            (Row.Intersect)
-  kAndnX = 2,   // X &= ~row[r]           (Row.Difference)
-  kMorXA = 3,   // M |= X & row[r]        (matched = matched.Union(remaining.Intersect(row)))
-  kMorXAn = 4,  // M |= X & ~row[r]       (matched = matched.Union(remaining.Difference(row)))
-  kMZero = 5,   // M = 0                  (NewRow())
-  kXFromM = 6,  // X = M
-  kZeroX = 7,   // X = 0
-  kSaveX = 8,   // S = X
-  kOrXS = 9,    // X |= S
-  kAndnXS = 10  // X &= ~S
-};
-
-__global__ void __launch_bounds__(256) k_bsi_range(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
-                                                  const uint32_t* __restrict__ base, uint32_t n_shards,
-                                                  const uint32_t* __restrict__ prog, uint32_t prog_len,
-                                                  uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
-                                                  uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts) {
-  __shared__ u64 lds[4][kWords];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
-  const uint64_t shard = wslot >> 4;
-  const uint32_t slot = wslot & 15;
-  if (shard >= n_shards) return;
-  const uint64_t r0 = base[shard];
-  u64 X[kWordsPerLane], M[kWordsPerLane], S[kWordsPerLane], T[kWordsPerLane];
-  frag_zero(X);
-  frag_zero(M);
-  frag_zero(S);
-  for (uint32_t pc = 0; pc < prog_len; ++pc) {
-    const uint32_t ins = prog[pc];
-    const uint32_t op = ins >> 24, r = ins & 0xFFFFFFu;
-    if (op <= kMorXAn) {
-      const Slot s = slots[(r0 + r) * kSlots + slot];
-      if (slot_n(s) == 0) frag_zero(T);
-      else frag_load(s, arena, lane, lds[wv], T);
-    }
-    switch (op) {
-      case kLoadX:
-#pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) X[q] = T[q];
-        break;
-      case kAndX:
-#pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) X[q] &= T[q];
-        break;
-      case kAndnX:
-#pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) X[q] &= ~T[q];
-        break;
-      case kMorXA:
-#pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) M[q] |= X[q] & T[q];
-        break;
-      case kMorXAn:
-#pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) M[q] |= X[q] & ~T[q];
-        break;
-      case kMZero: frag_zero(M); break;
-      case kXFromM:
-#pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) X[q] = M[q];
-        break;
-      case kZeroX: frag_zero(X); break;
-      case kSaveX:
-#pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) S[q] = X[q];
-        break;
-      case kOrXS:
-#pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) X[q] |= S[q];
-        break;
-      default:  // kAndnXS
-#pragma unroll
-        for (int q = 0; q < kWordsPerLane; ++q) X[q] &= ~S[q];
-        break;
-    }
-  }
-  const uint32_t c = wave_reduce_add(frag_popcount(X));
-  Slot so;
-  so.off = wslot * 8192ull;
-  so.len = kWords;
-  so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
-  if (c) frag_store_bitmap(arenaO + so.off, lane, X);
-  uint32_t rr = 0;
-  if (outRuns) rr = wave_reduce_add(frag_count_runs(X, lane));
-  if (lane == 0) {
-    outSlots[wslot] = so;
-    if (outRuns) outRuns[wslot] = rr;
-    if (c && out_counts) atomicAdd(&out_counts[shard], (u64)c);
-  }
 }
 
 // ---- Container.optimize() on the device ---------------------------------------------------------

@@ -59,6 +59,7 @@ SIGNATURES = {
     "fbk_batch_info": (C.c_int32, [_vp, _vp, _u32p, _u64p, _u64p]),
     "fbk_batch_download": (C.c_int32, [_vp, _vp, C.POINTER(ContainerDesc), C.c_uint64, _vp, C.c_uint64]),
     "fbk_count": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    "fbk_count_range": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
     "fbk_intersection_count": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
     "fbk_setop": (C.c_int32, [_vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vpp, _vp]),
     "fbk_plan_create": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vpp]),
@@ -71,8 +72,12 @@ SIGNATURES = {
     "fbk_plan_detach_output": (C.c_int32, [_vp, _vp, _vpp]),
     "fbk_union_n": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vpp, _vp]),
     "fbk_union_n_intersection_count": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp, _vp]),
+    "fbk_fold_n": (C.c_int32, [_vp, C.c_int32, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vpp, _vp]),
+    "fbk_fold_n_intersection_count": (C.c_int32, [_vp, C.c_int32, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp, _vp]),
     "fbk_count_matrix": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp, _vp]),
     "fbk_bsi_sum": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "fbk_bsi_min": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "fbk_bsi_max": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "fbk_bsi_range": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_uint32, C.c_int64, C.c_uint32, _vpp, _vp]),
     "fbk_bsi_range_between": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_uint32, _vpp, _vp]),
 }

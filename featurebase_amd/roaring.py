@@ -246,6 +246,36 @@ class Context:
         )
         return out
 
+    def fold_n(self, op: int, batch: Batch, groups, flags: int = 0) -> Tuple[Batch, np.ndarray]:
+        """groups: [n_groups, k] row ordinals; out row g = r0 <op> r1 <op> ... folded left to right
+        (executeIntersect/Union/Xor/DifferenceShard, executor.go:5357, 5382, 5513, 2950)."""
+        g = np.ascontiguousarray(groups, dtype=np.uint32).reshape(len(groups), -1) if len(groups) else np.zeros((0, 0), np.uint32)
+        n_groups, k = g.shape
+        out = np.zeros(n_groups, dtype=np.uint64)
+        h = C.c_void_p()
+        L.check(self.lib.fbk_fold_n(self.h, op, batch.h, g.ctypes.data, n_groups, k, flags, C.byref(h), out.ctypes.data))
+        return Batch(self, h.value), out
+
+    def fold_n_intersection_count(self, op: int, batch: Batch, groups, filt: Optional[Batch] = None, rows_f=None) -> np.ndarray:
+        g = np.ascontiguousarray(groups, dtype=np.uint32).reshape(len(groups), -1)
+        n_groups, k = g.shape
+        out = np.zeros(n_groups, dtype=np.uint64)
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        L.check(
+            self.lib.fbk_fold_n_intersection_count(
+                self.h, op, batch.h, g.ctypes.data, n_groups, k, filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None, out.ctypes.data
+            )
+        )
+        return out
+
+    def count_range(self, batch: Batch, rows, start: int, end: int) -> np.ndarray:
+        """out[i] = bits of rows[i] in [start, end), positions relative to the row (0..2^20):
+        Bitmap.CountRange (roaring.go:573)."""
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.zeros(r.size, dtype=np.uint64)
+        L.check(self.lib.fbk_count_range(self.h, batch.h, r.ctypes.data, r.size, start, end, out.ctypes.data))
+        return out
+
     # -- GroupBy / TopK count matrix -----------------------------------------------------
     def count_matrix(self, a: Batch, rows_a, b: Batch, rows_b, filt: Optional[Batch] = None, rows_f=None, per_shard: bool = False):
         """rows_a: [n_shards, n_a], rows_b: [n_shards, n_b], rows_f: [n_shards].
@@ -280,6 +310,27 @@ class Context:
             )
         )
         return sums, counts
+
+    def _bsi_minmax(self, fn, batch: Batch, base_rows, bit_depth: int, filt: Optional[Batch], rows_f):
+        base = np.ascontiguousarray(base_rows, dtype=np.uint32)
+        vals = np.zeros(base.size, dtype=np.int64)
+        counts = np.zeros(base.size, dtype=np.uint64)
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        L.check(
+            fn(
+                self.h, batch.h, base.ctypes.data, base.size, bit_depth,
+                filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None, vals.ctypes.data, counts.ctypes.data,
+            )
+        )
+        return vals, counts
+
+    def bsi_min(self, batch: Batch, base_rows, bit_depth: int, filt: Optional[Batch] = None, rows_f=None):
+        """Per shard (min, count): fragment.min (fragment.go:754)."""
+        return self._bsi_minmax(self.lib.fbk_bsi_min, batch, base_rows, bit_depth, filt, rows_f)
+
+    def bsi_max(self, batch: Batch, base_rows, bit_depth: int, filt: Optional[Batch] = None, rows_f=None):
+        """Per shard (max, count): fragment.max (fragment.go:803)."""
+        return self._bsi_minmax(self.lib.fbk_bsi_max, batch, base_rows, bit_depth, filt, rows_f)
 
     def bsi_range(self, batch: Batch, base_rows, op: int, bit_depth: int, predicate: int, flags: int = 0) -> Tuple[Batch, np.ndarray]:
         base = np.ascontiguousarray(base_rows, dtype=np.uint32)

@@ -155,6 +155,17 @@ int32_t fbk_batch_download(fbk_ctx* ctx, const fbk_batch* batch, fbk_container_d
 int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n,
                   uint64_t* out_counts);
 
+/* out[i] = number of bits of rows[i] in [start, end), positions relative to the row
+ * (0 <= start <= end <= 2^20).  Replaces Bitmap.CountRange (roaring.go:573-615) ->
+ * Container.countRange -> ArrayCountRange / BitmapCountRange / RunCountRange
+ * (roaring.go:3074-3232), which fragment.go:237,396,444 use to count one row of a fragment.
+ * The device counts bits; this equals the reference everywhere except on run containers that
+ * hold a run whose last value == end-1+1 (`iv.Last == end`), where RunCountRange's
+ * "subset of range" and "overlaps end" branches both fire and over-count (roaring.go:3216-3227)
+ * — a case the reference's own callers (container-aligned ranges) never produce. */
+int32_t fbk_count_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n, uint64_t start,
+                        uint64_t end, uint64_t* out_counts);
+
 /* out[i] = |A.rows_a[i] ∩ B.rows_b[i]| without materialising.  Replaces
  * RowSegment.IntersectionCount (row.go:556) -> Bitmap.IntersectionCount
  * (roaring.go:711-733) -> intersectionCount (roaring.go:4477-4614), one call per
@@ -229,6 +240,25 @@ int32_t fbk_union_n_intersection_count(fbk_ctx* ctx, const fbk_batch* batch, con
                                        uint64_t n_groups, uint32_t k, const fbk_batch* filter,
                                        const uint32_t* rows_f, uint64_t* out_counts);
 
+/* ---- n-way fold -----------------------------------------------------------------------
+ * Generalisation of fbk_union_n to the four set operations, folded left to right over the k
+ * rows of each group exactly as the executor's per-shard functions fold a call's children:
+ *   FBK_OP_AND     r0 & r1 & ... & r(k-1)    executeIntersectShard  executor.go:5357-5380
+ *   FBK_OP_OR      r0 | r1 | ...             executeUnionShard      executor.go:5382-5404
+ *   FBK_OP_XOR     r0 ^ r1 ^ ...             executeXorShard        executor.go:5513-5552
+ *   FBK_OP_ANDNOT  r0 \ r1 \ ... \ r(k-1)     executeDifferenceShard executor.go:2950-2983
+ * (Bitmap.IntersectInPlace / Difference with several others, roaring.go:855-925, 1564-1595.)
+ * One launch, the intermediate rows never touch HBM.  AND / ANDNOT need k >= 1. */
+int32_t fbk_fold_n(fbk_ctx* ctx, int32_t op, const fbk_batch* batch, const uint32_t* rows, uint64_t n_groups,
+                   uint32_t k, uint32_t flags, fbk_batch** out_batch, uint64_t* out_counts);
+
+/* out_counts[g] = |fold(group g) ∩ filter.rows_f[g]| (filter == NULL: |fold(group g)|), never
+ * materialised: Count(Intersect(...)) / Count(Union(...)) etc. in one pass
+ * (executeCount -> executeBitmapCallShard, executor.go:5839-5892). */
+int32_t fbk_fold_n_intersection_count(fbk_ctx* ctx, int32_t op, const fbk_batch* batch, const uint32_t* rows,
+                                      uint64_t n_groups, uint32_t k, const fbk_batch* filter,
+                                      const uint32_t* rows_f, uint64_t* out_counts);
+
 /* ---- count matrix (GroupBy / TopN / TopK shape) --------------------------------------------
  * For every shard s, out[s][i][j] = |A.rows_a[s*n_a+i] ∩ B.rows_b[s*n_b+j] ∩ F.rows_f[s]|
  * (filter may be NULL).  out_total[i*n_b+j] is the sum over shards (mergeGroupCounts /
@@ -258,6 +288,18 @@ int32_t fbk_count_matrix(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_
  * (executor.go:2205). */
 int32_t fbk_bsi_sum(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards,
                     uint32_t bit_depth, const fbk_batch* filter, const uint32_t* rows_f, int64_t* out_sums,
+                    uint64_t* out_counts);
+
+/* Per shard: (out_vals[s], out_counts[s]) = fragment.min / fragment.max (fragment.go:754-853):
+ * the smallest / largest stored value among the columns of exists ∩ filter and the number of
+ * columns holding it; (0, 0) when there is no such column.  Sign-magnitude planes, MSB -> LSB
+ * scan (minUnsigned :781, maxUnsigned :832).  The caller adds Base (field.go MinForShard /
+ * MaxForShard) and folds shards with ValCount.Smaller / Larger (executor.go:8446, 8526). */
+int32_t fbk_bsi_min(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards,
+                    uint32_t bit_depth, const fbk_batch* filter, const uint32_t* rows_f, int64_t* out_vals,
+                    uint64_t* out_counts);
+int32_t fbk_bsi_max(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards,
+                    uint32_t bit_depth, const fbk_batch* filter, const uint32_t* rows_f, int64_t* out_vals,
                     uint64_t* out_counts);
 
 /* out row s = columns of shard s whose value satisfies `op predicate` (fragment.rangeOp,

@@ -412,6 +412,98 @@ orc_bitmap* orc_bsi_range_between(const orc_bitmap* const* rows, int32_t n_rows,
   return o;
 }
 
+/* ---- BSI Min / Max: fragment.min / minUnsigned / max / maxUnsigned, fragment.go:754-853.
+ * `filter` may be NULL with has_filter == 0 ("no filter"); int64 arithmetic wraps as Go's does
+ * (min += 1 << uint(i) with i == 63). ---------------------------------------------------- */
+
+/* minUnsigned, fragment.go:781-801; `filter` is consumed */
+static void min_unsigned(const frag* f, orc_bitmap* filter, uint64_t bit_depth, int64_t* out_min, uint64_t* out_count) {
+  uint64_t mn = 0;
+  uint64_t count = orc_bitmap_count(filter);
+  for (int i = (int)bit_depth - 1; i >= 0; i--) {
+    orc_bitmap* row = row_difference(filter, frag_row(f, (uint64_t)(BSI_OFFSET + i)));
+    count = orc_bitmap_count(row);
+    if (count > 0) {
+      orc_bitmap_free(filter);
+      filter = row;
+    } else {
+      mn += go_shl64(1, (uint64_t)i);
+      if (i == 0) count = orc_bitmap_count(filter);
+      orc_bitmap_free(row);
+    }
+  }
+  orc_bitmap_free(filter);
+  *out_min = (int64_t)mn;
+  *out_count = count;
+}
+
+/* maxUnsigned, fragment.go:832-853; `filter` is consumed */
+static void max_unsigned(const frag* f, orc_bitmap* filter, uint64_t bit_depth, int64_t* out_max, uint64_t* out_count) {
+  uint64_t mx = 0;
+  uint64_t count = orc_bitmap_count(filter);
+  for (int i = (int)bit_depth - 1; i >= 0; i--) {
+    orc_bitmap* row = row_intersect(frag_row(f, (uint64_t)(BSI_OFFSET + i)), filter);
+    count = orc_bitmap_count(row);
+    if (count > 0) {
+      mx += go_shl64(1, (uint64_t)i);
+      orc_bitmap_free(filter);
+      filter = row;
+    } else {
+      if (i == 0) count = orc_bitmap_count(filter);
+      orc_bitmap_free(row);
+    }
+  }
+  orc_bitmap_free(filter);
+  *out_max = (int64_t)mx;
+  *out_count = count;
+}
+
+/* fragment.min, fragment.go:754-779 */
+void orc_bsi_min(const orc_bitmap* const* rows, int32_t n_rows, const orc_bitmap* filter, int32_t has_filter,
+                 uint64_t bit_depth, int64_t* out_min, uint64_t* out_count) {
+  frag f = {rows, n_rows};
+  *out_min = 0;
+  *out_count = 0;
+  orc_bitmap* consider = has_filter ? row_intersect(frag_row(&f, BSI_EXISTS), filter) : row_clone(frag_row(&f, BSI_EXISTS));
+  if (orc_bitmap_count(consider) == 0) {
+    orc_bitmap_free(consider);
+    return;
+  }
+  orc_bitmap* neg = row_intersect(frag_row(&f, BSI_SIGN), consider);
+  if (row_any(neg)) {
+    int64_t v;
+    max_unsigned(&f, neg, bit_depth, &v, out_count);
+    *out_min = (int64_t)(0 - (uint64_t)v);
+    orc_bitmap_free(consider);
+    return;
+  }
+  orc_bitmap_free(neg);
+  min_unsigned(&f, consider, bit_depth, out_min, out_count);
+}
+
+/* fragment.max, fragment.go:803-830 */
+void orc_bsi_max(const orc_bitmap* const* rows, int32_t n_rows, const orc_bitmap* filter, int32_t has_filter,
+                 uint64_t bit_depth, int64_t* out_max, uint64_t* out_count) {
+  frag f = {rows, n_rows};
+  *out_max = 0;
+  *out_count = 0;
+  orc_bitmap* consider = has_filter ? row_intersect(frag_row(&f, BSI_EXISTS), filter) : row_clone(frag_row(&f, BSI_EXISTS));
+  if (!row_any(consider)) {
+    orc_bitmap_free(consider);
+    return;
+  }
+  orc_bitmap* pos = row_difference(consider, frag_row(&f, BSI_SIGN));
+  if (!row_any(pos)) {
+    int64_t v;
+    orc_bitmap_free(pos);
+    min_unsigned(&f, consider, bit_depth, &v, out_count);
+    *out_max = (int64_t)(0 - (uint64_t)v);
+    return;
+  }
+  orc_bitmap_free(consider);
+  max_unsigned(&f, pos, bit_depth, out_max, out_count);
+}
+
 /* ---- TopK row counts: doTopK, executor.go:2705-2746, with topKFilter :2750-2774.
  * out_counts[r] = sum over the containers of row r of |container ∩ filter[slot]|
  * (or container.N() without a filter). */

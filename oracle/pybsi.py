@@ -22,6 +22,8 @@ def _lib():
         vp, i32, u64, i64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_int64
         sig = {
             "orc_bsi_sum": (None, [vp, i32, vp, i32, C.POINTER(i64), C.POINTER(u64)]),
+            "orc_bsi_min": (None, [vp, i32, vp, i32, u64, C.POINTER(i64), C.POINTER(u64)]),
+            "orc_bsi_max": (None, [vp, i32, vp, i32, u64, C.POINTER(i64), C.POINTER(u64)]),
             "orc_bsi_range": (vp, [vp, i32, i32, u64, i64]),
             "orc_bsi_range_between": (vp, [vp, i32, u64, i64, i64]),
             "orc_bsi_range_lt_unsigned": (vp, [vp, i32, vp, u64, u64, i32]),
@@ -78,6 +80,20 @@ def bsi_sum(frag: Fragment, filt: Optional[O.OBitmap], has_filter: bool):
     s, c = C.c_int64(), C.c_uint64()
     _lib().orc_bsi_sum(frag.arr, len(frag), filt.p if filt is not None else None, 1 if has_filter else 0, C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def bsi_min(frag: Fragment, filt: Optional[O.OBitmap], bit_depth: int):
+    """fragment.min (fragment.go:754): (min, count); filt None = no filter."""
+    v, c = C.c_int64(), C.c_uint64()
+    _lib().orc_bsi_min(frag.arr, len(frag), filt.p if filt is not None else None, 1 if filt is not None else 0, bit_depth, C.byref(v), C.byref(c))
+    return v.value, c.value
+
+
+def bsi_max(frag: Fragment, filt: Optional[O.OBitmap], bit_depth: int):
+    """fragment.max (fragment.go:803): (max, count); filt None = no filter."""
+    v, c = C.c_int64(), C.c_uint64()
+    _lib().orc_bsi_max(frag.arr, len(frag), filt.p if filt is not None else None, 1 if filt is not None else 0, bit_depth, C.byref(v), C.byref(c))
+    return v.value, c.value
 
 
 def bsi_range(frag: Fragment, op: int, bit_depth: int, predicate: int) -> O.OBitmap:

@@ -2,7 +2,7 @@
 """Extract the reference's BSI Range / Sum known-answer cases into a JSON fixture.
 
 Source: fragment_internal_test.go TestFragment_Sum (:452-521), TestFragment_Range
-(:606-916) and TestIntLTRegression (:3738-3756).  Each subtest is a list of
+(:606-916), TestFragment_MinMax (:524-604) and TestIntLTRegression (:3738-3756).  Each subtest is a list of
 setValue(col, bitDepth, value) calls followed by queries with literal expected columns;
 only those literals are recorded (with their line), never code.
 
@@ -115,8 +115,30 @@ def main():
     assert "n != 5" in blk and "n != 2" in blk
     sum_case = {"test": "TestFragment_Sum", "line": line_of(m.start()), "values": vals, "sums": sums}
 
+    # ---- TestFragment_MinMax (:524-604): values + per-filter (min|max, count) tables
+    m = re.search(r"^func TestFragment_MinMax\(", src, re.M)
+    m1 = re.search(r"^func ", src[m.end():], re.M)
+    blk = src[m.start(): m.end() + m1.start()]
+    depth = int(re.search(r"const bitDepth = (\d+)", blk).group(1))
+    vals = [[int(a), depth, int(b)] for a, b in re.findall(r"f\.setValue\(tx, (\d+), bitDepth, (-?\d+)\)", blk)]
+    minmax = {"test": "TestFragment_MinMax", "line": line_of(m.start()), "values": vals, "depth": depth}
+    for kind in ("Min", "Max"):
+        k0 = blk.index('t.Run("%s"' % kind)
+        sub = blk[k0: blk.index("for i, test := range tests", k0)]
+        rows = []
+        for q in re.finditer(r"\{filter: (nil|NewRow\(([^)]*)\)), exp: (-?\d+), cnt: (\d+)\}", sub):
+            flt = None if q.group(1) == "nil" else [int(x, 0) for x in q.group(2).replace(" ", "").split(",") if x]
+            rows.append({"filter": flt, "exp": int(q.group(3)), "cnt": int(q.group(4)), "line": line_of(m.start() + k0 + q.start())})
+        minmax[kind.lower()] = rows
+    assert len(minmax["min"]) == 6 and len(minmax["max"]) == 6 and len(vals) == 7
+
     with open(os.path.join(OUT, "fragment_bsi_cases.json"), "w") as f:
-        json.dump({"source": "fragment_internal_test.go:452-521, 606-916, 3738-3756", "range_cases": cases, "sum_case": sum_case}, f, indent=1)
+        json.dump(
+            {"source": "fragment_internal_test.go:452-604, 606-916, 3738-3756", "range_cases": cases, "sum_case": sum_case, "minmax_case": minmax},
+            f,
+            indent=1,
+        )
+    print("minmax:", minmax)
     nq = sum(len(c["queries"]) for c in cases)
     print(f"fragment_bsi_cases.json: {len(cases)} range subtests, {nq} queries; sum case with {len(vals)} values")
     for c in cases:

@@ -285,3 +285,131 @@ def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle):
     out.free()
     batch.free()
     F.free()
+
+
+def test_bsi_minmax_reference_cases_on_gpu(gpu_ctx, B):
+    """TestFragment_MinMax (fragment_internal_test.go:524-604) through fbk_bsi_min / fbk_bsi_max."""
+    mc = CASES["minmax_case"]
+    depth = mc["depth"]
+    fr = B.bsi_fragment_from_values({v[0]: v[2] for v in mc["values"]}, depth)
+    batch, base = upload_bsi(gpu_ctx, [fr])
+    for kind, fn in (("min", gpu_ctx.bsi_min), ("max", gpu_ctx.bsi_max)):
+        for t in mc[kind]:
+            if t["filter"] is None:
+                v, c = fn(batch, base, depth)
+            else:
+                F = gpu_ctx.upload([fbk_row_of_bitmap(B.row_from_columns(t["filter"]))])
+                v, c = fn(batch, base, depth, F, [0])
+                F.free()
+            assert (int(v[0]), int(c[0])) == (t["exp"], t["cnt"]), (kind, t)
+    batch.free()
+
+
+def test_bsi_minmax_random_multi_shard_vs_oracle(gpu_ctx, B):
+    """Mixed-encoding planes, several shards per launch, with and without a filter; includes
+    all-negative / all-positive shards, a shard with no values, depth 64 and depth 1."""
+    rng = D.rng_for(77)
+    for depth in (1, 7, 20, 63, 64):
+        frags, filts = [], []
+        for s in range(6):
+            ncol = [50000, 2000, 150, 1 << 16, 9, 0][s]
+            cols = rng.choice(1 << 20, size=ncol, replace=False)
+            hi = (1 << min(depth, 62))
+            mag = rng.integers(0, hi, size=ncol)
+            if s == 3:
+                mag = mag % 7  # many ties, sparse high planes
+            sign = {0: np.where(rng.random(ncol) < 0.5, -1, 1), 1: np.ones(ncol, dtype=np.int64), 2: -np.ones(ncol, dtype=np.int64)}.get(s % 3)
+            vals = {int(c): int(m) * int(g) for c, m, g in zip(cols, mag, sign)}
+            if depth == 64 and s == 1:
+                vals[int(cols[0])] = (1 << 63) + 5  # magnitude bit 63 set: int64 wrap (fragment.go:795, 842)
+            frags.append(B.bsi_fragment_from_values(vals, depth))
+            filts.append(B.row_from_columns([int(c) for c in cols[:: 2 + s]] + [5, 70000]))
+        batch, base = upload_bsi(gpu_ctx, frags)
+        F = gpu_ctx.upload([fbk_row_of_bitmap(f) for f in filts])
+        for fn, ofn in ((gpu_ctx.bsi_min, B.bsi_min), (gpu_ctx.bsi_max, B.bsi_max)):
+            v, c = fn(batch, base, depth)
+            for s, fr in enumerate(frags):
+                assert (int(v[s]), int(c[s])) == ofn(fr, None, depth), (depth, s)
+            v, c = fn(batch, base, depth, F, np.arange(len(frags)))
+            for s, fr in enumerate(frags):
+                assert (int(v[s]), int(c[s])) == ofn(fr, filts[s], depth), (depth, s, "filtered")
+        batch.free()
+        F.free()
+
+
+def test_fold_n_vs_oracle(gpu_ctx, oracle):
+    """n-way Intersect / Xor / Difference (and Union again) in one launch against the oracle's
+    left fold of Bitmap.Intersect / Xor / Difference(others...) — what executeIntersectShard,
+    executeXorShard and executeDifferenceShard compute child by child."""
+    O = oracle
+    rng = D.rng_for(43)
+    rows, groups = make_union_groups(rng, 6, 7)
+    # full containers (identity of AND, saturate OR / the subtrahend of ANDNOT) and nil slots
+    rows[groups[1][0]][1 * 16 + 3] = O.OContainer.run([(0, 65535)])
+    rows[groups[1][2]][1 * 16 + 3] = O.OContainer.run([(0, 65535)])
+    rows[groups[2][4]][2 * 16 + 5] = O.OContainer.run([(0, 65535)])
+    batch = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+    filt_rows = [D.random_row(rng, g) for g in range(len(groups))]
+    F = gpu_ctx.upload([D.to_fbk_row(r) for r in filt_rows])
+
+    def fold(op, bms):
+        if op == L.OP_OR:
+            return bms[0].union(*bms[1:])
+        if op == L.OP_ANDNOT:
+            return bms[0].difference(*bms[1:]) if len(bms) > 1 else bms[0]
+        acc = bms[0]
+        for b in bms[1:]:
+            acc = acc.intersect(b) if op == L.OP_AND else acc.xor(b)
+        return acc
+
+    for kk in (7, 2, 1):
+        gs = groups[:, :kk]
+        for op in (L.OP_AND, L.OP_OR, L.OP_XOR, L.OP_ANDNOT):
+            out, cnt = gpu_ctx.fold_n(op, batch, gs, L.SETOP_OPTIMIZE if kk == 7 else 0)
+            res = out.download()
+            got = gpu_ctx.fold_n_intersection_count(op, batch, gs, F, np.arange(len(gs)))
+            got_nf = gpu_ctx.fold_n_intersection_count(op, batch, gs)
+            for g, ids in enumerate(gs):
+                bms = [O.OBitmap.from_containers(list(rows[i].items())) for i in ids]
+                exp = fold(op, bms)
+                assert int(cnt[g]) == exp.count(), (op, kk, g)
+                assert (row_words(res[g]) == bitmap_words(exp)).all(), (op, kk, g)
+                if kk == 7:
+                    assert_optimized_like_oracle(O, res[g], exp)
+                f = O.OBitmap.from_containers(list(filt_rows[g].items()))
+                assert int(got[g]) == exp.intersection_count(f), (op, kk, g)
+                assert int(got_nf[g]) == exp.count()
+            out.free()
+    with pytest.raises(L.FbkError):
+        gpu_ctx.fold_n(L.OP_AND, batch, np.zeros((2, 0), dtype=np.uint32))
+    batch.free()
+    F.free()
+
+
+def test_count_range_vs_oracle(gpu_ctx, oracle):
+    """Bitmap.CountRange (roaring.go:573) per row: container-aligned ranges (what fragment.go
+    uses), ranges inside one container and ranges straddling several, on mixed encodings."""
+    O = oracle
+    rng = D.rng_for(47)
+    rows = [D.random_row(rng, r) for r in range(12)]
+    batch = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+    idx = np.arange(len(rows))
+    words = [row_words(D.to_fbk_row(r)) for r in rows]
+    ranges = [(0, 1 << 20), (0, 0), (65536, 131072), (5, 6), (100, 65536 + 77), (65535, 65537), (3 * 65536 + 12345, 9 * 65536 + 1),
+              (1 << 19, 1 << 20), ((1 << 20) - 1, 1 << 20), (64, 128), (63, 129), (1000, 1000)]
+    ranges += [tuple(sorted(int(x) for x in rng.integers(0, (1 << 20) + 1, size=2))) for _ in range(20)]
+    for s, e in ranges:
+        got = gpu_ctx.count_range(batch, idx, s, e)
+        for r in range(len(rows)):
+            bits = np.unpackbits(words[r].reshape(-1).view(np.uint8), bitorder="little")
+            truth = int(bits[s:e].sum())
+            assert int(got[r]) == truth, (r, s, e)
+            # the reference's own arithmetic, wherever RunCountRange's Last == end quirk
+            # (roaring.go:3216-3227) cannot fire: no run container ends exactly at `end`
+            bm = O.OBitmap.from_containers([(k & 15, c) for k, c in rows[r].items()])
+            quirk = any(c.typ == 3 and any(int(l) == (e & 0xFFFF) for _, l in c.data().reshape(-1, 2)) for _, c in bm.items())
+            if not quirk:
+                assert bm.count_range(s, e) == truth, (r, s, e)
+    with pytest.raises(L.FbkError):
+        gpu_ctx.count_range(batch, idx, 5, 4)
+    batch.free()

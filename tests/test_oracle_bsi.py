@@ -163,3 +163,83 @@ def test_executor_level_vectors(B, oracle):
     assert B.groupby_counts(a, b, B.row_from_columns([2, 70000])).tolist() == [[1, 1, 0], [1, 0, 0]]
     # UnionRows
     assert B.columns(B.union_rows(a)) == [0, 1, 2, 3, 70000]
+
+
+def val_count_smaller(a, b):
+    """ValCount.Smaller for integer fields, executor.go:8446-8468; a, b = (val, count)."""
+    if a[1] == 0 or (b[0] < a[0] and b[1] > 0):
+        return b
+    return (a[0], a[1] + (b[1] if a[0] == b[0] else 0))
+
+
+def val_count_larger(a, b):
+    """ValCount.Larger for integer fields, executor.go:8526-8548."""
+    if a[1] == 0 or (b[0] > a[0] and b[1] > 0):
+        return b
+    return (a[0], a[1] + (b[1] if a[0] == b[0] else 0))
+
+
+def test_fragment_minmax_golden(B):
+    """TestFragment_MinMax (fragment_internal_test.go:524-604)."""
+    mc = CASES["minmax_case"]
+    frag = B.bsi_fragment_from_values({v[0]: v[2] for v in mc["values"]}, mc["depth"])
+    for kind, fn in (("min", B.bsi_min), ("max", B.bsi_max)):
+        for t in mc[kind]:
+            flt = B.row_from_columns(t["filter"]) if t["filter"] is not None else None
+            assert fn(frag, flt, mc["depth"]) == (t["exp"], t["cnt"]), (kind, t)
+
+
+def test_minmax_executor_vectors_and_truth(B):
+    """TestExecutor_Execute_MinMax (executor_test.go:2530-2660): f = {0:20, 1:-5, 2:-5, 3:10,
+    SW:30, SW+2:40, 5SW+100:50, SW+1:60}; x=0 -> {0, 3, SW+1}, x=1 -> {1}, x=2 -> {SW+2};
+    Min: (-5,2), (10,1), (-5,1), (40,1); Max: (60,1), (60,1), (-5,1), (40,1).  The per-shard
+    results fold with ValCount.Smaller / Larger; shards without the field contribute (0, 0)."""
+    f = {0: 20, 1: -5, 2: -5, 3: 10, SW: 30, SW + 2: 40, 5 * SW + 100: 50, SW + 1: 60}
+    x = {0: [0, 3, SW + 1], 1: [1], 2: [SW + 2]}
+    exp_min = {None: (-5, 2), 0: (10, 1), 1: (-5, 1), 2: (40, 1)}
+    exp_max = {None: (60, 1), 0: (60, 1), 1: (-5, 1), 2: (40, 1)}
+    depth = 11  # bitDepth of an int field with range (-1110, 1000); Base = 0
+    by_shard = {}
+    for col, val in f.items():
+        by_shard.setdefault(col // SW, {})[col % SW] = val
+    for row in (None, 0, 1, 2):
+        mn, mx = (0, 0), (0, 0)
+        for sh in sorted(by_shard):
+            frag = B.bsi_fragment_from_values(by_shard[sh], depth)
+            if row is None:
+                flt = None
+            else:
+                # executeBitmapCallShard gives an empty Row for a shard without bits
+                flt = B.row_from_columns([c % SW for c in x[row] if c // SW == sh])
+            mn = val_count_smaller(mn, B.bsi_min(frag, flt, depth))
+            mx = val_count_larger(mx, B.bsi_max(frag, flt, depth))
+        assert mn == exp_min[row] and mx == exp_max[row], (row, mn, mx)
+    # randomized: truth is min/max over the python dict
+    rng = np.random.default_rng(11)
+    for trial in range(30):
+        depth = int(rng.integers(1, 64))
+        n = int(rng.integers(1, 300))
+        cols = rng.choice(1 << 20, size=n, replace=False)
+        lim = (1 << depth) - 1
+        kind = trial % 3
+        vals = {}
+        for c in cols:
+            m = int(rng.integers(0, lim + 1)) if depth < 63 else int(rng.integers(0, 1 << 62))
+            if kind == 0:
+                v = m
+            elif kind == 1:
+                v = -m
+            else:
+                v = m if rng.random() < 0.5 else -m
+            vals[int(c)] = v
+        frag = B.bsi_fragment_from_values(vals, depth)
+        fcols = [int(c) for c in cols[::2]] + [12345]
+        for flt_cols in (None, fcols):
+            sel = vals if flt_cols is None else {c: v for c, v in vals.items() if c in set(flt_cols)}
+            flt = None if flt_cols is None else B.row_from_columns(flt_cols)
+            tmin, tmax = min(sel.values()), max(sel.values())
+            assert B.bsi_min(frag, flt, depth) == (tmin, sum(1 for v in sel.values() if v == tmin)), (trial, depth)
+            assert B.bsi_max(frag, flt, depth) == (tmax, sum(1 for v in sel.values() if v == tmax)), (trial, depth)
+    # depth 64 wrap: 1 << 63 as int64 is MinInt64 (Go wraps, fragment.go:795)
+    frag = B.bsi_fragment_from_values({5: (1 << 63) + 3}, 64)
+    assert B.bsi_max(frag, None, 64) == (-(1 << 63) + 3, 1)
