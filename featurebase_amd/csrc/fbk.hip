@@ -17,6 +17,7 @@
 #include "fbk_kernels.hip.h"
 #include "fbk_query_kernels.hip.h"
 #include "fbk_bsi_kernels.hip.h"
+#include "fbk_wire_kernels.hip.h"
 
 using fbk::Slot;
 using fbk::u64;
@@ -895,3 +896,4 @@ int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* 
 }  // extern "C"
 
 #include "fbk_query_api.inc"
+#include "fbk_wire_api.inc"

@@ -114,6 +114,15 @@ class Batch:
             rows[d.row][int(d.key)] = Container(int(d.type), data, int(d.n))
         return rows
 
+    def to_roaring(self) -> bytes:
+        """The batch in the Pilosa roaring format (Bitmap.WriteTo, roaring.go:1730)."""
+        n = C.c_uint64()
+        L.check(self.ctx.lib.fbk_batch_roaring_size(self.ctx.h, self.h, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+        got = C.c_uint64()
+        L.check(self.ctx.lib.fbk_batch_download_roaring(self.ctx.h, self.h, buf.ctypes.data, n.value, C.byref(got)))
+        return buf[: got.value].tobytes()
+
     def free(self) -> None:
         if self.h:
             L.check(self.ctx.lib.fbk_batch_free(self.ctx.h, self.h))
@@ -195,6 +204,16 @@ class Context:
         h = C.c_void_p()
         L.check(self.lib.fbk_batch_upload(self.h, descs, n_desc, len(rows), payload, off, C.byref(h)))
         return Batch(self, h.value)
+
+    def upload_roaring(self, data: bytes) -> Tuple[Batch, np.ndarray]:
+        """A serialised roaring bitmap (Pilosa or official format) -> (batch, row ids): batch row
+        i holds the containers with key >> 4 == row_ids[i] (Bitmap.UnmarshalBinary, roaring.go:1945)."""
+        n = C.c_uint32()
+        h = C.c_void_p()
+        cap = max(len(data) // 2, 1)  # every container takes at least 2 payload bytes
+        ids = np.zeros(cap, dtype=np.uint64)
+        L.check(self.lib.fbk_batch_upload_roaring(self.h, data, len(data), C.byref(h), ids.ctypes.data, cap, C.byref(n)))
+        return Batch(self, h.value), ids[: n.value].copy()
 
     def upload_dense(self, words: np.ndarray) -> Batch:
         w = np.ascontiguousarray(words, dtype=np.uint64)

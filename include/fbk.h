@@ -148,6 +148,29 @@ int32_t fbk_batch_info(fbk_ctx* ctx, const fbk_batch* batch, uint32_t* n_rows,
 int32_t fbk_batch_download(fbk_ctx* ctx, const fbk_batch* batch, fbk_container_desc* descs_out,
                            uint64_t descs_cap, void* payload_out, uint64_t payload_cap);
 
+/* ---- serialised roaring (the reference's interchange format) ------------------------------
+ * fbk_batch_upload_roaring makes the containers of ONE serialised bitmap device resident:
+ * either the Pilosa format Bitmap.WriteTo emits (roaring.go:1730-1817: cookie 12348, 12-byte
+ * {key u64, type u16, N-1 u16} headers, u32 offsets, payloads with a u16 count prefix on run
+ * containers, :4054-4108) or the official RoaringBitmap format (cookies 12346 / 12347,
+ * readOfficialHeader roaring.go:6948-7006, runs stored {start, length-1} and converted on
+ * read, :2239-2247).  It replaces Bitmap.UnmarshalBinary / NewRoaringIterator
+ * (roaring.go:1945-2262) + the per-container copy into fragment storage
+ * (ImportRoaringBits, fragment.go:2038-2165): the blob crosses PCIe once and is unpacked by a
+ * device kernel.  Batch row i holds the containers whose key >> 4 equals out_row_ids[i]
+ * (ascending; for fragment storage that is the row ID, for a serialised Row the shard number);
+ * slot = key & 15.  out_row_ids may be NULL; *out_n_rows is always set. */
+int32_t fbk_batch_upload_roaring(fbk_ctx* ctx, const void* data, uint64_t len, fbk_batch** out_batch,
+                                 uint64_t* out_row_ids, uint32_t row_cap, uint32_t* out_n_rows);
+
+/* Serialise a batch in the Pilosa format (what Bitmap.WriteTo / writeToUnoptimized write,
+ * roaring.go:1730-1817): non-empty containers in (row, slot) order, whose keys must be
+ * strictly ascending.  Containers are written in their current encoding — WriteTo runs
+ * Optimize() first, so produce the batch with FBK_SETOP_OPTIMIZE to get byte-identical
+ * output.  fbk_batch_roaring_size reports the bytes needed. */
+int32_t fbk_batch_roaring_size(fbk_ctx* ctx, const fbk_batch* batch, uint64_t* out_bytes);
+int32_t fbk_batch_download_roaring(fbk_ctx* ctx, const fbk_batch* batch, void* out, uint64_t cap, uint64_t* out_len);
+
 /* ---- counts -------------------------------------------------------------------- */
 
 /* out[i] = Row.Count of rows[i]: sum of stored container N (roaring.go:542,

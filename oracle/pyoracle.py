@@ -22,7 +22,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("roaring_oracle.c", "bsi_oracle.c", "roaring_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("roaring_oracle.c", "bsi_oracle.c", "wire_oracle.c", "roaring_oracle.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libroaring_oracle.so"])
     return LIB_PATH
@@ -89,6 +89,9 @@ def lib() -> C.CDLL:
             "orc_count_kernel": (i32, [C.c_char_p, vp, vp]),
             "orc_dense_intersection_count": (u64, [vp, vp, u64, vp]),
             "orc_dense_intersect_count": (u64, [vp, vp, u64, vp, vp]),
+            "orc_roaring_marshal": (vp, [vp, i32, C.POINTER(u64)]),
+            "orc_wire_free": (None, [vp]),
+            "orc_roaring_unmarshal": (vp, [C.c_char_p, u64, C.POINTER(i32)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -338,6 +341,25 @@ class OBitmap:
 
     def difference(self, *others: "OBitmap") -> "OBitmap":
         return self._multi(lib().orc_bitmap_difference, others)
+
+    def marshal(self, optimize_first: bool = True) -> bytes:
+        """Bitmap.WriteTo (roaring.go:1730): Pilosa roaring format."""
+        n = C.c_uint64()
+        p = lib().orc_roaring_marshal(self.p, 1 if optimize_first else 0, C.byref(n))
+        try:
+            return C.string_at(p, n.value)
+        finally:
+            lib().orc_wire_free(p)
+
+    @staticmethod
+    def unmarshal(data: bytes) -> "OBitmap":
+        """Bitmap.UnmarshalBinary (Pilosa or official roaring format); ValueError on the
+        conditions the reference's iterators report as errors."""
+        err = C.c_int32()
+        p = lib().orc_roaring_unmarshal(data, len(data), C.byref(err))
+        if err.value or not p:
+            raise ValueError("malformed roaring data")
+        return OBitmap(p)
 
     def slice(self) -> List[int]:
         """All set bit positions (Bitmap.Slice, roaring.go:623)."""

@@ -159,6 +159,12 @@ void orc_groupby_counts(const orc_bitmap* const* a_rows, int32_t na, const orc_b
 /* BitmapRowsUnion (roaring/filter.go:294) */
 orc_bitmap* orc_union_rows(const orc_bitmap* const* rows, int32_t n_rows);
 
+/* ---- serialisation (wire_oracle.c): Bitmap.WriteTo (roaring.go:1730-1817) and
+ * UnmarshalBinary through NewRoaringIterator (:1945-2262), Pilosa and official formats ---- */
+uint8_t* orc_roaring_marshal(const orc_bitmap* b, int32_t optimize, uint64_t* out_len);
+void orc_wire_free(uint8_t* p);
+orc_bitmap* orc_roaring_unmarshal(const uint8_t* data, uint64_t len, int32_t* err);
+
 /* every worker thread makes `passes` passes over its own chunk of row pairs */
 uint64_t orc_dense_intersection_count_mt(const uint64_t* a, const uint64_t* b, uint64_t n_pairs, uint64_t* out_counts,
                                          int32_t n_threads, uint64_t passes);
