@@ -413,3 +413,34 @@ def test_count_range_vs_oracle(gpu_ctx, oracle):
     with pytest.raises(L.FbkError):
         gpu_ctx.count_range(batch, idx, 5, 4)
     batch.free()
+
+
+@pytest.mark.parametrize("n_shards,n_a,n_b,use_filter", [(3, 32, 32, True), (2, 37, 45, False), (5, 5, 3, True), (1, 1, 2, False), (9, 64, 33, True)])
+def test_count_matrix_dense_kernel_vs_numpy(gpu_ctx, n_shards, n_a, n_b, use_filter):
+    """The all-bitmap fast path of fbk_count_matrix (k_count_matrix_dense: chunked B ring in
+    LDS, per-lane accumulators, one transposing reduction) against numpy popcounts: full
+    matrix, per shard and in total, ragged tile edges, with and without the filter row."""
+    wa = D.dense_rows(n_shards * n_a, 0.3, 811)
+    wb = D.dense_rows(n_shards * n_b, 0.6, 812)
+    wf = D.dense_rows(n_shards, 0.5, 813)
+    wa[-1] = 0  # an empty row
+    wb[0] = np.uint64(0xFFFFFFFFFFFFFFFF)  # a full row
+    A, Bt = gpu_ctx.upload_dense(wa), gpu_ctx.upload_dense(wb)
+    F = gpu_ctx.upload_dense(wf) if use_filter else None
+    rng = np.random.default_rng(5)
+    ra = np.stack([rng.permutation(n_a) + s * n_a for s in range(n_shards)])  # rows in any order
+    rb = np.stack([rng.permutation(n_b) + s * n_b for s in range(n_shards)])
+    rf = np.arange(n_shards)
+    tot, ps = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf if use_filter else None, per_shard=True)
+    exp = np.zeros((n_shards, n_a, n_b), dtype=np.uint64)
+    for s in range(n_shards):
+        for i in range(n_a):
+            x = wa[ra[s, i]] & wf[s] if use_filter else wa[ra[s, i]]
+            for j in range(n_b):
+                exp[s, i, j] = np.bitwise_count(x & wb[rb[s, j]]).sum()
+    assert (ps == exp).all()
+    assert (tot == exp.sum(axis=0)).all()
+    A.free()
+    Bt.free()
+    if F is not None:
+        F.free()
