@@ -56,6 +56,8 @@ SIGNATURES = {
     "fbk_batch_upload": (C.c_int32, [_vp, C.POINTER(ContainerDesc), C.c_uint64, C.c_uint32, _vp, C.c_uint64, _vpp]),
     "fbk_batch_upload_dense": (C.c_int32, [_vp, _vp, C.c_uint32, _vpp]),
     "fbk_batch_upload_roaring": (C.c_int32, [_vp, _vp, C.c_uint64, _vpp, _vp, C.c_uint32, _u32p]),
+    "fbk_rbf_find_root": (C.c_int32, [_vp, C.c_uint64, C.c_char_p, _u32p]),
+    "fbk_batch_upload_rbf": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, _vpp, _vp, C.c_uint32, _u32p]),
     "fbk_batch_roaring_size": (C.c_int32, [_vp, _vp, _u64p]),
     "fbk_batch_download_roaring": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, _u64p]),
     "fbk_batch_free": (C.c_int32, [_vp, _vp]),

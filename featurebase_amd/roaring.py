@@ -215,6 +215,20 @@ class Context:
         L.check(self.lib.fbk_batch_upload_roaring(self.h, data, len(data), C.byref(h), ids.ctypes.data, cap, C.byref(n)))
         return Batch(self, h.value), ids[: n.value].copy()
 
+    def rbf_find_root(self, file_bytes: bytes, name: str) -> int:
+        pg = C.c_uint32()
+        L.check(self.lib.fbk_rbf_find_root(file_bytes, len(file_bytes), name.encode(), C.byref(pg)))
+        return pg.value
+
+    def upload_rbf(self, file_bytes: bytes, root_pgno: int) -> Tuple[Batch, np.ndarray]:
+        """One bitmap b-tree of an RBF file image -> (batch, row ids) (rbf/tx.go ContainerIterator)."""
+        n = C.c_uint32()
+        h = C.c_void_p()
+        cap = max(len(file_bytes) // 20, 1)  # a leaf cell takes at least 18 + 2 bytes
+        ids = np.zeros(cap, dtype=np.uint64)
+        L.check(self.lib.fbk_batch_upload_rbf(self.h, file_bytes, len(file_bytes), root_pgno, C.byref(h), ids.ctypes.data, cap, C.byref(n)))
+        return Batch(self, h.value), ids[: n.value].copy()
+
     def upload_dense(self, words: np.ndarray) -> Batch:
         w = np.ascontiguousarray(words, dtype=np.uint64)
         assert w.size % (SLOTS * BITMAP_WORDS) == 0

@@ -163,6 +163,19 @@ int32_t fbk_batch_download(fbk_ctx* ctx, const fbk_batch* batch, fbk_container_d
 int32_t fbk_batch_upload_roaring(fbk_ctx* ctx, const void* data, uint64_t len, fbk_batch** out_batch,
                                  uint64_t* out_row_ids, uint32_t row_cap, uint32_t* out_n_rows);
 
+/* RBF, the reference's storage file (rbf/rbf.go): make the containers of ONE bitmap b-tree
+ * (one fragment: index/field/view/shard, rbf.go rbfName) device resident straight from the file
+ * image.  `file` is the database file (or mmap) from page 0; `root_pgno` the bitmap's root page
+ * (fbk_rbf_find_root resolves a name through the root records, rbf.go:222-255).  The host walks
+ * branch pages and reads cell headers (rbf.go:488-520, 616-626); array / RLE cell payloads and
+ * the 8 KiB pages that BitmapPtr cells point to are moved into the arena by the device unpack
+ * kernel after ONE H2D copy of the file image.  Replaces Tx.ContainerIterator / OffsetRange ->
+ * cursor -> toContainer (rbf/tx.go:1333, 1586-1638, rbf/cursorx.go:230-266).  Row mapping as
+ * fbk_batch_upload_roaring: batch row i holds keys with key >> 4 == out_row_ids[i]. */
+int32_t fbk_rbf_find_root(const void* file, uint64_t len, const char* name, uint32_t* out_pgno);
+int32_t fbk_batch_upload_rbf(fbk_ctx* ctx, const void* file, uint64_t len, uint32_t root_pgno, fbk_batch** out_batch,
+                             uint64_t* out_row_ids, uint32_t row_cap, uint32_t* out_n_rows);
+
 /* Serialise a batch in the Pilosa format (what Bitmap.WriteTo / writeToUnoptimized write,
  * roaring.go:1730-1817): non-empty containers in (row, slot) order, whose keys must be
  * strictly ascending.  Containers are written in their current encoding — WriteTo runs

@@ -1,0 +1,69 @@
+"""GPU parity for fbk_batch_upload_rbf: RBF file image -> device resident rows, against the
+oracle's page reader; the reference-written fixture file; malformed trees are rejected."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import datagen as D
+from featurebase_amd import lib as L
+from test_oracle_rbf import FIX, fixture_file, random_fragment
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_written_file_on_gpu(gpu_ctx):
+    f = fixture_file()
+    root = gpu_ctx.rbf_find_root(f, FIX["bitmap"])
+    assert root == FIX["expect"]["root_pgno"]
+    batch, ids = gpu_ctx.upload_rbf(f, root)
+    rows = batch.download()
+    assert ids.tolist() == [0] and list(rows[0]) == [0]
+    c = rows[0][0]
+    assert c.typ == L.TYPE_ARRAY and c.n == 1 and c.data.tolist() == [100]
+    batch.free()
+    with pytest.raises(L.FbkError):
+        gpu_ctx.rbf_find_root(f, "nope")  # ErrBitmapNotFound
+
+
+def test_bad_bitmap_file_is_rejected(gpu_ctx):
+    """rbf/testdata/check/bad-bitmap: a branch cell points at pgno 65537 of a 4-page file
+    (rbf/tx_test.go:1293-1305)."""
+    f = b"".join(bytes.fromhex(h).ljust(8192, b"\0") for h in FIX["bad_bitmap_pages_hex_prefix"])
+    root = gpu_ctx.rbf_find_root(f, "x")
+    with pytest.raises(L.FbkError, match="out of bounds"):
+        gpu_ctx.upload_rbf(f, root)
+
+
+def test_fragment_trees_vs_oracle_reader(gpu_ctx, oracle):
+    from oracle import pyrbf
+
+    rng = D.rng_for(99)
+    frag = random_fragment(rng, 60, oracle)
+    other = random_fragment(rng, 2, oracle)
+    f = pyrbf.write_db({"i/f/standard/0": frag, "i/g/standard/7": other}, leaf_cells_per_page=7, branch_fanout=5)
+    for name, conts in (("i/f/standard/0", frag), ("i/g/standard/7", other)):
+        root = gpu_ctx.rbf_find_root(f, name)
+        assert root == pyrbf.find_root(f, name)
+        batch, ids = gpu_ctx.upload_rbf(f, root)
+        assert ids.tolist() == sorted({k >> 4 for k, _, _, _ in conts})
+        rows = batch.download()
+        got = {k: c for row in rows for k, c in row.items()}
+        assert sorted(got) == [k for k, _, _, _ in conts]
+        for k, t, n, payload in conts:
+            c = got[k]
+            assert (c.typ, c.n) == (t, n), k
+            assert np.array_equal(np.asarray(c.data).reshape(-1), np.asarray(payload).reshape(-1)), k
+        # uploaded rows behave like any other batch rows: row counts = sum of BitN
+        cnt = batch.count(np.arange(len(ids)))
+        for i, rid in enumerate(ids):
+            assert int(cnt[i]) == sum(n for k, _, n, _ in conts if k >> 4 == int(rid))
+        # and the RBF image re-serialises as the Pilosa roaring image of the same containers
+        items = []
+        for k, t, n, payload in conts:
+            oc = {1: oracle.OContainer.array, 3: lambda p: oracle.OContainer.run([tuple(x) for x in np.asarray(p).reshape(-1, 2)]),
+                  2: oracle.OContainer.bitmap}[t](payload)
+            items.append((k, oc))
+        assert batch.to_roaring() == oracle.OBitmap.from_containers(items).marshal(False)
+        batch.free()
