@@ -63,6 +63,11 @@ struct fbk_ctx {
   std::unordered_map<void*, uint64_t> pool_live;  // block -> bucket size
   uint64_t pool_cached_bytes = 0;
   uint64_t pool_cap_bytes = 8ull << 30;
+  // device fragment cache (fbk_cache_api.inc)
+  std::unordered_map<std::string, struct fbk_cache_entry*> cache;
+  std::vector<struct fbk_cache_entry*> cache_zombies;  // invalidated while pinned
+  uint64_t cache_bytes = 0, cache_cap_bytes = 128ull << 30, cache_clock = 0;
+  uint64_t cache_hits = 0, cache_misses = 0, cache_evictions = 0;
 };
 
 // Host mirror of one device-resident batch.
@@ -150,6 +155,8 @@ void pool_release_all(fbk_ctx* ctx) {
   ctx->pool_free_lists.clear();
   ctx->pool_cached_bytes = 0;
 }
+
+void cache_release_all(fbk_ctx* ctx);  // fbk_cache_api.inc needs fbk_batch: defined after it
 
 struct DevBuf {
   fbk_ctx* c = nullptr;
@@ -247,6 +254,7 @@ int32_t fbk_close(fbk_ctx* ctx) {
   if (!ctx) return FBK_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  cache_release_all(ctx);
   pool_release_all(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -899,3 +907,4 @@ int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* 
 
 #include "fbk_query_api.inc"
 #include "fbk_wire_api.inc"
+#include "fbk_cache_api.inc"

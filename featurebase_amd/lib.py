@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfbk.so")
 
 FBK_OK = 0
-FBK_E_INVALID, FBK_E_NODEVICE, FBK_E_HIP, FBK_E_NOMEM, FBK_E_CAPACITY = -1, -2, -3, -4, -5
+FBK_E_INVALID, FBK_E_NODEVICE, FBK_E_HIP, FBK_E_NOMEM, FBK_E_CAPACITY, FBK_E_NOTFOUND = -1, -2, -3, -4, -5, -6
 TYPE_NIL, TYPE_ARRAY, TYPE_BITMAP, TYPE_RUN = 0, 1, 2, 3
 OP_AND, OP_OR, OP_XOR, OP_ANDNOT = 0, 1, 2, 3
 SETOP_KEEP_BITMAP, SETOP_OPTIMIZE = 0, 1
@@ -63,6 +63,12 @@ SIGNATURES = {
     "fbk_batch_free": (C.c_int32, [_vp, _vp]),
     "fbk_batch_info": (C.c_int32, [_vp, _vp, _u32p, _u64p, _u64p]),
     "fbk_batch_download": (C.c_int32, [_vp, _vp, C.POINTER(ContainerDesc), C.c_uint64, _vp, C.c_uint64]),
+    "fbk_cache_put": (C.c_int32, [_vp, C.c_char_p, C.c_uint64, _vp, _vp, C.c_uint32]),
+    "fbk_cache_get": (C.c_int32, [_vp, C.c_char_p, C.c_uint64, _vpp, _vpp, _u32p]),
+    "fbk_cache_release": (C.c_int32, [_vp, _vp]),
+    "fbk_cache_invalidate": (C.c_int32, [_vp, C.c_char_p, _u32p]),
+    "fbk_cache_configure": (C.c_int32, [_vp, C.c_uint64]),
+    "fbk_cache_stats": (C.c_int32, [_vp, _u64p, _u64p, _u64p, _u64p, _u64p]),
     "fbk_count": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, _vp]),
     "fbk_count_range": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
     "fbk_intersection_count": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),

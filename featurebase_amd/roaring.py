@@ -81,6 +81,7 @@ class Batch:
     def __init__(self, ctx: "Context", handle: int):
         self.ctx = ctx
         self.h = C.c_void_p(handle)
+        self.owned = True  # False once handed to the device fragment cache
 
     def info(self) -> Tuple[int, int, int]:
         nr, nc, pb = C.c_uint32(), C.c_uint64(), C.c_uint64()
@@ -124,9 +125,9 @@ class Batch:
         return buf[: got.value].tobytes()
 
     def free(self) -> None:
-        if self.h:
+        if self.h and self.owned:
             L.check(self.ctx.lib.fbk_batch_free(self.ctx.h, self.h))
-            self.h = C.c_void_p(None)
+        self.h = C.c_void_p(None)
 
 
 class Plan:
@@ -238,6 +239,41 @@ class Context:
         return Batch(self, h.value)
 
     # -- one-shot ops -----------------------------------------------------------------
+    # -- device fragment cache ------------------------------------------------------------
+    def cache_put(self, key: str, version: int, batch: Batch, row_ids) -> None:
+        """The cache takes ownership of `batch` (do not free it)."""
+        ids = np.ascontiguousarray(row_ids, dtype=np.uint64)
+        L.check(self.lib.fbk_cache_put(self.h, key.encode(), version, batch.h, ids.ctypes.data, ids.size))
+        batch.owned = False
+
+    def cache_get(self, key: str, version: int) -> Optional[Tuple[Batch, np.ndarray]]:
+        """Pinned (batch, row ids) or None on a miss; call cache_release(batch) when done."""
+        h, ids, n = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        rc = self.lib.fbk_cache_get(self.h, key.encode(), version, C.byref(h), C.byref(ids), C.byref(n))
+        if rc == L.FBK_E_NOTFOUND:
+            return None
+        L.check(rc)
+        b = Batch(self, h.value)
+        b.owned = False
+        rid = np.ctypeslib.as_array(C.cast(ids, C.POINTER(C.c_uint64)), shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+        return b, rid
+
+    def cache_release(self, batch: Batch) -> None:
+        L.check(self.lib.fbk_cache_release(self.h, batch.h))
+
+    def cache_invalidate(self, key_prefix: str) -> int:
+        n = C.c_uint32()
+        L.check(self.lib.fbk_cache_invalidate(self.h, key_prefix.encode(), C.byref(n)))
+        return n.value
+
+    def cache_configure(self, cap_bytes: int) -> None:
+        L.check(self.lib.fbk_cache_configure(self.h, cap_bytes))
+
+    def cache_stats(self) -> dict:
+        v = [C.c_uint64() for _ in range(5)]
+        L.check(self.lib.fbk_cache_stats(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("entries", "bytes", "hits", "misses", "evictions"), (x.value for x in v)))
+
     def intersection_count(self, a: Batch, rows_a, b: Batch, rows_b) -> np.ndarray:
         ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
         rb = np.ascontiguousarray(rows_b, dtype=np.uint32)

@@ -59,6 +59,7 @@ extern "C" {
 #define FBK_E_HIP (-3)       /* HIP runtime error (message has hipGetErrorString) */
 #define FBK_E_NOMEM (-4)     /* host or device allocation failed */
 #define FBK_E_CAPACITY (-5)  /* caller-provided output buffer too small */
+#define FBK_E_NOTFOUND (-6)  /* cache miss (absent or stale entry) */
 
 /* container type codes — identical to roaring/roaring.go:53-58 */
 #define FBK_TYPE_NIL 0
@@ -183,6 +184,31 @@ int32_t fbk_batch_upload_rbf(fbk_ctx* ctx, const void* file, uint64_t len, uint3
  * output.  fbk_batch_roaring_size reports the bytes needed. */
 int32_t fbk_batch_roaring_size(fbk_ctx* ctx, const fbk_batch* batch, uint64_t* out_bytes);
 int32_t fbk_batch_download_roaring(fbk_ctx* ctx, const fbk_batch* batch, void* out, uint64_t cap, uint64_t* out_len);
+
+/* ---- device fragment cache ----------------------------------------------------------------
+ * The reference re-materialises a row from storage on every use (fragment.row,
+ * fragment.go:283-333; zero-copy views of mmapped pages valid inside one Tx,
+ * rbf/cursorx.go:243-247).  On the GPU the steady state keeps a fragment's rows resident:
+ * entries are keyed by the reference's fragment identity ("index/field/view/shard", the RBF
+ * bitmap name) and carry a version the host bumps whenever the fragment is written (every
+ * write path of fragment.go ends in one Tx commit), so a stale entry is a miss.
+ *   put        hands a batch (and the row ids fbk_batch_upload_rbf/_roaring returned) to the
+ *              cache, which now owns it; an existing entry under the key is replaced.
+ *   get        FBK_OK + the batch pinned for the caller, or FBK_E_NOTFOUND (absent / other
+ *              version; a stale entry is dropped).  The pointers stay valid until release.
+ *   release    unpins; invalidated or evicted entries are freed at their last release.
+ *   invalidate drops every entry whose key starts with key_prefix ("" = everything).
+ *   configure  sets the byte budget (default 128 GiB of the 288 GB HBM); least recently used
+ *              unpinned entries are evicted beyond it. */
+int32_t fbk_cache_put(fbk_ctx* ctx, const char* key, uint64_t version, fbk_batch* batch, const uint64_t* row_ids,
+                      uint32_t n_row_ids);
+int32_t fbk_cache_get(fbk_ctx* ctx, const char* key, uint64_t version, const fbk_batch** out_batch,
+                      const uint64_t** out_row_ids, uint32_t* out_n_row_ids);
+int32_t fbk_cache_release(fbk_ctx* ctx, const fbk_batch* batch);
+int32_t fbk_cache_invalidate(fbk_ctx* ctx, const char* key_prefix, uint32_t* out_dropped);
+int32_t fbk_cache_configure(fbk_ctx* ctx, uint64_t cap_bytes);
+int32_t fbk_cache_stats(fbk_ctx* ctx, uint64_t* entries, uint64_t* bytes, uint64_t* hits, uint64_t* misses,
+                        uint64_t* evictions);
 
 /* ---- counts -------------------------------------------------------------------- */
 

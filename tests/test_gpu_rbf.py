@@ -67,3 +67,59 @@ def test_fragment_trees_vs_oracle_reader(gpu_ctx, oracle):
             items.append((k, oc))
         assert batch.to_roaring() == oracle.OBitmap.from_containers(items).marshal(False)
         batch.free()
+
+
+def test_fragment_cache_hit_miss_invalidate_evict(gpu_ctx, oracle):
+    """Device fragment cache: resident fragments keyed by the RBF bitmap name + a write
+    version; pin / release, stale versions, prefix invalidation, LRU eviction by bytes."""
+    from oracle import pyrbf
+
+    ctx = gpu_ctx
+    ctx.cache_invalidate("")
+    base = ctx.cache_stats()
+    rng = D.rng_for(101)
+    frags = {f"i/f/standard/{s}": random_fragment(rng, 6, oracle) for s in range(4)}
+    f = pyrbf.write_db(frags)
+    sizes = {}
+    for name in frags:
+        batch, ids = ctx.upload_rbf(f, ctx.rbf_find_root(f, name))
+        ctx.cache_put(name, 7, batch, ids)
+    st = ctx.cache_stats()
+    assert st["entries"] == 4 and st["bytes"] > 0
+    # hit: same version; the pinned batch works like any batch
+    got = ctx.cache_get("i/f/standard/2", 7)
+    assert got is not None
+    b2, ids2 = got
+    assert ids2.tolist() == sorted({k >> 4 for k, _, _, _ in frags["i/f/standard/2"]})
+    cnt = b2.count(np.arange(len(ids2)))
+    assert int(cnt.sum()) == sum(n for _, _, n, _ in frags["i/f/standard/2"])
+    # miss: unknown key, and a newer version (the fragment was written) drops the stale entry
+    assert ctx.cache_get("i/f/standard/9", 7) is None
+    assert ctx.cache_get("i/f/standard/1", 8) is None
+    assert ctx.cache_stats()["entries"] == 3
+    # invalidating a pinned entry keeps it alive until release
+    assert ctx.cache_invalidate("i/f/standard/2") == 1
+    assert int(b2.count(np.arange(len(ids2))).sum()) == int(cnt.sum())
+    ctx.cache_release(b2)
+    with pytest.raises(L.FbkError):
+        ctx.cache_release(b2)  # no longer a cache entry
+    assert ctx.cache_get("i/f/standard/2", 7) is None
+    # prefix invalidation of the rest of the field
+    assert ctx.cache_invalidate("i/f/") == 2
+    assert ctx.cache_stats()["entries"] == 0
+    # LRU eviction: cap below two entries keeps only the most recently used
+    for name in list(frags)[:3]:
+        batch, ids = ctx.upload_rbf(f, ctx.rbf_find_root(f, name))
+        ctx.cache_put(name, 1, batch, ids)
+    one = ctx.cache_stats()["bytes"] // 3
+    g0 = ctx.cache_get("i/f/standard/0", 1)  # touch 0: now most recent
+    ctx.cache_release(g0[0])
+    ctx.cache_configure(int(one * 1.5))
+    st = ctx.cache_stats()
+    assert st["entries"] == 1 and st["evictions"] - base["evictions"] == 2
+    assert ctx.cache_get("i/f/standard/1", 1) is None
+    g0 = ctx.cache_get("i/f/standard/0", 1)
+    assert g0 is not None
+    ctx.cache_release(g0[0])
+    ctx.cache_configure(128 << 30)
+    ctx.cache_invalidate("")
