@@ -9,22 +9,26 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cpp", "test_row_api.cpp")
 BIN = os.path.join(ROOT, "build", "test_row_api")
+SRC_EXEC = os.path.join(ROOT, "tests", "cpp", "test_executor_api.cpp")
+BIN_EXEC = os.path.join(ROOT, "build", "test_executor_api")
 
 
-def compile_it():
+def compile_it(src=SRC, out=BIN):
     import __graft_entry__ as g
 
     g.build()
-    os.makedirs(os.path.dirname(BIN), exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     lib = os.path.join(ROOT, "featurebase_amd", "csrc")
     subprocess.check_call(
-        ["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), SRC, "-L", lib, "-lfbk", f"-Wl,-rpath,{lib}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", BIN]
+        ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-L", lib, "-lfbk", f"-Wl,-rpath,{lib}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", out]
     )
 
 
 def test_cpp_host_mirror_compiles():
     compile_it()
     assert os.path.exists(BIN)
+    compile_it(SRC_EXEC, BIN_EXEC)
+    assert os.path.exists(BIN_EXEC)
 
 
 @pytest.mark.gpu
@@ -33,3 +37,13 @@ def test_cpp_host_mirror_row_vectors_on_gpu():
     out = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "row api ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_executor_mirror_vectors_on_gpu():
+    """executor_test.go vectors (set-ops, TopK, Sum, Min/Max, ranges, GroupBy) through
+    include/fbk_executor.hpp, every operator on the GPU."""
+    compile_it(SRC_EXEC, BIN_EXEC)
+    out = subprocess.run([BIN_EXEC], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "executor api ok" in out.stdout
