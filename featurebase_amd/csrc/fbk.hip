@@ -17,6 +17,7 @@
 #include "fbk_kernels.hip.h"
 #include "fbk_query_kernels.hip.h"
 #include "fbk_fold_kernels.hip.h"
+#include "fbk_topk_kernels.hip.h"
 #include "fbk_bsi_kernels.hip.h"
 #include "fbk_matrix_kernels.hip.h"
 #include "fbk_wire_kernels.hip.h"

@@ -444,3 +444,48 @@ def test_count_matrix_dense_kernel_vs_numpy(gpu_ctx, n_shards, n_a, n_b, use_fil
     Bt.free()
     if F is not None:
         F.free()
+
+
+def test_rows_vs_filter_kernel_vs_oracle(gpu_ctx, oracle):
+    """fbk_count_matrix with one B row per shard and no extra filter = doTopK / fragment.top:
+    every encoding of the rows against every encoding of the filter, incl. full / empty / nil
+    containers, arrays past 4096 values and long run lists; 150 rows so that several row chunks
+    and a ragged last chunk are exercised."""
+    O = oracle
+    rng = D.rng_for(53)
+    n_shards, n_a = 3, 150
+    rows, ra = [], []
+    for s in range(n_shards):
+        ids = []
+        for i in range(n_a):
+            row = D.random_row(rng, s)
+            if i % 17 == 0:
+                row[s * 16 + 5] = O.OContainer.run([(0, 65535)])
+            if i % 19 == 0:
+                row[s * 16 + 6] = O.OContainer.array(np.sort(rng.choice(65536, size=6000, replace=False)))
+            if i % 23 == 0:
+                row[s * 16 + 7] = O.OContainer.run([(j * 20, j * 20 + 7) for j in range(3000)])
+            ids.append(len(rows))
+            rows.append(row)
+        ra.append(ids)
+    filt = []
+    for s in range(n_shards):
+        f = D.random_row(rng, s)
+        f[s * 16 + 0] = O.OContainer.bitmap(rng.integers(0, 1 << 63, size=1024, dtype=np.uint64))
+        f[s * 16 + 1] = O.OContainer.array(np.sort(rng.choice(65536, size=900, replace=False)))
+        f[s * 16 + 2] = O.OContainer.run([(100, 40000), (50000, 50001)])
+        f[s * 16 + 3] = O.OContainer.run([(0, 65535)])
+        f.pop(s * 16 + 4, None)  # nil filter slot: nothing counts there
+        filt.append(f)
+    A = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+    F = gpu_ctx.upload([D.to_fbk_row(r) for r in filt])
+    tot, ps = gpu_ctx.count_matrix(A, np.array(ra), F, np.arange(n_shards).reshape(-1, 1), per_shard=True)
+    exp = np.zeros((n_shards, n_a), dtype=np.uint64)
+    for s in range(n_shards):
+        for i in range(n_a):
+            r = rows[ra[s][i]]
+            exp[s, i] = sum(O.intersection_count(r[k], filt[s][k]) for k in r if k in filt[s])
+    assert (ps[:, :, 0] == exp).all()
+    assert (tot[:, 0] == exp.sum(axis=0)).all()
+    A.free()
+    F.free()
