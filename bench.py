@@ -34,6 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: one HIP runtime per process, see featurebase_amd/lib.py)
 
 SHARDS_PER_GPU = 1024
+REDUCE_BUCKET = 16  # steps per RCCL all-reduce when N > 1
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
@@ -113,20 +114,24 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n_gpus = max(world, 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (FBK_BENCH_BACKEND=gloo lets the N > 1 code path be smoke-tested on
+    # a single-GPU box: every rank then shares device 0 and the collectives go through gloo.)
+    backend = os.environ.get("FBK_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if n_gpus > 1:
         import torch.distributed as dist
 
         from featurebase_amd import dist as fdist
 
-        fdist.init("nccl", dev)  # backend "nccl" IS RCCL on ROCm
+        fdist.init(backend, dev)  # backend "nccl" IS RCCL on ROCm
 
     import datagen as D
     from featurebase_amd import lib as L
     from featurebase_amd.roaring import Context
 
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     stream = torch.cuda.Stream(device=dev)  # non-default: its handle is what fbk launches on
     ctx.set_stream(stream.cuda_stream)
 
@@ -144,11 +149,17 @@ def main():
         total = torch.zeros(1, dtype=torch.int64, device=dev)
     plan = ctx.plan(A, rows, B, rows, device_counts_ptr=counts.data_ptr())
 
+    # N > 1: the per-node totals of consecutive steps are all-reduced over RCCL/xGMI in buckets
+    # of REDUCE_BUCKET steps, asynchronously (featurebase_amd/dist.py BucketedCountReducer)
+    red = fdist.BucketedCountReducer(REDUCE_BUCKET, dev) if n_gpus > 1 else None
+
     def step():
         plan.intersection_count()  # per-shard |a ∩ b|
-        plan.total(total.data_ptr())  # per-node reduce
-        if n_gpus > 1:
-            fdist.all_reduce_counts(total)  # RCCL sum of the partial counts over xGMI
+        if red is None:
+            plan.total(total.data_ptr())  # per-node reduce
+        else:
+            plan.total(red.slot_ptr())  # per-node reduce into the bucket slot of this step
+            red.advance()  # RCCL sum of the partial counts over xGMI once the bucket is full
 
     def barrier():
         if n_gpus > 1:
@@ -157,12 +168,16 @@ def main():
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             step()
+        if red is not None:
+            red.flush()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        if red is not None:
+            reduced = red.flush()  # the tail bucket + every outstanding collective: inside the timed region
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -174,6 +189,13 @@ def main():
         assert int(got_counts.sum()) == local_expected, "GPU result differs from numpy popcount"
         if n_gpus == 1:
             assert int(total.item()) == local_expected
+        else:
+            # every reduced slot must hold the sum over ranks of the per-rank expected counts
+            ge = torch.tensor([local_expected], dtype=torch.int64, device=dev)
+            dist.all_reduce(ge)
+            vals = torch.cat([b for b in reduced]).cpu().numpy()
+            vals = vals[vals != 0]
+            assert vals.size > 0 and (vals == int(ge.item())).all(), "all-reduced totals differ from the sum of per-rank counts"
 
         # ---- roofline of the dominant kernel: HIP events around back-to-back launches
         # of k_icount_dense alone, on the stream it is launched on
@@ -263,7 +285,8 @@ def main():
                 "workload": "configs[1]: per GPU 1024 shards x 2 rows x 2^20 cols, bitmap x bitmap AND+popcount, density 50%",
                 "shards_per_gpu": n,
                 "containers_per_gpu": 2 * n * 16,
-                "op": "Count(Intersect(Row,Row)) as IntersectionCount + per-node sum" + (" + RCCL all-reduce" if n_gpus > 1 else ""),
+                "op": "Count(Intersect(Row,Row)) as IntersectionCount + per-node sum"
+                + (f" + RCCL all-reduce of the partial totals ({REDUCE_BUCKET} steps per collective, async)" if n_gpus > 1 else ""),
                 "parallelism": f"shards/{n_gpus}gpu",
             },
             "bits_scanned_GBps": n_gpus * 2 * n * 16 * 8192 / (dt / args.steps) / 1e9,

@@ -93,3 +93,55 @@ def test_two_ranks_reduce_to_single_process_result():
         assert total == exp_total and mat == exp_mat, (rank, total, exp_total)
         seen += mine
     assert sorted(seen) == list(range(n_shards))
+
+
+def _bucket_worker(rank: int, world: int, port: int, steps: int, bucket: int, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from featurebase_amd import dist as fd
+
+    fd.init("gloo")
+    red = fd.BucketedCountReducer(bucket)
+    seen = []
+    for k in range(steps):
+        if red.fill == 0 and k >= 2 * bucket:
+            # the bucket about to be refilled holds reduced values of steps k-2*bucket .. k-bucket-1
+            red._free(red.cur)
+            seen += red.buf[red.cur].tolist()
+        slot = red.slot()  # bench.py hands slot_ptr() to fbk_plan_total; here the "kernel" is a host write
+        slot[0] = (rank + 1) * 1000 + k  # this rank's partial total of step k
+        red.advance()
+    bufs = red.flush()
+    q.put((rank, seen, [b.tolist() for b in bufs], red.collectives))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_async_reduce_two_ranks():
+    """bench.py's N > 1 reduce: per-step partial totals collected in two alternating buckets, one
+    asynchronous all-reduce per bucket, tail flushed; every step's total is the sum over ranks."""
+    import torch.multiprocessing as mp
+
+    steps, bucket, world = 37, 8, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, steps, bucket, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = [q.get(timeout=240) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    expect = lambda k: sum((r + 1) * 1000 + k for r in range(world))  # noqa: E731
+    for rank, seen, bufs, collectives in results:
+        assert collectives == (steps + bucket - 1) // bucket
+        # buckets recycled during the run held the reduced totals of complete earlier buckets
+        assert seen == [expect(k) for k in range(len(seen))] and len(seen) == (steps // bucket - 2 + (1 if steps % bucket else 0)) * bucket
+        # after flush: the last full bucket and the partially filled tail bucket
+        tail = steps % bucket
+        last_full_start = (steps // bucket - 1) * bucket
+        flat = sorted(v for b in bufs for v in b if v)
+        assert flat == sorted([expect(k) for k in range(last_full_start, last_full_start + bucket)] + [expect(k) for k in range(steps - tail, steps)])
