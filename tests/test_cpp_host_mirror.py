@@ -11,6 +11,8 @@ SRC = os.path.join(ROOT, "tests", "cpp", "test_row_api.cpp")
 BIN = os.path.join(ROOT, "build", "test_row_api")
 SRC_EXEC = os.path.join(ROOT, "tests", "cpp", "test_executor_api.cpp")
 BIN_EXEC = os.path.join(ROOT, "build", "test_executor_api")
+SRC_THR = os.path.join(ROOT, "tests", "cpp", "test_threads.cpp")
+BIN_THR = os.path.join(ROOT, "build", "test_threads")
 
 
 def compile_it(src=SRC, out=BIN):
@@ -20,7 +22,7 @@ def compile_it(src=SRC, out=BIN):
     os.makedirs(os.path.dirname(out), exist_ok=True)
     lib = os.path.join(ROOT, "featurebase_amd", "csrc")
     subprocess.check_call(
-        ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-L", lib, "-lfbk", f"-Wl,-rpath,{lib}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", out]
+        ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), src, "-L", lib, "-lfbk", f"-Wl,-rpath,{lib}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", out]
     )
 
 
@@ -29,6 +31,17 @@ def test_cpp_host_mirror_compiles():
     assert os.path.exists(BIN)
     compile_it(SRC_EXEC, BIN_EXEC)
     assert os.path.exists(BIN_EXEC)
+    compile_it(SRC_THR, BIN_THR)
+    assert os.path.exists(BIN_THR)
+
+
+@pytest.mark.gpu
+def test_one_context_many_threads_on_gpu():
+    """8 OS threads x 25 rounds of Row operations on ONE context (the cgo calling pattern)."""
+    compile_it(SRC_THR, BIN_THR)
+    out = subprocess.run([BIN_THR], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "threads ok" in out.stdout
 
 
 @pytest.mark.gpu
