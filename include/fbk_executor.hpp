@@ -6,6 +6,7 @@
 //   executeIntersect/Union/Difference/XorShard  executor.go:5357, 5382, 2950, 5513 (left folds)
 //   executeRowBSIGroupShard (Row(v > k) ...)     executor.go:5249-5355, field.go:2412-2482
 //   executeSum / Min / Max (+ ValCount)          executor.go:2155-2275, 8438-8548
+//   executePercentile                            executor.go:1310-1595
 //   executeTopK (doTopK + PivotDescending)       executor.go:2357-2412, 2705-2746, bsi.go:18-62
 //   executeTopN (counts; the rank cache is not mirrored)   executor.go:2776-2868
 //   executeGroupBy (groupByIterator odometer)    executor.go:3918-3990, 8617-8934
@@ -315,6 +316,56 @@ class Executor {
   }
   ValCount Min(const std::string& field, const Call* filter = nullptr) { return minmax(field, filter, true); }
   ValCount Max(const std::string& field, const Call* filter = nullptr) { return minmax(field, filter, false); }
+
+  // ---- Percentile ----------------------------------------------------------------------------
+  // executePercentile, executor.go:1310-1595 (integer fields): binary search between Min and Max
+  // on Count(Row(field < x) ∩ filter) / Count(Row(field > x) ∩ filter).  Returns false for the
+  // "median of nothing is NULL" case (:1399-1402).
+  bool Percentile(const std::string& field, double nth, const Call* filter, ValCount* out) {
+    if (nth < 0 || nth > 100.0) throw Error(FBK_E_INVALID, "Percentile(): invalid nth value, should be a number between 0 and 100 inclusive");
+    idx_.Sync();
+    const Index::IntField& f = idx_.ints_.at(field);
+    auto count_of = [&](RowSet&& r) {
+      if (!filter) return count_rows(r);
+      RowSet fr = eval(*filter);
+      RowSet both = setop(FBK_OP_AND, r, fr);
+      return count_rows(both);
+    };
+    const uint64_t total = count_of(not_null(f));  // Count(Intersect(filter, Row(field != null)))
+    if (total == 0) return false;
+    const uint64_t desired_less = uint64_t((double(total) * nth) / 100.0);
+    const uint64_t desired_greater = uint64_t((double(total) * (100 - nth)) / 100.0);
+    ValCount mn;
+    if (desired_greater != 0) {
+      mn = Min(field, filter);
+      if (desired_less == 0) {
+        *out = mn;
+        return true;
+      }
+    }
+    const ValCount mx = Max(field, filter);
+    if (desired_greater == 0) {
+      *out = mx;
+      return true;
+    }
+    int64_t lo = mn.Val, hi = mx.Val, guess = mn.Val;
+    while (lo < hi) {
+      guess = (lo / 2) + (hi / 2) + (((lo % 2) + (hi % 2)) / 2);  // average without overflow (:1497-1501)
+      const uint64_t left = count_of(range(Call::Range(field, FBK_BSI_LT, guess)));
+      if (left > desired_less) {
+        hi = guess - 1;
+        continue;
+      }
+      const uint64_t right = count_of(range(Call::Range(field, FBK_BSI_GT, guess)));
+      if (right > desired_greater) {
+        lo = guess + 1;
+        continue;
+      }
+      break;
+    }
+    *out = ValCount{guess, 1};
+    return true;
+  }
 
   // ---- TopK / TopN ---------------------------------------------------------------------------
   // TopK(field, k, filter): per-row |row ∩ filter| over all shards (doTopK), then the rows in

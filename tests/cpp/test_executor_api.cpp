@@ -7,6 +7,7 @@
 //   TestExecutor_Execute_GroupBy (Basic / Filter / Aggregate)           executor_test.go:6035-6130
 //   Row(f > k) style BSI range calls                                    executor_test.go:3051-3160
 //   g++ -std=c++17 -I include tests/cpp/test_executor_api.cpp -L featurebase_amd/csrc -lfbk
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 
@@ -160,6 +161,121 @@ int main() {
       threw = true;
     }
     EXPECT(threw);  // "need at least one child call"
+  }
+  {  // ---- Percentile (executor_test.go:7587-7760): expectations from the reference's own checker ----
+    // Two host-side expectations over plain arrays: `checker` is the reference test's own
+    // getExpectedPercentile (executor_test.go:7631-7677); `exec` walks executePercentile's loop
+    // (executor.go:1396-1595).  They agree whenever the search ends "balanced"; when the bounds
+    // cross instead, executePercentile returns its LAST guess while the checker returns min —
+    // a quirk of the reference that parity keeps (the reference's test data never hits it).
+    auto checker = [](const std::vector<int64_t>& nums, double nth, bool* balanced) -> int64_t {
+      *balanced = true;
+      int64_t mn = nums[0], mx = nums[0];
+      for (int64_t v : nums) {
+        mn = std::min(mn, v);
+        mx = std::max(mx, v);
+      }
+      if (nth == 0.0) return mn;
+      if (nth == 100.0) return mx;
+      int64_t guess = 0;
+      const int less = int((double(nums.size()) * nth) / 100.0), greater = int((double(nums.size()) * (100 - nth)) / 100.0);
+      if (less == 0) return mn;
+      if (greater == 0) return mx;
+      while (mn < mx) {
+        guess = ((mx / 2) + (mn / 2)) + (((mx % 2) + (mn % 2)) / 2);
+        int l = 0, r = 0;
+        for (int64_t v : nums) {
+          if (v < guess) ++l;
+          else if (v > guess) ++r;
+        }
+        if (l > less) mx = guess - 1;
+        else if (r > greater) mn = guess + 1;
+        else return guess;
+      }
+      *balanced = false;
+      return mn;
+    };
+    auto exec = [](const std::vector<int64_t>& nums, double nth) -> int64_t {
+      int64_t mn = nums[0], mx = nums[0];
+      for (int64_t v : nums) {
+        mn = std::min(mn, v);
+        mx = std::max(mx, v);
+      }
+      const uint64_t less = uint64_t((double(nums.size()) * nth) / 100.0), greater = uint64_t((double(nums.size()) * (100 - nth)) / 100.0);
+      if (greater != 0 && less == 0) return mn;
+      if (greater == 0) return mx;
+      int64_t guess = mn;
+      while (mn < mx) {
+        guess = (mn / 2) + (mx / 2) + (((mn % 2) + (mx % 2)) / 2);
+        uint64_t l = 0, r = 0;
+        for (int64_t v : nums) {
+          if (v < guess) ++l;
+          else if (v > guess) ++r;
+        }
+        if (l > less) {
+          mx = guess - 1;
+          continue;
+        }
+        if (r > greater) {
+          mn = guess + 1;
+          continue;
+        }
+        break;
+      }
+      return guess;
+    };
+    Index idx;
+    idx.CreateSetField("val");
+    uint64_t seed = 42;
+    auto rnd = [&seed]() {
+      seed += 0x9E3779B97F4A7C15ull;
+      uint64_t z = seed;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      return z ^ (z >> 31);
+    };
+    std::vector<std::pair<uint64_t, int64_t>> vals;
+    std::vector<int64_t> foo_nums, all_nums;
+    int64_t lo = 0, hi = 0;
+    for (int i = 0; i < 100; ++i) {  // 100 users spread over 3 shards, values +-uint32, "foo"/"bar" coin flip
+      int64_t num = int64_t(rnd() & 0xFFFFFFFFu);
+      if (rnd() % 2 == 0) num = -num;
+      const uint64_t col = uint64_t(i) * 31 + (uint64_t(i) % 3) * SW;
+      const bool foo = rnd() % 2 == 0;
+      vals.push_back({col, num});
+      idx.SetBit("val", foo ? 0 : 1, col);
+      (foo ? foo_nums : all_nums).push_back(num);
+      lo = std::min(lo, num);
+      hi = std::max(hi, num);
+    }
+    all_nums.insert(all_nums.end(), foo_nums.begin(), foo_nums.end());
+    idx.CreateIntField("net_worth", lo, hi);
+    for (auto& cv : vals) idx.SetValue("net_worth", cv.first, cv.second);
+    Executor e(idx);
+    Call foo = Call::Row("val", 0);
+    int balanced_cases = 0;
+    for (double nth : {0.0, 10.0, 25.0, 50.0, 75.0, 90.0, 99.0, 100.0}) {
+      ValCount got;
+      bool bal = false;
+      EXPECT(e.Percentile("net_worth", nth, &foo, &got));
+      EXPECT(got.Val == exec(foo_nums, nth) && got.Count >= 1);
+      const int64_t chk = checker(foo_nums, nth, &bal);
+      if (bal) {
+        EXPECT(got.Val == chk);
+        ++balanced_cases;
+      }
+      EXPECT(e.Percentile("net_worth", nth, nullptr, &got));
+      EXPECT(got.Val == exec(all_nums, nth));
+      const int64_t chk2 = checker(all_nums, nth, &bal);
+      if (bal) {
+        EXPECT(got.Val == chk2);
+        ++balanced_cases;
+      }
+    }
+    EXPECT(balanced_cases >= 8);
+    ValCount none;
+    Call nobody = Call::Row("val", 77);
+    EXPECT(!e.Percentile("net_worth", 50, &nobody, &none));  // the median of nothing is NULL
   }
   if (failures) {
     std::printf("%d failure(s)\n", failures);
