@@ -64,6 +64,12 @@ struct fbk_ctx {
   std::unordered_map<void*, uint64_t> pool_live;  // block -> bucket size
   uint64_t pool_cached_bytes = 0;
   uint64_t pool_cap_bytes = 8ull << 30;
+  // Pinned host staging for the small index arrays every query uploads: a copy from pageable
+  // memory is staged by the runtime and costs 10-20 us per call; from pinned memory it is one
+  // asynchronous DMA.  Bump-allocated, reset at the start of every API call (each call that
+  // uses it synchronises the stream before returning).
+  uint8_t* h_stage = nullptr;
+  uint64_t h_stage_cap = 0, h_stage_used = 0;
   // device fragment cache (fbk_cache_api.inc)
   std::unordered_map<std::string, struct fbk_cache_entry*> cache;
   std::vector<struct fbk_cache_entry*> cache_zombies;  // invalidated while pinned
@@ -177,8 +183,55 @@ struct DevBuf {
 
 int32_t set_device(fbk_ctx* ctx) {
   HIP_TRY(hipSetDevice(ctx->device));
+  ctx->h_stage_used = 0;
   return FBK_OK;
 }
+
+// n bytes of pinned staging valid until the next API call on this context, or nullptr
+uint8_t* stage_alloc(fbk_ctx* ctx, uint64_t n) {
+  if (!ctx->h_stage) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 8u << 20, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    ctx->h_stage = static_cast<uint8_t*>(p);
+    ctx->h_stage_cap = 8u << 20;
+  }
+  const uint64_t at = (ctx->h_stage_used + 63) & ~uint64_t(63);
+  if (at + n > ctx->h_stage_cap) return nullptr;
+  ctx->h_stage_used = at + n;
+  return ctx->h_stage + at;
+}
+
+// Small results back to the host through the pinned staging area: queue, then ONE stream
+// synchronisation and plain memcpys (a device->pageable copy is staged by the runtime and
+// synchronises by itself, once per call).
+struct D2H {
+  struct Item {
+    void* dst;
+    const uint8_t* st;
+    uint64_t n;
+  };
+  fbk_ctx* ctx;
+  std::vector<Item> items;
+  explicit D2H(fbk_ctx* c) : ctx(c) {}
+  hipError_t add(void* dst, const void* dev, uint64_t n) {
+    if (n == 0) return hipSuccess;
+    if (uint8_t* st = stage_alloc(ctx, n)) {
+      items.push_back({dst, st, n});
+      return hipMemcpyAsync(st, dev, n, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    return hipMemcpyAsync(dst, dev, n, hipMemcpyDeviceToHost, ctx->stream);
+  }
+  hipError_t finish() {
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess)
+      for (const Item& it : items) std::memcpy(it.dst, it.st, it.n);
+    items.clear();
+    return e;
+  }
+};
 
 int32_t refresh_slots(fbk_batch* b) {
   if (!b->slots_stale) return FBK_OK;
@@ -195,7 +248,14 @@ int32_t upload_rows(fbk_ctx* ctx, const uint32_t* rows, uint64_t n, uint32_t n_r
       return fail(FBK_E_INVALID, "row index " + std::to_string(rows[i]) + " out of range (batch has " +
                                      std::to_string(n_rows_limit) + " rows)");
   HIP_TRY(out.alloc(ctx, std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
-  if (n) HIP_TRY(hipMemcpyAsync(out.p, rows, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  if (n) {
+    const void* src = rows;
+    if (uint8_t* st = stage_alloc(ctx, n * sizeof(uint32_t))) {
+      std::memcpy(st, rows, n * sizeof(uint32_t));
+      src = st;
+    }
+    HIP_TRY(hipMemcpyAsync(out.p, src, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  }
   return FBK_OK;
 }
 
@@ -257,6 +317,7 @@ int32_t fbk_close(fbk_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   cache_release_all(ctx);
   pool_release_all(ctx);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return FBK_OK;
@@ -596,8 +657,9 @@ int32_t fbk_count_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* ro
   hipLaunchKernelGGL(fbk::k_count_range, dim3(uint32_t(n * fbk::kSlots / 4)), dim3(256), 0, ctx->stream, b->d_slots,
                      b->d_arena, drows.as<uint32_t>(), n, uint32_t(start), uint32_t(end), dcnt.as<u64>());
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(out_counts, dcnt.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  D2H back(ctx);
+  HIP_TRY(back.add(out_counts, dcnt.p, n * 8));
+  HIP_TRY(back.finish());
   return FBK_OK;
 }
 
@@ -866,8 +928,9 @@ int32_t fbk_intersection_count(fbk_ctx* ctx, const fbk_batch* a, const uint32_t*
   if (int32_t rc = plan_create_locked(ctx, a, rows_a, b, rows_b, n_pairs, nullptr, &p)) return rc;
   int32_t rc = plan_icount_enqueue_locked(ctx, p);
   if (!rc) {
-    hipError_t e = hipMemcpyAsync(out_counts, p->d_counts, n_pairs * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    D2H back(ctx);
+    hipError_t e = back.add(out_counts, p->d_counts, n_pairs * sizeof(u64));
+    if (e == hipSuccess) e = back.finish();
     if (e != hipSuccess) rc = fail(FBK_E_HIP, std::string("intersection_count: ") + hipGetErrorString(e));
   }
   (void)hipStreamSynchronize(ctx->stream);

@@ -111,7 +111,14 @@ def config4(ctx, stream, n_shards, iters, n_a=32, n_b=32):
     exp = int(sum(np.bitwise_count(wa[s * n_a + 3] & wb[s * n_b + 5] & wf[s]).sum() for s in range(n_shards)))
     assert int(tot[3, 5]) == exp
     nbytes = n_shards * (n_a + n_b + 1) * 16 * 8192
+    # TopN shape on dense rows: the n_a rows of A against the single filter row per shard
+    t_topn = timed(stream, lambda: ctx.count_matrix(A, ra, F, rf.reshape(-1, 1)), iters)
+    topn_bytes = n_shards * (n_a + 1) * 16 * 8192
+    # n-way union of the same dense rows, fused with |union ∩ filter|
+    t_union = timed(stream, lambda: ctx.union_n_intersection_count(A, ra, F, rf), iters)
     return {
+        "topn_dense_gpu_s": t_topn, "topn_dense_GBps": topn_bytes / t_topn / 1e9,
+        "union_dense_gpu_s": t_union, "union_dense_GBps": topn_bytes / t_union / 1e9,
         "config": 4, "workload": f"{n_shards} shards x ({n_a} x {n_b} rows + filter), dense bitmaps, count matrix",
         "algorithmic_bytes_read_once": nbytes, "gpu_s": t, "GBps_vs_read_once": nbytes / t / 1e9,
         "set_ops_per_s": n_shards * 16 * n_a * n_b / t, "pair_bits_scanned_GBps": n_shards * n_a * n_b * 2 * 16 * 8192 / t / 1e9,
