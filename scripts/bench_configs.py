@@ -110,6 +110,17 @@ def config4(ctx, stream, n_shards, iters, n_a=32, n_b=32):
     tot = ctx.count_matrix(A, ra, B, rb, F, rf)
     exp = int(sum(np.bitwise_count(wa[s * n_a + 3] & wb[s * n_b + 5] & wf[s]).sum() for s in range(n_shards)))
     assert int(tot[3, 5]) == exp
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    t_reduce = None
+    if world > 1:  # mergeGroupCounts across nodes (executor.go:3728): one all-reduce of the nA x nB matrix
+        from featurebase_amd import dist as fdist
+
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t0 = time.perf_counter()
+        glob = fdist.reduce_count_vector(tot.reshape(-1), dev)
+        torch.cuda.synchronize()
+        t_reduce = time.perf_counter() - t0
+        assert int(glob.reshape(n_a, n_b)[3, 5]) == exp * world  # every rank generated the same shards here
     nbytes = n_shards * (n_a + n_b + 1) * 16 * 8192
     # TopN shape on dense rows: the n_a rows of A against the single filter row per shard
     t_topn = timed(stream, lambda: ctx.count_matrix(A, ra, F, rf.reshape(-1, 1)), iters)
@@ -119,6 +130,7 @@ def config4(ctx, stream, n_shards, iters, n_a=32, n_b=32):
     return {
         "topn_dense_gpu_s": t_topn, "topn_dense_GBps": topn_bytes / t_topn / 1e9,
         "union_dense_gpu_s": t_union, "union_dense_GBps": topn_bytes / t_union / 1e9,
+        "world_size": world, "matrix_allreduce_s": t_reduce,
         "config": 4, "workload": f"{n_shards} shards x ({n_a} x {n_b} rows + filter), dense bitmaps, count matrix",
         "algorithmic_bytes_read_once": nbytes, "gpu_s": t, "GBps_vs_read_once": nbytes / t / 1e9,
         "set_ops_per_s": n_shards * 16 * n_a * n_b / t, "pair_bits_scanned_GBps": n_shards * n_a * n_b * 2 * 16 * 8192 / t / 1e9,
@@ -156,16 +168,35 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=int, default=0)
     a = ap.parse_args()
-    ctx = Context(0)
+    # one process per GPU (torchrun): every rank holds its own shards; count-valued results are
+    # summed over ranks with one RCCL all-reduce (config 4's "partial-count reduce over xGMI")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("FBK_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    if world > 1:
+        from featurebase_amd import dist as fdist
+
+        fdist.init(backend, torch.device("cuda", dev_index))
+    ctx = Context(dev_index)
     stream = torch.cuda.Stream()
     ctx.set_stream(stream.cuda_stream)
     with torch.cuda.stream(stream):
+        rank0 = int(os.environ.get("RANK", "0")) == 0
         if a.only in (0, 4):
-            print(json.dumps(config4(ctx, stream, a.shards4, a.iters)), flush=True)
-        if a.only in (0, 5):
+            r = config4(ctx, stream, a.shards4, a.iters)
+            if rank0:
+                print(json.dumps(r), flush=True)
+        if a.only in (0, 5) and world == 1:
             print(json.dumps(config5(ctx, stream, a.iters)), flush=True)
-        if a.only in (0, 3):
+        if a.only in (0, 3) and world == 1:
             print(json.dumps(config3(ctx, stream, a.shards3, a.iters)), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
