@@ -489,3 +489,30 @@ def test_rows_vs_filter_kernel_vs_oracle(gpu_ctx, oracle):
     assert (tot[:, 0] == exp.sum(axis=0)).all()
     A.free()
     F.free()
+
+
+def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
+    """Groups of 150 rows: the descriptor window of the fold kernels (64 rows per pass) wraps
+    twice and ends ragged; all four ops, with a full container in the last window."""
+    O = oracle
+    rng = D.rng_for(59)
+    rows, groups = make_union_groups(rng, 2, 150)
+    rows[groups[1][140]][1 * 16 + 9] = O.OContainer.run([(0, 65535)])
+    batch = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+    for op in (L.OP_AND, L.OP_OR, L.OP_XOR, L.OP_ANDNOT):
+        out, cnt = gpu_ctx.fold_n(op, batch, groups)
+        res = out.download()
+        for g, ids in enumerate(groups):
+            bms = [O.OBitmap.from_containers(list(rows[i].items())) for i in ids]
+            if op == L.OP_OR:
+                exp = bms[0].union(*bms[1:])
+            elif op == L.OP_ANDNOT:
+                exp = bms[0].difference(*bms[1:])
+            else:
+                exp = bms[0]
+                for b in bms[1:]:
+                    exp = exp.intersect(b) if op == L.OP_AND else exp.xor(b)
+            assert int(cnt[g]) == exp.count(), (op, g)
+            assert (row_words(res[g]) == bitmap_words(exp)).all(), (op, g)
+        out.free()
+    batch.free()
