@@ -23,6 +23,10 @@ from featurebase_amd import lib as L  # noqa: E402
 from featurebase_amd.roaring import Context  # noqa: E402
 
 
+CPU_BASELINE = False
+ORACLE_ROWS3 = {}
+
+
 def timed(stream, fn, iters):
     fn()
     torch.cuda.synchronize()
@@ -40,6 +44,18 @@ def timed(stream, fn, iters):
 
 def encoded_bytes(c):
     return {1: 2 * c.length, 2: 8192, 3: 4 * c.length}[c.typ]
+
+
+def cpu_time(fn, min_s=1.0):
+    """seconds per call of fn on one host thread (repeated until min_s has elapsed)"""
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_s:
+            return dt / n
 
 
 def config3(ctx, stream, n_shards, iters):
@@ -60,6 +76,8 @@ def config3(ctx, stream, n_shards, iters):
                     row[s * 16 + slot] = D.to_fbk(c)
                     nbytes += encoded_bytes(c)
                     ncont += 1
+                    if s == 0:
+                        ORACLE_ROWS3.setdefault(r, []).append((slot, c))
             ids.append(len(rows))
             rows.append(row)
         groups.append(ids)
@@ -72,6 +90,8 @@ def config3(ctx, stream, n_shards, iters):
             row[s * 16 + slot] = D.to_fbk(c)
             nbytes += encoded_bytes(c)
             ncont += 1
+            if s == 0:
+                ORACLE_ROWS3.setdefault("filter", []).append((slot, c))
         frows.append(row)
     gen_s = time.time() - t0
     batch, F = ctx.upload(rows), ctx.upload(frows)
@@ -86,7 +106,17 @@ def config3(ctx, stream, n_shards, iters):
     t_pairs = timed(stream, lambda: ctx.intersection_count(batch, pair_a, F, pair_f), iters)
     filt_bytes = sum(encoded_bytes(c) for row in frows for c in row.values())
     set_ops = n_shards * 16 * k  # (k-1) unions + 1 intersection count per slot
+    cpu = None
+    if CPU_BASELINE:
+        from oracle import pyoracle as O
+
+        bms = [O.OBitmap.from_containers(ORACLE_ROWS3.get(r, [])) for r in range(k)]
+        fb = O.OBitmap.from_containers(ORACLE_ROWS3["filter"])
+        t_cpu = cpu_time(lambda: bms[0].union(*bms[1:]).intersection_count(fb))  # Bitmap.Union n-way + IntersectionCount
+        cpu = {"per_shard_s_1thread": t_cpu, "shards_per_s_1thread": 1 / t_cpu, "kind": "port",
+               "what": "oracle Bitmap.Union(63 others) + IntersectionCount(filter) of shard 0, one host thread"}
     return {
+        "cpu_baseline": cpu,
         "config": 3, "workload": f"{n_shards} shards x (64 rows + filter), mixed containers, Union-of-64 then IntersectionCount (fused)",
         "containers": ncont, "algorithmic_bytes": nbytes, "gpu_s": t, "GBps": nbytes / t / 1e9, "set_ops_per_s": set_ops / t,
         "materialised_union_gpu_s": tm, "host_gen_s": gen_s,
@@ -127,7 +157,20 @@ def config4(ctx, stream, n_shards, iters, n_a=32, n_b=32):
     topn_bytes = n_shards * (n_a + 1) * 16 * 8192
     # n-way union of the same dense rows, fused with |union ∩ filter|
     t_union = timed(stream, lambda: ctx.union_n_intersection_count(A, ra, F, rf), iters)
+    cpu = None
+    if CPU_BASELINE:
+        from oracle import pybsi as PB
+        from oracle import pyoracle as O
+
+        mk = lambda w: O.OBitmap.from_containers([(sl, O.OContainer.bitmap(np.asarray(w).reshape(16, 1024)[sl])) for sl in range(16)])  # noqa: E731
+        fa = PB.Fragment([mk(wa[i]) for i in range(n_a)])
+        fb = PB.Fragment([mk(wb[j]) for j in range(n_b)])
+        ff = mk(wf[0])
+        t_cpu = cpu_time(lambda: PB.groupby_counts(fa, fb, ff))
+        cpu = {"per_shard_s_1thread": t_cpu, "shards_per_s_1thread": 1 / t_cpu, "kind": "port",
+               "what": "oracle groupByIterator counts (32 x 32 rows + filter) of shard 0, one host thread"}
     return {
+        "cpu_baseline": cpu,
         "topn_dense_gpu_s": t_topn, "topn_dense_GBps": topn_bytes / t_topn / 1e9,
         "union_dense_gpu_s": t_union, "union_dense_GBps": topn_bytes / t_union / 1e9,
         "world_size": world, "matrix_allreduce_s": t_reduce,
@@ -152,7 +195,18 @@ def config5(ctx, stream, iters, n_shards=96, depth=64):
     t_sum = timed(stream, lambda: ctx.bsi_sum(batch, base, depth), iters)
     out.free()
     plane_bytes = n_shards * 16 * 8192
+    cpu = None
+    if CPU_BASELINE:
+        from oracle import pybsi as PB
+        from oracle import pyoracle as O
+
+        fr = PB.Fragment([O.OBitmap.from_containers([(sl, O.OContainer.bitmap(w[0, r, sl])) for sl in range(16)]) for r in range(depth + 2)])
+        t_sum_cpu = cpu_time(lambda: PB.bsi_sum(fr, None, False))
+        t_rng_cpu = cpu_time(lambda: PB.bsi_range(fr, PB.GT, depth, k))
+        cpu = {"sum_per_shard_s_1thread": t_sum_cpu, "range_per_shard_s_1thread": t_rng_cpu, "kind": "port",
+               "what": "oracle fragment.sum / fragment.rangeOp(GT) of shard 0 (66 dense rows), one host thread"}
     return {
+        "cpu_baseline": cpu,
         "config": 5, "workload": f"BSI {n_shards} shards x (64 planes + exists + sign), dense; Range(>2^62), Sum(filter=range), Sum",
         "range_gpu_s": t_range, "range_GBps": plane_bytes * (depth + 2 + 1) / t_range / 1e9,
         "range_note": "Range(> 2^62) reads exists, sign and all 64 planes once, writes 1 row",
@@ -167,7 +221,10 @@ def main():
     ap.add_argument("--shards4", type=int, default=128)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=int, default=0)
+    ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle on one shard of each config (one host thread)")
     a = ap.parse_args()
+    global CPU_BASELINE
+    CPU_BASELINE = a.cpu_baseline
     # one process per GPU (torchrun): every rank holds its own shards; count-valued results are
     # summed over ranks with one RCCL all-reduce (config 4's "partial-count reduce over xGMI")
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -15,14 +15,13 @@ def main():
     rows = list(cur.execute("select * from top_kernels"))
     print("# columns:", ", ".join(cols))
     name_i = cols.index("name")
-    print(f"{'kernel':110s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+    print(f"{'kernel':110s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
     for r in rows:
         d = dict(zip(cols, r))
-        tot = d.get("total_duration", 0) / 1e3
-        avg = d.get("average", 0) / 1e3
-        mn = d.get("min", d.get("minimum", 0)) / 1e3
-        mx = d.get("max", d.get("maximum", 0)) / 1e3
-        print(f"{str(r[name_i])[:110]:110s} {d.get('total_calls', 0):7d} {tot:12.3f} {avg:10.3f} {mn:10.3f} {mx:10.3f} {d.get('percentage', 0):6.2f}")
+        # the top_kernels view reports durations in microseconds
+        tot = d.get("total_duration", 0)
+        avg = d.get("average", 0)
+        print(f"{str(r[name_i])[:110]:110s} {d.get('total_calls', 0):7d} {tot:12.3f} {avg:10.3f} {d.get('percentage', 0):6.2f}")
 
 
 if __name__ == "__main__":

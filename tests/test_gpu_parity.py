@@ -63,7 +63,7 @@ def check_rows(O, ctx, rows_a, rows_b):
 
 
 def test_golden_container_combinations_on_gpu(gpu_ctx, oracle):
-    """The reference's 92-triple golden table (roaring_internal_test.go:2974-3771), every
+    """The reference's golden combination table (roaring_internal_test.go:2974-3771: 638 op entries), every
     op x 3x3 encodings, evaluated by the HIP kernels: one shard row per triple."""
     O = oracle
     mk = {
