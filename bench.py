@@ -155,11 +155,11 @@ def main():
     red = fdist.BucketedCountReducer(REDUCE_BUCKET, dev) if n_gpus > 1 else None
 
     def step():
-        plan.intersection_count()  # per-shard |a ∩ b|
+        # per-shard |a ∩ b| and the per-node reduce, fused into one launch (fbk.h)
         if red is None:
-            plan.total(total.data_ptr())  # per-node reduce
+            plan.intersection_count_total(total.data_ptr())
         else:
-            plan.total(red.slot_ptr())  # per-node reduce into the bucket slot of this step
+            plan.intersection_count_total(red.slot_ptr())  # the total lands in the bucket slot of this step
             red.advance()  # RCCL sum of the partial counts over xGMI once the bucket is full
 
     def barrier():

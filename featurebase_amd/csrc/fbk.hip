@@ -681,6 +681,7 @@ struct fbk_plan {
   uint32_t* d_rows_b = nullptr;
   u64* d_counts = nullptr;     // n_pairs (owned unless ext_counts)
   u64* d_total = nullptr;      // 1
+  uint32_t* d_done = nullptr;  // ticket counter of the fused count + total kernel (kept at 0 between launches)
   bool ext_counts = false;
   fbk_batch* out = nullptr;    // lazily created by the first set-op enqueue
   uint32_t* d_runs = nullptr;  // per output slot run count (optimize pass)
@@ -716,6 +717,7 @@ void free_plan_storage(fbk_plan* p) {
   if (p->d_rows_b) (void)ctx_free(p->ctx, p->d_rows_b);
   if (p->d_counts && !p->ext_counts) (void)ctx_free(p->ctx, p->d_counts);
   if (p->d_total) (void)ctx_free(p->ctx, p->d_total);
+  if (p->d_done) (void)ctx_free(p->ctx, p->d_done);
   if (p->d_runs) (void)ctx_free(p->ctx, p->d_runs);
   free_batch_storage(p->out);
   delete p;
@@ -738,6 +740,8 @@ int32_t plan_create_locked(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* row
   hipError_t e = ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_rows_a), rb);
   if (e == hipSuccess) e = ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_rows_b), rb);
   if (e == hipSuccess) e = ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_total), sizeof(u64));
+  if (e == hipSuccess) e = ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_done), sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemsetAsync(p->d_done, 0, sizeof(uint32_t), ctx->stream);
   if (e == hipSuccess) {
     if (ext_counts) {
       p->d_counts = static_cast<u64*>(ext_counts);
@@ -760,8 +764,11 @@ int32_t plan_create_locked(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* row
   return FBK_OK;
 }
 
-int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p) {
-  if (p->n_pairs == 0) return FBK_OK;
+int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total = nullptr) {
+  if (p->n_pairs == 0) {
+    if (fused_total) HIP_TRY(hipMemsetAsync(fused_total, 0, sizeof(u64), ctx->stream));
+    return FBK_OK;
+  }
   const uint32_t np = uint32_t(p->n_pairs);
   if (p->a->dense && p->b->dense) {
     // all-bitmap rows: pure streaming kernel.  slots-per-block 16 = one block per row
@@ -774,7 +781,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p) {
     if (spb != 16) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
 #define FBK_LAUNCH_DENSE(S)                                                                                       \
   hipLaunchKernelGGL(fbk::k_icount_dense<S>, dim3(np*(16 / S)), dim3(256), 0, ctx->stream, p->a->d_arena,         \
-                     p->d_rows_a, p->b->d_arena, p->d_rows_b, p->d_counts)
+                     p->d_rows_a, p->b->d_arena, p->d_rows_b, p->d_counts, fused_total, p->d_done, np)
     switch (spb) {
       case 1: FBK_LAUNCH_DENSE(1); break;
       case 2: FBK_LAUNCH_DENSE(2); break;
@@ -787,6 +794,8 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p) {
     HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,
                        p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts);
+    if (fused_total)
+      hipLaunchKernelGGL(fbk::k_sum_u64, dim3(1), dim3(256), 0, ctx->stream, p->d_counts, p->n_pairs, fused_total);
   }
   HIP_TRY(hipGetLastError());
   return FBK_OK;
@@ -864,6 +873,14 @@ int32_t fbk_plan_intersection_count(fbk_ctx* ctx, fbk_plan* plan) {
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   return plan_icount_enqueue_locked(ctx, plan);
+}
+
+int32_t fbk_plan_intersection_count_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null) {
+  if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  u64* dst = device_total_or_null ? static_cast<u64*>(device_total_or_null) : plan->d_total;
+  return plan_icount_enqueue_locked(ctx, plan, dst);
 }
 
 int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags) {

@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(256) k_icount_dense(const uint8_t* __restrict_
                                                      const uint32_t* __restrict__ rowsA,
                                                      const uint8_t* __restrict__ arenaB,
                                                      const uint32_t* __restrict__ rowsB,
-                                                     u64* __restrict__ out) {
+                                                     u64* __restrict__ out, u64* __restrict__ total,
+                                                     uint32_t* __restrict__ done, uint32_t n_pairs) {
   constexpr int kGroups = kSlots / SPB;
   const uint32_t pair = blockIdx.x / kGroups;
   const uint32_t grp = blockIdx.x % kGroups;
@@ -356,12 +357,40 @@ __global__ void __launch_bounds__(256) k_icount_dense(const uint8_t* __restrict_
   }
   c = wave_reduce_add(c);
   __shared__ uint32_t part[4];
+  __shared__ uint32_t s_last;
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
     u64 tot = (u64)part[0] + part[1] + part[2] + part[3];
-    if (kGroups == 1) out[pair] = tot;
-    else atomicAdd(&out[pair], tot);
+    s_last = 0;
+    if (!total) {
+      if (kGroups == 1) out[pair] = tot;
+      else atomicAdd(&out[pair], tot);
+    } else {
+      // Fused per-node reduce (executeCount's reduceFn, executor.go:5880): the block that
+      // finishes last sums the per-pair counts, so one step of the hot path is ONE launch.
+      // The blocks run on 8 XCDs with separate L2s: the count is published with an agent-scope
+      // atomic store (write-through, no L2-wide flush: a release FENCE here costs a full L2
+      // write-back per block and doubled the kernel time), completed before the ticket is taken.
+      if (kGroups == 1) __hip_atomic_store(&out[pair], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else atomicAdd(&out[pair], tot);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_last = (atomicAdd(done, 1u) == gridDim.x - 1) ? 1u : 0u;
+    }
+  }
+  if (!total) return;
+  __syncthreads();
+  if (!s_last) return;
+  u64 acc = 0;  // agent-scope loads: straight from the coherence point, no stale L2 lines
+  for (uint32_t i = threadIdx.x; i < n_pairs; i += 256) acc += __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+  __shared__ u64 tpart[4];
+  if ((threadIdx.x & 63) == 0) tpart[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *total = tpart[0] + tpart[1] + tpart[2] + tpart[3];
+    *done = 0;  // ready for the next launch (stream ordered)
   }
 }
 

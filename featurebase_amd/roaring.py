@@ -137,6 +137,10 @@ class Plan:
     def intersection_count(self) -> None:
         L.check(self.ctx.lib.fbk_plan_intersection_count(self.ctx.h, self.h))
 
+    def intersection_count_total(self, device_ptr: int = 0) -> None:
+        """Counts + per-node total in one launch (executeCount's mapFn + reduceFn)."""
+        L.check(self.ctx.lib.fbk_plan_intersection_count_total(self.ctx.h, self.h, C.c_void_p(device_ptr or None)))
+
     def setop(self, op: int, flags: int = 0) -> None:
         L.check(self.ctx.lib.fbk_plan_setop(self.ctx.h, self.h, op, flags))
 

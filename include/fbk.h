@@ -267,6 +267,12 @@ int32_t fbk_plan_free(fbk_ctx* ctx, fbk_plan* plan);
  * roaring.go:711-733).  Asynchronous. */
 int32_t fbk_plan_intersection_count(fbk_ctx* ctx, fbk_plan* plan);
 
+/* fbk_plan_intersection_count + fbk_plan_total in ONE launch: the per-node sum is fused into
+ * the counting kernel (its last block to finish adds up the per-pair counts), i.e. one step of
+ * Count(Intersect(Row, Row)) over all local shards — mapFn and reduceFn of executeCount,
+ * executor.go:5871-5880 — is a single kernel.  Asynchronous. */
+int32_t fbk_plan_intersection_count_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null);
+
 /* Enqueue out row i = A.rows_a[i] <op> B.rows_b[i] and counts[i] = its cardinality
  * (Bitmap.Intersect/Union/Xor/Difference + Count, roaring.go:736,1272,1598,1564;
  * executeCount's mapFn, executor.go:5871-5876).  The output batch is owned by the plan

@@ -235,3 +235,39 @@ def test_dense_many_shards_properties(gpu_ctx):
     plan.free()
     A.free()
     B.free()
+
+
+def test_fused_count_and_total_plan(gpu_ctx):
+    """fbk_plan_intersection_count_total: counts + per-node sum in one launch (last-block
+    reduce across all XCDs), repeated back to back, dense and mixed batches."""
+    import torch
+
+    n = 700
+    wa, wb = D.dense_rows(n, 0.5, 31), D.dense_rows(n, 0.3, 32)
+    A, B = gpu_ctx.upload_dense(wa), gpu_ctx.upload_dense(wb)
+    rows = np.arange(n)
+    plan = gpu_ctx.plan(A, rows, B, rows[::-1].copy())
+    exp = np.bitwise_count(wa & wb[::-1]).sum(axis=(1, 2)).astype(np.uint64) if wa.ndim == 3 else None
+    if exp is None:
+        exp = np.bitwise_count(wa.reshape(n, -1) & wb.reshape(n, -1)[::-1]).sum(axis=1).astype(np.uint64)
+    for _ in range(25):  # the ticket counter must be back at 0 after every launch
+        plan.intersection_count_total()
+    counts, total = plan.read(want_total=True)
+    assert (counts == exp).all() and total == int(exp.sum())
+    # into a caller-owned device cell
+    cell = torch.zeros(1, dtype=torch.int64, device="cuda")
+    plan.intersection_count_total(cell.data_ptr())
+    gpu_ctx.synchronize()
+    assert int(cell.item()) == int(exp.sum())
+    plan.free()
+    # mixed batch: generic kernel + sum kernel behind the same entry point
+    rng = D.rng_for(33)
+    ra = [D.random_row(rng, r) for r in range(40)]
+    M = gpu_ctx.upload([D.to_fbk_row(r) for r in ra])
+    p2 = gpu_ctx.plan(M, np.arange(40), A, np.arange(40))
+    p2.intersection_count_total()
+    c2, t2 = p2.read(want_total=True)
+    assert t2 == int(c2.sum()) and t2 > 0
+    p2.free()
+    for b in (A, B, M):
+        b.free()
