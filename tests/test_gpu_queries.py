@@ -516,3 +516,50 @@ def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
             assert (row_words(res[g]) == bitmap_words(exp)).all(), (op, g)
         out.free()
     batch.free()
+
+
+@pytest.mark.parametrize("a_dense,b_dense,f_mode", [(False, False, "mixed"), (True, False, "none"), (False, True, "dense"), (False, False, "none")])
+def test_count_matrix_mixed_rows_take_the_densify_path(gpu_ctx, oracle, B, a_dense, b_dense, f_mode):
+    """nA x nB >= 64 with array / run containers among the rows: fbk_count_matrix densifies the
+    referenced rows into temporary bitmap rows and runs the dense matrix kernel; every mix of
+    dense and encoded operands, checked against the oracle's groupByIterator counts."""
+    O = oracle
+    rng = D.rng_for(57)
+    n_shards, n_a, n_b = 5, 48, 43  # width >= 2048: densify whatever the container sizes
+
+    def obm(row):
+        return O.OBitmap.from_containers(list(row.items()))
+
+    def side(n, dense, seed):
+        if dense:
+            w = D.dense_rows(n_shards * n, 0.3, seed).reshape(n_shards * n, 16, 1024)
+            rows = [[{k: O.OContainer.bitmap(w[s * n + i, k]) for k in range(16)} for i in range(n)] for s in range(n_shards)]
+            return gpu_ctx.upload_dense(w.reshape(-1)), rows
+        rows = [[D.random_row(rng, 0, p_missing=0.25) for _ in range(n)] for s in range(n_shards)]
+        return gpu_ctx.upload([D.to_fbk_row(r) for s in rows for r in s]), rows
+
+    A, a_rows = side(n_a, a_dense, 571)
+    Bt, b_rows = side(n_b, b_dense, 572)
+    F, f_rows = None, None
+    if f_mode == "mixed":
+        f_rows = [D.random_row(rng, 0, p_missing=0.2) for _ in range(n_shards)]
+        F = gpu_ctx.upload([D.to_fbk_row(r) for r in f_rows])
+    elif f_mode == "dense":
+        wf = D.dense_rows(n_shards, 0.6, 573).reshape(n_shards, 16, 1024)
+        f_rows = [{k: O.OContainer.bitmap(wf[s, k]) for k in range(16)} for s in range(n_shards)]
+        F = gpu_ctx.upload_dense(wf.reshape(-1))
+    perm = np.random.default_rng(3).permutation(n_shards)  # shards in any order
+    ra = np.stack([np.arange(n_a)[::-1] + s * n_a for s in perm])
+    rb = np.stack([np.arange(n_b) + s * n_b for s in perm])
+    tot, ps = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
+    exp_tot = np.zeros((n_a, n_b), dtype=np.uint64)
+    for k, s in enumerate(perm):
+        fa = B.Fragment([obm(r) for r in a_rows[s][::-1]])
+        fb = B.Fragment([obm(r) for r in b_rows[s]])
+        e = B.groupby_counts(fa, fb, obm(f_rows[s]) if F is not None else None)
+        assert (ps[k] == e).all(), (k, s)
+        exp_tot += e
+    assert (tot == exp_tot).all()
+    for b in (A, Bt, F):
+        if b is not None:
+            b.free()
