@@ -4,9 +4,13 @@
 //
 // out[shard][i][j] (+)= sum over the block's slots of |A[shard][i] ∩ F[shard] ∩ B[shard][j]|.
 //
-// This shape is NOT HBM-bound: nA*nB pairs per slot reuse nA+nB containers, so with 32 x 32
-// rows the 64-bit AND + popcount work (4 VALU ops per word pair) is 1.3x the HBM time at full
-// rate.  The kernel is therefore organised around the VALU:
+// This shape is NOT HBM-bound: nA*nB pairs per slot reuse nA+nB containers.  Per 64-bit word pair
+// the work is 2 x v_and_b32 + 2 x v_bcnt_u32_b32; measured on this chip (scripts/valu_rate.hip)
+// a SIMD issues one wave64 v_and every 2.2 cycles but one v_bcnt only every 3.9 (half rate), and
+// an and->bcnt stream with two wavefronts per SIMD averages 2.9-3.2 cycles per instruction.
+// 32 x 32 rows x 16 slots x 128 shards = 2.1 M container pairs x 64 instructions per lane is
+// therefore >= 175 us of pure VALU issue, against 168 us for reading every container once at
+// 6.5 TB/s.  The kernel is organised around the VALU:
 //   * one 512-thread block (8 wavefronts) per (shard, slot group, 32 A rows, 32 B columns);
 //     wavefront w owns A rows 4w..4w+3 and all 32 columns;
 //   * the container dimension is cut into 4 chunks of 2 KiB.  Per step (slot, chunk) the 32 B
@@ -19,8 +23,12 @@
 //   * the 64-lane reduction happens once per block, as a transposing butterfly that leaves
 //     lane l with the total of pair l (63 shuffles for 64 values instead of 64 x 6).
 // The first version (A tile of whole containers in registers, B ring of whole containers,
-// a wave reduction per pair) measured 644 us on 128 shards x 32 x 32 rows; its per-pair
-// reductions and the un-overlapped A-tile loads were a third of the time each.
+// a wave reduction per pair) measured 644 us on 128 shards x 32 x 32 rows; this one 350 us,
+// i.e. half of the VALU issue rate the microbenchmark reaches with the same instruction mix.
+// Ablations on the GPU: without barriers -14 us, without the DMA -50 us, without the A loads
+// -58 us, the bare arithmetic + LDS reads 260 us; the schedule of the LDS reads (see below)
+// does not matter.  What holds the arithmetic at 1.35x of the microbenchmark is not identified
+// yet (VGPR bank conflicts / LDS return traffic on the register file are the candidates).
 #pragma once
 #include "fbk_kernels.hip.h"
 
@@ -57,7 +65,13 @@ __global__ void __launch_bounds__(512) k_count_matrix_dense(
     const uint8_t* __restrict__ arenaA, const uint32_t* __restrict__ rowsA, uint32_t nA, const uint8_t* __restrict__ arenaB,
     const uint32_t* __restrict__ rowsB, uint32_t nBtot, const uint8_t* __restrict__ arenaF,
     const uint32_t* __restrict__ rowsF, uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard) {
-  __shared__ u64 ring[2][kMxNB][kMxChunkBytes / 8];  // 128 KiB
+  // Two separate LDS objects, not one [2][...] array: the compiler must be able to prove that the
+  // global->LDS DMA filling one buffer cannot alias the ds_reads of the other, otherwise it puts
+  // s_waitcnt vmcnt(0) in front of every ds_read and the "prefetch" of the next step (DMA and the
+  // A loads) is serialised with the arithmetic (seen in the ISA of the first version; that alone
+  // cost a third of the kernel time).
+  __shared__ u64 ring0[kMxNB][kMxChunkBytes / 8];  // 64 KiB
+  __shared__ u64 ring1[kMxNB][kMxChunkBytes / 8];  // 64 KiB
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int lane = threadIdx.x & 63;
@@ -104,12 +118,12 @@ __global__ void __launch_bounds__(512) k_count_matrix_dense(
   auto step_off = [&](uint32_t st) -> uint32_t {  // byte offset of (slot, chunk) inside a row
     return (sg * spb + st / kMxChunks) * 8192u + (st % kMxChunks) * kMxChunkBytes;
   };
-  auto stage_b = [&](uint32_t st, int buf) {  // this wave's 4 B chunks -> ring[buf]
+  auto stage_b = [&](uint32_t st, u64 (*ring)[kMxChunkBytes / 8]) {  // this wave's 4 B chunks -> ring
     const uint32_t off = step_off(st) + loff;
 #pragma unroll
     for (int q = 0; q < kPerWave; ++q) {
       if (pb[q]) {
-        uint8_t* l = reinterpret_cast<uint8_t*>(&ring[buf][wv * kPerWave + q][0]);
+        uint8_t* l = reinterpret_cast<uint8_t*>(&ring[wv * kPerWave + q][0]);
         __builtin_amdgcn_global_load_lds((gptr_t)(pb[q] + off), (lptr_t)l, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(pb[q] + off + 1024), (lptr_t)(l + 1024), 16, 0, 0);
       }
@@ -148,8 +162,8 @@ __global__ void __launch_bounds__(512) k_count_matrix_dense(
   struct BPair {
     ulonglong2 b0, b1, c0, c1;  // chunk of column j (b) and of column j+1 (c)
   };
-  auto compute = [&](const MxA& A, int buf) {
-    const ulonglong2* q = reinterpret_cast<const ulonglong2*>(&ring[buf][0][0]) + lane;
+  auto compute = [&](const MxA& A, const u64 (*ring)[kMxChunkBytes / 8]) {
+    const ulonglong2* q = reinterpret_cast<const ulonglong2*>(&ring[0][0]) + lane;
     auto read_pair = [&](int j, BPair& P) {
       const ulonglong2* qn = q + j * (kMxChunkBytes / 16);
       P.b0 = qn[0];
@@ -157,9 +171,9 @@ __global__ void __launch_bounds__(512) k_count_matrix_dense(
       P.c0 = qn[128];
       P.c1 = qn[192];
     };
-    auto count_pair = [&](int j, const BPair& P) {
+    auto count_half = [&](int j, const BPair& P, int a0) {
 #pragma unroll
-      for (int a = 0; a < kMxTA; ++a) {
+      for (int a = a0; a < a0 + kMxTA / 2; ++a) {
         pc(acc[a][j], A.w[a][0], P.b0.x);
         pc(acc[a][j + 1], A.w[a][0], P.c0.x);
         pc(acc[a][j], A.w[a][1], P.b0.y);
@@ -170,47 +184,55 @@ __global__ void __launch_bounds__(512) k_count_matrix_dense(
         pc(acc[a][j + 1], A.w[a][3], P.c1.y);
       }
     };
-    // Two register sets alternate: the chunks of column pair j+2 are read from LDS while pair j
-    // is counted.  Each pair sits in its own basic block (a branch on a scalar the compiler
-    // cannot see through): instruction selection otherwise hoists all 64 LDS reads of the step
-    // above the arithmetic (256 live registers -> 2.5 KB of spills per lane); sched_barrier
-    // does not stop that and sched_group_barrier takes minutes to compile here.
+    // Two register sets alternate; every basic block is closed by a branch on a scalar the
+    // compiler cannot see through, which pins the order (instruction selection otherwise hoists
+    // all 64 LDS reads of the step above the arithmetic: 256 live registers, 2.5 KB of spills per
+    // lane; sched_barrier does not stop that and sched_group_barrier takes minutes to compile).
+    // Per column pair: block 1 counts A rows 0..1, block 2 issues the LDS reads of the NEXT pair
+    // and counts A rows 2..3 — so the s_waitcnt lgkmcnt(0) that opens the next pair's block 1
+    // finds its data 64 VALU instructions old instead of freshly issued.  (Issuing the reads
+    // as asm a whole pair ahead with an exact lgkmcnt(4), or halving the number of branches,
+    // changes nothing measurable: 350 us either way.)
     BPair P, Q;
     read_pair(0, P);
-#pragma unroll
-    for (int j = 0; j < kMxNB; j += 4) {
+    auto opaque = [] {
       uint32_t one;
       asm volatile("s_mov_b32 %0, 1" : "=s"(one));
-      if (one) {
+      return one;
+    };
+#pragma unroll
+    for (int j = 0; j < kMxNB; j += 4) {
+      if (opaque()) count_half(j, P, 0);
+      if (opaque()) {
         read_pair(j + 2, Q);
-        count_pair(j, P);
+        count_half(j, P, kMxTA / 2);
       }
-      asm volatile("s_mov_b32 %0, 1" : "=s"(one));
-      if (one) {
+      if (opaque()) count_half(j + 2, Q, 0);
+      if (opaque()) {
         if (j + 4 < kMxNB) read_pair(j + 4, P);
-        count_pair(j + 2, Q);
+        count_half(j + 2, Q, kMxTA / 2);
       }
     }
   };
 
   MxA A0, A1;
-  stage_b(0, 0);
+  stage_b(0, ring0);
   load_a(0, A0);
   for (uint32_t st = 0; st < steps; st += 2) {
-    // even step: compute from ring[0] with A0 while ring[1] / A1 are being filled
+    // even step: compute from ring0 with A0 while ring1 / A1 are being filled
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stage_b(st + 1, 1);
+    stage_b(st + 1, ring1);
     load_a(st + 1, A1);
-    compute(A0, 0);
+    compute(A0, ring0);
     // odd step
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (st + 2 < steps) {
-      stage_b(st + 2, 0);
+      stage_b(st + 2, ring0);
       load_a(st + 2, A0);
     }
-    compute(A1, 1);
+    compute(A1, ring1);
   }
 
   // one reduction per block: two passes of 64 values (a = 0,1 then a = 2,3)
