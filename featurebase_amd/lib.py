@@ -11,7 +11,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfbk.so")
+LIB_PATH = os.environ.get("FBK_LIB_PATH") or os.path.join(_HERE, "csrc", "libfbk.so")  # override: A/B builds of the same ABI
 
 FBK_OK = 0
 FBK_E_INVALID, FBK_E_NODEVICE, FBK_E_HIP, FBK_E_NOMEM, FBK_E_CAPACITY, FBK_E_NOTFOUND = -1, -2, -3, -4, -5, -6
