@@ -333,7 +333,9 @@ int32_t fbk_fold_n_intersection_count(fbk_ctx* ctx, int32_t op, const fbk_batch*
  * Pairs.Add arithmetic, executor.go:3728, 2852); out_per_shard (n_shards*n_a*n_b, may be
  * NULL) keeps the per-shard matrices.  Replaces groupByIterator.Next's
  * rows[last].intersectionCount(rows[last-1]) (executor.go:8893) and, with n_b == 1 and
- * B = the filter row, doTopK / fragment.top (executor.go:2705-2746, fragment.go:1317). */
+ * B = the filter row, doTopK / fragment.top (executor.go:2705-2746, fragment.go:1317).
+ * Limits: n_a, n_b <= 4096 for a matrix; with n_b == 1 (the TopK / TopN shape, served by a
+ * dedicated rows-vs-filter kernel) n_a <= 2^22. */
 int32_t fbk_count_matrix(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a,
                          const fbk_batch* b, const uint32_t* rows_b, uint32_t n_b, const fbk_batch* filter,
                          const uint32_t* rows_f, uint32_t n_shards, uint64_t* out_total,

@@ -563,3 +563,31 @@ def test_count_matrix_mixed_rows_take_the_densify_path(gpu_ctx, oracle, B, a_den
     for b in (A, Bt, F):
         if b is not None:
             b.free()
+
+
+def test_rows_vs_filter_many_rows(gpu_ctx, oracle):
+    """TopK over a field with more rows than the matrix limit (5000 sparse rows x 2 shards)."""
+    O = oracle
+    rng = D.rng_for(61)
+    n_shards, n_a = 2, 5000
+    rows = []
+    for s in range(n_shards):
+        for i in range(n_a):
+            slot = int(rng.integers(0, 16))
+            vals = np.sort(rng.choice(65536, size=int(rng.integers(1, 40)), replace=False))
+            rows.append({s * 16 + slot: O.OContainer.array(vals)})
+    filt = [D.random_row(rng, s) for s in range(n_shards)]
+    A = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+    F = gpu_ctx.upload([D.to_fbk_row(r) for r in filt])
+    ra = np.arange(n_shards * n_a).reshape(n_shards, n_a)
+    tot, ps = gpu_ctx.count_matrix(A, ra, F, np.arange(n_shards).reshape(-1, 1), per_shard=True)
+    for s in range(n_shards):
+        for i in range(0, n_a, 37):
+            r = rows[s * n_a + i]
+            exp = sum(O.intersection_count(c, filt[s][k]) for k, c in r.items() if k in filt[s])
+            assert int(ps[s, i, 0]) == exp, (s, i)
+    assert int(tot.sum()) == int(ps.sum())
+    with pytest.raises(L.FbkError):
+        gpu_ctx.count_matrix(A, ra, A, ra)  # a 5000 x 5000 matrix is refused
+    A.free()
+    F.free()
