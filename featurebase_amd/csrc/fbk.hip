@@ -72,6 +72,7 @@ struct fbk_ctx {
   uint64_t h_stage_cap = 0, h_stage_used = 0;
   // device fragment cache (fbk_cache_api.inc)
   std::unordered_map<std::string, struct fbk_cache_entry*> cache;
+  std::unordered_map<const fbk_batch*, struct fbk_cache_entry*> cache_by_batch;  // release() looks entries up by handle
   std::vector<struct fbk_cache_entry*> cache_zombies;  // invalidated while pinned
   uint64_t cache_bytes = 0, cache_cap_bytes = 128ull << 30, cache_clock = 0;
   uint64_t cache_hits = 0, cache_misses = 0, cache_evictions = 0;

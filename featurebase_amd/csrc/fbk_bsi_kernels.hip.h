@@ -361,6 +361,7 @@ __global__ void __launch_bounds__(1024) k_bsi_minmax(const Slot* __restrict__ sl
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;  // = slot
   const uint64_t shard = blockIdx.x;
+  if (shard >= n_shards) return;  // block-uniform
   const uint64_t r0 = base[shard];
   auto row_total = [&](uint32_t c, int buf) -> uint32_t {  // block-wide row cardinality
     if (lane == 0) s_cnt[buf][wv] = c;

@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(256, 4) k_fold_scatter(const Slot* __restrict_
   const uint64_t cell = blockIdx.x;  // (group, slot)
   const uint64_t g = cell >> 4;
   const uint32_t slot = cell & 15;
+  if (g >= n_groups) return;  // block-uniform
   uint32_t* acc32 = reinterpret_cast<uint32_t*>(acc);
   {
     ulonglong2 z;

@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(256) k_fold_n(const Slot* __restrict__ slots, 
   const uint64_t cell = blockIdx.x;  // (group, slot)
   const uint64_t g = cell >> 4;
   const uint32_t slot = cell & 15;
+  if (g >= n_groups) return;  // block-uniform
   if (threadIdx.x == 0) s_short = 0;
   __syncthreads();
   u64 acc[kWordsPerLane];
