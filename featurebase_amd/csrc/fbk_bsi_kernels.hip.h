@@ -450,4 +450,62 @@ __global__ void __launch_bounds__(1024) k_bsi_minmax(const Slot* __restrict__ sl
   }
 }
 
+// ---- BSI adder ---------------------------------------------------------------------------------
+// roaring.Add (roaring/add.go:12-849), used by AddBSI (bsi.go:83-175) to merge the per-shard
+// TopK count BSIs: z = x + y over unsigned bit-sliced values, plane i of z = x_i ^ y_i ^ carry,
+// carry' = majority(x_i, y_i, carry) — a ripple-carry adder evaluated for 65 536 columns at a
+// time.  One block per (group, slot) in the block layout: the carry lives in 4 u64 per thread
+// while the planes of both operands stream past once and the sum planes stream out; plane D
+// (D = max depth) receives the final carry.  Nil planes read as zero.
+__global__ void __launch_bounds__(256) k_bsi_add(const Slot* __restrict__ slotsX, const uint8_t* __restrict__ arenaX,
+                                                const uint32_t* __restrict__ rowsX, uint32_t dx,
+                                                const Slot* __restrict__ slotsY, const uint8_t* __restrict__ arenaY,
+                                                const uint32_t* __restrict__ rowsY, uint32_t dy, uint64_t n_groups,
+                                                uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
+                                                uint32_t* __restrict__ outRuns) {
+  __shared__ u64 scratch[kWords];
+  __shared__ u64 part[4];
+  __shared__ uint8_t tops[512];
+  const int t = threadIdx.x;
+  const uint64_t g = blockIdx.x >> 4;
+  const uint32_t slot = blockIdx.x & 15;
+  if (g >= n_groups) return;
+  const uint32_t D = max(dx, dy);
+  u64 c[kBW], x[kBW], y[kBW], z[kBW];
+  bfrag_zero(c);
+  for (uint32_t i = 0; i <= D; ++i) {
+    bfrag_zero(x);
+    bfrag_zero(y);
+    if (i < dx) bfrag_load(slotsX[(uint64_t)rowsX[g * dx + i] * kSlots + slot], arenaX, t, scratch, x);
+    if (i < dy) bfrag_load(slotsY[(uint64_t)rowsY[g * dy + i] * kSlots + slot], arenaY, t, scratch, y);
+#pragma unroll
+    for (int q = 0; q < kBW; ++q) {
+      z[q] = x[q] ^ y[q] ^ c[q];
+      c[q] = (x[q] & y[q]) | (c[q] & (x[q] ^ y[q]));
+    }
+    const uint64_t cell = (g * (D + 1) + i) * kSlots + slot;
+    const uint32_t n = (uint32_t)block_reduce_add_u64(bfrag_popcount(z), part);
+    Slot so;
+    so.off = cell * 8192ull;
+    so.len = kWords;
+    so.tn = make_tn(n ? kTypeBitmap : kTypeNil, n);
+    if (n) bfrag_store_bitmap(arenaO + so.off, t, z);
+    uint32_t rr = 0;
+    if (outRuns) {  // bitmapCountRuns for the optimize() pass
+      __syncthreads();
+      tops[t] = (uint8_t)(z[1] >> 63);
+      tops[256 + t] = (uint8_t)(z[3] >> 63);
+      __syncthreads();
+      const u64 l0 = t ? tops[t - 1] : 0, l1 = tops[255 + t];
+      const uint32_t r = __popcll(z[0] & ~((z[0] << 1) | l0)) + __popcll(z[1] & ~((z[1] << 1) | (z[0] >> 63))) +
+                         __popcll(z[2] & ~((z[2] << 1) | l1)) + __popcll(z[3] & ~((z[3] << 1) | (z[2] >> 63)));
+      rr = (uint32_t)block_reduce_add_u64(r, part);
+    }
+    if (t == 0) {
+      outSlots[cell] = so;
+      if (outRuns) outRuns[cell] = rr;
+    }
+  }
+}
+
 }  // namespace fbk

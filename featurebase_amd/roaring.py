@@ -405,6 +405,16 @@ class Context:
         """Per shard (max, count): fragment.max (fragment.go:803)."""
         return self._bsi_minmax(self.lib.fbk_bsi_max, batch, base_rows, bit_depth, filt, rows_f)
 
+    def bsi_add(self, x: Batch, rows_x, y: Batch, rows_y, flags: int = 0) -> Batch:
+        """rows_x: [n_groups, depth_x], rows_y: [n_groups, depth_y] plane rows (bit i = column i);
+        out rows g*(D+1)+i = plane i of x + y (roaring.Add, roaring/add.go:12)."""
+        rx = np.ascontiguousarray(rows_x, dtype=np.uint32).reshape(len(rows_x), -1)
+        ry = np.ascontiguousarray(rows_y, dtype=np.uint32).reshape(len(rows_y), -1)
+        assert rx.shape[0] == ry.shape[0]
+        h = C.c_void_p()
+        L.check(self.lib.fbk_bsi_add(self.h, x.h, rx.ctypes.data, rx.shape[1], y.h, ry.ctypes.data, ry.shape[1], rx.shape[0], flags, C.byref(h)))
+        return Batch(self, h.value)
+
     def bsi_range(self, batch: Batch, base_rows, op: int, bit_depth: int, predicate: int, flags: int = 0) -> Tuple[Batch, np.ndarray]:
         base = np.ascontiguousarray(base_rows, dtype=np.uint32)
         counts = np.zeros(base.size, dtype=np.uint64)

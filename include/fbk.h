@@ -372,6 +372,14 @@ int32_t fbk_bsi_max(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_r
                     uint32_t bit_depth, const fbk_batch* filter, const uint32_t* rows_f, int64_t* out_vals,
                     uint64_t* out_counts);
 
+/* Unsigned BSI addition z = x + y, plane by plane (ripple carry): roaring.Add
+ * (roaring/add.go:12-849), which AddBSI (bsi.go:83-175) uses to merge per-shard TopK counts.
+ * Group g of x is the depth_x rows rows_x[g*depth_x + i] (plane i = bit i, no exists / sign
+ * planes), likewise y; out row g*(D+1) + i is plane i of the sum, D = max(depth_x, depth_y),
+ * plane D holding the final carry.  Output container keys are the slot numbers 0..15. */
+int32_t fbk_bsi_add(fbk_ctx* ctx, const fbk_batch* x, const uint32_t* rows_x, uint32_t depth_x, const fbk_batch* y,
+                    const uint32_t* rows_y, uint32_t depth_y, uint64_t n_groups, uint32_t flags, fbk_batch** out_batch);
+
 /* out row s = columns of shard s whose value satisfies `op predicate` (fragment.rangeOp,
  * fragment.go:937-1208); container keys of the result are the slot numbers 0..15. */
 int32_t fbk_bsi_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards,

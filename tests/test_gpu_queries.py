@@ -591,3 +591,69 @@ def test_rows_vs_filter_many_rows(gpu_ctx, oracle):
         gpu_ctx.count_matrix(A, ra, A, ra)  # a 5000 x 5000 matrix is refused
     A.free()
     F.free()
+
+
+def test_bsi_add_is_integer_addition(gpu_ctx, oracle):
+    """TestAdd (roaring/add_test.go:311-407) on the device adder: random position -> count maps
+    (heavy-tailed, up to 2^44), bit-sliced into planes of any encoding; the planes of
+    fbk_bsi_add decode to x + y at every position.  Operands of different depth, a group where
+    one operand is empty, and carries into plane D."""
+    O = oracle
+    rng = D.rng_for(67)
+    n_groups = 4
+
+    def planes_of(vals, depth):
+        rows = []
+        for i in range(depth):
+            bm = O.bitmap_from_values([p for p, v in vals.items() if (v >> i) & 1])
+            rows.append({k: D.to_fbk(c) for k, c in bm.items() if c.n})
+        return rows
+
+    xs, ys = [], []
+    for g in range(n_groups):
+        n = [3000, 40, 70000, 500][g]
+        pos = rng.choice(1 << 20, size=n, replace=False)
+        heavy = lambda m: (rng.pareto(1.2, size=m) * 7).astype(np.uint64) % (1 << 44)  # noqa: E731
+        xv = {int(p): int(v) for p, v in zip(pos, heavy(n)) if v}
+        yv = {int(p): int(v) for p, v in zip(pos[: n // 2], heavy(n // 2)) if v}
+        extra = rng.choice(1 << 20, size=n // 3 + 1, replace=False)
+        for p, v in zip(extra, heavy(len(extra))):
+            if v:
+                yv[int(p)] = int(v)
+        if g == 1:
+            yv = {}  # "there are no values in y" (bsi.go:158)
+        if g == 3:
+            xv.update({5: (1 << 44) - 1, 6: (1 << 44) - 1})  # carries ripple through every plane
+            yv.update({5: 1, 6: (1 << 44) - 1})
+        xs.append(xv)
+        ys.append(yv)
+    dx, dy = 44, 44
+    for depths in ((44, 44), (44, 20), (7, 44)):
+        dx, dy = depths
+        xm = [{p: v & ((1 << dx) - 1) for p, v in xv.items() if v & ((1 << dx) - 1)} for xv in xs]
+        ym = [{p: v & ((1 << dy) - 1) for p, v in yv.items() if v & ((1 << dy) - 1)} for yv in ys]
+        xrows = [r for xv in xm for r in planes_of(xv, dx)]
+        yrows = [r for yv in ym for r in planes_of(yv, dy)]
+        X, Y = gpu_ctx.upload(xrows), gpu_ctx.upload(yrows)
+        rx = np.arange(n_groups * dx).reshape(n_groups, dx)
+        ry = np.arange(n_groups * dy).reshape(n_groups, dy)
+        for flags in (0, L.SETOP_OPTIMIZE):
+            out = gpu_ctx.bsi_add(X, rx, Y, ry, flags)
+            rows = out.download()
+            Dp = max(dx, dy) + 1
+            assert len(rows) == n_groups * Dp
+            for g in range(n_groups):
+                got = {}
+                for i in range(Dp):
+                    for k, c in rows[g * Dp + i].items():
+                        bits = np.unpackbits(c.words().view(np.uint8), bitorder="little")
+                        for v in np.nonzero(bits)[0]:
+                            p = ((k & 15) << 16) + int(v)
+                            got[p] = got.get(p, 0) | (1 << i)
+                exp = dict(xm[g])
+                for p, v in ym[g].items():
+                    exp[p] = exp.get(p, 0) + v
+                assert got == exp, (depths, flags, g)
+            out.free()
+        X.free()
+        Y.free()
