@@ -4,6 +4,7 @@
 #include "../../include/fbk.h"
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>  // device radix sort / unique for fbk_bsi_distinct (plumbing, not the hot path)
 
 #include <algorithm>
 #include <cstdio>

@@ -508,4 +508,93 @@ __global__ void __launch_bounds__(256) k_bsi_add(const Slot* __restrict__ slotsX
   }
 }
 
+// ---- BSI Distinct: bit planes -> per-column values ------------------------------------------------
+// executeDistinctShardBSI (executor.go:2034-2153) walks the exists bitmap bit by bit and gathers
+// the value of every column from the bit planes.  Here that is a 64 x 64 bit-matrix transpose in
+// registers: lane i of a wavefront holds 64 columns' worth of plane i (one u64), a 6-stage
+// butterfly of lane exchanges turns it into lane j holding the 64-bit value of column j, and the
+// values of the columns in exists ∩ filter are appended to a global list (sorted and
+// de-duplicated afterwards).  Operands must be DENSE rows (k_densify_rows makes them so): lane i
+// reads a whole 128-byte line of plane i per round, i.e. 16 word positions per load.
+//   rows[shard] = ordinal of the exists row; +1 sign, +2+i plane i.   One block per (shard, slot).
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, kWave), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, kWave);
+  return ((u64)hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ rows,
+                                                   uint32_t n_shards, uint32_t depth, const uint8_t* __restrict__ farena,
+                                                   const uint32_t* __restrict__ frows, long long* __restrict__ out,
+                                                   u64* __restrict__ cursor) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t shard = blockIdx.x >> 4, slot = blockIdx.x & 15;
+  if (shard >= n_shards) return;
+  const uint64_t rowBytes = (uint64_t)kSlots * 8192;
+  const uint8_t* ex = arena + (uint64_t)rows[shard] * rowBytes + slot * 8192ull;
+  const uint8_t* sg = ex + rowBytes;
+  const uint8_t* fl = farena ? farena + (uint64_t)frows[shard] * rowBytes + slot * 8192ull : nullptr;
+  const uint8_t* mine = ex + (uint64_t)(2 + lane) * rowBytes;  // plane `lane` (unused when lane >= depth)
+  for (int round = 0; round < 16; ++round) {
+    const uint32_t w0 = (uint32_t)wv * 256u + (uint32_t)round * 16u;  // first word of this round
+    // the 16 exists / filter / sign words of the round: lanes 0..15 fetch one each
+    u64 e = 0, sgn = 0;
+    if (lane < 16) {
+      e = reinterpret_cast<const u64*>(ex)[w0 + lane];
+      if (fl) e &= reinterpret_cast<const u64*>(fl)[w0 + lane];
+      sgn = reinterpret_cast<const u64*>(sg)[w0 + lane];
+    }
+    uint32_t pc = __popcll(e);  // lanes >= 16 hold 0
+    uint32_t incl = pc;         // inclusive prefix over the 16 words
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 15, kWave);
+    if (total == 0) continue;  // wave-uniform: no column of these 1024 has a value
+    u64 basepos = 0;
+    if (lane == 0) basepos = atomicAdd(cursor, (u64)total);
+    basepos = ((u64)__shfl((int)(uint32_t)(basepos >> 32), 0, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)basepos, 0, kWave);
+    // this lane's plane: 16 words = one 128-byte line
+    u64 pw[16];
+    if (lane < (int)depth) {
+      const ulonglong2* q = reinterpret_cast<const ulonglong2*>(mine + (uint64_t)w0 * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const ulonglong2 v = ld_stream(&q[k]);
+        pw[2 * k] = v.x;
+        pw[2 * k + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pw[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const u64 ek = ((u64)(uint32_t)__shfl((int)(uint32_t)(e >> 32), k, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)e, k, kWave);
+      if (ek != 0) {  // wave-uniform
+      const u64 sk = ((u64)(uint32_t)__shfl((int)(uint32_t)(sgn >> 32), k, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)sgn, k, kWave);
+      const uint32_t before = __shfl(incl - pc, k, kWave);  // values emitted by words 0..k-1 of the round
+      // 64 x 64 transpose: row = lane (plane), bit = column  ->  row = column, bit = plane
+      u64 v = pw[k];
+#pragma unroll
+      for (int st = 0; st < 6; ++st) {
+        const int j = 32 >> st;
+        const u64 km = st == 0 ? 0x00000000FFFFFFFFull : st == 1 ? 0x0000FFFF0000FFFFull : st == 2 ? 0x00FF00FF00FF00FFull
+                     : st == 3 ? 0x0F0F0F0F0F0F0F0Full : st == 4 ? 0x3333333333333333ull : 0x5555555555555555ull;
+        const u64 x = shfl_xor_u64(v, j);
+        v = (lane & j) ? (((x >> j) & km) | (v & ~km)) : ((v & km) | ((x & km) << j));
+      }
+      if ((ek >> lane) & 1ull) {
+        const u64 below = lane ? (ek & (~0ull >> (64 - lane))) : 0ull;
+        // value *= -1 for negative columns (int64 wrap-around as in the reference, executor.go:2123)
+        const long long val = ((sk >> lane) & 1ull) ? (long long)(0ull - v) : (long long)v;
+        out[basepos + before + __popcll(below)] = val;
+      }
+      }
+    }
+  }
+}
+
 }  // namespace fbk

@@ -405,6 +405,23 @@ class Context:
         """Per shard (max, count): fragment.max (fragment.go:803)."""
         return self._bsi_minmax(self.lib.fbk_bsi_max, batch, base_rows, bit_depth, filt, rows_f)
 
+    def bsi_distinct(self, batch: Batch, base_rows, bit_depth: int, filt: Optional[Batch] = None, rows_f=None) -> np.ndarray:
+        """Sorted distinct stored values (int64, Base not added) of the columns in exists ∩ filter
+        over all given shards (executeDistinctShardBSI, executor.go:2034)."""
+        base = np.ascontiguousarray(base_rows, dtype=np.uint32)
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        n = C.c_uint64()
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, dtype=np.int64)
+            rc = self.lib.fbk_bsi_distinct(self.h, batch.h, base.ctypes.data, base.size, bit_depth, filt.h if filt is not None else None,
+                                           rf.ctypes.data if rf is not None else None, out.ctypes.data, cap, C.byref(n))
+            if rc == L.FBK_E_CAPACITY:
+                cap = int(n.value)
+                continue
+            L.check(rc)
+            return out[: n.value].copy()
+
     def bsi_add(self, x: Batch, rows_x, y: Batch, rows_y, flags: int = 0) -> Batch:
         """rows_x: [n_groups, depth_x], rows_y: [n_groups, depth_y] plane rows (bit i = column i);
         out rows g*(D+1)+i = plane i of x + y (roaring.Add, roaring/add.go:12)."""

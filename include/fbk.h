@@ -372,6 +372,17 @@ int32_t fbk_bsi_max(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_r
                     uint32_t bit_depth, const fbk_batch* filter, const uint32_t* rows_f, int64_t* out_vals,
                     uint64_t* out_counts);
 
+/* Distinct values of a BSI field among the columns of exists ∩ filter over all the shards given:
+ * executeDistinctShardBSI (executor.go:2034-2153) — which gathers every column's value from the
+ * bit planes — followed by the SignedRow.Union reduce over shards (executor.go:1190-1196).
+ * out_values receives the sorted distinct stored values (sign applied, Base NOT added: the
+ * caller adds bsiGroup.Base and splits into SignedRow{Neg, Pos}); *out_n their number, also when
+ * FBK_E_CAPACITY reports that `cap` was too small.  The planes are transposed on the device
+ * (64 x 64 bit-matrix transpose in registers), sorted and de-duplicated there. */
+int32_t fbk_bsi_distinct(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards,
+                         uint32_t bit_depth, const fbk_batch* filter, const uint32_t* rows_f, int64_t* out_values,
+                         uint64_t cap, uint64_t* out_n);
+
 /* Unsigned BSI addition z = x + y, plane by plane (ripple carry): roaring.Add
  * (roaring/add.go:12-849), which AddBSI (bsi.go:83-175) uses to merge per-shard TopK counts.
  * Group g of x is the depth_x rows rows_x[g*depth_x + i] (plane i = bit i, no exists / sign

@@ -367,6 +367,38 @@ class Executor {
     return true;
   }
 
+  // ---- Distinct -----------------------------------------------------------------------------
+  // Distinct(field=int field, filter): the distinct values (Base added) in ascending order —
+  // the SignedRow{Neg, Pos} of executeDistinct (executor.go:1170-1230, 2034-2153) flattened.
+  std::vector<int64_t> Distinct(const std::string& field, const Call* filter = nullptr) {
+    idx_.Sync();
+    const Index::IntField& f = idx_.ints_.at(field);
+    std::vector<int64_t> out;
+    const size_t n = idx_.shards_.size();
+    if (n == 0) return out;
+    std::vector<uint32_t> base = base_rows(f);
+    uint64_t cnt = 0, cap = 1024;
+    for (;;) {
+      out.assign(cap, 0);
+      int32_t rc;
+      if (filter) {
+        RowSet fr = eval(*filter);
+        rc = fbk_bsi_distinct(idx_.ctx_, f.batch, base.data(), uint32_t(n), f.bit_depth, fr.batch(), fr.rows().data(), out.data(), cap, &cnt);
+      } else {
+        rc = fbk_bsi_distinct(idx_.ctx_, f.batch, base.data(), uint32_t(n), f.bit_depth, nullptr, nullptr, out.data(), cap, &cnt);
+      }
+      if (rc == FBK_E_CAPACITY) {
+        cap = cnt;
+        continue;
+      }
+      check(rc);
+      break;
+    }
+    out.resize(cnt);
+    for (int64_t& v : out) v += f.base;  // value += int64(offset), executor.go:2126
+    return out;
+  }
+
   // ---- TopK / TopN ---------------------------------------------------------------------------
   // TopK(field, k, filter): per-row |row ∩ filter| over all shards (doTopK), then the rows in
   // descending count order, ascending id inside one count, zero counts dropped

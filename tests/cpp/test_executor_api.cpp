@@ -121,6 +121,10 @@ int main() {
     EXPECT(e.Columns(Call::Between("f", 10, 40)) == (V{0, 3, SW, SW + 2}));
     EXPECT(e.Columns(Call::Range("foo", FBK_BSI_LTE, 30)) == (V{0, SW}));  // base 10: stored magnitudes are value - 10
     EXPECT(e.Count(Call::Nary(Call::kIntersect, {Call::Range("f", FBK_BSI_GT, 0), x0})) == 3);
+    // Distinct(field=f): f = {20, -5, -5, 10, 30, 40, 50, 60}; Distinct(Row(x=0), field=f): cols {0, 3, SW+1}
+    EXPECT(e.Distinct("f") == (std::vector<int64_t>{-5, 10, 20, 30, 40, 50, 60}));
+    EXPECT(e.Distinct("f", &x0) == (std::vector<int64_t>{10, 20, 60}));
+    EXPECT(e.Distinct("foo") == (std::vector<int64_t>{20, 30, 40, 50, 60}));  // Base 10 added back
   }
   {  // ---- GroupBy (executor_test.go:6035-6130) ----
     Index idx;

@@ -657,3 +657,59 @@ def test_bsi_add_is_integer_addition(gpu_ctx, oracle):
             out.free()
         X.free()
         Y.free()
+
+
+def test_bsi_distinct_vs_definition(gpu_ctx, B):
+    """fbk_bsi_distinct against the definition executeDistinctShardBSI implements
+    (executor.go:2034-2153: the value of every column of exists ∩ filter, then the set union over
+    shards): mixed-encoding planes (densify path) and dense planes, with and without a filter,
+    depth 64 with magnitude bit 63 (int64 wrap), many ties, an empty shard."""
+    rng = D.rng_for(71)
+    for depth in (5, 20, 64):
+        frags, filts, vals_all = [], [], []
+        for s in range(5):
+            ncol = [30000, 700, 1 << 16, 0, 11][s]
+            cols = rng.choice(1 << 20, size=ncol, replace=False)
+            hi = 1 << min(depth, 62)
+            mag = rng.integers(0, hi, size=ncol)
+            if s in (0, 2):
+                mag = mag % 1000  # many repeated values
+            sign = np.where(rng.random(ncol) < 0.4, -1, 1)
+            vals = {int(c): int(m) * int(g) for c, m, g in zip(cols, mag, sign)}
+            if depth == 64 and s == 1:
+                vals[int(cols[0])] = (1 << 63) + 9  # wraps to a negative int64 as in the reference
+                vals[int(cols[1])] = -((1 << 63) + 9)
+            vals_all.append(vals)
+            frags.append(B.bsi_fragment_from_values(vals, depth))
+            filts.append(B.row_from_columns([int(c) for c in cols[:: 2 + s]] + [5, 70000]))
+        batch, base = upload_bsi(gpu_ctx, frags)
+        F = gpu_ctx.upload([fbk_row_of_bitmap(f) for f in filts])
+
+        def wrap(v):
+            v &= (1 << 64) - 1
+            return v - (1 << 64) if v >= (1 << 63) else v
+
+        exp_all = sorted({wrap(v) for vals in vals_all for v in vals.values()})
+        got = gpu_ctx.bsi_distinct(batch, base, depth)
+        assert got.tolist() == exp_all, depth
+        exp_f = set()
+        for s, vals in enumerate(vals_all):
+            fs = set(B.columns(filts[s]))
+            exp_f |= {wrap(v) for c, v in vals.items() if c in fs}
+        got = gpu_ctx.bsi_distinct(batch, base, depth, F, np.arange(5))
+        assert got.tolist() == sorted(exp_f), depth
+        batch.free()
+        F.free()
+    # dense planes (no densify pass): config 5's layout, values checked through their count
+    n_shards, depth = 3, 12
+    w = D.dense_rows(n_shards * (depth + 2), 0.5, 901).reshape(n_shards, depth + 2, 16, 1024)
+    w[:, 1:] &= w[:, :1]
+    batch = gpu_ctx.upload_dense(w.reshape(-1))
+    base = np.arange(n_shards, dtype=np.uint32) * (depth + 2)
+    got = gpu_ctx.bsi_distinct(batch, base, depth)
+    bits = np.unpackbits(w.reshape(n_shards, depth + 2, -1).view(np.uint8), axis=2, bitorder="little").astype(np.int64)
+    mag = sum(bits[:, 2 + i] << i for i in range(depth))
+    val = np.where(bits[:, 1] == 1, -mag, mag)
+    exp = np.unique(val[bits[:, 0] == 1])
+    assert got.tolist() == exp.tolist()
+    batch.free()
