@@ -58,7 +58,7 @@ struct ValCount {  // executor.go:8380; integer fields only
 
 // A PQL bitmap call (the subset on the hot path).
 struct Call {
-  enum Kind { kRow, kRange, kBetween, kIntersect, kUnion, kDifference, kXor } kind = kRow;
+  enum Kind { kRow, kRange, kBetween, kIntersect, kUnion, kDifference, kXor, kNot, kAll } kind = kRow;
   std::string field;
   uint64_t row = 0;    // Row(field=row)
   int32_t op = 0;      // FBK_BSI_* for Row(field <op> value)
@@ -85,6 +85,17 @@ struct Call {
     c.field = std::move(f);
     c.value = lo;
     c.value2 = hi;
+    return c;
+  }
+  static Call Not(Call child) {  // Not(x) = existence row \ x (executeNotShard, executor.go:5554-5604)
+    Call c;
+    c.kind = kNot;
+    c.children.push_back(std::move(child));
+    return c;
+  }
+  static Call All() {  // All(): the existence row (executeAllCallShard, executor.go:5606)
+    Call c;
+    c.kind = kAll;
     return c;
   }
   static Call Nary(Kind k, std::vector<Call> ch) {
@@ -152,6 +163,7 @@ class Index {
   }
   void SetBit(const std::string& field, uint64_t row, uint64_t col) {  // Set(col, field=row)
     sets_.at(field).bits[row].insert(col);
+    sets_[kExistence].bits[0].insert(col);  // IndexOptions.TrackExistence: the "_exists" field, row 0
     dirty_ = true;
   }
   void SetValue(const std::string& field, uint64_t col, int64_t value) {  // Set(col, field=value), field.go:1497-1543
@@ -162,9 +174,11 @@ class Index {
     const uint64_t mag = bv < 0 ? uint64_t(-bv) : uint64_t(bv);
     const uint32_t need = mag ? 64u - uint32_t(__builtin_clzll(mag)) : 0u;  // bitDepthInt64, field.go:2507
     f.bit_depth = std::max(f.bit_depth, need);
+    sets_[kExistence].bits[0].insert(col);
     dirty_ = true;
   }
   fbk_ctx* ctx() { return ctx_; }
+  static constexpr const char* kExistence = "_exists";  // existenceFieldName, index.go
 
  private:
   friend class Executor;
@@ -513,6 +527,12 @@ class Executor {
       case Call::kRow: return leaf_row(c.field, c.row);
       case Call::kRange:
       case Call::kBetween: return range(c);
+      case Call::kAll: return leaf_row(Index::kExistence, 0);
+      case Call::kNot: {
+        if (c.children.size() != 1) throw Error(FBK_E_INVALID, "Not() requires exactly one child");
+        RowSet ex = leaf_row(Index::kExistence, 0), child = eval(c.children[0]);
+        return setop(FBK_OP_ANDNOT, ex, child);
+      }
       default: break;
     }
     if (c.children.empty()) throw Error(FBK_E_INVALID, "empty call");  // e.g. "Intersect() requires at least 1 child"

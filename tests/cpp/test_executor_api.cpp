@@ -69,6 +69,11 @@ int main() {
     EXPECT(e.Columns(Call::Nary(Call::kDifference, {R(20), R(21), R(30)})) == (V{}));       // {SW+1} \ {..,SW+1,..}
     EXPECT(e.Columns(Call::Nary(Call::kIntersect, {R(20), R(30), R(40)})) == (V{SW + 1, SW + 2}));
     EXPECT(e.Count(R(99)) == 0);  // a row that does not exist is empty
+    // Not() / All() over the tracked existence row: every column set so far is
+    // {0,1,2,3,4, SW+1, SW+2}; Not(Row(general=10)) = existence \ {1,2,3}
+    EXPECT(e.Columns(Call::All()) == (V{0, 1, 2, 3, 4, SW + 1, SW + 2}));
+    EXPECT(e.Columns(Call::Not(R(10))) == (V{0, 4, SW + 1, SW + 2}));
+    EXPECT(e.Count(Call::Not(Call::Nary(Call::kUnion, {R(10), R(20), R(30)}))) == 1);  // only column 4 is left
   }
   {  // ---- TopK (executor_test.go:1758-1809): rows {0, 10, 20} -> {10: 4, 0: 3} ----
     Index idx;
