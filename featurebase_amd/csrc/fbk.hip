@@ -21,6 +21,7 @@
 #include "fbk_topk_kernels.hip.h"
 #include "fbk_bsi_kernels.hip.h"
 #include "fbk_matrix_kernels.hip.h"
+#include "fbk_matrix_mfma.hip.h"
 #include "fbk_wire_kernels.hip.h"
 
 using fbk::Slot;

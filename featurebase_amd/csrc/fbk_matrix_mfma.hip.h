@@ -1,0 +1,214 @@
+// fbk_matrix_mfma.hip.h — the many-row IntersectionCount matrix (GroupBy / TopN / TopK shape,
+// executor.go:8880-8934, 2705-2774) for DENSE rows, on the matrix cores.
+//
+// out[shard][i][j] (+)= sum over the block's slots of |A[shard][i] ∩ F[shard] ∩ B[shard][j]|
+//
+// is C = A' · Bᵀ over {0,1} with K = 65536 bit positions per container: nA x nB pairs reuse
+// nA + nB containers, so unlike every other kernel of this library the shape is arithmetic-bound
+// on the vector ALU (k_count_matrix_dense: 2.1 M container pairs x 64 v_and / v_bcnt per lane,
+// 350 us for 128 shards x 32 x 32 rows, twice the time it takes to read the rows once).  The
+// matrix cores do the pair work instead: v_mfma_i32_32x32x32_i8 multiplies a 32-row x 32-byte A
+// operand with a 32-column x 32-byte B operand, and a bit becomes a byte with ONE v_and:
+//
+//   a = bswap(A & F), b = bitreverse(B)          (per 32-bit word, once)
+//   for k in 0..7:  opA = a & (0x01010101 << k)           -> byte value 2^k where the bit is set
+//                   opB = b & (0x01010101 << (7 - k))     -> byte value 2^(7-k) at the same source bit
+//
+// so every matching bit contributes 2^k · 2^(7-k) = 128, except that a byte with bit 7 set is
+// -128 in i8: the k = 0 and k = 7 products are -128 and go to a second accumulator; the count is
+// (P - N) >> 7, exact in i32 (at most 2^20 bits x 128 per shard).  Which source bit lands on which
+// K index is irrelevant as long as A and B use the same mapping, which leaves the lane -> data
+// assignment free: lane (r = lane & 31, g = lane >> 5) consumes 16-byte pieces of ITS row r.
+//
+// Per 32 bytes of every row: 8 MFMAs (256 matrix-core cycles per SIMD) against 76 VALU
+// instructions, so a wavefront per SIMD keeps up with HBM: the kernel is organised around
+// the memory system again.
+//   * one 256-thread block (4 wavefronts, one per SIMD) per (shard, slot group, 32 A rows, 32 B
+//     rows); the wavefronts split K — wave w owns the 128-byte pieces 4m + w of every container —
+//     and never synchronise until the final reduction;
+//   * a wave stages its own step (32 A + 32 B row pieces + the filter piece = 8.3 KB) with
+//     global->LDS DMA, 8 lanes per 128-byte line (coalesced), 3 steps deep: 2 steps = 66 KB per CU
+//     in flight while the third is consumed;
+//   * inside a row's 128 bytes the eight 16-byte pieces are rotated by (row >> 1) on the way in
+//     (a permutation inside one cache line, free), so that the 16 lanes of a ds_read_b128 pass hit
+//     16 different bank groups.
+#pragma once
+#include "fbk_kernels.hip.h"
+
+namespace fbk {
+
+constexpr int kMmWaves = 4;
+constexpr int kMmDepth = 3;
+constexpr int kMmPiece = 128;                          // bytes of every row per step
+constexpr int kMmStageU4 = (64 * kMmPiece + 256) / 16;  // uint4 per stage: A 4 KiB, B 4 KiB, F 128 B (+pad)
+
+typedef int mm_v4i __attribute__((ext_vector_type(4)));
+typedef int mm_v16i __attribute__((ext_vector_type(16)));
+
+typedef uint32_t mm_u4 __attribute__((ext_vector_type(4)));
+
+template <bool HAS_F>
+__global__ void __launch_bounds__(256, 1) k_count_matrix_mfma(
+    const uint8_t* __restrict__ arenaA, const uint32_t* __restrict__ rowsA, uint32_t nA, const uint8_t* __restrict__ arenaB,
+    const uint32_t* __restrict__ rowsB, uint32_t nBtot, const uint8_t* __restrict__ arenaF,
+    const uint32_t* __restrict__ rowsF, uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard) {
+  // The ring is read with ds_read_b128 written as asm: the compiler's waitcnt pass otherwise puts
+  // s_waitcnt vmcnt(0) in front of every LDS read that might alias a pending global->LDS DMA
+  // (it cannot count DMA steps across the loop back-edge), which would serialise the prefetch
+  // with the arithmetic.  vmcnt / lgkmcnt are managed by hand below.
+  __shared__ uint4 ring[kMmDepth][kMmWaves][kMmStageU4];
+  __shared__ uint32_t red[kMmWaves][16][64];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t agroups = (nA + 31) / 32;
+  const uint32_t btiles = (nBtot + 31) / 32;
+  const uint32_t sgroups = kSlots / spb;
+  uint32_t b = blockIdx.x;
+  const uint32_t bt = b % btiles;
+  b /= btiles;
+  const uint32_t ag = b % agroups;
+  b /= agroups;
+  const uint32_t sg = b % sgroups;
+  const uint32_t shard = b / sgroups;
+  if (shard >= n_shards) return;
+  const uint32_t i0 = ag * 32, j0 = bt * 32;
+  const uint64_t rowBytes = (uint64_t)kSlots * 8192;
+
+  // DMA side: instruction n covers rows 8n..8n+7, lane -> (row 8n + lane/8, LDS position lane%8),
+  // which holds piece (position - row/2) mod 8 of the row's 128 bytes.  Rows past the end of the
+  // matrix re-read its last row (their products are never written out).
+  const uint8_t* pa[4];
+  const uint8_t* pb[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const uint32_t rr = 8 * n + (lane >> 3);
+    const uint32_t piece = ((lane & 7) - (rr >> 1)) & 7;
+    const uint32_t ia = min(i0 + rr, nA - 1), ib = min(j0 + rr, nBtot - 1);
+    pa[n] = arenaA + (uint64_t)rowsA[(uint64_t)shard * nA + ia] * rowBytes + piece * 16;
+    pb[n] = arenaB + (uint64_t)rowsB[(uint64_t)shard * nBtot + ib] * rowBytes + piece * 16;
+  }
+  const uint8_t* pf = nullptr;
+  if (HAS_F) pf = arenaF + (uint64_t)rowsF[shard] * rowBytes + (lane & 7) * 16;
+
+  // consumer side: lane (r, g) reads piece 2t + g of row r in octet t
+  const uint32_t r = lane & 31, g = lane >> 5;
+  const uint32_t rot = (g + (r >> 1)) & 7;
+  constexpr uint32_t kStageBytes = kMmStageU4 * 16;
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)&ring[0][wv][0];  // LDS byte address of this wave's stage 0
+  uint32_t offAB[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) offAB[t] = lds0 + r * 128 + ((rot + 2 * t) & 7) * 16;
+  const uint32_t offF = lds0 + g * 16;
+
+  mm_v16i accP0 = {}, accP1 = {}, accN = {};
+
+  const uint32_t steps = spb * (8192 / (kMmPiece * kMmWaves));  // 16 per slot
+  auto stage = [&](uint32_t st) {
+    const uint32_t off = (sg * spb + (st >> 4)) * 8192u + ((st & 15) * kMmWaves + wv) * kMmPiece;
+    uint8_t* l = reinterpret_cast<uint8_t*>(&ring[st % kMmDepth][wv][0]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) __builtin_amdgcn_global_load_lds((gptr_t)(pa[n] + off), (lptr_t)(l + n * 1024), 16, 0, 0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      __builtin_amdgcn_global_load_lds((gptr_t)(pb[n] + off), (lptr_t)(l + 4096 + n * 1024), 16, 0, 0);
+    if (HAS_F) {
+      if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(pf + off), (lptr_t)(l + 8192), 16, 0, 0);
+    }
+  };
+  struct Oct {
+    mm_u4 A, B, F;
+  };
+  auto issue = [&](Oct& o, uint32_t sbase, int t) {  // LDS reads of octet t of the stage at byte offset sbase
+    if (HAS_F)
+      asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:4096\n\tds_read_b128 %2, %4 offset:%5"
+                   : "=&v"(o.A), "=&v"(o.B), "=&v"(o.F)
+                   : "v"(offAB[t] + sbase), "v"(offF + sbase), "n"(8192 + 32 * t));
+    else
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(o.A), "=&v"(o.B) : "v"(offAB[t] + sbase));
+  };
+  auto landed = [&](Oct& o, bool more_behind) {  // o's reads are complete (LDS returns in order)
+    if (HAS_F) {
+      if (more_behind) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(o.A), "+v"(o.B), "+v"(o.F));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.A), "+v"(o.B), "+v"(o.F));
+    } else {
+      if (more_behind) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(o.A), "+v"(o.B));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.A), "+v"(o.B));
+    }
+  };
+  constexpr uint32_t M = 0x01010101u;
+  auto octet = [&](const Oct& o) {
+    uint32_t a[4], bb[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      a[d] = __builtin_bswap32(HAS_F ? (o.A[d] & o.F[d]) : o.A[d]);
+      bb[d] = __builtin_bitreverse32(o.B[d]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      mm_v4i oa, ob;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        oa[d] = (int)(a[d] & (M << k));
+        ob[d] = (int)(bb[d] & (M << (7 - k)));
+      }
+      if (k == 0 || k == 7) accN = __builtin_amdgcn_mfma_i32_32x32x32_i8(oa, ob, accN, 0, 0, 0);
+      else if (k & 1) accP0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(oa, ob, accP0, 0, 0, 0);
+      else accP1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(oa, ob, accP1, 0, 0, 0);
+    }
+  };
+  constexpr int kOps = HAS_F ? 9 : 8;  // vmem instructions per staged step
+
+  Oct X, Y;
+  stage(0);
+  if (steps > 1) {
+    stage(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  issue(X, 0, 0);
+  for (uint32_t st = 0; st < steps; ++st) {
+    if (st + 2 < steps) stage(st + 2);
+    const uint32_t sb = (st % kMmDepth) * (kMmWaves * kStageBytes);
+    issue(Y, sb, 1);
+    landed(X, true);
+    octet(X);
+    issue(X, sb, 2);
+    landed(Y, true);
+    octet(Y);
+    issue(Y, sb, 3);
+    landed(X, true);
+    octet(X);
+    const bool more = st + 1 < steps;
+    if (more) {
+      // stage st + 1 has landed once only stage st + 2's DMA (if any) is still in flight
+      if (st + 2 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      issue(X, ((st + 1) % kMmDepth) * (kMmWaves * kStageBytes), 0);
+    }
+    landed(Y, more);
+    octet(Y);
+  }
+
+  // cross-wave reduction through LDS
+#pragma unroll
+  for (int q = 0; q < 16; ++q) red[wv][q][lane] = (uint32_t)(accP0[q] + accP1[q] - accN[q]) >> 7;
+  __syncthreads();
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const int q = wv * 4 + q4;
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kMmWaves; ++w) tot += red[w][q][lane];
+    const uint32_t i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), j = lane & 31;
+    if (i0 + i < nA && j0 + j < nBtot && tot) {
+      u64* dst = &out_shard[((uint64_t)shard * nA + i0 + i) * nBtot + j0 + j];
+      if (spb == kSlots) *dst = tot;
+      else atomicAdd(dst, (u64)tot);
+    }
+  }
+}
+
+}  // namespace fbk
