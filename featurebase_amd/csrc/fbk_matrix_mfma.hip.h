@@ -37,8 +37,11 @@
 
 namespace fbk {
 
-constexpr int kMmWaves = 4;
-constexpr int kMmDepth = 3;
+// product configuration (scripts/tune_matrix.hip: 4 waves x 2 stages = 66 KB of LDS, two blocks per
+// CU; the non-temporal policy on the DMA is worth 10-15 %, as on every other streaming kernel here)
+constexpr int kMmWaves = 4;  // wavefronts per block
+constexpr int kMmDepth = 2;  // DMA ring depth (steps)
+constexpr int kMmAux = 2;    // cache policy of the global->LDS DMA: nt
 constexpr int kMmPiece = 128;                          // bytes of every row per step
 constexpr int kMmStageU4 = (64 * kMmPiece + 256) / 16;  // uint4 per stage: A 4 KiB, B 4 KiB, F 128 B (+pad)
 
@@ -47,8 +50,8 @@ typedef int mm_v16i __attribute__((ext_vector_type(16)));
 
 typedef uint32_t mm_u4 __attribute__((ext_vector_type(4)));
 
-template <bool HAS_F>
-__global__ void __launch_bounds__(256, 1) k_count_matrix_mfma(
+template <bool HAS_F, int WAVES = kMmWaves, int DEPTH = kMmDepth, int AUX = kMmAux>
+__global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
     const uint8_t* __restrict__ arenaA, const uint32_t* __restrict__ rowsA, uint32_t nA, const uint8_t* __restrict__ arenaB,
     const uint32_t* __restrict__ rowsB, uint32_t nBtot, const uint8_t* __restrict__ arenaF,
     const uint32_t* __restrict__ rowsF, uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard) {
@@ -56,8 +59,7 @@ __global__ void __launch_bounds__(256, 1) k_count_matrix_mfma(
   // s_waitcnt vmcnt(0) in front of every LDS read that might alias a pending global->LDS DMA
   // (it cannot count DMA steps across the loop back-edge), which would serialise the prefetch
   // with the arithmetic.  vmcnt / lgkmcnt are managed by hand below.
-  __shared__ uint4 ring[kMmDepth][kMmWaves][kMmStageU4];
-  __shared__ uint32_t red[kMmWaves][16][64];
+  __shared__ uint4 ring[DEPTH][WAVES][kMmStageU4];
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int lane = threadIdx.x & 63;
@@ -104,17 +106,18 @@ __global__ void __launch_bounds__(256, 1) k_count_matrix_mfma(
 
   mm_v16i accP0 = {}, accP1 = {}, accN = {};
 
-  const uint32_t steps = spb * (8192 / (kMmPiece * kMmWaves));  // 16 per slot
+  constexpr uint32_t kStepsPerSlot = 8192 / (kMmPiece * WAVES);
+  const uint32_t steps = spb * kStepsPerSlot;
   auto stage = [&](uint32_t st) {
-    const uint32_t off = (sg * spb + (st >> 4)) * 8192u + ((st & 15) * kMmWaves + wv) * kMmPiece;
-    uint8_t* l = reinterpret_cast<uint8_t*>(&ring[st % kMmDepth][wv][0]);
+    const uint32_t off = (sg * spb + st / kStepsPerSlot) * 8192u + ((st % kStepsPerSlot) * WAVES + wv) * kMmPiece;
+    uint8_t* l = reinterpret_cast<uint8_t*>(&ring[st % DEPTH][wv][0]);
 #pragma unroll
-    for (int n = 0; n < 4; ++n) __builtin_amdgcn_global_load_lds((gptr_t)(pa[n] + off), (lptr_t)(l + n * 1024), 16, 0, 0);
+    for (int n = 0; n < 4; ++n) __builtin_amdgcn_global_load_lds((gptr_t)(pa[n] + off), (lptr_t)(l + n * 1024), 16, 0, AUX);
 #pragma unroll
     for (int n = 0; n < 4; ++n)
-      __builtin_amdgcn_global_load_lds((gptr_t)(pb[n] + off), (lptr_t)(l + 4096 + n * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(pb[n] + off), (lptr_t)(l + 4096 + n * 1024), 16, 0, AUX);
     if (HAS_F) {
-      if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(pf + off), (lptr_t)(l + 8192), 16, 0, 0);
+      if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(pf + off), (lptr_t)(l + 8192), 16, 0, AUX);
     }
   };
   struct Oct {
@@ -160,18 +163,21 @@ __global__ void __launch_bounds__(256, 1) k_count_matrix_mfma(
   };
   constexpr int kOps = HAS_F ? 9 : 8;  // vmem instructions per staged step
 
+  // the step about to be read has landed once at most `younger` later steps are still in flight
+  auto dma_landed = [&](uint32_t younger) {
+    static_assert(DEPTH >= 2 && DEPTH <= 5, "ring depth");
+    if (DEPTH > 4 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kOps) : "memory");
+    else if (DEPTH > 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kOps) : "memory");
+    else if (DEPTH > 2 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   Oct X, Y;
-  stage(0);
-  if (steps > 1) {
-    stage(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  for (uint32_t st = 0; st + 1 < (uint32_t)DEPTH && st < steps; ++st) stage(st);
+  dma_landed(min((uint32_t)DEPTH - 2, steps - 1));
   issue(X, 0, 0);
   for (uint32_t st = 0; st < steps; ++st) {
-    if (st + 2 < steps) stage(st + 2);
-    const uint32_t sb = (st % kMmDepth) * (kMmWaves * kStageBytes);
+    if (st + DEPTH - 1 < steps) stage(st + DEPTH - 1);
+    const uint32_t sb = (st % DEPTH) * (WAVES * kStageBytes);
     issue(Y, sb, 1);
     landed(X, true);
     octet(X);
@@ -183,25 +189,25 @@ __global__ void __launch_bounds__(256, 1) k_count_matrix_mfma(
     octet(X);
     const bool more = st + 1 < steps;
     if (more) {
-      // stage st + 1 has landed once only stage st + 2's DMA (if any) is still in flight
-      if (st + 2 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      issue(X, ((st + 1) % kMmDepth) * (kMmWaves * kStageBytes), 0);
+      dma_landed(min((uint32_t)DEPTH - 2, steps - 2 - st));
+      issue(X, ((st + 1) % DEPTH) * (WAVES * kStageBytes), 0);
     }
     landed(Y, more);
     octet(Y);
   }
 
-  // cross-wave reduction through LDS
+  // cross-wave reduction through LDS: every wave parks its 32 x 32 partial counts in its own
+  // (fully consumed) stage 0, then each wave totals 16 / WAVES of the 16 accumulator registers
+  uint32_t* red = reinterpret_cast<uint32_t*>(&ring[0][wv][0]);  // [16][64]
 #pragma unroll
-  for (int q = 0; q < 16; ++q) red[wv][q][lane] = (uint32_t)(accP0[q] + accP1[q] - accN[q]) >> 7;
+  for (int q = 0; q < 16; ++q) red[q * 64 + lane] = (uint32_t)(accP0[q] + accP1[q] - accN[q]) >> 7;
   __syncthreads();
 #pragma unroll
-  for (int q4 = 0; q4 < 4; ++q4) {
-    const int q = wv * 4 + q4;
+  for (int qq = 0; qq < 16 / WAVES; ++qq) {
+    const int q = wv * (16 / WAVES) + qq;
     uint32_t tot = 0;
 #pragma unroll
-    for (int w = 0; w < kMmWaves; ++w) tot += red[w][q][lane];
+    for (int w = 0; w < WAVES; ++w) tot += reinterpret_cast<const uint32_t*>(&ring[0][w][0])[q * 64 + lane];
     const uint32_t i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), j = lane & 31;
     if (i0 + i < nA && j0 + j < nBtot && tot) {
       u64* dst = &out_shard[((uint64_t)shard * nA + i0 + i) * nBtot + j0 + j];

@@ -417,8 +417,8 @@ def test_count_range_vs_oracle(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("n_shards,n_a,n_b,use_filter", [(3, 32, 32, True), (2, 37, 45, False), (5, 5, 3, True), (1, 1, 2, False), (9, 64, 33, True)])
 def test_count_matrix_dense_kernel_vs_numpy(gpu_ctx, n_shards, n_a, n_b, use_filter):
-    """The all-bitmap fast path of fbk_count_matrix (k_count_matrix_dense: chunked B ring in
-    LDS, per-lane accumulators, one transposing reduction) against numpy popcounts: full
+    """The all-bitmap fast path of fbk_count_matrix (k_count_matrix_mfma: bits expanded to i8
+    bytes, v_mfma_i32_32x32x32_i8 tiles, per-wave DMA ring) against numpy popcounts: full
     matrix, per shard and in total, ragged tile edges, with and without the filter row."""
     wa = D.dense_rows(n_shards * n_a, 0.3, 811)
     wb = D.dense_rows(n_shards * n_b, 0.6, 812)
@@ -440,6 +440,16 @@ def test_count_matrix_dense_kernel_vs_numpy(gpu_ctx, n_shards, n_a, n_b, use_fil
                 exp[s, i, j] = np.bitwise_count(x & wb[rb[s, j]]).sum()
     assert (ps == exp).all()
     assert (tot == exp.sum(axis=0)).all()
+    # every slots-per-block split of the launch (16 = whole shards with plain stores, smaller =
+    # atomic adds of partial matrices), and the vector-ALU kernel kept for A/B measurements
+    try:
+        for spb in ("16", "8", "4", "2", "1"):
+            os.environ["FBK_MATRIX_SPB"] = spb
+            tot2, ps2 = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf if use_filter else None, per_shard=True)
+            assert (ps2 == exp).all(), spb
+            assert (tot2 == tot).all(), spb
+    finally:
+        os.environ.pop("FBK_MATRIX_SPB", None)
     A.free()
     Bt.free()
     if F is not None:
