@@ -2,6 +2,11 @@
 // shape, executor.go:8880-8934, 2705-2774) for DENSE batches: every container of the rows
 // involved is a bitmap at row*128 KiB + slot*8 KiB, so no descriptor is read at all.
 //
+// This is the VECTOR-ALU version.  The product path is k_count_matrix_mfma
+// (fbk_matrix_mfma.hip.h, 1.9x faster and HBM-bound); this kernel stays selectable with
+// FBK_MATRIX_VALU=1 for A/B measurements and as the independent cross-check of
+// scripts/tune_matrix.hip.  k_densify_rows at the end of this file serves both.
+//
 // out[shard][i][j] (+)= sum over the block's slots of |A[shard][i] ∩ F[shard] ∩ B[shard][j]|.
 //
 // This shape is NOT HBM-bound: nA*nB pairs per slot reuse nA+nB containers.  Per 64-bit word pair

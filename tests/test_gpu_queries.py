@@ -530,12 +530,13 @@ def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("a_dense,b_dense,f_mode", [(False, False, "mixed"), (True, False, "none"), (False, True, "dense"), (False, False, "none")])
 def test_count_matrix_mixed_rows_take_the_densify_path(gpu_ctx, oracle, B, a_dense, b_dense, f_mode):
-    """nA x nB >= 64 with array / run containers among the rows: fbk_count_matrix densifies the
+    """nA x nB >= 100 with array / run containers among the rows: fbk_count_matrix densifies the
     referenced rows into temporary bitmap rows and runs the dense matrix kernel; every mix of
-    dense and encoded operands, checked against the oracle's groupByIterator counts."""
+    dense and encoded operands, checked against the oracle's groupByIterator counts — and against
+    the generic pair kernel (FBK_MATRIX_DENSIFY=0) on the same call."""
     O = oracle
     rng = D.rng_for(57)
-    n_shards, n_a, n_b = 5, 48, 43  # width >= 2048: densify whatever the container sizes
+    n_shards, n_a, n_b = 5, 48, 43
 
     def obm(row):
         return O.OBitmap.from_containers(list(row.items()))
@@ -570,6 +571,12 @@ def test_count_matrix_mixed_rows_take_the_densify_path(gpu_ctx, oracle, B, a_den
         assert (ps[k] == e).all(), (k, s)
         exp_tot += e
     assert (tot == exp_tot).all()
+    try:
+        os.environ["FBK_MATRIX_DENSIFY"] = "0"
+        tot_g, ps_g = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
+    finally:
+        os.environ.pop("FBK_MATRIX_DENSIFY", None)
+    assert (tot_g == tot).all() and (ps_g == ps).all()
     for b in (A, Bt, F):
         if b is not None:
             b.free()
