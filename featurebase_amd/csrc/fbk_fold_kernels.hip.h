@@ -7,13 +7,22 @@
 //   array   one ds_or_b32 per value                          (arrayToBitmap, roaring.go:3756)
 //   run     masked ds_or_b32 on the two boundary dwords, whole dwords in between; long runs are
 //           filled by all 64 lanes together                  (splatRun, container_stash.go:696-729)
-//   bitmap  ds_or_b64 of the 16 words each lane fetched
+//   bitmap  ds_or_b64 of the words each lane fetched
 // so there is no per-container zero / decode / read-back of a scratch bitmap, no register
-// accumulator and no cross-wave combine: the only state per lane is the payload prefetch ring
-// (3 containers deep), which keeps 12 payloads per block in flight.  The previous kernel
-// (decode every container into a per-wave scratch, accumulate in registers, prefetch depth 1,
-// 256 VGPRs -> 2 waves per SIMD) measured 296 us on 256 shards x 64 mixed rows (581 MB).
-// Unions of sparse rows are dominated by per-container latency, not bytes.
+// accumulator and no cross-wave combine.
+//
+// The payloads reach the wave as ONE sequence of 1 KiB chunks (64 lanes x 16 bytes) through a
+// ring of 6 chunks = 24 registers: 57 VGPRs in all, 8 wavefronts per SIMD.  History, 128 shards
+// x 64 mixed rows (291 MB of payload):
+//   296 us  decode every container into a per-wave scratch, accumulate in registers (256 VGPRs)
+//   107 us  direct scatter, ring of 3 whole containers (96 registers of which 27 % held payload:
+//           the average container is 2.2 KB) — 4 waves per SIMD; making that kernel branch-free or
+//           a fifth of its code size changed nothing, dummy ORs for the lanes past the end of an
+//           array made it 40 % slower (the LDS serialises same-address atomics)
+//    70 us  this version (4.2 TB/s; 4.8 TB/s at 384 shards).  Ring depths 4 .. 7 measure the
+//           same, 8 .. 16 are slower: occupancy, not bytes in flight per wave, is what counts.
+// scripts/rand_read.hip: HBM delivers 6.1 TB/s for random 2 KiB reads, so the access pattern is
+// not the limit; what remains is the per-block chain rows -> descriptors -> payload at the start.
 //   OP 1 (OR)      r0 | r1 | ...               roaring.go:1455-1560, filter.go:327-334
 //   OP 2 (XOR)     r0 ^ r1 ^ ...               executor.go:5513-5552 (values of one array / the
 //                  runs of one container are disjoint, so XOR-ing them in one by one is exact)
@@ -29,72 +38,82 @@ __device__ __forceinline__ void lds_acc32(uint32_t* p, uint32_t m) {
   else atomicOr(p, m);
 }
 
-// one prefetched payload (<= 8 KiB) into the shared accumulator
+// dwords [ws+1, we) of the accumulator become all ones (the interior of a run).  OR / ANDNOT: a
+// plain store — whatever other waves OR into the dword concurrently, all ones is the result;
+// XOR has to flip.
 template <int OP>
-__device__ __forceinline__ void scatter_raw(const Raw& r, uint32_t type, uint32_t len, int lane, uint32_t* acc32) {
+__device__ __forceinline__ void lds_fill32(uint32_t* p) {
+  if (OP == 2) atomicXor(p, ~0u);
+  else *(__attribute__((address_space(3))) uint32_t*)p = ~0u;  // explicit LDS store (a volatile generic store is a flat_store + vmcnt(0))
+}
+
+// row j (64 x 16 bytes) of a prefetched payload; j is wave-uniform, so this is a scalar branch
+// tree around four v_mov — it lets the loops over rows below stay rolled (the fully unrolled
+// version of this file was 16 000 instructions long, three copies of every path)
+// One 1 KiB chunk (64 lanes x 16 bytes = d[0..3] per lane) of a payload: row j of container
+// (type, len).  Everything but d and lane is wave-uniform.
+template <int OP>
+__device__ __forceinline__ void scatter_chunk(const uint32_t (&d)[4], uint32_t type, uint32_t len, uint32_t j, int lane,
+                                              uint32_t* acc32) {
   if (type == kTypeBitmap) {
     u64* acc64 = reinterpret_cast<u64*>(acc32);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t w = (j * kWave + lane) * 2;
-      if (OP == 2) {
-        atomicXor(&acc64[w], r.v[j].x);
-        atomicXor(&acc64[w + 1], r.v[j].y);
-      } else {
-        if (r.v[j].x) atomicOr(&acc64[w], r.v[j].x);
-        if (r.v[j].y) atomicOr(&acc64[w + 1], r.v[j].y);
-      }
+    const uint32_t w = (j * kWave + lane) * 2;
+    const u64 x = ((u64)d[1] << 32) | d[0], y = ((u64)d[3] << 32) | d[2];
+    if (OP == 2) {
+      atomicXor(&acc64[w], x);
+      atomicXor(&acc64[w + 1], y);
+    } else {
+      atomicOr(&acc64[w], x);
+      atomicOr(&acc64[w + 1], y);
     }
     return;
   }
   if (type == kTypeArray) {
+    const uint32_t row0 = j * (kWave * 8u);  // first element of this row of 16-byte chunks
+    if (row0 + kWave * 8u <= len) {          // scalar: all 512 values of the row exist, no predicate at all
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t e0 = (j * kWave + lane) * 8u;
-      if (e0 < len) {
-        const u64 lo = r.v[j].x, hi = r.v[j].y;
+      for (int q = 0; q < 4; ++q) {
+        lds_acc32<OP>(&acc32[(d[q] >> 5) & 0x7FFu], 1u << (d[q] & 31));
+        lds_acc32<OP>(&acc32[d[q] >> 21], 1u << ((d[q] >> 16) & 31));
+      }
+    } else {
+      // the ragged last row: lanes past the end sit out (a dummy OR would not be free — the LDS
+      // serialises same-address atomics, measured)
+      const uint32_t e0 = row0 + lane * 8u;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const uint32_t a = (uint32_t)(lo >> (16 * t)) & 0xFFFFu, b = (uint32_t)(hi >> (16 * t)) & 0xFFFFu;
-          if (e0 + t < len) lds_acc32<OP>(&acc32[a >> 5], 1u << (a & 31));
-          if (e0 + 4 + t < len) lds_acc32<OP>(&acc32[b >> 5], 1u << (b & 31));
-        }
+      for (int q = 0; q < 4; ++q) {
+        if (e0 + 2 * q < len) lds_acc32<OP>(&acc32[(d[q] >> 5) & 0x7FFu], 1u << (d[q] & 31));
+        if (e0 + 2 * q + 1 < len) lds_acc32<OP>(&acc32[d[q] >> 21], 1u << ((d[q] >> 16) & 31));
       }
     }
     return;
   }
-  // runs: 4 intervals per 16-byte chunk
+  // runs: 4 intervals {start u16, last u16} per 16-byte chunk
+  const uint32_t i0 = (j * kWave + lane) * 4u;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const uint32_t i0 = (j * kWave + lane) * 4u;
-    if (__ballot(i0 < len) == 0) break;  // wave-uniform: no lane has intervals in this chunk row
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const u64 q = (t < 2) ? r.v[j].x : r.v[j].y;
-      const uint32_t iv = (uint32_t)(q >> (32 * (t & 1)));
-      const bool on = i0 + t < len;
-      const uint32_t s = iv & 0xFFFFu, l = iv >> 16;
-      const uint32_t ws = s >> 5, we = l >> 5;
-      const uint32_t ms = ~0u << (s & 31), ml = ~0u >> (31 - (l & 31));
-      if (on) {
-        if (ws == we) {
-          lds_acc32<OP>(&acc32[ws], ms & ml);
-        } else {
-          lds_acc32<OP>(&acc32[ws], ms);
-          lds_acc32<OP>(&acc32[we], ml);
-        }
+  for (int t = 0; t < 4; ++t) {
+    const bool on = i0 + t < len;
+    const uint32_t s = d[t] & 0xFFFFu, l = d[t] >> 16;
+    const uint32_t ws = s >> 5, we = l >> 5;
+    const uint32_t ms = ~0u << (s & 31), ml = ~0u >> (31 - (l & 31));
+    if (on) {
+      if (ws == we) {
+        lds_acc32<OP>(&acc32[ws], ms & ml);
+      } else {
+        lds_acc32<OP>(&acc32[ws], ms);
+        lds_acc32<OP>(&acc32[we], ml);
       }
-      const uint32_t inner = (on && we > ws + 1) ? we - ws - 1 : 0;
-      // short interiors: the owning lane; long ones (> 4 dwords): all 64 lanes together
-      if (inner && inner <= 4)
-        for (uint32_t d = ws + 1; d < we; ++d) lds_acc32<OP>(&acc32[d], ~0u);
-      u64 longm = __ballot(inner > 4);
-      while (longm) {
-        const int src = __builtin_ctzll(longm);
-        longm &= longm - 1;
-        const uint32_t bs = __shfl(ws, src, kWave), be = __shfl(we, src, kWave);
-        for (uint32_t d = bs + 1 + lane; d < be; d += kWave) lds_acc32<OP>(&acc32[d], ~0u);
-      }
+    }
+    const uint32_t inner = (on && we > ws + 1) ? we - ws - 1 : 0;
+    // short interiors: the owning lane; long ones (> 4 dwords): all 64 lanes together
+    if (inner && inner <= 4)
+      for (uint32_t q = ws + 1; q < we; ++q) lds_fill32<OP>(&acc32[q]);
+    u64 longm = __ballot(inner > 4);
+    while (longm) {
+      const int src = __builtin_ctzll(longm);  // scalar
+      longm &= longm - 1;
+      const uint32_t bs = __builtin_amdgcn_readlane(ws, src), be = __builtin_amdgcn_readlane(we, src);
+      for (uint32_t q = bs + 1 + lane; q < be; q += kWave) lds_fill32<OP>(&acc32[q]);
     }
   }
 }
@@ -127,7 +146,7 @@ __device__ __forceinline__ void scatter_big(const uint8_t* __restrict__ p, uint3
 }
 
 template <int OP, bool WRITE>
-__global__ void __launch_bounds__(256, 4) k_fold_scatter(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+__global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
                                                      const uint32_t* __restrict__ rows, uint64_t n_groups, uint32_t k,
                                                      const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,
                                                      const uint32_t* __restrict__ frows, uint8_t* __restrict__ arenaO,
@@ -207,9 +226,7 @@ __global__ void __launch_bounds__(256, 4) k_fold_scatter(const Slot* __restrict_
       shortcut = true;
       break;
     }
-    // this wave's containers: i = wv, wv+4, ...; payload prefetch ring 3 deep
-    constexpr int D = 3;
-    Raw R[D];
+    // this wave's containers: i = wv, wv+4, ...
     auto meta = [&](uint32_t i, u64& off, uint32_t& len, uint32_t& tn) {
       // wave-uniform values: pull them into SGPRs so the type dispatch is scalar branching
       const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mine.off, (int)(i & 63));
@@ -218,35 +235,78 @@ __global__ void __launch_bounds__(256, 4) k_fold_scatter(const Slot* __restrict_
       len = __builtin_amdgcn_readlane(mine.len, (int)(i & 63));
       tn = __builtin_amdgcn_readlane(mine.tn, (int)(i & 63));
     };
-    auto issue = [&](uint32_t i, Raw& r) {
-      if (i < cnt) {
-        u64 off;
-        uint32_t len, tn;
-        meta(i, off, len, tn);
-        const uint32_t bytes = payload_bytes(tn >> 24, len);
-        if ((tn & 0xFFFFFFu) != 0 && bytes <= 8192u) raw_load(arena + off, bytes, lane, r);
-      }
-    };
-    auto consume = [&](uint32_t i, const Raw& r) {
-      if (i < cnt) {
-        u64 off;
-        uint32_t len, tn;
-        meta(i, off, len, tn);
-        if ((tn & 0xFFFFFFu) != 0) {
-          const uint32_t bytes = payload_bytes(tn >> 24, len);
-          if (bytes <= 8192u) scatter_raw<OP>(r, tn >> 24, len, lane, acc32);
-          else scatter_big<OP>(arena + off, tn >> 24, len, lane, acc32);
+    // payloads beyond 8 KiB (arrays > 4096 values, > 2048 runs: legal, outside roaring policy) do
+    // not fit the ring: they are scattered straight from global memory, dealt to the waves in turn
+    {
+      u64 bigm = __ballot((mine.tn & 0xFFFFFFu) != 0 && payload_bytes(mine.tn >> 24, mine.len) > 8192u);
+      for (uint32_t ord = 0; bigm; ++ord) {
+        const uint32_t i = (uint32_t)__builtin_ctzll(bigm);
+        bigm &= bigm - 1;
+        if ((ord & 3u) == (uint32_t)wv) {
+          u64 off;
+          uint32_t len, tn;
+          meta(i, off, len, tn);
+          scatter_big<OP>(arena + off, tn >> 24, len, lane, acc32);
         }
       }
-    };
+    }
+    {
+      // ---- chunk-granular ring: the wave's containers as ONE sequence of 1 KiB chunks ----
+      constexpr int NCH = 6;
+      typedef uint32_t Chunk __attribute__((ext_vector_type(4)));
+      Chunk C[NCH];
+      // chunks of lane l's container (0: nil / empty / beyond 8 KiB, not part of the sequence)
+      const uint32_t my_bytes = payload_bytes(mine.tn >> 24, mine.len);
+      const uint32_t nr = ((mine.tn & 0xFFFFFFu) != 0 && my_bytes <= 8192u) ? (my_bytes + 1023u) >> 10 : 0u;
+      auto next_valid = [&](uint32_t i) {
+        while (i < cnt && __builtin_amdgcn_readlane(nr, (int)(i & 63)) == 0) i += 4;
+        return i;
+      };
+      uint32_t pi = next_valid(wv), pj = 0;  // producer: next chunk to load
+      uint32_t ci = pi, cj = 0;              // consumer: next chunk to scatter
+      auto advance = [&](uint32_t& i, uint32_t& j) {
+        if (++j == (uint32_t)__builtin_amdgcn_readlane(nr, (int)(i & 63))) {
+          j = 0;
+          i = next_valid(i + 4);
+        }
+      };
+      // Exactly ONE load instruction per step, written as asm, so that "the chunk issued NCH steps
+      // ago has landed" is the constant s_waitcnt vmcnt(NCH - 1): left to the compiler, the
+      // conditional loads of a rolled ring end in vmcnt(0) before every use (seen in the ISA), which
+      // serialises the ring.  Lanes past the end of a payload re-read its first 16 bytes and an
+      // exhausted producer reads the first 16 bytes of the arena: always a valid address, never a
+      // change of EXEC around the load.
+      auto load_chunk = [&](Chunk& c) {
+        const uint8_t* p = arena;
+        if (pi < cnt) {
+          u64 off;
+          uint32_t len, tn;
+          meta(pi, off, len, tn);
+          const uint32_t bytes = payload_bytes(tn >> 24, len);
+          const uint32_t b0 = pj * 1024u + lane * 16u;
+          p = arena + off + (b0 < bytes ? b0 : 0u);
+          advance(pi, pj);
+        }
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(c) : "v"(p));
+      };
 #pragma unroll
-    for (int d = 0; d < D; ++d) issue(wv + 4 * d, R[d]);
-    for (uint32_t i = wv; i < cnt; i += 4 * D) {
+      for (int q = 0; q < NCH; ++q) load_chunk(C[q]);
+      while (ci < cnt) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        consume(i + 4 * d, R[d]);
-        issue(i + 4 * (d + D), R[d]);
+        for (int q = 0; q < NCH; ++q) {
+          if (ci < cnt) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(C[q]) : "n"(NCH - 1));
+            const uint32_t len = __builtin_amdgcn_readlane(mine.len, (int)(ci & 63));
+            const uint32_t tn = __builtin_amdgcn_readlane(mine.tn, (int)(ci & 63));
+            const uint32_t d[4] = {C[q][0], C[q][1], C[q][2], C[q][3]};
+            scatter_chunk<OP>(d, tn >> 24, len, cj, lane, acc32);
+            advance(ci, cj);
+            load_chunk(C[q]);
+          }
+        }
       }
+      // loads still in flight target registers the compiler is about to reuse
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
   if (shortcut && lane == 0) s_short = 1;
