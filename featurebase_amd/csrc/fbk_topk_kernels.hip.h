@@ -12,16 +12,18 @@
 //           whatever the run length              (intersectionCountBitmapRun via BitmapCountRange,
 //                                                 roaring.go:4559-4567, 3092-3125)
 //   bitmap  16 words per lane AND-ed with the LDS copy (popcountAndSlice, roaring.go:6928)
-// Each wavefront walks rows w, w+4, ... with a 3-deep payload prefetch ring.  Pairing every row
-// with the filter through the generic pair kernel (k_icount) re-reads and re-decodes the filter
-// container once per row: 193 us vs the bytes-once time of the fused union (104 us) on
-// 128 shards x 64 mixed rows.
+// Each wavefront walks rows w, w+4, ... and receives their payloads as ONE sequence of 1 KiB
+// chunks through a 6-chunk register ring (asm loads, constant vmcnt — same scheme and same
+// reasons as fbk_fold_kernels.hip.h: 8 wavefronts per SIMD beat a deep ring of whole containers).
+// Pairing every row with the filter through the generic pair kernel (k_icount) re-reads and
+// re-decodes the filter container once per row: 193 us on 128 shards x 64 mixed rows; this
+// kernel with a ring of 3 whole containers: 114 us.
 #pragma once
 #include "fbk_query_kernels.hip.h"
 
 namespace fbk {
 
-__global__ void __launch_bounds__(256, 4) k_rows_vs_filter(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
+__global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
                                                           const uint32_t* __restrict__ rowsA, uint32_t nA,
                                                           const Slot* __restrict__ slotsF, const uint8_t* __restrict__ arenaF,
                                                           const uint32_t* __restrict__ rowsF, uint32_t n_shards,
@@ -92,8 +94,6 @@ __global__ void __launch_bounds__(256, 4) k_rows_vs_filter(const Slot* __restric
     mine.tn = 0;
     if (base + lane < i_end) mine = slotsA[(uint64_t)arow[base + lane] * kSlots + slot];
     const uint32_t cnt = min(64u, i_end - base);
-    constexpr int D = 3;
-    Raw R[D];
     auto meta = [&](uint32_t i, u64& off, uint32_t& len, uint32_t& tn) {
       const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mine.off, (int)(i & 63));
       const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(mine.off >> 32), (int)(i & 63));
@@ -101,34 +101,26 @@ __global__ void __launch_bounds__(256, 4) k_rows_vs_filter(const Slot* __restric
       len = __builtin_amdgcn_readlane(mine.len, (int)(i & 63));
       tn = __builtin_amdgcn_readlane(mine.tn, (int)(i & 63));
     };
-    auto needs_payload = [&](uint32_t tn) {  // intersectionCount short-circuits, roaring.go:4478-4486
-      const uint32_t n = tn & 0xFFFFFFu;
-      return n != 0 && n != 65536u && !f_full;
-    };
-    auto issue = [&](uint32_t i, Raw& r) {
-      if (i < cnt) {
+    const uint32_t my_n = mine.tn & 0xFFFFFFu, my_bytes = payload_bytes(mine.tn >> 24, mine.len);
+    // intersectionCount's short-circuits on the stored N (roaring.go:4478-4486) need no payload:
+    // the lane that holds the descriptor adds the count itself (rows are dealt to waves by i & 3)
+    const bool trivial = my_n != 0 && (f_full || my_n == 65536u);
+    if (trivial && (uint32_t)(lane & 3) == (uint32_t)wv && base + lane < i_end)
+      atomicAdd(&out_shard[(uint64_t)shard * nA + base + lane], (u64)(f_full ? my_n : nf));
+    // payloads beyond 8 KiB (arrays > 4096 values / > 2048 runs: outside roaring policy) do not fit
+    // the ring: counted straight from global memory, dealt to the waves in turn
+    {
+      u64 bigm = __ballot(my_n != 0 && !trivial && my_bytes > 8192u);
+      for (uint32_t ord = 0; bigm; ++ord) {
+        const uint32_t i = (uint32_t)__builtin_ctzll(bigm);
+        bigm &= bigm - 1;
+        if ((ord & 3u) != (uint32_t)wv) continue;
         u64 off;
         uint32_t len, tn;
         meta(i, off, len, tn);
-        const uint32_t bytes = payload_bytes(tn >> 24, len);
-        if (needs_payload(tn) && bytes <= 8192u) raw_load(arenaA + off, bytes, lane, r);
-      }
-    };
-    auto consume = [&](uint32_t i, const Raw& r) {
-      if (i >= cnt) return;
-      u64 off;
-      uint32_t len, tn;
-      meta(i, off, len, tn);
-      const uint32_t n = tn & 0xFFFFFFu, type = tn >> 24;
-      if (n == 0) return;
-      uint32_t c = 0;
-      if (f_full) {
-        c = (lane == 0) ? n : 0;  // a.N == 65536 -> b.N
-      } else if (n == 65536u) {
-        c = (lane == 0) ? nf : 0;
-      } else if (payload_bytes(type, len) > 8192u) {  // arrays > 4096 values / > 2048 runs: outside roaring policy
         const uint8_t* p = arenaA + off;
-        if (type == kTypeArray) {
+        uint32_t c = 0;
+        if ((tn >> 24) == kTypeArray) {
           const uint16_t* q = reinterpret_cast<const uint16_t*>(p);
           for (uint32_t k = lane; k < len; k += kWave) {
             const uint32_t e = q[k];
@@ -141,53 +133,99 @@ __global__ void __launch_bounds__(256, 4) k_rows_vs_filter(const Slot* __restric
             c += rank_of((iv >> 16) + 1u) - rank_of(iv & 0xFFFFu);
           }
         }
-      } else if (type == kTypeBitmap) {
-        const ulonglong2* qf = reinterpret_cast<const ulonglong2*>(F);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const ulonglong2 f = qf[j * kWave + lane];
-          c += __popcll(r.v[j].x & f.x) + __popcll(r.v[j].y & f.y);
-        }
+        c = wave_reduce_add(c);
+        if (lane == 0 && c) atomicAdd(&out_shard[(uint64_t)shard * nA + base + i], (u64)c);
+      }
+    }
+    // ---- the other containers: one sequence of 1 KiB chunks through a register ring ----
+    constexpr int NCH = 6;
+    typedef uint32_t Chunk __attribute__((ext_vector_type(4)));
+    Chunk C[NCH];
+    const uint32_t nr = (my_n != 0 && !trivial && my_bytes <= 8192u) ? (my_bytes + 1023u) >> 10 : 0u;  // chunks of lane l's container
+    auto next_valid = [&](uint32_t i) {
+      while (i < cnt && __builtin_amdgcn_readlane(nr, (int)(i & 63)) == 0) i += 4;
+      return i;
+    };
+    uint32_t pi = next_valid(wv), pj = 0;  // producer: next chunk to load
+    uint32_t ci = pi, cj = 0;              // consumer: next chunk to count
+    auto advance = [&](uint32_t& i, uint32_t& j) -> bool {  // true: container i is finished
+      if (++j == (uint32_t)__builtin_amdgcn_readlane(nr, (int)(i & 63))) {
+        j = 0;
+        i = next_valid(i + 4);
+        return true;
+      }
+      return false;
+    };
+    // exactly one load instruction per step (see fbk_fold_kernels.hip.h): lanes past the end of a
+    // payload re-read its first 16 bytes, an exhausted producer the first 16 bytes of the arena
+    auto load_chunk = [&](Chunk& c) {
+      const uint8_t* p = arenaA;
+      if (pi < cnt) {
+        u64 off;
+        uint32_t len, tn;
+        meta(pi, off, len, tn);
+        const uint32_t bytes = payload_bytes(tn >> 24, len);
+        const uint32_t b0 = pj * 1024u + lane * 16u;
+        p = arenaA + off + (b0 < bytes ? b0 : 0u);
+        advance(pi, pj);
+      }
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(c) : "v"(p));
+    };
+    // |chunk j of container (type, len) ∩ F|, this lane's share
+    auto count_chunk = [&](const uint32_t (&d)[4], uint32_t type, uint32_t len, uint32_t j) -> uint32_t {
+      uint32_t c = 0;
+      if (type == kTypeBitmap) {
+        const ulonglong2 f = reinterpret_cast<const ulonglong2*>(F)[j * kWave + lane];
+        c = __popcll((((u64)d[1] << 32) | d[0]) & f.x) + __popcll((((u64)d[3] << 32) | d[2]) & f.y);
       } else if (type == kTypeArray) {
+        const uint32_t row0 = j * (kWave * 8u);
+        if (row0 + kWave * 8u <= len) {  // scalar: a whole row of 512 values
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t e0 = (j * kWave + lane) * 8u;
-          if (e0 < len) {
-            const u64 lo = r.v[j].x, hi = r.v[j].y;
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t a = d[q] & 0xFFFFu, bb = d[q] >> 16;
+            c += ((F32[a >> 5] >> (a & 31)) & 1u) + ((F32[bb >> 5] >> (bb & 31)) & 1u);
+          }
+        } else {
+          const uint32_t e0 = row0 + lane * 8u;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const uint32_t a = (uint32_t)(lo >> (16 * q)) & 0xFFFFu, bb = (uint32_t)(hi >> (16 * q)) & 0xFFFFu;
-              if (e0 + q < len) c += (F32[a >> 5] >> (a & 31)) & 1u;
-              if (e0 + 4 + q < len) c += (F32[bb >> 5] >> (bb & 31)) & 1u;
-            }
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t a = d[q] & 0xFFFFu, bb = d[q] >> 16;
+            if (e0 + 2 * q < len) c += (F32[a >> 5] >> (a & 31)) & 1u;
+            if (e0 + 2 * q + 1 < len) c += (F32[bb >> 5] >> (bb & 31)) & 1u;
           }
         }
       } else {  // run: 4 intervals per 16-byte chunk
+        const uint32_t i0 = (j * kWave + lane) * 4u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t i0 = (j * kWave + lane) * 4u;
-          if (i0 < len) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const u64 w = (q < 2) ? r.v[j].x : r.v[j].y;
-              const uint32_t iv = (uint32_t)(w >> (32 * (q & 1)));
-              if (i0 + q < len) c += rank_of((iv >> 16) + 1u) - rank_of(iv & 0xFFFFu);
-            }
-          }
-        }
+        for (int q = 0; q < 4; ++q)
+          if (i0 + q < len) c += rank_of((d[q] >> 16) + 1u) - rank_of(d[q] & 0xFFFFu);
       }
-      c = wave_reduce_add(c);
-      if (lane == 0 && c) atomicAdd(&out_shard[(uint64_t)shard * nA + base + i], (u64)c);
+      return c;
     };
 #pragma unroll
-    for (int d = 0; d < D; ++d) issue(wv + 4 * d, R[d]);
-    for (uint32_t i = wv; i < cnt; i += 4 * D) {
+    for (int q = 0; q < NCH; ++q) load_chunk(C[q]);
+    uint32_t c = 0;
+    while (ci < cnt) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        consume(i + 4 * d, R[d]);
-        issue(i + 4 * (d + D), R[d]);
+      for (int q = 0; q < NCH; ++q) {
+        if (ci < cnt) {
+          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(C[q]) : "n"(NCH - 1));
+          const uint32_t len = __builtin_amdgcn_readlane(mine.len, (int)(ci & 63));
+          const uint32_t tn = __builtin_amdgcn_readlane(mine.tn, (int)(ci & 63));
+          const uint32_t d[4] = {C[q][0], C[q][1], C[q][2], C[q][3]};
+          c += count_chunk(d, tn >> 24, len, cj);
+          const uint32_t row = ci;
+          if (advance(ci, cj)) {
+            c = wave_reduce_add(c);
+            if (lane == 0 && c) atomicAdd(&out_shard[(uint64_t)shard * nA + base + row], (u64)c);
+            c = 0;
+          }
+          load_chunk(C[q]);
+        }
       }
     }
+    // loads still in flight target registers the compiler is about to reuse
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 }
 
