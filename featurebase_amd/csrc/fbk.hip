@@ -246,7 +246,7 @@ int32_t refresh_slots(fbk_batch* b) {
 }
 
 int32_t upload_rows(fbk_ctx* ctx, const uint32_t* rows, uint64_t n, uint32_t n_rows_limit, DevBuf& out) {
-  for (uint64_t i = 0; i < n; ++i)
+  for (uint64_t i = 0; n_rows_limit != UINT32_MAX && i < n; ++i)  // UINT32_MAX: the caller has validated the indices
     if (rows[i] >= n_rows_limit)
       return fail(FBK_E_INVALID, "row index " + std::to_string(rows[i]) + " out of range (batch has " +
                                      std::to_string(n_rows_limit) + " rows)");

@@ -619,4 +619,90 @@ __global__ void __launch_bounds__(256) k_encode_write(const Slot* __restrict__ c
   if (lane == 0) outSlots[i] = so;
 }
 
+// ---- Shift: every column of a row moves up by one ---------------------------------------------
+// Row.Shift / RowSegment.Shift / Bitmap.Shift(1) (row.go:374-396, 613-626; roaring.go:1629-1662,
+// shiftArray / shiftBitmap / shiftRun :6184-6257).  The reference shifts container by container
+// and carries the bit that leaves value 65535 into value 0 of the next key — including, at the end
+// of a shard's segment, into a container keyed one past the segment ("TODO: deal with overflow"),
+// which Row.Columns() then reports as column (shard + 1) * ShardWidth.  Observable result: the
+// shift of the whole column space; the carry row below is how that bit gets into the next shard.
+//
+// bit 65535 of a container (its carry out), from the encoded form
+__device__ __forceinline__ bool slot_top_bit(const Slot& s, const uint8_t* __restrict__ arena) {
+  const uint32_t n = slot_n(s);
+  if (n == 0) return false;
+  if (n == 65536u) return true;
+  const uint8_t* p = arena + s.off;
+  if (slot_type(s) == kTypeBitmap) return (reinterpret_cast<const u64*>(p)[kWords - 1] >> 63) != 0;
+  if (slot_type(s) == kTypeArray) return reinterpret_cast<const uint16_t*>(p)[s.len - 1] == 0xFFFFu;
+  return reinterpret_cast<const uint16_t*>(p)[2 * s.len - 1] == 0xFFFFu;  // `last` of the last interval
+}
+
+// One wavefront per (output row i, slot): out = rows[i] << 1, with bit 0 of slot 0 taken from bit
+// 65535 of slot 15 of carry_rows[i] (the row of the previous shard); either index may be
+// kNoRow (an absent row / no predecessor).
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+__global__ void __launch_bounds__(256) k_shift(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                              const uint32_t* __restrict__ rows, const uint32_t* __restrict__ carry_rows,
+                                              uint64_t n_rows, uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
+                                              uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts) {
+  __shared__ u64 lds[4][kWords];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
+  const uint64_t i = wslot >> 4;
+  const uint32_t slot = wslot & 15;
+  if (i >= n_rows) return;
+  const uint32_t row = rows[i], crow = carry_rows ? carry_rows[i] : kNoRow;
+  Slot s, sp;
+  s.off = sp.off = 0;
+  s.len = sp.len = 0;
+  s.tn = sp.tn = 0;
+  if (row != kNoRow) s = slots[(uint64_t)row * kSlots + slot];
+  if (slot > 0) {
+    if (row != kNoRow) sp = slots[(uint64_t)row * kSlots + slot - 1];
+  } else if (crow != kNoRow) {
+    sp = slots[(uint64_t)crow * kSlots + (kSlots - 1)];
+  }
+  const bool carry_in = slot_top_bit(sp, arena);
+  Slot so;
+  so.off = wslot * 8192ull;
+  so.len = kWords;
+  so.tn = 0;
+  if (slot_n(s) == 0 && !carry_in) {
+    if (lane == 0) {
+      outSlots[wslot] = so;
+      if (outRuns) outRuns[wslot] = 0;
+    }
+    return;
+  }
+  u64 w[kWordsPerLane];
+  if (slot_n(s) == 0) frag_zero(w);
+  else frag_load(s, arena, lane, lds[wv], w);
+  // lane l holds words 128j + 2l (w[2j]) and 128j + 2l + 1 (w[2j+1]); the bit shifted into word k
+  // is the top bit of word k - 1
+  u64 top_odd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) top_odd[j] = w[2 * j + 1] >> 63;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u64 in = (u64)__shfl_up((unsigned)top_odd[j], 1, kWave);                 // word 128j + 2l - 1 (lane l - 1)
+    const u64 wrap = j ? (u64)__shfl((unsigned)top_odd[j - 1], 63, kWave) : (carry_in ? 1ull : 0ull);  // word 128j - 1
+    if (lane == 0) in = wrap;
+    const u64 even = w[2 * j];
+    w[2 * j] = (even << 1) | in;
+    w[2 * j + 1] = (w[2 * j + 1] << 1) | (even >> 63);
+  }
+  frag_store_bitmap(arenaO + so.off, lane, w);
+  const uint32_t c = wave_reduce_add(frag_popcount(w));
+  uint32_t r = 0;
+  if (outRuns) r = wave_reduce_add(frag_count_runs(w, lane));
+  if (lane == 0) {
+    so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
+    outSlots[wslot] = so;
+    if (outRuns) outRuns[wslot] = r;
+    if (out_counts && c) atomicAdd(&out_counts[i], (u64)c);
+  }
+}
+
 }  // namespace fbk

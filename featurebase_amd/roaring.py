@@ -341,6 +341,19 @@ class Context:
         )
         return out
 
+    NO_ROW = 0xFFFFFFFF
+
+    def shift(self, batch: Batch, rows, carry_rows=None, flags: int = 0) -> Tuple[Batch, np.ndarray]:
+        """out row i = rows[i] shifted up by one column, column 0 taken from the last column of
+        carry_rows[i] (the previous shard's row); NO_ROW = absent (Row.Shift, row.go:374)."""
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        cr = np.ascontiguousarray(carry_rows, dtype=np.uint32) if carry_rows is not None else None
+        assert cr is None or cr.size == r.size
+        out = np.zeros(r.size, dtype=np.uint64)
+        h = C.c_void_p()
+        L.check(self.lib.fbk_shift(self.h, batch.h, r.ctypes.data, cr.ctypes.data if cr is not None else None, r.size, flags, C.byref(h), out.ctypes.data))
+        return Batch(self, h.value), out
+
     def count_range(self, batch: Batch, rows, start: int, end: int) -> np.ndarray:
         """out[i] = bits of rows[i] in [start, end), positions relative to the row (0..2^20):
         Bitmap.CountRange (roaring.go:573)."""

@@ -383,6 +383,19 @@ int32_t fbk_bsi_distinct(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* b
                          uint32_t bit_depth, const fbk_batch* filter, const uint32_t* rows_f, int64_t* out_values,
                          uint64_t cap, uint64_t* out_n);
 
+/* Shift: out row i = rows[i] with every column moved up by one — Row.Shift (row.go:374-396) /
+ * RowSegment.Shift (:613-626) / Bitmap.Shift(1) (roaring/roaring.go:1629-1662; shiftArray,
+ * shiftBitmap, shiftRun :6184-6257), which executeShiftShard (executor.go:5818-5836) applies n
+ * times.  The reference lets the bit that leaves a shard's last column fall into a container
+ * keyed one past the segment, which Row.Columns() reports as the first column of the next shard;
+ * here that bit is handed over explicitly: carry_rows[i] (or NULL) names the row of the
+ * PREVIOUS shard whose column ShardWidth-1 becomes column 0 of out row i.  Either index may be
+ * FBK_NO_ROW: rows[i] absent (a shard that exists only to receive the carried bit), no
+ * predecessor.  out_counts[i] = cardinality of out row i (rows left empty are nil containers). */
+#define FBK_NO_ROW 0xFFFFFFFFu
+int32_t fbk_shift(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, const uint32_t* carry_rows, uint64_t n_rows,
+                  uint32_t flags, fbk_batch** out_batch, uint64_t* out_counts);
+
 /* Unsigned BSI addition z = x + y, plane by plane (ripple carry): roaring.Add
  * (roaring/add.go:12-849), which AddBSI (bsi.go:83-175) uses to merge per-shard TopK counts.
  * Group g of x is the depth_x rows rows_x[g*depth_x + i] (plane i = bit i, no exists / sign

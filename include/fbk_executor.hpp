@@ -58,7 +58,7 @@ struct ValCount {  // executor.go:8380; integer fields only
 
 // A PQL bitmap call (the subset on the hot path).
 struct Call {
-  enum Kind { kRow, kRange, kBetween, kIntersect, kUnion, kDifference, kXor, kNot, kAll } kind = kRow;
+  enum Kind { kRow, kRange, kBetween, kIntersect, kUnion, kDifference, kXor, kNot, kAll, kShift } kind = kRow;
   std::string field;
   uint64_t row = 0;    // Row(field=row)
   int32_t op = 0;      // FBK_BSI_* for Row(field <op> value)
@@ -97,6 +97,19 @@ struct Call {
     Call c;
     c.kind = kAll;
     return c;
+  }
+  static Call Shift(Call child, int64_t n) {  // Shift(x, n=n): executeShiftShard, executor.go:5818-5836
+    Call c;
+    c.kind = kShift;
+    c.value = n;
+    c.children.push_back(std::move(child));
+    return c;
+  }
+  bool ContainsShift() const {
+    if (kind == kShift) return true;
+    for (const Call& ch : children)
+      if (ch.ContainsShift()) return true;
+    return false;
   }
   static Call Nary(Kind k, std::vector<Call> ch) {
     Call c;
@@ -294,25 +307,61 @@ class Executor {
  public:
   explicit Executor(Index& idx) : idx_(idx) {}
 
+ private:
+  // The shards a query is evaluated over: the index's shards — plus, when the query contains a
+  // Shift, the successor of every shard.  The reference lets the bit shifted out of a shard's last
+  // column fall into a container keyed one past the segment, which Row.Columns() reports as the
+  // first column of the next shard whether or not that shard holds data (row.go:366-373); here
+  // that bit needs a row to land in.  (A shift moves a bit by one column, so the successor shards
+  // are enough for any n < ShardWidth.)
+  const std::vector<uint64_t>& shards() const { return cur_ ? *cur_ : idx_.shards_; }
+  struct Scope {
+    Executor& e;
+    bool mine = false;
+    Scope(Executor& ex, std::initializer_list<const Call*> calls) : e(ex) {
+      e.idx_.Sync();
+      if (e.cur_) return;
+      bool shift = false;
+      for (const Call* c : calls) shift = shift || (c && c->ContainsShift());
+      if (!shift) return;
+      std::set<uint64_t> u(e.idx_.shards_.begin(), e.idx_.shards_.end());
+      for (uint64_t sh : e.idx_.shards_) u.insert(sh + 1);
+      e.ext_.assign(u.begin(), u.end());
+      e.cur_ = &e.ext_;
+      mine = true;
+    }
+    ~Scope() {
+      if (mine) e.cur_ = nullptr;
+    }
+  };
+  std::vector<uint64_t> ext_;
+  const std::vector<uint64_t>* cur_ = nullptr;
+
+ public:
+
   // ---- bitmap calls --------------------------------------------------------------------------
+  // (a RowSet of a query containing Shift has one row per shard AND successor shard: use Count /
+  // Columns rather than the raw rows)
   RowSet Bitmap(const Call& c) {
-    idx_.Sync();
+    Scope sc(*this, {&c});
     return eval(c);
   }
   uint64_t Count(const Call& c) {  // executeCount: sum over shards of Row.Count()
-    RowSet r = Bitmap(c);
+    Scope sc(*this, {&c});
+    RowSet r = eval(c);
     return count_rows(r);
   }
   std::vector<uint64_t> Columns(const Call& c) {  // Row.Columns() of the result, ascending
-    RowSet r = Bitmap(c);
+    Scope sc(*this, {&c});
+    RowSet r = eval(c);
     return columns(r);
   }
 
   // ---- Sum / Min / Max -----------------------------------------------------------------------
   ValCount Sum(const std::string& field, const Call* filter = nullptr) {
-    idx_.Sync();
+    Scope sc(*this, {filter});
     const Index::IntField& f = idx_.ints_.at(field);
-    const size_t n = idx_.shards_.size();
+    const size_t n = shards().size();
     if (n == 0) return {};
     std::vector<uint32_t> base = base_rows(f);
     std::vector<int64_t> sums(n);
@@ -337,7 +386,7 @@ class Executor {
   // "median of nothing is NULL" case (:1399-1402).
   bool Percentile(const std::string& field, double nth, const Call* filter, ValCount* out) {
     if (nth < 0 || nth > 100.0) throw Error(FBK_E_INVALID, "Percentile(): invalid nth value, should be a number between 0 and 100 inclusive");
-    idx_.Sync();
+    Scope sc(*this, {filter});
     const Index::IntField& f = idx_.ints_.at(field);
     auto count_of = [&](RowSet&& r) {
       if (!filter) return count_rows(r);
@@ -385,10 +434,10 @@ class Executor {
   // Distinct(field=int field, filter): the distinct values (Base added) in ascending order —
   // the SignedRow{Neg, Pos} of executeDistinct (executor.go:1170-1230, 2034-2153) flattened.
   std::vector<int64_t> Distinct(const std::string& field, const Call* filter = nullptr) {
-    idx_.Sync();
+    Scope sc(*this, {filter});
     const Index::IntField& f = idx_.ints_.at(field);
     std::vector<int64_t> out;
-    const size_t n = idx_.shards_.size();
+    const size_t n = shards().size();
     if (n == 0) return out;
     std::vector<uint32_t> base = base_rows(f);
     uint64_t cnt = 0, cap = 1024;
@@ -435,9 +484,9 @@ class Executor {
   std::vector<GroupCount> GroupBy(const std::vector<std::string>& fields, const Call* filter = nullptr,
                                   const std::string& agg_field = "", uint64_t limit = 0) {
     if (fields.empty()) throw Error(FBK_E_INVALID, "need at least one child call");  // executor.go:3927
-    idx_.Sync();
+    Scope sc(*this, {filter});
     std::vector<GroupCount> out;
-    const size_t n = idx_.shards_.size();
+    const size_t n = shards().size();
     if (n == 0) return out;
     std::unique_ptr<RowSet> prefix;  // filter ∩ rows of the fields before the last two
     if (filter) prefix.reset(new RowSet(eval(*filter)));
@@ -451,14 +500,14 @@ class Executor {
   RowSet leaf_row(const std::string& field, uint64_t row) {
     const Index::SetField& f = idx_.sets_.at(field);
     std::vector<uint32_t> rows;
-    for (uint64_t s : idx_.shards_) {
+    for (uint64_t s : shards()) {
       auto it = f.ordinal.find({s, row});
       rows.push_back(it == f.ordinal.end() ? f.empty_row : it->second);
     }
     return RowSet(idx_.ctx_, f.batch, std::move(rows), false);
   }
   RowSet fresh(fbk_batch* b) {
-    std::vector<uint32_t> rows(idx_.shards_.size());
+    std::vector<uint32_t> rows(shards().size());
     for (size_t i = 0; i < rows.size(); ++i) rows[i] = uint32_t(i);
     return RowSet(idx_.ctx_, b, std::move(rows), true);
   }
@@ -469,7 +518,7 @@ class Executor {
   }
   std::vector<uint32_t> base_rows(const Index::IntField& f) const {
     std::vector<uint32_t> base;
-    for (uint64_t s : idx_.shards_) {
+    for (uint64_t s : shards()) {
       auto it = f.base_row.find(s);
       base.push_back(it == f.base_row.end() ? f.empty_base : it->second);
     }
@@ -479,7 +528,7 @@ class Executor {
     return RowSet(idx_.ctx_, f.batch, base_rows(f), false);
   }
   RowSet empty_set(const Index::IntField& f) {
-    return RowSet(idx_.ctx_, f.batch, std::vector<uint32_t>(idx_.shards_.size(), f.empty_base), false);
+    return RowSet(idx_.ctx_, f.batch, std::vector<uint32_t>(shards().size(), f.empty_base), false);
   }
   // executeRowBSIGroupShard, executor.go:5249-5355, with bsiGroup.baseValue / baseValueBetween
   RowSet range(const Call& c) {
@@ -528,6 +577,21 @@ class Executor {
       case Call::kRange:
       case Call::kBetween: return range(c);
       case Call::kAll: return leaf_row(Index::kExistence, 0);
+      case Call::kShift: {
+        if (c.children.size() != 1) throw Error(FBK_E_INVALID, c.children.empty() ? "Shift() requires an input row" : "Shift() only accepts a single row input");
+        if (c.value < 0) throw Error(FBK_E_INVALID, "cannot shift by negative values");  // row.go:375-377
+        RowSet acc = eval(c.children[0]);
+        const std::vector<uint64_t>& sh = shards();
+        for (int64_t i = 0; i < c.value; ++i) {  // Row.Shift: n single-column shifts (row.go:383-393)
+          std::vector<uint32_t> carry(sh.size(), FBK_NO_ROW);
+          for (size_t k = 1; k < sh.size(); ++k)
+            if (sh[k - 1] + 1 == sh[k]) carry[k] = acc.rows()[k - 1];  // last column of the previous shard
+          fbk_batch* o = nullptr;
+          check(fbk_shift(idx_.ctx_, acc.batch(), acc.rows().data(), carry.data(), sh.size(), FBK_SETOP_OPTIMIZE, &o, nullptr));
+          acc = fresh(o);
+        }
+        return acc;
+      }
       case Call::kNot: {
         if (c.children.size() != 1) throw Error(FBK_E_INVALID, "Not() requires exactly one child");
         RowSet ex = leaf_row(Index::kExistence, 0), child = eval(c.children[0]);
@@ -566,7 +630,7 @@ class Executor {
     std::vector<uint64_t> out;
     for (uint64_t i = 0; i < nc; ++i) {
       const fbk_container_desc& d = descs[i];
-      const uint64_t hb = (idx_.shards_[d.row] * 16 + (d.key & 15)) << 16;
+      const uint64_t hb = (shards()[d.row] * 16 + (d.key & 15)) << 16;
       const uint64_t* w = reinterpret_cast<const uint64_t*>(payload.data() + d.off);  // keep-bitmap output: 1024 words
       for (uint32_t k = 0; k < FBK_BITMAP_WORDS; ++k)
         for (uint64_t x = w[k]; x; x &= x - 1) out.push_back(hb | (uint64_t(k) * 64 + uint64_t(__builtin_ctzll(x))));
@@ -575,9 +639,9 @@ class Executor {
     return out;
   }
   ValCount minmax(const std::string& field, const Call* filter, bool is_min) {
-    idx_.Sync();
+    Scope sc(*this, {filter});
     const Index::IntField& f = idx_.ints_.at(field);
-    const size_t n = idx_.shards_.size();
+    const size_t n = shards().size();
     ValCount out;
     if (n == 0) return out;
     std::vector<uint32_t> base = base_rows(f);
@@ -599,15 +663,15 @@ class Executor {
   }
   // counts of every row of a set field (optionally ∩ filter), summed over shards, ascending id
   std::vector<Pair> row_counts(const std::string& field, const Call* filter) {
-    idx_.Sync();
+    Scope sc(*this, {filter});
     const Index::SetField& f = idx_.sets_.at(field);
-    const size_t n = idx_.shards_.size(), nr = f.row_ids.size();
+    const size_t n = shards().size(), nr = f.row_ids.size();
     std::vector<Pair> out;
     if (n == 0 || nr == 0) return out;
     std::vector<uint32_t> rows_a(n * nr);
     for (size_t s = 0; s < n; ++s)
       for (size_t i = 0; i < nr; ++i) {
-        auto it = f.ordinal.find({idx_.shards_[s], f.row_ids[i]});
+        auto it = f.ordinal.find({shards()[s], f.row_ids[i]});
         rows_a[s * nr + i] = it == f.ordinal.end() ? f.empty_row : it->second;
       }
     std::vector<uint64_t> tot(nr);
@@ -626,11 +690,11 @@ class Executor {
     return out;
   }
   std::vector<uint32_t> field_rows(const Index::SetField& f) {
-    const size_t n = idx_.shards_.size(), nr = f.row_ids.size();
+    const size_t n = shards().size(), nr = f.row_ids.size();
     std::vector<uint32_t> rows(n * nr);
     for (size_t s = 0; s < n; ++s)
       for (size_t i = 0; i < nr; ++i) {
-        auto it = f.ordinal.find({idx_.shards_[s], f.row_ids[i]});
+        auto it = f.ordinal.find({shards()[s], f.row_ids[i]});
         rows[s * nr + i] = it == f.ordinal.end() ? f.empty_row : it->second;
       }
     return rows;
@@ -660,7 +724,7 @@ class Executor {
   // prefix ∩ row (gbi.rows[i].row.Intersect(gbi.rows[i-1].row), executor.go:8829-8834)
   bool group_by_rec(const std::vector<std::string>& fields, size_t level, const RowSet* prefix, const std::string& agg_field, uint64_t limit,
                     std::vector<FieldRow>& group, std::vector<GroupCount>& out) {
-    const size_t n = idx_.shards_.size();
+    const size_t n = shards().size();
     const Index::SetField& fa = idx_.sets_.at(fields[level]);
     const size_t na = fa.row_ids.size();
     if (na == 0) return true;

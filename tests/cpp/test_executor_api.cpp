@@ -75,6 +75,43 @@ int main() {
     EXPECT(e.Columns(Call::Not(R(10))) == (V{0, 4, SW + 1, SW + 2}));
     EXPECT(e.Count(Call::Not(Call::Nary(Call::kUnion, {R(10), R(20), R(30)}))) == 1);  // only column 4 is left
   }
+  {  // ---- Shift (TestExecutor_Execute_Shift, executor_test.go:6590-6676) ----
+    auto shifted = [](std::initializer_list<uint64_t> cols, int64_t n, int nest = 1) {
+      Index idx;
+      idx.CreateSetField("general");
+      for (uint64_t c : cols) idx.SetBit("general", 10, c);
+      Executor e(idx);
+      Call c = Call::Row("general", 10);
+      for (int i = 0; i < nest; ++i) c = Call::Shift(std::move(c), n);
+      return e.Columns(c);
+    };
+    EXPECT(shifted({0}, 1) == (V{1}));                 // "Shift Bit 0"
+    EXPECT(shifted({0}, 1, 2) == (V{2}));              // Shift(Shift(..., n=1), n=1)
+    EXPECT(shifted({65535}, 1) == (V{65536}));         // "Shift container boundary"
+    EXPECT(shifted({1, SW - 1, SW + 1}, 1) == (V{2, SW, SW + 2}));  // "Shift shard boundary"
+    EXPECT(shifted({1, SW - 1, SW + 1}, 1, 2) == (V{3, SW + 1, SW + 3}));
+    EXPECT(shifted({SW - 2, SW - 1, SW, SW + 2}, 1) == (V{SW - 1, SW, SW + 1, SW + 3}));  // "no create"
+    EXPECT(shifted({SW - 2, SW - 1, SW, SW + 2}, 1, 2) == (V{SW, SW + 1, SW + 2, SW + 4}));
+    EXPECT(shifted({1, SW - 1, SW + 1}, 2) == (V{3, SW + 1, SW + 3}));  // n = 2 in one call (Row.Shift loops)
+    EXPECT(shifted({SW - 1, 3 * SW - 1}, 1) == (V{SW, 3 * SW}));        // carried into shards that hold no data
+    EXPECT(shifted({5}, 0) == (V{5}));
+    {
+      Index idx;
+      idx.CreateSetField("general");
+      idx.SetBit("general", 10, SW - 1);
+      idx.SetBit("general", 11, SW);
+      Executor e(idx);
+      // the shifted row meets another row in the successor shard
+      EXPECT(e.Count(Call::Nary(Call::kIntersect, {Call::Shift(Call::Row("general", 10), 1), Call::Row("general", 11)})) == 1);
+      bool threw = false;
+      try {
+        e.Columns(Call::Shift(Call::Row("general", 10), -1));
+      } catch (const Error&) {
+        threw = true;  // "cannot shift by negative values", row.go:375-377
+      }
+      EXPECT(threw);
+    }
+  }
   {  // ---- TopK (executor_test.go:1758-1809): rows {0, 10, 20} -> {10: 4, 0: 3} ----
     Index idx;
     idx.CreateSetField("f");

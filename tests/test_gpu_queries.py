@@ -730,3 +730,70 @@ def test_bsi_distinct_vs_definition(gpu_ctx, B):
     exp = np.unique(val[bits[:, 0] == 1])
     assert got.tolist() == exp.tolist()
     batch.free()
+
+
+@pytest.mark.parametrize("flags", [0, L.SETOP_OPTIMIZE])
+def test_shift_vs_oracle(gpu_ctx, oracle, flags):
+    """fbk_shift against the restated Row.Shift (oracle/pyshift.py, pinned to the reference's own
+    vectors in tests/test_oracle_shift.py): rows of every encoding over shards 0, 1 and 3, the last
+    column of several containers and shards set so that carries cross container AND shard
+    boundaries — into an existing shard (1), into a shard that exists only because of the carried
+    bit (2 and 4) — then shifted three times."""
+    from oracle import pyshift as S
+
+    O = oracle
+    rng = D.rng_for(61)
+    SW = 1 << 20
+    shards = [0, 1, 3]
+    segs = {}
+    for sh in shards:
+        row = D.random_row(rng, sh, p_missing=0.2)
+        for slot in (2, 7, 15):  # force value 65535 (carry out) in every encoding
+            key = sh * 16 + slot
+            words = row[key].words() if key in row else np.zeros(1024, dtype=np.uint64)
+            words[1023] |= np.uint64(1) << np.uint64(63)
+            typ = [O.ARRAY, O.BITMAP, O.RUN][slot % 3]
+            c = O.OContainer.from_words(words, typ) if int(np.bitwise_count(words).sum()) < 4096 or typ != O.ARRAY else O.OContainer.bitmap(words)
+            row[key] = c
+        if sh == 1:
+            row.pop(sh * 16 + 0, None)  # the carry from shard 0 lands in a nil container
+        segs[sh] = sorted(row.items())
+    want = segs
+    have = {sh: {k: c for k, c in items} for sh, items in segs.items()}  # shard -> {key: oracle container}
+    for step in range(3):
+        want = S.row_shift(want, 1)
+        exp_cols = S.row_columns(want)
+        # one device call per step: every shard that has a row or a predecessor with a row
+        out_shards = sorted(set(have) | {s + 1 for s in have})
+        order = sorted(have)
+        batch = gpu_ctx.upload([D.to_fbk_row(have[s]) for s in order])
+        idx = {s: i for i, s in enumerate(order)}
+        rows = [idx.get(s, gpu_ctx.NO_ROW) for s in out_shards]
+        carry = [idx.get(s - 1, gpu_ctx.NO_ROW) for s in out_shards]
+        out, counts = gpu_ctx.shift(batch, rows, carry, flags)
+        got_rows = out.download()
+        got_cols, new_have = [], {}
+        for i, s in enumerate(out_shards):
+            n = 0
+            for key, c in got_rows[i].items():
+                assert key >> 4 == s, (key, s)  # output keys carry the shard of the row
+                vals = np.nonzero(np.unpackbits(c.words().view(np.uint8), bitorder="little"))[0]
+                got_cols.extend(((key << 16) + vals).tolist())
+                n += vals.size
+            assert n == int(counts[i])
+            if n:
+                new_have[s] = {k: O.OContainer.from_words(c.words(), O.BITMAP) for k, c in got_rows[i].items()}
+        assert sorted(got_cols) == exp_cols, step
+        if flags & L.SETOP_OPTIMIZE:  # Container.optimize() encodings on the way out
+            for i in range(len(out_shards)):
+                for key, c in got_rows[i].items():
+                    assert c.typ == O.optimize(O.OContainer.bitmap(c.words())).typ
+        have = new_have
+        batch.free()
+        out.free()
+    with pytest.raises(L.FbkError):
+        b = gpu_ctx.upload([D.to_fbk_row(D.random_row(rng, 0))])
+        try:
+            gpu_ctx.shift(b, [5])
+        finally:
+            b.free()
