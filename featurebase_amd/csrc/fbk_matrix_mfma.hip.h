@@ -42,32 +42,43 @@ namespace fbk {
 constexpr int kMmWaves = 4;  // wavefronts per block
 constexpr int kMmDepth = 2;  // DMA ring depth (steps)
 constexpr int kMmAux = 2;    // cache policy of the global->LDS DMA: nt
-constexpr int kMmPiece = 128;                          // bytes of every row per step
-constexpr int kMmStageU4 = (64 * kMmPiece + 256) / 16;  // uint4 per stage: A 4 KiB, B 4 KiB, F 128 B (+pad)
+constexpr int kMmPiece = 128;  // bytes of every row per step
 
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v16i __attribute__((ext_vector_type(16)));
-
 typedef uint32_t mm_u4 __attribute__((ext_vector_type(4)));
 
-template <bool HAS_F, int WAVES = kMmWaves, int DEPTH = kMmDepth, int AUX = kMmAux>
+// TM x TN: 32-row tiles of A and of B per block.  1 x 1 is the HBM-bound shape (a 32 x 32 matrix
+// reads every row once); for larger matrices a block computes TM x TN tiles from ONE expansion of
+// its TM A operands and TN B operands — 2 x 2 halves the VALU, LDS and DMA work per MFMA, which is
+// what bounds a matrix of many tiles (128 x 128 rows x 64 shards: 1256 us with 1 x 1 tiles, where
+// the matrix cores alone would need 437 us).
+template <bool HAS_F, int WAVES = kMmWaves, int DEPTH = kMmDepth, int AUX = kMmAux, int TM = 1, int TN = 1>
 __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
     const uint8_t* __restrict__ arenaA, const uint32_t* __restrict__ rowsA, uint32_t nA, const uint8_t* __restrict__ arenaB,
     const uint32_t* __restrict__ rowsB, uint32_t nBtot, const uint8_t* __restrict__ arenaF,
     const uint32_t* __restrict__ rowsF, uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard) {
+  // stage of one wave and one step: A rows, B rows (128 bytes each), the filter piece
+  constexpr uint32_t kABytes = TM * 32 * kMmPiece, kBBytes = TN * 32 * kMmPiece;
+  constexpr uint32_t kStageBytes = kABytes + kBBytes + 256;
   // The ring is read with ds_read_b128 written as asm: the compiler's waitcnt pass otherwise puts
   // s_waitcnt vmcnt(0) in front of every LDS read that might alias a pending global->LDS DMA
   // (it cannot count DMA steps across the loop back-edge), which would serialise the prefetch
   // with the arithmetic.  vmcnt / lgkmcnt are managed by hand below.
-  __shared__ uint4 ring[DEPTH][WAVES][kMmStageU4];
+  __shared__ uint4 ring[DEPTH][WAVES][kStageBytes / 16];
+  static_assert(kStageBytes >= TM * TN * 16 * 64 * 4, "the final reduction parks the partial counts in stage 0");
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t agroups = (nA + 31) / 32;
-  const uint32_t btiles = (nBtot + 31) / 32;
+  const uint32_t agroups = (nA + 32 * TM - 1) / (32 * TM);
+  const uint32_t btiles = (nBtot + 32 * TN - 1) / (32 * TN);
   const uint32_t sgroups = kSlots / spb;
   uint32_t b = blockIdx.x;
+  // The tiles of one (shard, slot group) read the same rows.  Workgroups go to the 8 XCDs round
+  // robin and every XCD has its own L2, so consecutive block ids would put those tiles on 8
+  // different L2s; with ids that differ by 8 they share one and the rows come from HBM once.
+  if (agroups * btiles > 1 && (gridDim.x & 7u) == 0) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
   const uint32_t bt = b % btiles;
   b /= btiles;
   const uint32_t ag = b % agroups;
@@ -75,36 +86,50 @@ __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
   const uint32_t sg = b % sgroups;
   const uint32_t shard = b / sgroups;
   if (shard >= n_shards) return;
-  const uint32_t i0 = ag * 32, j0 = bt * 32;
+  const uint32_t i0 = ag * 32 * TM, j0 = bt * 32 * TN;
   const uint64_t rowBytes = (uint64_t)kSlots * 8192;
 
   // DMA side: instruction n covers rows 8n..8n+7, lane -> (row 8n + lane/8, LDS position lane%8),
   // which holds piece (position - row/2) mod 8 of the row's 128 bytes.  Rows past the end of the
   // matrix re-read its last row (their products are never written out).
-  const uint8_t* pa[4];
-  const uint8_t* pb[4];
+  const uint8_t* pa[4 * TM];
+  const uint8_t* pb[4 * TN];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
+  for (int n = 0; n < 4 * TM; ++n) {
     const uint32_t rr = 8 * n + (lane >> 3);
     const uint32_t piece = ((lane & 7) - (rr >> 1)) & 7;
-    const uint32_t ia = min(i0 + rr, nA - 1), ib = min(j0 + rr, nBtot - 1);
-    pa[n] = arenaA + (uint64_t)rowsA[(uint64_t)shard * nA + ia] * rowBytes + piece * 16;
-    pb[n] = arenaB + (uint64_t)rowsB[(uint64_t)shard * nBtot + ib] * rowBytes + piece * 16;
+    pa[n] = arenaA + (uint64_t)rowsA[(uint64_t)shard * nA + min(i0 + rr, nA - 1)] * rowBytes + piece * 16;
+  }
+#pragma unroll
+  for (int n = 0; n < 4 * TN; ++n) {
+    const uint32_t rr = 8 * n + (lane >> 3);
+    const uint32_t piece = ((lane & 7) - (rr >> 1)) & 7;
+    pb[n] = arenaB + (uint64_t)rowsB[(uint64_t)shard * nBtot + min(j0 + rr, nBtot - 1)] * rowBytes + piece * 16;
   }
   const uint8_t* pf = nullptr;
   if (HAS_F) pf = arenaF + (uint64_t)rowsF[shard] * rowBytes + (lane & 7) * 16;
 
-  // consumer side: lane (r, g) reads piece 2t + g of row r in octet t
+  // consumer side: lane (r, g) reads piece 2t + g of row r (of every tile) in octet t
   const uint32_t r = lane & 31, g = lane >> 5;
-  const uint32_t rot = (g + (r >> 1)) & 7;
-  constexpr uint32_t kStageBytes = kMmStageU4 * 16;
+  const uint32_t rot = (g + (r >> 1)) & 7;  // (32 rows per tile: the rotation repeats per tile)
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)&ring[0][wv][0];  // LDS byte address of this wave's stage 0
   uint32_t offAB[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) offAB[t] = lds0 + r * 128 + ((rot + 2 * t) & 7) * 16;
   const uint32_t offF = lds0 + g * 16;
 
-  mm_v16i accP0 = {}, accP1 = {}, accN = {};
+  // per tile: P collects the +128 products (k = 1..6), N the -128 ones (k = 0, 7); a single tile
+  // alternates between two P accumulators so that consecutive MFMAs never chain on one
+  constexpr int NP = (TM * TN == 1) ? 2 : 1;
+  mm_v16i accP[TM][TN][NP], accN[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+#pragma unroll
+      for (int h = 0; h < NP; ++h) accP[m][n][h] = mm_v16i{};
+      accN[m][n] = mm_v16i{};
+    }
 
   constexpr uint32_t kStepsPerSlot = 8192 / (kMmPiece * WAVES);
   const uint32_t steps = spb * kStepsPerSlot;
@@ -112,63 +137,76 @@ __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
     const uint32_t off = (sg * spb + st / kStepsPerSlot) * 8192u + ((st % kStepsPerSlot) * WAVES + wv) * kMmPiece;
     uint8_t* l = reinterpret_cast<uint8_t*>(&ring[st % DEPTH][wv][0]);
 #pragma unroll
-    for (int n = 0; n < 4; ++n) __builtin_amdgcn_global_load_lds((gptr_t)(pa[n] + off), (lptr_t)(l + n * 1024), 16, 0, AUX);
+    for (int n = 0; n < 4 * TM; ++n) __builtin_amdgcn_global_load_lds((gptr_t)(pa[n] + off), (lptr_t)(l + n * 1024), 16, 0, AUX);
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
-      __builtin_amdgcn_global_load_lds((gptr_t)(pb[n] + off), (lptr_t)(l + 4096 + n * 1024), 16, 0, AUX);
+    for (int n = 0; n < 4 * TN; ++n)
+      __builtin_amdgcn_global_load_lds((gptr_t)(pb[n] + off), (lptr_t)(l + kABytes + n * 1024), 16, 0, AUX);
     if (HAS_F) {
-      if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(pf + off), (lptr_t)(l + 8192), 16, 0, AUX);
+      if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(pf + off), (lptr_t)(l + kABytes + kBBytes), 16, 0, AUX);
     }
   };
+  constexpr int kOps = 4 * TM + 4 * TN + (HAS_F ? 1 : 0);  // vmem instructions per staged step
+  constexpr int kReads = TM + TN + (HAS_F ? 1 : 0);         // LDS reads per octet
   struct Oct {
-    mm_u4 A, B, F;
+    mm_u4 A[TM], B[TN], F;
   };
   auto issue = [&](Oct& o, uint32_t sbase, int t) {  // LDS reads of octet t of the stage at byte offset sbase
-    if (HAS_F)
-      asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:4096\n\tds_read_b128 %2, %4 offset:%5"
-                   : "=&v"(o.A), "=&v"(o.B), "=&v"(o.F)
-                   : "v"(offAB[t] + sbase), "v"(offF + sbase), "n"(8192 + 32 * t));
-    else
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(o.A), "=&v"(o.B) : "v"(offAB[t] + sbase));
+    const uint32_t ab = offAB[t] + sbase;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o.A[m]) : "v"(ab), "n"(m * 4096));
+#pragma unroll
+    for (int n = 0; n < TN; ++n) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o.B[n]) : "v"(ab), "n"(kABytes + n * 4096));
+    if (HAS_F) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o.F) : "v"(offF + sbase), "n"(kABytes + kBBytes + 32 * t));
   };
   auto landed = [&](Oct& o, bool more_behind) {  // o's reads are complete (LDS returns in order)
-    if (HAS_F) {
-      if (more_behind) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(o.A), "+v"(o.B), "+v"(o.F));
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.A), "+v"(o.B), "+v"(o.F));
-    } else {
-      if (more_behind) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(o.A), "+v"(o.B));
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.A), "+v"(o.B));
-    }
+    if (more_behind) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(kReads) : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the values are defined from here on: nothing that uses them may be scheduled above the wait
+#pragma unroll
+    for (int m = 0; m < TM; ++m) asm volatile("" : "+v"(o.A[m]));
+#pragma unroll
+    for (int n = 0; n < TN; ++n) asm volatile("" : "+v"(o.B[n]));
+    if (HAS_F) asm volatile("" : "+v"(o.F));
   };
   constexpr uint32_t M = 0x01010101u;
   auto octet = [&](const Oct& o) {
-    uint32_t a[4], bb[4];
+    uint32_t a[TM][4], bb[TN][4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      a[d] = __builtin_bswap32(HAS_F ? (o.A[d] & o.F[d]) : o.A[d]);
-      bb[d] = __builtin_bitreverse32(o.B[d]);
-    }
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) a[m][d] = __builtin_bswap32(HAS_F ? (o.A[m][d] & o.F[d]) : o.A[m][d]);
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) bb[n][d] = __builtin_bitreverse32(o.B[n][d]);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      mm_v4i oa, ob;
+      mm_v4i oa[TM], ob[TN];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        oa[d] = (int)(a[d] & (M << k));
-        ob[d] = (int)(bb[d] & (M << (7 - k)));
-      }
-      if (k == 0 || k == 7) accN = __builtin_amdgcn_mfma_i32_32x32x32_i8(oa, ob, accN, 0, 0, 0);
-      else if (k & 1) accP0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(oa, ob, accP0, 0, 0, 0);
-      else accP1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(oa, ob, accP1, 0, 0, 0);
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) oa[m][d] = (int)(a[m][d] & (M << k));
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ob[n][d] = (int)(bb[n][d] & (M << (7 - k)));
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          if (k == 0 || k == 7) accN[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(oa[m], ob[n], accN[m][n], 0, 0, 0);
+          else accP[m][n][k % NP] = __builtin_amdgcn_mfma_i32_32x32x32_i8(oa[m], ob[n], accP[m][n][k % NP], 0, 0, 0);
+        }
     }
   };
-  constexpr int kOps = HAS_F ? 9 : 8;  // vmem instructions per staged step
 
   // the step about to be read has landed once at most `younger` later steps are still in flight
   auto dma_landed = [&](uint32_t younger) {
     static_assert(DEPTH >= 2 && DEPTH <= 5, "ring depth");
-    if (DEPTH > 4 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kOps) : "memory");
-    else if (DEPTH > 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kOps) : "memory");
-    else if (DEPTH > 2 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");
+    static_assert((DEPTH - 2) * kOps <= 63, "vmcnt is a 6-bit counter");
+    if (DEPTH > 4 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH > 4 ? 3 * kOps : 0) : "memory");
+    else if (DEPTH > 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH > 3 ? 2 * kOps : 0) : "memory");
+    else if (DEPTH > 2 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH > 2 ? kOps : 0) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   Oct X, Y;
@@ -196,19 +234,27 @@ __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
     octet(Y);
   }
 
-  // cross-wave reduction through LDS: every wave parks its 32 x 32 partial counts in its own
-  // (fully consumed) stage 0, then each wave totals 16 / WAVES of the 16 accumulator registers
-  uint32_t* red = reinterpret_cast<uint32_t*>(&ring[0][wv][0]);  // [16][64]
+  // cross-wave reduction through LDS: every wave parks its partial counts in its own (fully
+  // consumed) stage 0, then the waves share out the TM*TN*16 accumulator registers
+  uint32_t* red = reinterpret_cast<uint32_t*>(&ring[0][wv][0]);  // [TM*TN*16][64]
 #pragma unroll
-  for (int q = 0; q < 16; ++q) red[q * 64 + lane] = (uint32_t)(accP0[q] + accP1[q] - accN[q]) >> 7;
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        red[((m * TN + n) * 16 + q) * 64 + lane] = (uint32_t)(accP[m][n][0][q] + (NP > 1 ? accP[m][n][NP - 1][q] : 0) - accN[m][n][q]) >> 7;
   __syncthreads();
+  constexpr int kRegs = TM * TN * 16;
+  static_assert(kRegs % WAVES == 0, "accumulator registers are dealt evenly to the waves");
 #pragma unroll
-  for (int qq = 0; qq < 16 / WAVES; ++qq) {
-    const int q = wv * (16 / WAVES) + qq;
+  for (int qq = 0; qq < kRegs / WAVES; ++qq) {
+    const int x = wv * (kRegs / WAVES) + qq;  // (tile, register): wave-uniform
+    const int tile = x >> 4, q = x & 15;
     uint32_t tot = 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) tot += reinterpret_cast<const uint32_t*>(&ring[0][w][0])[q * 64 + lane];
-    const uint32_t i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), j = lane & 31;
+    for (int w = 0; w < WAVES; ++w) tot += reinterpret_cast<const uint32_t*>(&ring[0][w][0])[x * 64 + lane];
+    const uint32_t i = (tile / TN) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), j = (tile % TN) * 32 + (lane & 31);
     if (i0 + i < nA && j0 + j < nBtot && tot) {
       u64* dst = &out_shard[((uint64_t)shard * nA + i0 + i) * nBtot + j0 + j];
       if (spb == kSlots) *dst = tot;

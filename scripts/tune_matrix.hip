@@ -110,22 +110,20 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(fbk::k_count_matrix_dense, dim3(blocks), dim3(512), 0, 0, p.A, p.rowsA, p.nA, p.B, p.rowsB, p.nB, p.F,
                            p.rowsF, p.shards, spb, p.out);
       }, p, iters, &ref);
-#define VARIANT(W, D, AUX)                                                                                                 \
-  time_kernel("mfma<F, W=" #W ", D=" #D ", aux=" #AUX ">", [&] {                                                            \
-    hipLaunchKernelGGL((fbk::k_count_matrix_mfma<true, W, D, AUX>), dim3(blocks), dim3(W * 64), 0, 0, p.A, p.rowsA, p.nA, p.B, \
+#define VARIANT(W, D, AUX, TM, TN)                                                                                         \
+  time_kernel("mfma<F, W=" #W ", D=" #D ", aux=" #AUX ", " #TM "x" #TN ">", [&] {                                           \
+    const uint32_t blocks = p.shards * (16 / spb) * ((p.nA + 32 * TM - 1) / (32 * TM)) * ((p.nB + 32 * TN - 1) / (32 * TN)); \
+    hipLaunchKernelGGL((fbk::k_count_matrix_mfma<true, W, D, AUX, TM, TN>), dim3(blocks), dim3(W * 64), 0, 0, p.A, p.rowsA, p.nA, p.B, \
                        p.rowsB, p.nB, p.F, p.rowsF, p.shards, spb, p.out);                                                 \
   }, p, iters, &got);                                                                                                      \
   if (!ref.empty() && got != ref) printf("   MISMATCH vs valu kernel\n");
-    VARIANT(4, 3, 0)
-    VARIANT(4, 3, 1)
-    VARIANT(4, 3, 2)
-    VARIANT(4, 3, 3)
-    VARIANT(4, 3, 16)
-    VARIANT(4, 3, 17)
-    VARIANT(4, 3, 18)
-    VARIANT(4, 2, 2)
-    VARIANT(8, 2, 2)
-    VARIANT(4, 4, 2)
+    VARIANT(4, 2, 2, 1, 1)
+    VARIANT(4, 3, 2, 1, 1)
+    VARIANT(4, 2, 2, 2, 2)
+    VARIANT(4, 2, 2, 2, 1)
+    VARIANT(4, 2, 2, 1, 2)
+    VARIANT(2, 2, 2, 2, 2)
+    VARIANT(2, 3, 2, 2, 2)
     time_kernel("mfma<noF, W=4, D=3>", [&] {
       hipLaunchKernelGGL((fbk::k_count_matrix_mfma<false, 4, 3>), dim3(blocks), dim3(256), 0, 0, p.A, p.rowsA, p.nA, p.B, p.rowsB,
                          p.nB, (const uint8_t*)nullptr, (const uint32_t*)nullptr, p.shards, spb, p.out);

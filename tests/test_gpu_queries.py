@@ -415,11 +415,12 @@ def test_count_range_vs_oracle(gpu_ctx, oracle):
     batch.free()
 
 
-@pytest.mark.parametrize("n_shards,n_a,n_b,use_filter", [(3, 32, 32, True), (2, 37, 45, False), (5, 5, 3, True), (1, 1, 2, False), (9, 64, 33, True)])
+@pytest.mark.parametrize("n_shards,n_a,n_b,use_filter", [(3, 32, 32, True), (2, 37, 45, False), (5, 5, 3, True), (1, 1, 2, False), (9, 64, 33, True), (2, 40, 8, True), (2, 8, 70, False), (1, 100, 97, True)])
 def test_count_matrix_dense_kernel_vs_numpy(gpu_ctx, n_shards, n_a, n_b, use_filter):
     """The all-bitmap fast path of fbk_count_matrix (k_count_matrix_mfma: bits expanded to i8
     bytes, v_mfma_i32_32x32x32_i8 tiles, per-wave DMA ring) against numpy popcounts: full
-    matrix, per shard and in total, ragged tile edges, with and without the filter row."""
+    matrix, per shard and in total, ragged tile edges, with and without the filter row; every
+    register tiling of the kernel (1 x 1, 2 x 1, 1 x 2, 2 x 2 tiles of 32 rows per block)."""
     wa = D.dense_rows(n_shards * n_a, 0.3, 811)
     wb = D.dense_rows(n_shards * n_b, 0.6, 812)
     wf = D.dense_rows(n_shards, 0.5, 813)
