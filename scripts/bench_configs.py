@@ -71,9 +71,10 @@ def config3(ctx, stream, n_shards, iters):
             d = D.zipf_density(r)
             row = {}
             for slot in range(16):
-                c = D.mixed_container_for_density(rng, d, rng.random() < 0.25)
+                rs = rng.random() < 0.25
+                c = D.fbk_container_of_vals(D.mixed_vals_for_density(rng, d, rs))  # numpy only: no oracle code while measuring
                 if c is not None and c.n:
-                    row[s * 16 + slot] = D.to_fbk(c)
+                    row[s * 16 + slot] = c
                     nbytes += encoded_bytes(c)
                     ncont += 1
                     if s == 0:
@@ -86,8 +87,8 @@ def config3(ctx, stream, n_shards, iters):
         rng = D.rng_for(3500 + s)
         row = {}
         for slot in range(16):
-            c = D.mixed_container_for_density(rng, 0.5, False)
-            row[s * 16 + slot] = D.to_fbk(c)
+            c = D.fbk_container_of_vals(D.mixed_vals_for_density(rng, 0.5, False))
+            row[s * 16 + slot] = c
             nbytes += encoded_bytes(c)
             ncont += 1
             if s == 0:
@@ -111,8 +112,11 @@ def config3(ctx, stream, n_shards, iters):
     if CPU_BASELINE:
         from oracle import pyoracle as O
 
-        bms = [O.OBitmap.from_containers(ORACLE_ROWS3.get(r, [])) for r in range(k)]
-        fb = O.OBitmap.from_containers(ORACLE_ROWS3["filter"])
+        def to_oracle(c):  # the same encoding and bytes, as an oracle container (only in this --cpu-baseline leg)
+            return O.OContainer.array(c.data) if c.typ == O.ARRAY else O.OContainer.run(c.data.tolist()) if c.typ == O.RUN else O.OContainer.bitmap(c.data, c.n)
+
+        bms = [O.OBitmap.from_containers([(sl, to_oracle(c)) for sl, c in ORACLE_ROWS3.get(r, [])]) for r in range(k)]
+        fb = O.OBitmap.from_containers([(sl, to_oracle(c)) for sl, c in ORACLE_ROWS3["filter"]])
         t_cpu = cpu_time(lambda: bms[0].union(*bms[1:]).intersection_count(fb))  # Bitmap.Union n-way + IntersectionCount
         cpu = {"per_shard_s_1thread": t_cpu, "shards_per_s_1thread": 1 / t_cpu, "kind": "port",
                "what": "oracle Bitmap.Union(63 others) + IntersectionCount(filter) of shard 0, one host thread"}

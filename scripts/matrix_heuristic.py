@@ -41,9 +41,10 @@ def main():
                 for r in range(n_rows):
                     row = {}
                     for slot in range(16):
-                        c = D.mixed_container_for_density(rng, d, rng.random() < 0.25)
+                        rs = rng.random() < 0.25
+                        c = D.fbk_container_of_vals(D.mixed_vals_for_density(rng, d, rs))
                         if c is not None and c.n:
-                            row[s * 16 + slot] = D.to_fbk(c)
+                            row[s * 16 + slot] = c
                             nbytes += encoded_bytes(c)
                             ncont += 1
                     rows.append(row)

@@ -145,6 +145,33 @@ def zipf_density(r: int) -> float:
     return float(min(0.5, max(0.001, 0.5 * (r + 1) ** -1.1)))
 
 
+def mixed_vals_for_density(rng, d: float, run_structured: bool) -> np.ndarray:
+    """The values of one container of a config-3 row (same draws as mixed_container_for_density)."""
+    if run_structured:
+        nr = int(rng.choice([16, 32, 128, 1024]))
+        return vals_runs(rng, nr, min(0.95, max(0.02, d * 2)))
+    return vals_density(rng, d)
+
+
+def fbk_container_of_vals(vals: np.ndarray):
+    """Sorted values -> featurebase_amd.roaring.Container in the encoding Container.optimize()
+    picks (roaring.go:3412-3461: run if runs <= 2048 and runs <= n/2, else array if n < 4096,
+    else bitmap), with numpy only: the benchmark scripts generate their inputs with this, so that
+    nothing under oracle/ runs while they measure (tests/test_datagen.py checks it against the
+    oracle's optimize())."""
+    from featurebase_amd.roaring import Container
+
+    n = int(vals.size)
+    if n == 0:
+        return None
+    rs = runs_of_vals(vals)
+    if len(rs) <= 2048 and len(rs) <= n // 2:
+        return Container.run(rs, n)
+    if n < 4096:
+        return Container.array(vals.astype(np.uint16))
+    return Container.bitmap(words_of(vals), n)
+
+
 def mixed_container_for_density(rng, d: float, run_structured: bool):
     """One container of a config-3 row: encoding chosen by optimize() (roaring.go:3412)."""
     from oracle import pyoracle as O
