@@ -451,6 +451,14 @@ def test_count_matrix_dense_kernel_vs_numpy(gpu_ctx, n_shards, n_a, n_b, use_fil
             assert (tot2 == tot).all(), spb
     finally:
         os.environ.pop("FBK_MATRIX_SPB", None)
+    # the total alone (no per-shard matrices asked for) is reduced in passes over the shards: force
+    # passes of one or two shards
+    try:
+        os.environ["FBK_MATRIX_PASS_KB"] = str(max(1, (2 * n_a * n_b * 8) // 1024))
+        tot3 = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf if use_filter else None)
+        assert (tot3 == tot).all()
+    finally:
+        os.environ.pop("FBK_MATRIX_PASS_KB", None)
     A.free()
     Bt.free()
     if F is not None:
