@@ -141,10 +141,10 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    from featurebase_amd import dist as fdist
+
     if n_gpus > 1:
         import torch.distributed as dist
-
-        from featurebase_amd import dist as fdist
 
         fdist.init(backend, dev)  # backend "nccl" IS RCCL on ROCm
 
@@ -170,21 +170,17 @@ def main():
         total = torch.zeros(1, dtype=torch.int64, device=dev)
     plan = ctx.plan(A, rows, B, rows, device_counts_ptr=counts.data_ptr())
 
-    # N > 1: the per-node totals of consecutive steps are all-reduced over RCCL/xGMI in buckets
-    # of REDUCE_BUCKET steps, asynchronously (featurebase_amd/dist.py BucketedCountReducer)
-    red = fdist.BucketedCountReducer(REDUCE_BUCKET, dev) if n_gpus > 1 else None
+    # The per-node totals of consecutive steps land in consecutive slots of a small device vector
+    # (featurebase_amd/dist.py BucketedCountReducer): the vector is cleared once per REDUCE_BUCKET
+    # steps and, for N > 1, all-reduced over RCCL/xGMI once per REDUCE_BUCKET steps, asynchronously.
+    red = fdist.BucketedCountReducer(REDUCE_BUCKET, dev)
 
     def step():
-        # per-shard |a ∩ b| (k_icount_dense) + the per-node reduce (k_sum_u64).  Two launches on
-        # purpose: the single-launch variant fbk_plan_intersection_count_total (last block to
-        # finish sums the per-shard counts) measures 42.0 us against 38.9 + 2.3 us here — its
-        # ticket + final pass is a serial tail behind the last workgroup.
-        plan.intersection_count()
-        if red is None:
-            plan.total(total.data_ptr())
-        else:
-            plan.total(red.slot_ptr())  # the total lands in the bucket slot of this step
-            red.advance()  # RCCL sum of the partial counts over xGMI once the bucket is full
+        # per-shard |a ∩ b| and the per-node reduce in ONE launch: every workgroup of k_icount_dense
+        # adds its count to the step's (zeroed) slot.  Measured alternatives: a second launch
+        # (k_sum_u64) +2.3 us, "last workgroup sums the per-shard counts" +3.1 us per step.
+        plan.intersection_count_accumulate(red.slot_ptr())
+        red.advance()  # N > 1: RCCL sum of the partial counts over xGMI once the bucket is full
 
     def barrier():
         if n_gpus > 1:
@@ -193,16 +189,14 @@ def main():
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             step()
-        if red is not None:
-            red.flush()
+        red.flush()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        if red is not None:
-            reduced = red.flush()  # the tail bucket + every outstanding collective: inside the timed region
+        reduced = red.flush()  # the tail bucket + every outstanding collective: inside the timed region
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -212,21 +206,19 @@ def main():
         local_expected = int(np.bitwise_count(wa & wb).sum())
         got_counts = counts.cpu().numpy().view(np.uint64)
         assert int(got_counts.sum()) == local_expected, "GPU result differs from numpy popcount"
-        if n_gpus == 1:
-            assert int(total.item()) == local_expected
-        else:
-            # every reduced slot must hold the sum over ranks of the per-rank expected counts
-            ge = torch.tensor([local_expected], dtype=torch.int64, device=dev)
+        # every used slot must hold the sum over ranks of the per-rank expected counts
+        ge = torch.tensor([local_expected], dtype=torch.int64, device=dev)
+        if n_gpus > 1:
             dist.all_reduce(ge)
-            vals = torch.cat([b for b in reduced]).cpu().numpy()
-            vals = vals[vals != 0]
-            assert vals.size > 0 and (vals == int(ge.item())).all(), "all-reduced totals differ from the sum of per-rank counts"
+        vals = torch.cat([b for b in reduced]).cpu().numpy()
+        vals = vals[vals != 0]
+        assert vals.size > 0 and (vals == int(ge.item())).all(), "reduced totals differ from the sum of the per-shard counts"
 
         # ---- roofline of the dominant kernel: HIP events around back-to-back launches
         # of k_icount_dense alone, on the stream it is launched on
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         kiters = max(args.steps, 50)
-        kernel_step = (lambda: plan.intersection_count())  # the dominant launch of a timed step (k_sum_u64 is the other)
+        kernel_step = (lambda: plan.intersection_count_accumulate(total.data_ptr()))  # the launch the timed steps make
         for _ in range(5):
             kernel_step()
         torch.cuda.synchronize()

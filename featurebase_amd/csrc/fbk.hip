@@ -767,7 +767,7 @@ int32_t plan_create_locked(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* row
   return FBK_OK;
 }
 
-int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total = nullptr) {
+int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total = nullptr, u64* accum = nullptr) {
   if (p->n_pairs == 0) {
     if (fused_total) HIP_TRY(hipMemsetAsync(fused_total, 0, sizeof(u64), ctx->stream));
     return FBK_OK;
@@ -784,7 +784,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
     if (spb != 16) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
 #define FBK_LAUNCH_DENSE(S)                                                                                       \
   hipLaunchKernelGGL(fbk::k_icount_dense<S>, dim3(np*(16 / S)), dim3(256), 0, ctx->stream, p->a->d_arena,         \
-                     p->d_rows_a, p->b->d_arena, p->d_rows_b, p->d_counts, fused_total, p->d_done, np)
+                     p->d_rows_a, p->b->d_arena, p->d_rows_b, p->d_counts, fused_total, p->d_done, np, accum)
     switch (spb) {
       case 1: FBK_LAUNCH_DENSE(1); break;
       case 2: FBK_LAUNCH_DENSE(2); break;
@@ -799,6 +799,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
                        p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts);
     if (fused_total)
       hipLaunchKernelGGL(fbk::k_sum_u64, dim3(1), dim3(256), 0, ctx->stream, p->d_counts, p->n_pairs, fused_total);
+    if (accum) hipLaunchKernelGGL(fbk::k_sum_u64_add, dim3(1), dim3(256), 0, ctx->stream, p->d_counts, p->n_pairs, accum);
   }
   HIP_TRY(hipGetLastError());
   return FBK_OK;
@@ -884,6 +885,13 @@ int32_t fbk_plan_intersection_count_total(fbk_ctx* ctx, fbk_plan* plan, void* de
   if (int32_t rc = set_device(ctx)) return rc;
   u64* dst = device_total_or_null ? static_cast<u64*>(device_total_or_null) : plan->d_total;
   return plan_icount_enqueue_locked(ctx, plan, dst);
+}
+
+int32_t fbk_plan_intersection_count_accumulate(fbk_ctx* ctx, fbk_plan* plan, void* device_accum) {
+  if (!ctx || !plan || !device_accum) return fail(FBK_E_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (int32_t rc = set_device(ctx)) return rc;
+  return plan_icount_enqueue_locked(ctx, plan, nullptr, static_cast<u64*>(device_accum));
 }
 
 int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags) {

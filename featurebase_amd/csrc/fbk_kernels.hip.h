@@ -336,7 +336,8 @@ __global__ void __launch_bounds__(256) k_icount_dense(const uint8_t* __restrict_
                                                      const uint8_t* __restrict__ arenaB,
                                                      const uint32_t* __restrict__ rowsB,
                                                      u64* __restrict__ out, u64* __restrict__ total,
-                                                     uint32_t* __restrict__ done, uint32_t n_pairs) {
+                                                     uint32_t* __restrict__ done, uint32_t n_pairs,
+                                                     u64* __restrict__ accum) {
   constexpr int kGroups = kSlots / SPB;
   const uint32_t pair = blockIdx.x / kGroups;
   const uint32_t grp = blockIdx.x % kGroups;
@@ -366,6 +367,9 @@ __global__ void __launch_bounds__(256) k_icount_dense(const uint8_t* __restrict_
     if (!total) {
       if (kGroups == 1) out[pair] = tot;
       else atomicAdd(&out[pair], tot);
+      // per-node reduce by accumulation: every block adds its count to *accum, which the caller
+      // zeroed beforehand — no ticket, no final pass, nothing serial behind the last workgroup
+      if (accum && tot) atomicAdd(accum, tot);
     } else {
       // Fused per-node reduce (executeCount's reduceFn, executor.go:5880): the block that
       // finishes last sums the per-pair counts, so one step of the hot path is ONE launch.
@@ -527,6 +531,18 @@ __global__ void __launch_bounds__(256) k_sum_u64(const u64* __restrict__ counts,
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) *total = part[0] + part[1] + part[2] + part[3];
+}
+
+// *total += sum(counts[0..n)): the accumulate form of the per-node reduce (the caller zeroed *total)
+__global__ void __launch_bounds__(256) k_sum_u64_add(const u64* __restrict__ counts, uint64_t n, u64* __restrict__ total) {
+  u64 acc = 0;
+  for (uint64_t i = threadIdx.x; i < n; i += 256) acc += counts[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+  __shared__ u64 part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(total, part[0] + part[1] + part[2] + part[3]);
 }
 
 }  // namespace fbk

@@ -77,6 +77,7 @@ SIGNATURES = {
     "fbk_plan_free": (C.c_int32, [_vp, _vp]),
     "fbk_plan_intersection_count": (C.c_int32, [_vp, _vp]),
     "fbk_plan_intersection_count_total": (C.c_int32, [_vp, _vp, _vp]),
+    "fbk_plan_intersection_count_accumulate": (C.c_int32, [_vp, _vp, _vp]),
     "fbk_plan_setop": (C.c_int32, [_vp, _vp, C.c_int32, C.c_uint32]),
     "fbk_plan_total": (C.c_int32, [_vp, _vp, _vp]),
     "fbk_plan_read": (C.c_int32, [_vp, _vp, _vp, _vp]),

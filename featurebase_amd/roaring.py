@@ -141,6 +141,10 @@ class Plan:
         """Counts + per-node total in one launch (executeCount's mapFn + reduceFn)."""
         L.check(self.ctx.lib.fbk_plan_intersection_count_total(self.ctx.h, self.h, C.c_void_p(device_ptr or None)))
 
+    def intersection_count_accumulate(self, device_ptr: int) -> None:
+        """Counts + per-node reduce by accumulation into a zeroed uint64 at device_ptr (one launch)."""
+        L.check(self.ctx.lib.fbk_plan_intersection_count_accumulate(self.ctx.h, self.h, C.c_void_p(device_ptr)))
+
     def setop(self, op: int, flags: int = 0) -> None:
         L.check(self.ctx.lib.fbk_plan_setop(self.ctx.h, self.h, op, flags))
 

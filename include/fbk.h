@@ -273,6 +273,13 @@ int32_t fbk_plan_intersection_count(fbk_ctx* ctx, fbk_plan* plan);
  * executor.go:5871-5880 — is a single kernel.  Asynchronous. */
 int32_t fbk_plan_intersection_count_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null);
 
+/* The same counts, with the per-node reduce done by accumulation: every workgroup adds its count
+ * to *device_accum (device memory, uint64), which the CALLER has zeroed — e.g. one slot of a
+ * vector that is cleared once per N steps, or of an all-reduce bucket.  One launch and nothing
+ * serial behind the last workgroup (fbk_plan_intersection_count_total pays ~3 us for its final
+ * pass, fbk_plan_intersection_count + fbk_plan_total ~2 us for the second launch). */
+int32_t fbk_plan_intersection_count_accumulate(fbk_ctx* ctx, fbk_plan* plan, void* device_accum);
+
 /* Enqueue out row i = A.rows_a[i] <op> B.rows_b[i] and counts[i] = its cardinality
  * (Bitmap.Intersect/Union/Xor/Difference + Count, roaring.go:736,1272,1598,1564;
  * executeCount's mapFn, executor.go:5871-5876).  The output batch is owned by the plan

@@ -250,7 +250,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_copy, dim3(1024), dim3(256), 0, 0, (const ulonglong2*)B[s], (ulonglong2*)O[s], setBytes / 32);
   });
   // reference result
-  hipLaunchKernelGGL(fbk::k_icount_dense<16>, dim3(n), dim3(256), 0, 0, A[0], rows, B[0], rows, out, (fbk::u64*)nullptr, (uint32_t*)nullptr, (uint32_t)n);
+  hipLaunchKernelGGL(fbk::k_icount_dense<16>, dim3(n), dim3(256), 0, 0, A[0], rows, B[0], rows, out, (fbk::u64*)nullptr, (uint32_t*)nullptr, (uint32_t)n, (fbk::u64*)nullptr);
   CK(hipMemcpy(ref.data(), out, n * 8, hipMemcpyDeviceToHost));
   auto check = [&](const char* nm) {
     CK(hipMemcpy(got.data(), out, n * 8, hipMemcpyDeviceToHost));
@@ -260,10 +260,10 @@ int main(int argc, char** argv) {
         return;
       }
   };
-  TIME("icount product <16>", rd, hipLaunchKernelGGL(fbk::k_icount_dense<16>, dim3(n), dim3(256), 0, 0, A[s], rows, B[s], rows, out, (fbk::u64*)nullptr, (uint32_t*)nullptr, (uint32_t)n));
+  TIME("icount product <16>", rd, hipLaunchKernelGGL(fbk::k_icount_dense<16>, dim3(n), dim3(256), 0, 0, A[s], rows, B[s], rows, out, (fbk::u64*)nullptr, (uint32_t*)nullptr, (uint32_t)n, (fbk::u64*)nullptr));
   TIME("icount product <4> +memset", rd, {
     CK(hipMemsetAsync(out, 0, n * 8, 0));
-    hipLaunchKernelGGL(fbk::k_icount_dense<4>, dim3(n * 4), dim3(256), 0, 0, A[s], rows, B[s], rows, out, (fbk::u64*)nullptr, (uint32_t*)nullptr, (uint32_t)n);
+    hipLaunchKernelGGL(fbk::k_icount_dense<4>, dim3(n * 4), dim3(256), 0, 0, A[s], rows, B[s], rows, out, (fbk::u64*)nullptr, (uint32_t*)nullptr, (uint32_t)n, (fbk::u64*)nullptr);
   });
   TIME("icount wave/container +memset", rd, {
     CK(hipMemsetAsync(out, 0, n * 8, 0));

@@ -259,6 +259,14 @@ def test_fused_count_and_total_plan(gpu_ctx):
     plan.intersection_count_total(cell.data_ptr())
     gpu_ctx.synchronize()
     assert int(cell.item()) == int(exp.sum())
+    # the accumulate form: every workgroup adds into a zeroed cell; three launches add up
+    acc = torch.zeros(2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        plan.intersection_count_accumulate(acc.data_ptr() + 8)
+    gpu_ctx.synchronize()
+    assert acc.tolist() == [0, 3 * int(exp.sum())]
+    assert (plan.read() == exp).all()
     plan.free()
     # mixed batch: generic kernel + sum kernel behind the same entry point
     rng = D.rng_for(33)
@@ -268,6 +276,11 @@ def test_fused_count_and_total_plan(gpu_ctx):
     p2.intersection_count_total()
     c2, t2 = p2.read(want_total=True)
     assert t2 == int(c2.sum()) and t2 > 0
+    acc = torch.zeros(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    p2.intersection_count_accumulate(acc.data_ptr())
+    gpu_ctx.synchronize()
+    assert int(acc.item()) == t2
     p2.free()
     for b in (A, B, M):
         b.free()
