@@ -262,45 +262,59 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
         while (i < cnt && __builtin_amdgcn_readlane(nr, (int)(i & 63)) == 0) i += 4;
         return i;
       };
-      uint32_t pi = next_valid(wv), pj = 0;  // producer: next chunk to load
-      uint32_t ci = pi, cj = 0;              // consumer: next chunk to scatter
-      auto advance = [&](uint32_t& i, uint32_t& j) {
-        if (++j == (uint32_t)__builtin_amdgcn_readlane(nr, (int)(i & 63))) {
-          j = 0;
-          i = next_valid(i + 4);
+      // producer (next chunk to load) and consumer (next chunk to scatter): position in the
+      // sequence plus the descriptor of the current container, held in scalar registers and
+      // refreshed only when the container changes (8 v_readlane per chunk otherwise)
+      struct Cursor {
+        uint32_t i, j, nr, len, tn, bytes;
+        u64 off;
+      };
+      auto fetch = [&](Cursor& k) {
+        k.j = 0;
+        if (k.i < cnt) {
+          meta(k.i, k.off, k.len, k.tn);
+          k.bytes = payload_bytes(k.tn >> 24, k.len);
+          k.nr = (k.bytes + 1023u) >> 10;
         }
       };
+      auto advance = [&](Cursor& k) {
+        if (++k.j == k.nr) {
+          k.i = next_valid(k.i + 4);
+          fetch(k);
+        }
+      };
+      Cursor P, Q;
+      P.i = next_valid(wv);
+      P.nr = P.len = P.tn = P.bytes = 0;
+      P.off = 0;
+      fetch(P);
+      Q = P;
       // Exactly ONE load instruction per step, written as asm, so that "the chunk issued NCH steps
       // ago has landed" is the constant s_waitcnt vmcnt(NCH - 1): left to the compiler, the
       // conditional loads of a rolled ring end in vmcnt(0) before every use (seen in the ISA), which
       // serialises the ring.  Lanes past the end of a payload re-read its first 16 bytes and an
       // exhausted producer reads the first 16 bytes of the arena: always a valid address, never a
       // change of EXEC around the load.
+      const uint32_t lane16 = lane * 16u;
       auto load_chunk = [&](Chunk& c) {
         const uint8_t* p = arena;
-        if (pi < cnt) {
-          u64 off;
-          uint32_t len, tn;
-          meta(pi, off, len, tn);
-          const uint32_t bytes = payload_bytes(tn >> 24, len);
-          const uint32_t b0 = pj * 1024u + lane * 16u;
-          p = arena + off + (b0 < bytes ? b0 : 0u);
-          advance(pi, pj);
+        if (P.i < cnt) {
+          const uint32_t b0 = P.j * 1024u + lane16;
+          p = arena + P.off + (b0 < P.bytes ? b0 : 0u);
+          advance(P);
         }
         asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(c) : "v"(p));
       };
 #pragma unroll
       for (int q = 0; q < NCH; ++q) load_chunk(C[q]);
-      while (ci < cnt) {
+      while (Q.i < cnt) {
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-          if (ci < cnt) {
+          if (Q.i < cnt) {
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(C[q]) : "n"(NCH - 1));
-            const uint32_t len = __builtin_amdgcn_readlane(mine.len, (int)(ci & 63));
-            const uint32_t tn = __builtin_amdgcn_readlane(mine.tn, (int)(ci & 63));
             const uint32_t d[4] = {C[q][0], C[q][1], C[q][2], C[q][3]};
-            scatter_chunk<OP>(d, tn >> 24, len, cj, lane, acc32);
-            advance(ci, cj);
+            scatter_chunk<OP>(d, Q.tn >> 24, Q.len, Q.j, lane, acc32);
+            advance(Q);
             load_chunk(C[q]);
           }
         }

@@ -146,28 +146,44 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
       while (i < cnt && __builtin_amdgcn_readlane(nr, (int)(i & 63)) == 0) i += 4;
       return i;
     };
-    uint32_t pi = next_valid(wv), pj = 0;  // producer: next chunk to load
-    uint32_t ci = pi, cj = 0;              // consumer: next chunk to count
-    auto advance = [&](uint32_t& i, uint32_t& j) -> bool {  // true: container i is finished
-      if (++j == (uint32_t)__builtin_amdgcn_readlane(nr, (int)(i & 63))) {
-        j = 0;
-        i = next_valid(i + 4);
+    // producer (next chunk to load) and consumer (next chunk to count): position in the sequence
+    // plus the descriptor of the current container, held in scalar registers and refreshed only
+    // when the container changes (8 v_readlane per chunk otherwise)
+    struct Cursor {
+      uint32_t i, j, nr, len, tn, bytes;
+      u64 off;
+    };
+    auto fetch = [&](Cursor& k) {
+      k.j = 0;
+      if (k.i < cnt) {
+        meta(k.i, k.off, k.len, k.tn);
+        k.bytes = payload_bytes(k.tn >> 24, k.len);
+        k.nr = (k.bytes + 1023u) >> 10;
+      }
+    };
+    auto advance = [&](Cursor& k) -> bool {  // true: the container is finished
+      if (++k.j == k.nr) {
+        k.i = next_valid(k.i + 4);
+        fetch(k);
         return true;
       }
       return false;
     };
+    Cursor P, Q;
+    P.i = next_valid(wv);
+    P.nr = P.len = P.tn = P.bytes = 0;
+    P.off = 0;
+    fetch(P);
+    Q = P;
     // exactly one load instruction per step (see fbk_fold_kernels.hip.h): lanes past the end of a
     // payload re-read its first 16 bytes, an exhausted producer the first 16 bytes of the arena
+    const uint32_t lane16 = lane * 16u;
     auto load_chunk = [&](Chunk& c) {
       const uint8_t* p = arenaA;
-      if (pi < cnt) {
-        u64 off;
-        uint32_t len, tn;
-        meta(pi, off, len, tn);
-        const uint32_t bytes = payload_bytes(tn >> 24, len);
-        const uint32_t b0 = pj * 1024u + lane * 16u;
-        p = arenaA + off + (b0 < bytes ? b0 : 0u);
-        advance(pi, pj);
+      if (P.i < cnt) {
+        const uint32_t b0 = P.j * 1024u + lane16;
+        p = arenaA + P.off + (b0 < P.bytes ? b0 : 0u);
+        advance(P);
       }
       asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(c) : "v"(p));
     };
@@ -205,17 +221,15 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
 #pragma unroll
     for (int q = 0; q < NCH; ++q) load_chunk(C[q]);
     uint32_t c = 0;
-    while (ci < cnt) {
+    while (Q.i < cnt) {
 #pragma unroll
       for (int q = 0; q < NCH; ++q) {
-        if (ci < cnt) {
+        if (Q.i < cnt) {
           asm volatile("s_waitcnt vmcnt(%1)" : "+v"(C[q]) : "n"(NCH - 1));
-          const uint32_t len = __builtin_amdgcn_readlane(mine.len, (int)(ci & 63));
-          const uint32_t tn = __builtin_amdgcn_readlane(mine.tn, (int)(ci & 63));
           const uint32_t d[4] = {C[q][0], C[q][1], C[q][2], C[q][3]};
-          c += count_chunk(d, tn >> 24, len, cj);
-          const uint32_t row = ci;
-          if (advance(ci, cj)) {
+          c += count_chunk(d, Q.tn >> 24, Q.len, Q.j);
+          const uint32_t row = Q.i;
+          if (advance(Q)) {
             c = wave_reduce_add(c);
             if (lane == 0 && c) atomicAdd(&out_shard[(uint64_t)shard * nA + base + row], (u64)c);
             c = 0;
