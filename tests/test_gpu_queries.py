@@ -806,3 +806,57 @@ def test_shift_vs_oracle(gpu_ctx, oracle, flags):
             gpu_ctx.shift(b, [5])
         finally:
             b.free()
+
+
+def test_chunk_ring_boundaries(gpu_ctx, oracle):
+    """The fold and TopK kernels consume payloads as 1 KiB chunks (512 array values / 256 runs /
+    128 bitmap words): arrays and run lists whose lengths sit on, just before and just after every
+    chunk edge, singletons, the largest policy sizes (4095 values, 2048 runs) and the first sizes
+    beyond them — one group per shape so that a miscounted chunk cannot cancel out — through
+    fold OR / XOR / ANDNOT (with counts), the fused |∪ ∩ F| and the rows-vs-filter counts."""
+    O = oracle
+    rng = D.rng_for(67)
+    array_sizes = [1, 7, 8, 9, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 3071, 3072, 3073, 4095, 4096, 4097, 6000]
+    run_counts = [1, 3, 4, 5, 255, 256, 257, 511, 512, 513, 1024, 2047, 2048, 2049, 3000]
+    shapes = []
+    for n in array_sizes:
+        shapes.append(O.OContainer.array(np.sort(rng.choice(65536, size=n, replace=False))))
+    for r in run_counts:
+        starts = np.sort(rng.choice(65536 // 8, size=r, replace=False)) * 8  # runs of 1..6 values, never adjacent
+        shapes.append(O.OContainer.run([(int(s), int(s + rng.integers(0, 6))) for s in starts]))
+    shapes.append(O.OContainer.run([(0, 65535)]))
+    shapes.append(O.OContainer.bitmap(rng.integers(0, 2**64, 1024, dtype=np.uint64)))
+    # group g = [shape g, a bitmap row, shape (g+1) % n]: slot = g % 16 of shard row 0
+    rows, groups = [], []
+    partner = O.OContainer.bitmap(rng.integers(0, 2**64, 1024, dtype=np.uint64) & rng.integers(0, 2**64, 1024, dtype=np.uint64))
+    for g, c in enumerate(shapes):
+        slot = g % 16
+        ids = []
+        for cc in (c, partner, shapes[(g + 1) % len(shapes)]):
+            ids.append(len(rows))
+            rows.append({slot: cc})
+        groups.append(ids)
+    batch = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+    frow = {s: O.OContainer.bitmap(rng.integers(0, 2**64, 1024, dtype=np.uint64)) for s in range(16)}
+    F = gpu_ctx.upload([D.to_fbk_row(frow)])
+    fb = O.OBitmap.from_containers(list(frow.items()))
+    obm = [O.OBitmap.from_containers(list(r.items())) for r in rows]
+    for op in (L.OP_OR, L.OP_XOR, L.OP_ANDNOT):
+        out, cnt = gpu_ctx.fold_n(op, batch, groups)
+        res = out.download()
+        for g, ids in enumerate(groups):
+            bms = [obm[i] for i in ids]
+            exp = bms[0].union(*bms[1:]) if op == L.OP_OR else bms[0].difference(*bms[1:]) if op == L.OP_ANDNOT else bms[0].xor(bms[1]).xor(bms[2])
+            assert int(cnt[g]) == exp.count(), (op, g)
+            assert (row_words(res[g]) == bitmap_words(exp)).all(), (op, g)
+        out.free()
+    fused = gpu_ctx.union_n_intersection_count(batch, groups, F, np.zeros(len(groups), dtype=np.uint32))
+    for g, ids in enumerate(groups):
+        bms = [obm[i] for i in ids]
+        assert int(fused[g]) == bms[0].union(*bms[1:]).intersection_count(fb), g
+    # rows vs filter: every row of the batch against the filter row (one "shard" of len(rows) rows)
+    tot = gpu_ctx.count_matrix(batch, np.arange(len(rows)).reshape(1, -1), F, np.zeros((1, 1), dtype=np.uint32))
+    for i in range(len(rows)):
+        assert int(tot[i, 0]) == obm[i].intersection_count(fb), i
+    batch.free()
+    F.free()
