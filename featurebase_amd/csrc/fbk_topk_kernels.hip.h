@@ -243,4 +243,34 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
   }
 }
 
+// ---- TopK / TopN selection on the device ------------------------------------------------------
+// counts[shard][i] = cardinality of row i of the shard from the stored container counts
+// (Row.Count, row.go:446: the sum of the segment counts) — TopK without a filter
+__global__ void __launch_bounds__(256) k_row_cardinality(const Slot* __restrict__ slots, const uint32_t* __restrict__ rows,
+                                                        uint64_t n, u64* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const Slot* s = slots + (uint64_t)rows[i] * kSlots;
+  u64 c = 0;
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k) c += slot_n(s[k]);
+  out[i] = c;
+}
+
+__global__ void __launch_bounds__(256) k_iota_u32(uint32_t* __restrict__ v, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+// number of leading non-zero keys of a descending sequence (binary search by one thread)
+__global__ void k_count_nonzero_desc(const u64* __restrict__ keys, uint32_t n, uint32_t* __restrict__ out) {
+  uint32_t lo = 0, hi = n;  // first index with key == 0
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (keys[mid] != 0) lo = mid + 1;
+    else hi = mid;
+  }
+  *out = lo;
+}
+
 }  // namespace fbk

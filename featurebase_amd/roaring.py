@@ -345,6 +345,24 @@ class Context:
         )
         return out
 
+    def topk(self, a: Batch, rows_a, k: int = 0, filt: Optional[Batch] = None, rows_f=None) -> Tuple[np.ndarray, np.ndarray]:
+        """rows_a: [n_shards, n_a]; (row indices, counts) of the k rows with the largest
+        |row ∩ filter| summed over the shards (count descending, index ascending; zeros dropped)."""
+        ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
+        n_shards, n_a = ra.shape
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        cap = n_a if k == 0 else min(k, n_a)
+        idx = np.zeros(max(cap, 1), dtype=np.uint32)
+        cnt = np.zeros(max(cap, 1), dtype=np.uint64)
+        n = C.c_uint32()
+        L.check(
+            self.lib.fbk_topk(
+                self.h, a.h, ra.ctypes.data, n_a, filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None,
+                n_shards, k, idx.ctypes.data, cnt.ctypes.data, cap, C.byref(n),
+            )
+        )
+        return idx[: n.value].copy(), cnt[: n.value].copy()
+
     NO_ROW = 0xFFFFFFFF
 
     def shift(self, batch: Batch, rows, carry_rows=None, flags: int = 0) -> Tuple[Batch, np.ndarray]:

@@ -390,6 +390,20 @@ int32_t fbk_bsi_distinct(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* b
                          uint32_t bit_depth, const fbk_batch* filter, const uint32_t* rows_f, int64_t* out_values,
                          uint64_t cap, uint64_t* out_n);
 
+/* TopK / TopN: totals[i] = sum over the shards of |A[shard][i] ∩ F[shard]| (of the stored row
+ * cardinalities when filter == NULL), ordered on the device by count descending and row index
+ * ascending inside one count, rows with a zero count dropped, at most k results (k = 0: all) —
+ * executeTopK / doTopK (executor.go:2705-2774) with the order of BSIData.PivotDescending
+ * (bsi.go:18-62); executeTopN / fragment.top (fragment.go:1317-1437) count the same intersections
+ * (their rank-cache thresholds are approximations the device does not need).  rows_a is
+ * [n_shards][n_a] (row i of every shard = the same field row), rows_f [n_shards].
+ * out_index[j] = i, out_count[j] = totals[i]; *out_n = number of results, also when
+ * FBK_E_CAPACITY reports that `cap` was too small.  Only the k winners cross the bus, not n_a
+ * counts: a field may have millions of rows (n_a <= 2^22). */
+int32_t fbk_topk(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a, const fbk_batch* filter,
+                 const uint32_t* rows_f, uint32_t n_shards, uint32_t k, uint32_t* out_index, uint64_t* out_count, uint32_t cap,
+                 uint32_t* out_n);
+
 /* Shift: out row i = rows[i] with every column moved up by one — Row.Shift (row.go:374-396) /
  * RowSegment.Shift (:613-626) / Bitmap.Shift(1) (roaring/roaring.go:1629-1662; shiftArray,
  * shiftBitmap, shiftRun :6184-6257), which executeShiftShard (executor.go:5818-5836) applies n

@@ -466,11 +466,29 @@ class Executor {
   // TopK(field, k, filter): per-row |row ∩ filter| over all shards (doTopK), then the rows in
   // descending count order, ascending id inside one count, zero counts dropped
   // (BSIData.PivotDescending, bsi.go:18-62).  k == 0: no limit.
+  // Counting, the reduce over shards and the ordering all happen on the device (fbk_topk): only
+  // the k winners come back.
   std::vector<Pair> TopK(const std::string& field, uint64_t k, const Call* filter = nullptr) {
-    std::vector<Pair> p = row_counts(field, filter);
-    std::stable_sort(p.begin(), p.end(), [](const Pair& a, const Pair& b) { return a.Count > b.Count; });
-    if (k && p.size() > k) p.resize(k);
-    return p;
+    Scope sc(*this, {filter});
+    const Index::SetField& f = idx_.sets_.at(field);
+    const size_t n = shards().size(), nr = f.row_ids.size();
+    std::vector<Pair> out;
+    if (n == 0 || nr == 0) return out;
+    const std::vector<uint32_t> rows_a = field_rows(f);
+    const uint32_t cap = uint32_t(k && k < nr ? k : nr);
+    std::vector<uint32_t> idx(cap);
+    std::vector<uint64_t> cnt(cap);
+    uint32_t got = 0;
+    if (filter) {
+      RowSet fr = eval(*filter);
+      check(fbk_topk(idx_.ctx_, f.batch, rows_a.data(), uint32_t(nr), fr.batch(), fr.rows().data(), uint32_t(n), uint32_t(cap == nr ? 0 : cap),
+                     idx.data(), cnt.data(), cap, &got));
+    } else {
+      check(fbk_topk(idx_.ctx_, f.batch, rows_a.data(), uint32_t(nr), nullptr, nullptr, uint32_t(n), uint32_t(cap == nr ? 0 : cap), idx.data(),
+                     cnt.data(), cap, &got));
+    }
+    for (uint32_t i = 0; i < got; ++i) out.push_back({f.row_ids[idx[i]], cnt[i]});  // row_ids ascending: index order = id order
+    return out;
   }
   // TopN(field, n, src): the same counts ordered by Pairs.Less (count descending; the reference's
   // tie order is unspecified, cache.go:436, here ascending id); the rank-cache thresholds of
@@ -659,34 +677,6 @@ class Executor {
       const ValCount v = counts[s] ? ValCount{vals[s] + f.base, int64_t(counts[s])} : ValCount{};
       out = is_min ? out.Smaller(v) : out.Larger(v);
     }
-    return out;
-  }
-  // counts of every row of a set field (optionally ∩ filter), summed over shards, ascending id
-  std::vector<Pair> row_counts(const std::string& field, const Call* filter) {
-    Scope sc(*this, {filter});
-    const Index::SetField& f = idx_.sets_.at(field);
-    const size_t n = shards().size(), nr = f.row_ids.size();
-    std::vector<Pair> out;
-    if (n == 0 || nr == 0) return out;
-    std::vector<uint32_t> rows_a(n * nr);
-    for (size_t s = 0; s < n; ++s)
-      for (size_t i = 0; i < nr; ++i) {
-        auto it = f.ordinal.find({shards()[s], f.row_ids[i]});
-        rows_a[s * nr + i] = it == f.ordinal.end() ? f.empty_row : it->second;
-      }
-    std::vector<uint64_t> tot(nr);
-    if (filter) {
-      RowSet fr = eval(*filter);
-      check(fbk_count_matrix(idx_.ctx_, f.batch, rows_a.data(), uint32_t(nr), fr.batch(), fr.rows().data(), 1, nullptr, nullptr, uint32_t(n),
-                             tot.data(), nullptr));
-    } else {
-      std::vector<uint64_t> c(n * nr);
-      check(fbk_count(idx_.ctx_, f.batch, rows_a.data(), c.size(), c.data()));
-      for (size_t s = 0; s < n; ++s)
-        for (size_t i = 0; i < nr; ++i) tot[i] += c[s * nr + i];
-    }
-    for (size_t i = 0; i < nr; ++i)
-      if (tot[i]) out.push_back({f.row_ids[i], tot[i]});
     return out;
   }
   std::vector<uint32_t> field_rows(const Index::SetField& f) {

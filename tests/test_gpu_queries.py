@@ -860,3 +860,57 @@ def test_chunk_ring_boundaries(gpu_ctx, oracle):
         assert int(tot[i, 0]) == obm[i].intersection_count(fb), i
     batch.free()
     F.free()
+
+
+@pytest.mark.parametrize("use_filter", [True, False])
+def test_topk_on_device_vs_oracle(gpu_ctx, oracle, use_filter):
+    """fbk_topk (counts, reduce over shards and the PivotDescending order on the device) against
+    oracle intersection counts ordered on the host: ties (duplicated rows) keep ascending row index,
+    rows without a common column are dropped, k = 0 / 1 / 7 / more than there are, several passes
+    over the shards, and the FBK_E_CAPACITY report."""
+    O = oracle
+    rng = D.rng_for(71)
+    n_shards, n_a = 3, 90
+    rows, ra = [], []
+    for s in range(n_shards):
+        ids = []
+        base = [D.random_row(rng, s, p_missing=0.5) for _ in range(n_a)]
+        for i in range(n_a):
+            if i % 10 == 9:
+                base[i] = base[i - 1]  # a tie: the same columns as the previous row
+            if i % 13 == 0:
+                base[i] = {}  # a row with no columns at all
+            ids.append(len(rows))
+            rows.append(base[i])
+        ra.append(ids)
+    frows = [D.random_row(rng, s, p_missing=0.3) for s in range(n_shards)]
+    A = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+    F = gpu_ctx.upload([D.to_fbk_row(r) for r in frows])
+    ra = np.array(ra, dtype=np.uint32)
+    tot = np.zeros(n_a, dtype=np.int64)
+    for s in range(n_shards):
+        fb = O.OBitmap.from_containers(list(frows[s].items()))
+        for i in range(n_a):
+            bm = O.OBitmap.from_containers(list(rows[ra[s, i]].items()))
+            tot[i] += bm.intersection_count(fb) if use_filter else bm.count()
+    order = sorted([i for i in range(n_a) if tot[i]], key=lambda i: (-tot[i], i))
+    assert len(order) < n_a and len(set(tot[order].tolist())) < len(order)  # zeros and ties are present
+    fargs = (F, np.arange(n_shards)) if use_filter else (None, None)
+    for k in (0, 1, 7, 1000):
+        idx, cnt = gpu_ctx.topk(A, ra, k, *fargs)
+        exp = order if k == 0 else order[:k]
+        assert idx.tolist() == exp and cnt.tolist() == tot[exp].tolist(), k
+    try:  # one shard per pass
+        os.environ["FBK_MATRIX_PASS_KB"] = "1"
+        idx, cnt = gpu_ctx.topk(A, ra, 5, *fargs)
+        assert idx.tolist() == order[:5] and cnt.tolist() == tot[order[:5]].tolist()
+    finally:
+        os.environ.pop("FBK_MATRIX_PASS_KB", None)
+    # a buffer smaller than the result: FBK_E_CAPACITY and the needed size
+    import ctypes as C
+
+    small_i, small_c, n = np.zeros(2, np.uint32), np.zeros(2, np.uint64), C.c_uint32()
+    rc = gpu_ctx.lib.fbk_topk(gpu_ctx.h, A.h, ra.ctypes.data, n_a, None, None, n_shards, 0, small_i.ctypes.data, small_c.ctypes.data, 2, C.byref(n))
+    assert rc == L.FBK_E_CAPACITY and n.value == len([i for i in range(n_a) if any(rows[ra[s, i]] for s in range(n_shards))])
+    A.free()
+    F.free()
