@@ -398,8 +398,8 @@ int32_t fbk_bsi_distinct(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* b
  * (their rank-cache thresholds are approximations the device does not need).  rows_a is
  * [n_shards][n_a] (row i of every shard = the same field row), rows_f [n_shards].
  * out_index[j] = i, out_count[j] = totals[i]; *out_n = number of results, also when
- * FBK_E_CAPACITY reports that `cap` was too small.  Only the k winners cross the bus, not n_a
- * counts: a field may have millions of rows (n_a <= 2^22). */
+ * FBK_E_CAPACITY reports that `cap` was too small.  Fields of more than 4096 rows are ordered by
+ * a device radix sort and only the k winners cross the bus, not n_a counts (n_a <= 2^22). */
 int32_t fbk_topk(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a, const fbk_batch* filter,
                  const uint32_t* rows_f, uint32_t n_shards, uint32_t k, uint32_t* out_index, uint64_t* out_count, uint32_t cap,
                  uint32_t* out_n);

@@ -896,10 +896,15 @@ def test_topk_on_device_vs_oracle(gpu_ctx, oracle, use_filter):
     order = sorted([i for i in range(n_a) if tot[i]], key=lambda i: (-tot[i], i))
     assert len(order) < n_a and len(set(tot[order].tolist())) < len(order)  # zeros and ties are present
     fargs = (F, np.arange(n_shards)) if use_filter else (None, None)
-    for k in (0, 1, 7, 1000):
-        idx, cnt = gpu_ctx.topk(A, ra, k, *fargs)
-        exp = order if k == 0 else order[:k]
-        assert idx.tolist() == exp and cnt.tolist() == tot[exp].tolist(), k
+    try:
+        for mode in ("0", "1"):  # ordered on the host (small fields) / by the device radix sort
+            os.environ["FBK_TOPK_DEVICE_SORT"] = mode
+            for k in (0, 1, 7, 1000):
+                idx, cnt = gpu_ctx.topk(A, ra, k, *fargs)
+                exp = order if k == 0 else order[:k]
+                assert idx.tolist() == exp and cnt.tolist() == tot[exp].tolist(), (mode, k)
+    finally:
+        os.environ.pop("FBK_TOPK_DEVICE_SORT", None)
     try:  # one shard per pass
         os.environ["FBK_MATRIX_PASS_KB"] = "1"
         idx, cnt = gpu_ctx.topk(A, ra, 5, *fargs)
@@ -910,7 +915,13 @@ def test_topk_on_device_vs_oracle(gpu_ctx, oracle, use_filter):
     import ctypes as C
 
     small_i, small_c, n = np.zeros(2, np.uint32), np.zeros(2, np.uint64), C.c_uint32()
-    rc = gpu_ctx.lib.fbk_topk(gpu_ctx.h, A.h, ra.ctypes.data, n_a, None, None, n_shards, 0, small_i.ctypes.data, small_c.ctypes.data, 2, C.byref(n))
-    assert rc == L.FBK_E_CAPACITY and n.value == len([i for i in range(n_a) if any(rows[ra[s, i]] for s in range(n_shards))])
+    need = len([i for i in range(n_a) if any(rows[ra[s, i]] for s in range(n_shards))])
+    for mode in ("0", "1"):
+        os.environ["FBK_TOPK_DEVICE_SORT"] = mode
+        try:
+            rc = gpu_ctx.lib.fbk_topk(gpu_ctx.h, A.h, ra.ctypes.data, n_a, None, None, n_shards, 0, small_i.ctypes.data, small_c.ctypes.data, 2, C.byref(n))
+        finally:
+            os.environ.pop("FBK_TOPK_DEVICE_SORT", None)
+        assert rc == L.FBK_E_CAPACITY and n.value == need
     A.free()
     F.free()
