@@ -284,3 +284,32 @@ def test_fused_count_and_total_plan(gpu_ctx):
     p2.free()
     for b in (A, B, M):
         b.free()
+
+
+def test_reference_bitmap_level_vectors_through_the_abi(gpu_ctx, oracle):
+    """TestBitmap_IntersectionCount_* and testBM() (roaring/roaring_test.go:1283-1387, 1661-1684),
+    the reference's own known answers, through fbk_intersection_count / fbk_count / fbk_setop:
+    both orders, as the reference checks them."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import go_bitmap_vectors as V
+    from test_oracle_bitmap_vectors import file_bitmap
+
+    O = oracle
+    rows, want = [], []
+    for name, a, b, n in V.CASES:
+        rows.append(dict(file_bitmap(O, *a)))  # keys 0..15: one shard row each
+        rows.append(dict(file_bitmap(O, *b)))
+        want.append(n)
+    batch = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+    ia = np.arange(0, len(rows), 2)
+    got = gpu_ctx.intersection_count(batch, ia, batch, ia + 1)
+    rev = gpu_ctx.intersection_count(batch, ia + 1, batch, ia)
+    assert got.tolist() == want and rev.tolist() == want
+    out, cnt = gpu_ctx.setop(L.OP_AND, batch, ia, batch, ia + 1)
+    assert cnt.tolist() == want
+    out.free()
+    tb = [i for i, c in enumerate(V.CASES) if c[0] == "Mixed/self"][0]
+    assert int(batch.count([2 * tb])[0]) == V.TEST_BM_COUNT  # "count 75007"
+    batch.free()

@@ -1,0 +1,45 @@
+"""The oracle's Bitmap.IntersectionCount / Count against the reference's bitmap-level known
+answers (tests/golden/go_bitmap_vectors.py: roaring_test.go:1283-1387, testBM() :1661-1684)."""
+import sys, os
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import go_bitmap_vectors as V  # noqa: E402
+
+
+def file_bitmap(O, values, optimized):
+    """NewFileBitmap(values...) [+ Optimize()] as (key, oracle container) pairs."""
+    groups = {}
+    for v in values:
+        groups.setdefault(v >> 16, []).append(v & 0xFFFF)
+    out = []
+    for key in sorted(groups):
+        lo = np.array(sorted(set(groups[key])), dtype=np.uint16)
+        if lo.size < 4096:
+            c = O.OContainer.array(lo)
+        else:
+            w = np.zeros(65536, dtype=np.uint8)
+            w[lo] = 1
+            c = O.OContainer.bitmap(np.packbits(w, bitorder="little").view(np.uint64), int(lo.size))
+        out.append((key, O.optimize(c) if optimized else c))
+    return out
+
+
+def test_testbm_count_and_encodings(oracle):
+    O = oracle
+    items = file_bitmap(O, *V.TEST_BM)
+    bm = O.OBitmap.from_containers(items)
+    assert bm.count() == V.TEST_BM_COUNT
+    # "the array", "the bitmap", "small run", "large run" (roaring_test.go:1665-1681)
+    assert [(k, c.typ) for k, c in items] == [(1, O.ARRAY), (2, O.BITMAP), (3, O.RUN), (4, O.RUN)]
+
+
+@pytest.mark.parametrize("name,a,b,want", V.CASES, ids=[c[0] for c in V.CASES])
+def test_bitmap_intersection_count_vectors(oracle, name, a, b, want):
+    O = oracle
+    A = O.OBitmap.from_containers(file_bitmap(O, *a))
+    B = O.OBitmap.from_containers(file_bitmap(O, *b))
+    assert A.intersection_count(B) == want
+    assert B.intersection_count(A) == want  # "unexpected n (reverse)"
