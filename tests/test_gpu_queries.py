@@ -925,3 +925,24 @@ def test_topk_on_device_vs_oracle(gpu_ctx, oracle, use_filter):
         assert rc == L.FBK_E_CAPACITY and n.value == need
     A.free()
     F.free()
+
+
+def test_fragment_topn_vectors_through_fbk_topk(gpu_ctx, oracle):
+    """TestFragment_TopN_Intersect / _Intersect_Large (fragment_internal_test.go:1174-1252), the
+    reference's own TopN known answers, through fbk_topk (one shard; both orderings paths)."""
+    from oracle import pybsi as PB
+    from test_oracle_bsi import topn_vectors
+
+    for rows, src, n, want in topn_vectors():
+        ids = sorted(rows)
+        batch = gpu_ctx.upload([fbk_row_of_bitmap(PB.row_from_columns(rows[i])) if rows[i] else {} for i in ids])
+        F = gpu_ctx.upload([fbk_row_of_bitmap(PB.row_from_columns(src))])
+        try:
+            for mode in ("0", "1"):
+                os.environ["FBK_TOPK_DEVICE_SORT"] = mode
+                idx, cnt = gpu_ctx.topk(batch, np.arange(len(ids)).reshape(1, -1), n, F, np.zeros(1, dtype=np.uint32))
+                assert [(ids[i], int(c)) for i, c in zip(idx.tolist(), cnt.tolist())] == want, mode
+        finally:
+            os.environ.pop("FBK_TOPK_DEVICE_SORT", None)
+        batch.free()
+        F.free()

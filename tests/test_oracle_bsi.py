@@ -243,3 +243,22 @@ def test_minmax_executor_vectors_and_truth(B):
     # depth 64 wrap: 1 << 63 as int64 is MinInt64 (Go wraps, fragment.go:795)
     frag = B.bsi_fragment_from_values({5: (1 << 63) + 3}, 64)
     assert B.bsi_max(frag, None, 64) == (-(1 << 63) + 3, 1)
+
+
+def topn_vectors():
+    """TestFragment_TopN_Intersect and _Intersect_Large (fragment_internal_test.go:1174-1252):
+    (row id -> columns, src columns, N, expected [(id, count)])."""
+    small = ({100: [1, 10, 11, 12], 101: [1, 2, 3, 4], 102: [1, 2, 4, 5, 6], 103: [1000, 1001, 1002]}, [1, 2, 3], 3, [(101, 3), (102, 2), (100, 1)])
+    large = ({i: list(range(i)) for i in range(1000)}, list(range(980, 1000)), 10, [(999 - d, 19 - d) for d in range(10)])
+    return [small, large]
+
+
+def test_fragment_topn_intersect_vectors(oracle):
+    from oracle import pybsi as B
+
+    for rows, src, n, want in topn_vectors():
+        ids = sorted(rows)
+        frag = B.Fragment([B.row_from_columns(rows[i]) if rows[i] else None for i in ids])
+        cnt = B.topk_row_counts(frag, B.row_from_columns(src))
+        pairs = sorted([(ids[k], int(c)) for k, c in enumerate(cnt) if c], key=lambda p: (-p[1], p[0]))[:n]
+        assert pairs == want
