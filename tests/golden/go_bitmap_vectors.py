@@ -31,3 +31,49 @@ CASES = [
     ("Mixed/1", TEST_BM, ([0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 65536], False), 1),
     ("Mixed/3", TEST_BM, ([131072], False), 1),
 ]
+
+
+def _run_bitmap(run_len, space_len, offset, limit_sub):
+    v = []
+    i = 0
+    while i < 65536 - run_len - limit_sub:
+        v.extend(offset + i + j for j in range(run_len))
+        i += run_len + space_len
+    return v
+
+
+_BIG = list(range(628, 2683301))
+_EVEN10K = list(range(0, 10000, 2))
+SW = 1 << 20
+
+# (name, op, bm0, bm1, expected count, expected Slice() or None): TestBitmap_Intersection (:483),
+# _Union1 (:781), _Intersection_Empty (:942), _IntersectArrayArray (:953), _IntersectBitmapBitmap
+# (:979), _IntersectRunRun (:1000), _Difference* (:1041-1089), _Union (:1091), _Xor* (:1124-1216)
+SETOP_CASES = [
+    ("Intersection", "and", ([0, 2683177], False), (_BIG, False), 1, None),
+    ("Union1/a", "or", ([0, 2683177], False), (_BIG + [4000000], False), 2682675, None),
+    ("Union1/testBM", "or", TEST_BM, ([0, 2683177], False), 75009, None),
+    ("Union1/self", "or", TEST_BM, TEST_BM, 75007, None),
+    ("Intersection_Empty", "and", ([0, 2683177], False), ([], False), 0, []),
+    ("IntersectArrayArray", "and", ([0, 1, 7, 9, 11, 2683, 5005], False), ([0, 2683, 2684, 5000], False), 2, [0, 2683]),
+    ("IntersectArrayArray/rev", "and", ([0, 2683, 2684, 5000], False), ([0, 1, 7, 9, 11, 2683, 5005], False), 2, [0, 2683]),
+    ("IntersectBitmapBitmap", "and", (list(range(0, 65536, 2)), False), (list(range(0, 65536, 3)), False), 10923, None),
+    ("IntersectRunRun/array", "and", ([0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15], True), ([5, 6, 7, 8, 9, 10, 11], True), 3, [5, 10, 11]),
+    ("IntersectRunRun/bitmap", "and", (_run_bitmap(25, 8, 25 // 2 + 8, 25 // 2 + 8), True), (_run_bitmap(32, 1, 0, 0), True), 47628, None),
+    ("Difference", "andnot", ([0, 2683177], False), (_BIG, False), 1, [0]),
+    ("Difference2", "andnot", ([0, 1, 2, 131072, 262144, SW + 5, SW + 7], False), ([2, 3, 100000, 262144, 2 * SW + 1], False), 5,
+     [0, 1, 131072, SW + 5, SW + 7]),
+    ("Difference_Empty", "andnot", ([0, 2683177], False), ([], False), 2, [0, 2683177]),
+    ("DifferenceArrayArray", "andnot", ([0, 4, 8, 12, 16, 20], False), ([1, 3, 6, 9, 12, 15, 18], False), 5, None),
+    ("DifferenceArrayRun", "andnot", ([0, 4, 8, 12, 16, 20, 36, 40, 44], False), ([1, 2, 3, 4, 5, 6, 7, 8, 9, 30, 31, 32, 33, 34, 35, 36], True), 6, None),
+    ("Union", "or", ([0, 1000001, 1000002, 1000003], False), ([0, 50000, 1000001, 1000002], False), 5, None),
+    ("Xor/a", "xor", ([0, 1, 2, 3], False), TEST_BM, 75011, None),
+    ("Xor/b", "xor", TEST_BM, ([0, 1, 2, 3], False), 75011, None),
+    ("Xor/self", "xor", TEST_BM, TEST_BM, 0, []),
+    ("Xor_ArrayArray", "xor", ([0, 1000001, 1000002, 1000003], False), ([0, 50000, 1000001, 1000002], False), 2, [50000, 1000003]),
+    ("Xor_Empty", "xor", ([0, 50000, 1000001, 1000002], False), ([], False), 4, None),
+    ("Xor_ArrayBitmap", "xor", ([1, 70, 200, 4097, 4098], False), (_EVEN10K, False), 4999, None),
+    ("Xor_ArrayBitmap/rev", "xor", (_EVEN10K, False), ([1, 70, 200, 4097, 4098], False), 4999, None),
+    ("Xor_ArrayBitmap/empty", "xor", (_EVEN10K, False), ([], False), 5000, None),
+    ("Xor_BitmapBitmap", "xor", (list(range(1, 10000, 2)), False), (_EVEN10K, False), 10000, None),
+]

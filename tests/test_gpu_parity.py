@@ -313,3 +313,49 @@ def test_reference_bitmap_level_vectors_through_the_abi(gpu_ctx, oracle):
     tb = [i for i, c in enumerate(V.CASES) if c[0] == "Mixed/self"][0]
     assert int(batch.count([2 * tb])[0]) == V.TEST_BM_COUNT  # "count 75007"
     batch.free()
+
+
+def test_reference_bitmap_level_setop_vectors_through_the_abi(gpu_ctx, oracle):
+    """TestBitmap_Intersection / _Union1 / _Intersect* / _Difference* / _Union / _Xor*
+    (roaring/roaring_test.go:483-1216) through fbk_setop: the bitmaps are cut into shard rows
+    (16 container keys each, as fragment.row does), one row pair per shard either operand touches;
+    result cardinalities summed over the shards and, where the reference checks them, the
+    columns of the result."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import go_bitmap_vectors as V
+    from test_oracle_bitmap_vectors import file_bitmap
+
+    O = oracle
+    ops = {"and": L.OP_AND, "or": L.OP_OR, "andnot": L.OP_ANDNOT, "xor": L.OP_XOR}
+    cache = {}
+
+    def shard_rows(spec):
+        key = id(spec[0]), spec[1]
+        if key not in cache:
+            rows = {}
+            for k, c in file_bitmap(O, *spec):
+                rows.setdefault(k >> 4, {})[k] = c
+            cache[key] = rows
+        return cache[key]
+
+    for name, op, a, b, want, want_slice in V.SETOP_CASES:
+        ra, rb = shard_rows(a), shard_rows(b)
+        shards = sorted(set(ra) | set(rb)) or [0]
+        batch = gpu_ctx.upload([D.to_fbk_row(ra.get(s, {})) for s in shards] + [D.to_fbk_row(rb.get(s, {})) for s in shards])
+        n = len(shards)
+        for flags in (0, L.SETOP_OPTIMIZE):
+            out, cnt = gpu_ctx.setop(ops[op], batch, np.arange(n), batch, np.arange(n) + n, flags)
+            assert int(cnt.sum()) == want, (name, flags)
+            if want_slice is not None:
+                cols = []
+                for i, row in enumerate(out.download()):
+                    for k, c in row.items():
+                        vals = np.nonzero(np.unpackbits(c.words().view(np.uint8), bitorder="little"))[0]
+                        cols.extend((((shards[i] * 16 + (k & 15)) << 16) + vals).tolist())
+                assert sorted(cols) == want_slice, (name, flags)
+            out.free()
+        if op == "and":  # the count-only form of the same intersections
+            assert int(gpu_ctx.intersection_count(batch, np.arange(n), batch, np.arange(n) + n).sum()) == want, name
+        batch.free()

@@ -11,19 +11,21 @@ import go_bitmap_vectors as V  # noqa: E402
 
 def file_bitmap(O, values, optimized):
     """NewFileBitmap(values...) [+ Optimize()] as (key, oracle container) pairs."""
-    groups = {}
-    for v in values:
-        groups.setdefault(v >> 16, []).append(v & 0xFFFF)
+    v = np.unique(np.asarray(values, dtype=np.uint64))
     out = []
-    for key in sorted(groups):
-        lo = np.array(sorted(set(groups[key])), dtype=np.uint16)
+    if v.size == 0:
+        return out
+    keys = v >> np.uint64(16)
+    starts = np.concatenate([[0], np.nonzero(np.diff(keys))[0] + 1, [v.size]])
+    for a, b in zip(starts[:-1], starts[1:]):
+        lo = (v[a:b] & np.uint64(0xFFFF)).astype(np.uint16)
         if lo.size < 4096:
             c = O.OContainer.array(lo)
         else:
             w = np.zeros(65536, dtype=np.uint8)
             w[lo] = 1
             c = O.OContainer.bitmap(np.packbits(w, bitorder="little").view(np.uint64), int(lo.size))
-        out.append((key, O.optimize(c) if optimized else c))
+        out.append((int(keys[a]), O.optimize(c) if optimized else c))
     return out
 
 
@@ -43,3 +45,16 @@ def test_bitmap_intersection_count_vectors(oracle, name, a, b, want):
     B = O.OBitmap.from_containers(file_bitmap(O, *b))
     assert A.intersection_count(B) == want
     assert B.intersection_count(A) == want  # "unexpected n (reverse)"
+
+
+@pytest.mark.parametrize("name,op,a,b,want,want_slice", V.SETOP_CASES, ids=[c[0] for c in V.SETOP_CASES])
+def test_bitmap_setop_vectors(oracle, name, op, a, b, want, want_slice):
+    """TestBitmap_Intersection / _Union1 / _Intersect* / _Difference* / _Union / _Xor*
+    (roaring_test.go:483-1216): result cardinalities and, where the reference checks them, contents."""
+    O = oracle
+    A = O.OBitmap.from_containers(file_bitmap(O, *a))
+    B = O.OBitmap.from_containers(file_bitmap(O, *b))
+    r = {"and": lambda: A.intersect(B), "or": lambda: A.union(B), "andnot": lambda: A.difference(B), "xor": lambda: A.xor(B)}[op]()
+    assert r.count() == want
+    if want_slice is not None:
+        assert r.slice() == want_slice
