@@ -257,24 +257,39 @@ __global__ void __launch_bounds__(512) k_count_matrix_dense(
 }
 
 // Rows of any encoding -> temporary dense rows (16 bitmap cells of 8 KiB each), so that the
-// VALU-organised matrix kernel above can run on array / run containers too: decoding a
-// container once and writing 8 KiB is cheap next to the nA x nB pair work that follows.
-// One wavefront per (row ordinal, slot); nil / empty containers become all-zero cells.
-__global__ void __launch_bounds__(256) k_densify_rows(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
-                                                     const uint32_t* __restrict__ rows, uint64_t n_rows,
-                                                     uint8_t* __restrict__ out) {
+// matrix kernels can run on array / run containers too: decoding a container once and writing
+// 8 KiB is cheap next to the nA x nB pair work that follows.  One wavefront per (row ordinal,
+// slot); nil / empty containers become all-zero cells.  Up to three sources (the A rows, the B
+// rows, the filter rows of one count-matrix call) share ONE launch.
+struct DensifySrc {
+  const Slot* slots;
+  const uint8_t* arena;
+  const uint32_t* rows;
+  uint64_t n_rows;
+  uint8_t* out;
+};
+struct DensifyArgs {
+  DensifySrc src[3];
+};
+__global__ void __launch_bounds__(256) k_densify_rows(DensifyArgs args) {
   __shared__ u64 lds[4][kWords];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
+  uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
+  int which = 0;  // wave-uniform
+  while (which < 3 && wslot >= args.src[which].n_rows * kSlots) {
+    wslot -= args.src[which].n_rows * kSlots;
+    ++which;
+  }
+  if (which == 3) return;
+  const DensifySrc& S = args.src[which];
   const uint64_t i = wslot >> 4;
   const uint32_t slot = wslot & 15;
-  if (i >= n_rows) return;
-  const Slot s = slots[(uint64_t)rows[i] * kSlots + slot];
+  const Slot s = S.slots[(uint64_t)S.rows[i] * kSlots + slot];
   u64 w[kWordsPerLane];
   if (slot_n(s) == 0) frag_zero(w);
-  else frag_load(s, arena, lane, lds[wv], w);
-  frag_store_bitmap(out + wslot * 8192ull, lane, w);
+  else frag_load(s, S.arena, lane, lds[wv], w);
+  frag_store_bitmap(S.out + wslot * 8192ull, lane, w);
 }
 
 }  // namespace fbk
