@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -204,6 +205,16 @@ class Device {
   Row Union(const Row& a, const Row& b) { return setop(FBK_OP_OR, a, b); }         // row.go:288
   Row Difference(const Row& a, const Row& b) { return setop(FBK_OP_ANDNOT, a, b); }  // row.go:333
   Row Xor(const Row& a, const Row& b) { return setop(FBK_OP_XOR, a, b); }          // row.go:268
+  // Row.Shift, row.go:374-396: n single-column shifts of every segment.  The reference leaves the
+  // bit shifted out of a shard's last column in that segment, under a container key of the NEXT
+  // shard ("TODO: deal with overflow", row.go:615) — Columns() reports it as the first column of
+  // the next shard; here it is carried into the next shard's segment, the same columns.
+  Row Shift(const Row& a, int64_t n) {
+    if (n < 0) throw Error(FBK_E_INVALID, "cannot shift by negative values");
+    Row work = a;
+    for (int64_t i = 0; i < n; ++i) work = shift1(work);
+    return work;
+  }
 
  private:
   struct Pairing {
@@ -250,6 +261,81 @@ class Device {
     if (payload.empty()) payload.push_back(0);
     check(fbk_batch_upload(ctx_, descs.data(), descs.size(), uint32_t(p.both.size()), payload.data(), payload.size(), &b));
     return b;
+  }
+  fbk_batch* upload_segments(const std::vector<const RowSegment*>& segs) {
+    Pairing p;
+    for (const RowSegment* sg : segs) p.both.emplace_back(sg, sg);
+    return upload(p, Row(), true);
+  }
+  // containers of an output batch -> segments (row r of the batch = shard shards[r])
+  void download_segments(fbk_batch* bo, const std::vector<uint64_t>& shards, const std::vector<uint64_t>& counts,
+                         std::map<uint64_t, RowSegment>& out) {
+    uint32_t n_rows = 0;
+    uint64_t nc = 0, pb = 0;
+    check(fbk_batch_info(ctx_, bo, &n_rows, &nc, &pb));
+    std::vector<fbk_container_desc> descs(nc ? nc : 1);
+    std::vector<uint8_t> payload(pb ? pb : 1);
+    check(fbk_batch_download(ctx_, bo, descs.data(), nc, payload.data(), pb));
+    for (size_t r = 0; r < shards.size(); ++r) {
+      RowSegment sg;
+      sg.shard = shards[r];
+      sg.n = counts[r];
+      out[sg.shard] = std::move(sg);
+    }
+    for (uint64_t i = 0; i < nc; ++i) {
+      const fbk_container_desc& d = descs[i];
+      RowSegment& sg = out[shards[d.row]];
+      const uint8_t* src = payload.data() + d.off;
+      if (d.type == FBK_TYPE_ARRAY) {
+        std::vector<uint16_t> v(d.len);
+        std::memcpy(v.data(), src, size_t(d.len) * 2);
+        sg.data.Put(d.key, Container::NewContainerArray(std::move(v)));
+      } else if (d.type == FBK_TYPE_RUN) {
+        std::vector<Interval16> v(d.len);
+        std::memcpy(v.data(), src, size_t(d.len) * 4);
+        sg.data.Put(d.key, Container::NewContainerRunN(std::move(v), d.n));
+      } else {
+        std::vector<uint64_t> v(FBK_BITMAP_WORDS);
+        std::memcpy(v.data(), src, 8192);
+        sg.data.Put(d.key, Container::NewContainerBitmapN(std::move(v), d.n));
+      }
+    }
+  }
+  Row shift1(const Row& a) {
+    if (a.Segments.empty()) return a;
+    std::vector<const RowSegment*> segs;
+    std::map<uint64_t, uint32_t> idx;  // shard -> row of the uploaded batch
+    std::set<uint64_t> out_shards;
+    for (const RowSegment& sg : a.Segments) {
+      idx[sg.shard] = uint32_t(segs.size());
+      segs.push_back(&sg);
+      out_shards.insert(sg.shard);
+      out_shards.insert(sg.shard + 1);  // may receive the carried bit
+    }
+    std::vector<uint64_t> shards(out_shards.begin(), out_shards.end());
+    std::vector<uint32_t> rows(shards.size(), FBK_NO_ROW), carry(shards.size(), FBK_NO_ROW);
+    for (size_t i = 0; i < shards.size(); ++i) {
+      auto it = idx.find(shards[i]);
+      if (it != idx.end()) rows[i] = it->second;
+      if (shards[i] > 0 && (it = idx.find(shards[i] - 1)) != idx.end()) carry[i] = it->second;
+    }
+    fbk_batch *ba = upload_segments(segs), *bo = nullptr;
+    std::vector<uint64_t> counts(shards.size());
+    int32_t rc = fbk_shift(ctx_, ba, rows.data(), carry.data(), shards.size(), FBK_SETOP_OPTIMIZE, &bo, counts.data());
+    fbk_batch_free(ctx_, ba);
+    check(rc);
+    std::map<uint64_t, RowSegment> out;
+    try {
+      download_segments(bo, shards, counts, out);
+    } catch (...) {
+      fbk_batch_free(ctx_, bo);
+      throw;
+    }
+    fbk_batch_free(ctx_, bo);
+    Row r;
+    for (auto& kv : out)
+      if (kv.second.n) r.Segments.push_back(std::move(kv.second));
+    return r;
   }
   Row setop(int32_t op, const Row& a, const Row& b) {
     Pairing p = pair_segments(a, b);

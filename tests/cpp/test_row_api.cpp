@@ -51,6 +51,26 @@ int main() {
     EXPECT(res.Count() == 2);
     EXPECT(res.Columns() == exp);
   }
+  {  // Row.Shift (row.go:374-396) with the columns of TestExecutor_Execute_Shift (executor_test.go:6590-6676)
+    const uint64_t SW = ShardWidth;
+    EXPECT(dev.Shift(Row::NewRow({0}), 1).Columns() == (V{1}));
+    EXPECT(dev.Shift(dev.Shift(Row::NewRow({0}), 1), 1).Columns() == (V{2}));
+    EXPECT(dev.Shift(Row::NewRow({65535}), 1).Columns() == (V{65536}));
+    EXPECT(dev.Shift(Row::NewRow({1, SW - 1, SW + 1}), 1).Columns() == (V{2, SW, SW + 2}));
+    EXPECT(dev.Shift(Row::NewRow({1, SW - 1, SW + 1}), 2).Columns() == (V{3, SW + 1, SW + 3}));
+    EXPECT(dev.Shift(Row::NewRow({SW - 2, SW - 1, SW, SW + 2}), 1).Columns() == (V{SW - 1, SW, SW + 1, SW + 3}));
+    Row far = dev.Shift(Row::NewRow({SW - 1, 5 * SW - 1}), 1);  // carried into shards that held nothing
+    EXPECT(far.Columns() == (V{SW, 5 * SW}));
+    EXPECT(far.Count() == 2 && far.Segments.size() == 2 && far.Segments[0].shard == 1 && far.Segments[1].shard == 5);
+    EXPECT(dev.Shift(Row::NewRow({7}), 0).Columns() == (V{7}));
+    bool threw = false;
+    try {
+      dev.Shift(Row::NewRow({7}), -1);
+    } catch (const fbk::Error&) {
+      threw = true;
+    }
+    EXPECT(threw);
+  }
   {  // TestRow_IsEmpty, row_test.go:105-116
     Row r1 = Row::NewRow({1, ShardWidth}), r2 = Row::NewRow({0, 2 * ShardWidth});
     Row res = dev.Intersect(r2, r1);
