@@ -1,7 +1,7 @@
 """Size-independent properties at BASELINE.json's full sizes (where the CPU oracle would take
-minutes): config 5 — BSI 64-bit field over 96 shards (100 M columns) — and config 4's 32 x 32
-count matrix over 128 shards; config 2 at its full 1024 shards is checked inside bench.py
-against numpy popcounts on every run."""
+minutes): config 5 — BSI 64-bit field over 96 shards (100 M columns) —, config 4's 32 x 32
+count matrix over 128 shards and config 3's Union-of-64 over 256 shards of mixed containers;
+config 2 at its full 1024 shards is checked inside bench.py against numpy popcounts on every run."""
 import numpy as np
 import pytest
 
@@ -82,4 +82,48 @@ def test_config4_count_matrix_properties_full_slice(gpu_ctx):
     tot_nf = gpu_ctx.count_matrix(A, ra, Bt, rb)
     assert (tot_nf >= tot).all()
     for b in (bf, A, Bt, F):
+        b.free()
+
+
+def test_config3_union_of_64_properties_full_size(gpu_ctx):
+    """BASELINE config 3 at its full 256 shards x (64 mixed rows + filter): the fused
+    |∪ rows ∩ F| against the same quantity through the materialised union, inclusion-exclusion
+    with the difference, and bounds that hold whatever the data (32 distinct shard contents,
+    repeated — the properties do not care)."""
+    n_shards, k, distinct = 256, 64, 32
+    content, fcontent = [], []
+    for s in range(distinct):
+        rng = D.rng_for(3000 + s)
+        rows = []
+        for r in range(k):
+            d = D.zipf_density(r)
+            row = {}
+            for slot in range(16):
+                rs = rng.random() < 0.25
+                c = D.fbk_container_of_vals(D.mixed_vals_for_density(rng, d, rs))
+                if c is not None and c.n:
+                    row[slot] = c
+            rows.append(row)
+        content.append(rows)
+        frng = D.rng_for(3500 + s)
+        fcontent.append({slot: D.fbk_container_of_vals(D.mixed_vals_for_density(frng, 0.5, False)) for slot in range(16)})
+    rows = [content[s % distinct][r] for s in range(n_shards) for r in range(k)]
+    batch = gpu_ctx.upload(rows)
+    F = gpu_ctx.upload([fcontent[s % distinct] for s in range(n_shards)])
+    groups = np.arange(n_shards * k, dtype=np.uint32).reshape(n_shards, k)
+    fidx = np.arange(n_shards)
+    fused = gpu_ctx.union_n_intersection_count(batch, groups, F, fidx)
+    un, un_cnt = gpu_ctx.union_n(batch, groups)
+    via_union = gpu_ctx.intersection_count(un, fidx, F, fidx)
+    assert (fused == via_union).all()
+    diff, diff_cnt = gpu_ctx.setop(L.OP_ANDNOT, un, fidx, F, fidx)
+    assert (fused + diff_cnt == un_cnt).all()  # |U ∩ F| + |U \\ F| = |U|
+    row_cnt = batch.count(groups.reshape(-1)).reshape(n_shards, k)
+    assert (un_cnt >= row_cnt.max(axis=1)).all() and (un_cnt <= row_cnt.sum(axis=1)).all()
+    assert (fused <= F.count(fidx)).all()
+    assert (fused[:distinct] == fused[distinct : 2 * distinct]).all()  # repeated content, repeated answers
+    # the TopK shape on the same rows: per-row counts against the filter sum to at least the fused union count
+    tot = gpu_ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1), per_shard=True)[1][:, :, 0]
+    assert (tot.sum(axis=1) >= fused).all() and (tot.max(axis=1) <= fused).all()
+    for b in (diff, un, batch, F):
         b.free()
