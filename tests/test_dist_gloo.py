@@ -145,3 +145,25 @@ def test_bucketed_async_reduce_two_ranks():
         last_full_start = (steps // bucket - 1) * bucket
         flat = sorted(v for b in bufs for v in b if v)
         assert flat == sorted([expect(k) for k in range(last_full_start, last_full_start + bucket)] + [expect(k) for k in range(steps - tail, steps)])
+
+
+def test_bucketed_reducer_without_a_process_group():
+    """N = 1 (bench.py at --gpus 1): no collective, the buckets are only cleared on reuse and
+    every step's slot keeps what was accumulated into it."""
+    import torch
+
+    from featurebase_amd.dist import BucketedCountReducer
+
+    red = BucketedCountReducer(4, torch.device("cpu"))
+    seen = []
+    for step in range(10):
+        slot = red.slot()
+        assert int(slot.item()) == 0  # cleared before reuse
+        slot += 100 + step  # what the accumulate kernel does on the device
+        seen.append(100 + step)
+        red.advance()
+    bufs = red.flush()
+    assert red.collectives == 3  # 4 + 4 + tail of 2
+    vals = torch.cat(bufs).tolist()
+    # the last two buckets hold steps 4..7 and 8..9 (+ two cleared slots)
+    assert sorted(v for v in vals if v) == seen[4:]
