@@ -262,6 +262,38 @@ int32_t upload_rows(fbk_ctx* ctx, const uint32_t* rows, uint64_t n, uint32_t n_r
   return FBK_OK;
 }
 
+// Several row-index arrays of one call in ONE host->device copy (each copy is a launch of its own:
+// ~5 us apiece on the calls that take rows for A, B and the filter).  d[i] points into `out`.
+struct RowsArg {
+  const uint32_t* rows;
+  uint64_t n;
+  uint32_t limit;  // UINT32_MAX: validated by the caller
+};
+int32_t upload_rows_multi(fbk_ctx* ctx, std::initializer_list<RowsArg> args, DevBuf& out, const uint32_t** d) {
+  uint64_t total = 0;
+  for (const RowsArg& a : args) {
+    for (uint64_t i = 0; a.limit != UINT32_MAX && i < a.n; ++i)
+      if (a.rows[i] >= a.limit)
+        return fail(FBK_E_INVALID, "row index " + std::to_string(a.rows[i]) + " out of range (batch has " +
+                                       std::to_string(a.limit) + " rows)");
+    total += (a.n + 3) & ~uint64_t(3);  // 16-byte aligned segments
+  }
+  HIP_TRY(out.alloc(ctx, std::max<uint64_t>(total, 4) * sizeof(uint32_t)));
+  uint8_t* st = total ? stage_alloc(ctx, total * sizeof(uint32_t)) : nullptr;
+  uint64_t at = 0;
+  int k = 0;
+  for (const RowsArg& a : args) {
+    d[k++] = static_cast<const uint32_t*>(out.p) + at;
+    if (a.n) {
+      if (st) std::memcpy(st + at * sizeof(uint32_t), a.rows, a.n * sizeof(uint32_t));
+      else HIP_TRY(hipMemcpyAsync(static_cast<uint32_t*>(out.p) + at, a.rows, a.n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    at += (a.n + 3) & ~uint64_t(3);
+  }
+  if (st && total) HIP_TRY(hipMemcpyAsync(out.p, st, total * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  return FBK_OK;
+}
+
 bool is_gfx950(const hipDeviceProp_t& p) { return std::strncmp(p.gcnArchName, "gfx950", 6) == 0; }
 
 }  // namespace
