@@ -104,3 +104,31 @@ COUNT_RANGE_CASES = [
     ("RunCountRange/2", (list(range(65536, 65554)), True), [(3, 2, 0)]),
     ("RunCountRange/3", ([1, 2, 3, 4], True), [(1, 3, 2)]),
 ]
+
+
+# TestBitmap_Intersect*InPlace (roaring_test.go:499-780): the in-place forms (intersectInPlace,
+# roaring.go:855-1269) must leave the same contents as the allocating ones — same tuple layout as
+# SETOP_CASES, every one an intersection.
+_A7 = [0, 1, 7, 9, 11, 2683, 5005]
+_THIRDS1 = list(range(1, 65536, 3))
+_R25 = _run_bitmap(25, 8, 25 // 2 + 8, 25 // 2 + 8)
+_R32 = _run_bitmap(32, 1, 0, 0)
+INPLACE_CASES = [
+    ("IntersectionInPlace", "and", ([0, 2683177], False), (_BIG, False), 1, None),
+    ("IntersectionInPlace_Empty/a", "and", ([0, 2683177], False), ([], False), 0, []),
+    ("IntersectionInPlace_Empty/b", "and", ([], False), ([0, 2683177], False), 0, []),
+    ("IntersectArrayBitmapInPlace", "and", (_A7, False), (_THIRDS1, False), 4, [1, 7, 2683, 5005]),
+    ("IntersectArrayRunInPlace", "and", (_A7, False), ([5, 6, 7, 8, 9, 10, 11, 13], True), 3, [7, 9, 11]),
+    ("IntersectBitmapArrayInPlace", "and", (_THIRDS1, False), (_A7, False), 4, [1, 7, 2683, 5005]),
+    ("IntersectBitmapRunInPlace", "and", (_R32, False), (_R25, True), 47628, None),
+    ("IntersectRunRunInPlace/array", "and", ([0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15], True), ([5, 6, 7, 8, 9, 10, 11, 13], True), 4, [5, 10, 11, 13]),
+    ("IntersectRunRunInPlace/bitmap", "and", (_R25, True), (_R32, True), 47628, None),
+    ("IntersectRunArrayInPlace", "and", ([0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15], True), ([5, 6, 7, 8, 9, 10, 11, 13], False), 4, [5, 10, 11, 13]),
+    ("IntersectRunBitmapInPlace", "and", (_R25, True), (_R32, False), 47628, None),
+]
+SETOP_CASES += INPLACE_CASES
+
+# bm0.IntersectInPlace(bm11, bm12) (roaring_test.go:640-654): a three-way fold
+FOLD_CASES = [
+    ("IntersectInPlace(bm11, bm12)", "and", [(_A7, False), ([5, 6, 7, 8, 9, 10, 11, 13, 2683], False), ([6, 7, 10, 13, 2683], False)], 2, [7, 2683]),
+]

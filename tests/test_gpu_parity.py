@@ -316,8 +316,8 @@ def test_reference_bitmap_level_vectors_through_the_abi(gpu_ctx, oracle):
 
 
 def test_reference_bitmap_level_setop_vectors_through_the_abi(gpu_ctx, oracle):
-    """TestBitmap_Intersection / _Union1 / _Intersect* / _Difference* / _Union / _Xor*
-    (roaring/roaring_test.go:483-1216) through fbk_setop: the bitmaps are cut into shard rows
+    """TestBitmap_Intersection / _Union1 / _Intersect* (incl. the *InPlace forms, :499-780) /
+    _Difference* / _Union / _Xor* (roaring/roaring_test.go:483-1216) through fbk_setop: the bitmaps are cut into shard rows
     (16 container keys each, as fragment.row does), one row pair per shard either operand touches;
     result cardinalities summed over the shards and, where the reference checks them, the
     columns of the result."""
@@ -358,6 +358,23 @@ def test_reference_bitmap_level_setop_vectors_through_the_abi(gpu_ctx, oracle):
             out.free()
         if op == "and":  # the count-only form of the same intersections
             assert int(gpu_ctx.intersection_count(batch, np.arange(n), batch, np.arange(n) + n).sum()) == want, name
+        batch.free()
+    # bm0.IntersectInPlace(bm11, bm12): a three-way fold through fbk_fold_n
+    for name, op, specs, want, want_slice in V.FOLD_CASES:
+        parts = [shard_rows(sp) for sp in specs]
+        shards = sorted(set().union(*[set(p) for p in parts])) or [0]
+        n = len(shards)
+        batch = gpu_ctx.upload([D.to_fbk_row(p.get(s, {})) for p in parts for s in shards])
+        groups = np.array([[j * n + i for j in range(len(parts))] for i in range(n)], dtype=np.uint32)
+        out, cnt = gpu_ctx.fold_n(ops[op], batch, groups)
+        assert int(cnt.sum()) == want, name
+        cols = []
+        for i, row in enumerate(out.download()):
+            for k, c in row.items():
+                vals = np.nonzero(np.unpackbits(c.words().view(np.uint8), bitorder="little"))[0]
+                cols.extend((((shards[i] * 16 + (k & 15)) << 16) + vals).tolist())
+        assert sorted(cols) == want_slice, name
+        out.free()
         batch.free()
 
 

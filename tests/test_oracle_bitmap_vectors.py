@@ -71,3 +71,14 @@ def test_bitmap_count_range_vectors(oracle, name, spec, ranges):
     for s, e, want in ranges:
         got = bm.count_range(s, e) if s <= e else 0  # start > end: the reference's loop counts nothing
         assert got == want, (s, e)
+
+
+@pytest.mark.parametrize("name,op,specs,want,want_slice", V.FOLD_CASES, ids=[c[0] for c in V.FOLD_CASES])
+def test_bitmap_fold_vectors(oracle, name, op, specs, want, want_slice):
+    """bm0.IntersectInPlace(bm11, bm12), roaring_test.go:640-654."""
+    O = oracle
+    bms = [O.OBitmap.from_containers(file_bitmap(O, *s)) for s in specs]
+    r = bms[0]
+    for b in bms[1:]:
+        r = r.intersect(b)
+    assert r.count() == want and r.slice() == want_slice
