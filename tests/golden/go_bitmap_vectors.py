@@ -129,6 +129,18 @@ INPLACE_CASES = [
 SETOP_CASES += INPLACE_CASES
 
 # bm0.IntersectInPlace(bm11, bm12) (roaring_test.go:640-654): a three-way fold
+_TB_ARRAY = ([(1 << 16) + i for i in range(0, 1024, 4)], True)
+_TB_BITMAP = ([(2 << 16) + i for i in range(0, 16384, 2)], True)
+_TB_SMALLRUN = ([(3 << 16) + i for i in range(1024)], True)
+_TB_LARGERUN = ([(4 << 16) + i for i in range(65535)], True)
+# (name, op, [bm0, others...], expected count, expected Slice() or None): the first bitmap folded
+# with the others left to right — IntersectInPlace(bm11, bm12) (roaring_test.go:640-654),
+# UnionInPlace1 (:808-846: result starts empty), DifferenceInPlace (:2051-2091)
 FOLD_CASES = [
     ("IntersectInPlace(bm11, bm12)", "and", [(_A7, False), ([5, 6, 7, 8, 9, 10, 11, 13, 2683], False), ([6, 7, 10, 13, 2683], False)], 2, [7, 2683]),
+    ("UnionInPlace1/a", "or", [([], False), ([0, 2683177], False), (_BIG + [4000000], False)], 2682675, None),
+    ("UnionInPlace1/testBM", "or", [([], False), TEST_BM, ([0, 2683177], False)], 75009, None),
+    ("UnionInPlace1/self", "or", [([], False), TEST_BM, TEST_BM], 75007, None),
+    ("DifferenceInPlace/all", "andnot", [TEST_BM, _TB_ARRAY, _TB_BITMAP, _TB_SMALLRUN, _TB_LARGERUN], 0, []),
+    ("DifferenceInPlace/but-array", "andnot", [TEST_BM, _TB_BITMAP, _TB_SMALLRUN, _TB_LARGERUN], 256, [(1 << 16) + i for i in range(0, 1024, 4)]),
 ]

