@@ -928,21 +928,24 @@ def test_topk_on_device_vs_oracle(gpu_ctx, oracle, use_filter):
 
 
 def test_fragment_topn_vectors_through_fbk_topk(gpu_ctx, oracle):
-    """TestFragment_TopN_Intersect / _Intersect_Large (fragment_internal_test.go:1174-1252), the
-    reference's own TopN known answers, through fbk_topk (one shard; both orderings paths)."""
+    """TestFragment_TopN_Intersect / _Intersect_Large / _IDs (fragment_internal_test.go:1174-1273),
+    the reference's own TopN known answers, through fbk_topk (one shard; both ordering paths;
+    the RowIDs form passes the chosen rows — a missing id is an empty row — and no filter)."""
     from oracle import pybsi as PB
     from test_oracle_bsi import topn_vectors
 
-    for rows, src, n, want in topn_vectors():
-        ids = sorted(rows)
-        batch = gpu_ctx.upload([fbk_row_of_bitmap(PB.row_from_columns(rows[i])) if rows[i] else {} for i in ids])
-        F = gpu_ctx.upload([fbk_row_of_bitmap(PB.row_from_columns(src))])
+    for rows, src, n, want, row_ids in topn_vectors():
+        ids = sorted(rows) if row_ids is None else row_ids
+        batch = gpu_ctx.upload([fbk_row_of_bitmap(PB.row_from_columns(rows[i])) if rows.get(i) else {} for i in ids])
+        F = gpu_ctx.upload([fbk_row_of_bitmap(PB.row_from_columns(src))]) if src is not None else None
+        fargs = (F, np.zeros(1, dtype=np.uint32)) if F is not None else (None, None)
         try:
             for mode in ("0", "1"):
                 os.environ["FBK_TOPK_DEVICE_SORT"] = mode
-                idx, cnt = gpu_ctx.topk(batch, np.arange(len(ids)).reshape(1, -1), n, F, np.zeros(1, dtype=np.uint32))
+                idx, cnt = gpu_ctx.topk(batch, np.arange(len(ids)).reshape(1, -1), n, *fargs)
                 assert [(ids[i], int(c)) for i, c in zip(idx.tolist(), cnt.tolist())] == want, mode
         finally:
             os.environ.pop("FBK_TOPK_DEVICE_SORT", None)
         batch.free()
-        F.free()
+        if F is not None:
+            F.free()

@@ -246,19 +246,20 @@ def test_minmax_executor_vectors_and_truth(B):
 
 
 def topn_vectors():
-    """TestFragment_TopN_Intersect and _Intersect_Large (fragment_internal_test.go:1174-1252):
-    (row id -> columns, src columns, N, expected [(id, count)])."""
-    small = ({100: [1, 10, 11, 12], 101: [1, 2, 3, 4], 102: [1, 2, 4, 5, 6], 103: [1000, 1001, 1002]}, [1, 2, 3], 3, [(101, 3), (102, 2), (100, 1)])
-    large = ({i: list(range(i)) for i in range(1000)}, list(range(980, 1000)), 10, [(999 - d, 19 - d) for d in range(10)])
-    return [small, large]
+    """TestFragment_TopN_Intersect, _Intersect_Large and _IDs (fragment_internal_test.go:1174-1273):
+    (row id -> columns, src columns or None, N (0 = all), expected [(id, count)], RowIDs or None)."""
+    small = ({100: [1, 10, 11, 12], 101: [1, 2, 3, 4], 102: [1, 2, 4, 5, 6], 103: [1000, 1001, 1002]}, [1, 2, 3], 3, [(101, 3), (102, 2), (100, 1)], None)
+    large = ({i: list(range(i)) for i in range(1000)}, list(range(980, 1000)), 10, [(999 - d, 19 - d) for d in range(10)], None)
+    ids = ({100: [1, 2, 3], 101: [4, 5, 6, 7], 102: [8, 9, 10, 11, 12]}, None, 0, [(101, 4), (100, 3)], [100, 101, 200])  # row 200 does not exist
+    return [small, large, ids]
 
 
 def test_fragment_topn_intersect_vectors(oracle):
     from oracle import pybsi as B
 
-    for rows, src, n, want in topn_vectors():
-        ids = sorted(rows)
-        frag = B.Fragment([B.row_from_columns(rows[i]) if rows[i] else None for i in ids])
-        cnt = B.topk_row_counts(frag, B.row_from_columns(src))
-        pairs = sorted([(ids[k], int(c)) for k, c in enumerate(cnt) if c], key=lambda p: (-p[1], p[0]))[:n]
-        assert pairs == want
+    for rows, src, n, want, row_ids in topn_vectors():
+        ids = sorted(rows) if row_ids is None else row_ids
+        frag = B.Fragment([B.row_from_columns(rows[i]) if rows.get(i) else None for i in ids])
+        cnt = B.topk_row_counts(frag, B.row_from_columns(src) if src is not None else None)
+        pairs = sorted([(ids[k], int(c)) for k, c in enumerate(cnt) if c], key=lambda p: (-p[1], p[0]))
+        assert (pairs[:n] if n else pairs) == want
