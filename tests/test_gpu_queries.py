@@ -949,3 +949,44 @@ def test_fragment_topn_vectors_through_fbk_topk(gpu_ctx, oracle):
         batch.free()
         if F is not None:
             F.free()
+
+
+def test_bsi_add_reference_cases(gpu_ctx, oracle):
+    """TestBSIAddCases (bsi_test.go:116-160): the reference's own AddBSI inputs — twenty positions
+    with counts up to 9 023 592 401, and the two-position case — through fbk_bsi_add; every
+    position decodes to a + b."""
+    O = oracle
+    cases = [
+        ([161311, 611110, 82544, 996022, 836077, 64964, 480737, 156534, 240525, 580896, 239236, 54607, 1019438, 894260, 17570, 884645, 936658, 682651, 987695, 390274],
+         [17, 1, 2846, 45437619, 23781, 36, 88, 168691, 13417, 1301, 10, 71, 0, 176, 1010, 21, 1, 509, 17, 4],
+         [24, 288, 12737, 14, 150, 21, 24, 354, 0, 19, 5, 150, 3940, 121, 25, 621, 7, 9023592401, 6033, 7]),
+        ([17570, 54607], [1010, 71], [25, 150]),
+    ]
+    depth = 34  # 9023592401 < 2^34
+
+    def planes_of(vals):
+        rows = []
+        for i in range(depth):
+            bm = O.bitmap_from_values([p for p, v in vals.items() if (v >> i) & 1])
+            rows.append({k: D.to_fbk(c) for k, c in bm.items() if c.n})
+        return rows
+
+    xrows, yrows = [], []
+    for pos, a, b in cases:
+        xrows += planes_of(dict(zip(pos, a)))
+        yrows += planes_of(dict(zip(pos, b)))
+    X, Y = gpu_ctx.upload(xrows), gpu_ctx.upload(yrows)
+    r = np.arange(len(cases) * depth).reshape(len(cases), depth)
+    out = gpu_ctx.bsi_add(X, r, Y, r, L.SETOP_OPTIMIZE)
+    rows = out.download()
+    for g, (pos, a, b) in enumerate(cases):
+        got = {}
+        for i in range(depth + 1):
+            for k, c in rows[g * (depth + 1) + i].items():
+                bits = np.unpackbits(c.words().view(np.uint8), bitorder="little")
+                for v in np.nonzero(bits)[0]:
+                    p = ((k & 15) << 16) + int(v)
+                    got[p] = got.get(p, 0) | (1 << i)
+        assert got == {p: x + y for p, x, y in zip(pos, a, b) if x + y}, g
+    for bt in (out, X, Y):
+        bt.free()
