@@ -10,17 +10,25 @@ all-reduce (the exchange step executor.go:6449 mapReduce does over HTTP).
 
     python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `value` = container set-ops per second over all N GPUs
-(a set-op = one container pair with equal keys); weak scaling (1024 shards
-per GPU).  Also reported: bits-scanned GB/s, the roofline of the dominant kernel (HIP
-events around back-to-back launches), the materialising variant, and the CPU oracle timed
-on this box's host cores as `cpu_baseline`.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself
+(torch.distributed.run, one rank per GPU, RCCL; when the box has fewer than N GPUs the ranks share
+the devices and reduce over gloo — flagged as "oversubscribed" in the output).  Under torchrun it
+reads RANK / LOCAL_RANK / WORLD_SIZE as usual.  Prints ONE JSON line on rank 0.
+
+`value` = container set-ops per second over all N GPUs (a set-op = one container pair with equal
+keys); weak scaling (1024 shards per GPU).  Also in the line: the distribution of
+the step time over repeated timed regions, bits-scanned GB/s, the roofline of the dominant kernel
+(HIP events around back-to-back launches), the materialising variant, `secondary` = BASELINE.json
+configs 3, 4 and 5 at their per-GPU sizes (N = 1), for N > 1 the per-step-collective and
+host-add latency modes and the in-library multi-device path (fbk_group_*), and the CPU oracle
+timed on this box's host cores as `cpu_baseline`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -31,11 +39,39 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402  (first: one HIP runtime per process, see featurebase_amd/lib.py)
 
 SHARDS_PER_GPU = 1024
-REDUCE_BUCKET = 16  # steps per RCCL all-reduce when N > 1
+REDUCE_BUCKET = 16  # steps per RCCL all-reduce when N > 1 (throughput mode)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def dist_of(xs):
+    """median / p10 / p90 of a list of samples"""
+    v = sorted(xs)
+    n = len(v)
+    return {"median": v[n // 2], "p10": v[n // 10], "p90": v[min(n - 1, (n * 9) // 10)], "n": n}
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1: start the N ranks (one per GPU) and pass rank 0's line through."""
+    import torch
+
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    env = dict(os.environ)
+    if n_dev < args.gpus:
+        # fewer devices than ranks: the ranks share the devices (rank r -> device r mod n_dev) and the
+        # collectives run over gloo.  This is the complete N > 1 code path on a smaller box, NOT a
+        # scaling measurement; the output line says "oversubscribed": true.
+        env["FBK_BENCH_BACKEND"] = "gloo"
+        print(f"[bench] {n_dev} device(s) visible for --gpus {args.gpus}: ranks share devices, gloo collectives", file=sys.stderr, flush=True)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(wa: np.ndarray, wb: np.ndarray, budget_s: float = 15.0):
@@ -119,26 +155,272 @@ def cpu_baseline(wa: np.ndarray, wb: np.ndarray, budget_s: float = 15.0):
     }
 
 
+# ---- secondary configurations (N = 1): BASELINE.json configs 3, 4, 5 ------------------------------
+
+
+def _cpu_time(fn, min_s=1.0):
+    """seconds per call of fn on one host thread (repeated until min_s has elapsed)"""
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_s:
+            return dt / n
+
+
+def _timed_call(torch, stream, fn, iters, warm=2):
+    """One C-ABI call end to end: GPU time between the first and the last operation it enqueues (HIP
+    events on the library's stream) and host wall time, over `iters` calls."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gpu, wall = [], []
+    for _ in range(iters):
+        e0.record(stream)
+        t0 = time.perf_counter()
+        fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        wall.append((time.perf_counter() - t0) * 1e6)
+        gpu.append(e0.elapsed_time(e1) * 1e3)
+    return dist_of(gpu), dist_of(wall)
+
+
+def _entry(name, kernel, alg_bytes, gpu_us, wall_us, **extra):
+    t = gpu_us["median"] * 1e-6
+    out = {
+        "name": name,
+        "kernel": kernel,
+        "algorithmic_bytes": int(alg_bytes),
+        "gpu_us": gpu_us,
+        "wall_us": wall_us,
+        "achieved_GBps": alg_bytes / t / 1e9,
+        "frac": alg_bytes / t / 1e9 / HBM_PEAK_GBPS,
+        "timing": "one C-ABI call end to end (index upload, launches, result download): HIP events on the stream; kernel-only times are in profiles/",
+    }
+    out.update(extra)
+    return out
+
+
+def gpu_random_rows(torch, dev, n_rows: int, seed: int) -> np.ndarray:
+    """n_rows x 16 x 1024 uint64 of fair random bits, generated on the device (numpy needs ~1 s per GB)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    t = torch.randint(-(2**63), 2**63 - 1, (n_rows, 16, 1024), dtype=torch.int64, device=dev, generator=g)
+    return t.cpu().numpy().view(np.uint64)
+
+
+def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
+    from featurebase_amd import lib as L
+
+    out = []
+    iters = args.secondary_iters
+    # ---- config 3: mixed containers, Union-of-64 then IntersectionCount; TopK shape; GroupBy 32 x 32 ----
+    if pre3 is not None:
+        rows, groups, filt, gen_s = pre3
+        n3 = groups.shape[0]
+        t0 = time.perf_counter()
+        batch = ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
+        F = ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
+        up_s = time.perf_counter() - t0
+        fidx = np.arange(n3)
+        nbytes = rows.bytes + filt.bytes
+        ncont = len(rows.key) + len(filt.key)
+        cpu3 = None
+        got3 = ctx.union_n_intersection_count(batch, groups, F, fidx)
+        mat3 = ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx, per_shard=True)[1]
+        topn3 = ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1), per_shard=True)[1]
+        if want_cpu:
+            from oracle import pybsi as PB
+            from oracle import pyoracle as O
+
+            d0 = rows.descs()
+            pay = rows.payload()
+
+            def ocont(d, buf):
+                p = buf[int(d["off"]):]
+                if d["type"] == 1:
+                    return O.OContainer.array(p[: 2 * int(d["len"])].view(np.uint16))
+                if d["type"] == 3:
+                    return O.OContainer.run(p[: 4 * int(d["len"])].view(np.uint16).reshape(-1, 2).tolist())
+                return O.OContainer.bitmap(p[:8192].view(np.uint64), int(d["n"]))
+
+            k = groups.shape[1]
+            bms = []
+            for r in range(k):  # shard 0's rows are rows 0..k-1
+                sel = d0[d0["row"] == r]
+                bms.append(O.OBitmap.from_containers([(int(d["key"]) & 15, ocont(d, pay)) for d in sel]))
+            fd, fp = filt.descs(), filt.payload()
+            fb = O.OBitmap.from_containers([(int(d["key"]) & 15, ocont(d, fp)) for d in fd[fd["row"] == 0]])
+            assert int(got3[0]) == bms[0].union(*bms[1:]).intersection_count(fb), "config 3: GPU and oracle disagree on shard 0"
+            e_mat = PB.groupby_counts(PB.Fragment(bms[:32]), PB.Fragment(bms[32:]), fb)
+            assert (mat3[0] == e_mat).all(), "config 3 GroupBy: GPU and oracle disagree on shard 0"
+            assert [int(x) for x in topn3[0, :, 0]] == [b.intersection_count(fb) for b in bms], "config 3 TopN: GPU and oracle disagree"
+            t_cpu = _cpu_time(lambda: bms[0].union(*bms[1:]).intersection_count(fb))
+            t_cpu_gb = _cpu_time(lambda: PB.groupby_counts(PB.Fragment(bms[:32]), PB.Fragment(bms[32:]), fb))
+            cpu3 = {"kind": "port", "cores": 1, "sample": "shard 0 (64 mixed rows + filter), oracle Bitmap.Union(63 others) + IntersectionCount, one host thread",
+                    "per_shard_s": t_cpu, "value": 16 * k / t_cpu, "unit": "set-ops/s", "groupby_32x32_per_shard_s": t_cpu_gb}
+        common = {"shards": n3, "containers": ncont, "host_gen_s": gen_s, "upload_s": up_s, "parity": "shard 0 checked against the oracle" if want_cpu else "unchecked (--no-cpu-baseline)"}
+        g, w = _timed_call(torch, stream, lambda: ctx.union_n_intersection_count(batch, groups, F, fidx), iters)
+        out.append(_entry("config3: Union-of-64 rows then IntersectionCount(filter), fused, mixed array/run/bitmap rows (rank-law density 0.001-0.5)",
+                          "k_fold_scatter<OR>", nbytes + 8 * n3, g, w, set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), cpu_baseline=cpu3, **common))
+        g, w = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1)), iters)
+        out.append(_entry("config3 rows, TopN/TopK shape: 64 rows x 1 filter row per shard", "k_rows_vs_filter", nbytes + 8 * 64 * n3, g, w,
+                          set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), **common))
+        g, w = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx), max(5, iters // 2))
+        out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows", "k_count_matrix_fused / k_densify_rows + k_count_matrix_mfma",
+                          nbytes + 8 * 1024 * n3, g, w, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6), **common))
+        g, w = _timed_call(torch, stream, lambda: ctx.union_n(batch, groups, L.SETOP_OPTIMIZE)[0].free(), max(5, iters // 2))
+        out.append(_entry("config3 rows, Union-of-64 materialised + optimize() re-encode", "k_fold_scatter<OR> + k_encode_*", nbytes, g, w, **common))
+        batch.free()
+        F.free()
+    # ---- config 4 (per-GPU slice of the 8192-shard configuration): 32 x 32 count matrix + filter, dense ----
+    n4, n_a, n_b = args.shards4, 32, 32
+    if n4:
+        t0 = time.perf_counter()
+        wa, wb, wf = gpu_random_rows(torch, dev, n4 * n_a, 41), gpu_random_rows(torch, dev, n4 * n_b, 42), gpu_random_rows(torch, dev, n4, 43)
+        gen_s = time.perf_counter() - t0
+        A, B, F = ctx.upload_dense(wa), ctx.upload_dense(wb), ctx.upload_dense(wf)
+        ra, rb, rf = np.arange(n4 * n_a).reshape(n4, n_a), np.arange(n4 * n_b).reshape(n4, n_b), np.arange(n4)
+        tot = ctx.count_matrix(A, ra, B, rb, F, rf)
+        exp = int(sum(np.bitwise_count(wa[s * n_a + 3] & wb[s * n_b + 5] & wf[s]).sum() for s in range(n4)))
+        assert int(tot[3, 5]) == exp, "config 4: GPU and numpy disagree"
+        cpu4 = None
+        if want_cpu:
+            from oracle import pybsi as PB
+            from oracle import pyoracle as O
+
+            mk = lambda w: O.OBitmap.from_containers([(sl, O.OContainer.bitmap(np.asarray(w).reshape(16, 1024)[sl])) for sl in range(16)])  # noqa: E731
+            fa, fb, ff = PB.Fragment([mk(wa[i]) for i in range(n_a)]), PB.Fragment([mk(wb[j]) for j in range(n_b)]), mk(wf[0])
+            ps0 = ctx.count_matrix(A, ra[:1], B, rb[:1], F, rf[:1])
+            assert (ps0 == PB.groupby_counts(fa, fb, ff)).all(), "config 4: GPU and oracle disagree on shard 0"
+            t_cpu = _cpu_time(lambda: PB.groupby_counts(fa, fb, ff))
+            cpu4 = {"kind": "port", "cores": 1, "sample": "shard 0 (32 x 32 dense rows + filter), oracle groupByIterator counts, one host thread",
+                    "per_shard_s": t_cpu, "value": 16 * n_a * n_b / t_cpu, "unit": "set-ops/s"}
+        nbytes = n4 * (n_a + n_b + 1) * 16 * 8192
+        g, w = _timed_call(torch, stream, lambda: ctx.count_matrix(A, ra, B, rb, F, rf), max(5, iters // 2))
+        out.append(_entry(f"config4 slice: {n4} shards x (32 x 32 rows + filter), dense bitmaps, IntersectionCount matrix", "k_count_matrix_mfma",
+                          nbytes + 8 * n_a * n_b * n4, g, w, shards=n4, host_gen_s=gen_s, set_ops_per_s=n4 * 16 * n_a * n_b / (g["median"] * 1e-6),
+                          pair_bits_scanned_GBps=n4 * n_a * n_b * 2 * 16 * 8192 / (g["median"] * 1e-6) / 1e9, cpu_baseline=cpu4,
+                          parity=f"cell (3,5) vs numpy over all shards" + ("; shard 0 vs the oracle" if want_cpu else "")))
+        for b in (A, B, F):
+            b.free()
+        del wa, wb, wf
+    # ---- config 5: BSI Range(> k) + Sum, 64 bit planes + exists + sign, 100 M columns = 96 shards ----
+    n5, depth = args.shards5, 64
+    if n5:
+        w = gpu_random_rows(torch, dev, n5 * (depth + 2), 51).reshape(n5, depth + 2, 16, 1024)
+        w[:, 0] = np.uint64(0xFFFFFFFFFFFFFFFF)  # exists: every column has a value
+        w[-1, 0, 6:] = 0  # last shard partial (100M columns = 95 full shards + 385 280 columns)
+        batch = ctx.upload_dense(w.reshape(-1))
+        base = np.arange(n5, dtype=np.uint32) * (depth + 2)
+        kk = 1 << 62
+        plane_bytes = n5 * 16 * 8192
+        rng_out, rng_cnt = ctx.bsi_range(batch, base, L.BSI_GT, depth, kk)
+        sums, cnts = ctx.bsi_sum(batch, base, depth, rng_out, np.arange(n5))
+        cpu5 = None
+        if want_cpu:
+            from oracle import pybsi as PB
+            from oracle import pyoracle as O
+
+            fr = PB.Fragment([O.OBitmap.from_containers([(sl, O.OContainer.bitmap(w[0, r, sl])) for sl in range(16)]) for r in range(depth + 2)])
+            e_rng = PB.bsi_range(fr, PB.GT, depth, kk)
+            assert int(rng_cnt[0]) == e_rng.count(), "config 5 Range: GPU and oracle disagree on shard 0"
+            e_sum, e_cnt = PB.bsi_sum(fr, e_rng, True)
+            assert (int(sums[0]), int(cnts[0])) == (int(e_sum), int(e_cnt)), "config 5 Sum: GPU and oracle disagree on shard 0"
+            t_sum = _cpu_time(lambda: PB.bsi_sum(fr, None, False))
+            t_rng = _cpu_time(lambda: PB.bsi_range(fr, PB.GT, depth, kk))
+            cpu5 = {"kind": "port", "cores": 1, "sample": "shard 0 (66 dense rows), oracle fragment.rangeOp(GT) / fragment.sum, one host thread",
+                    "range_per_shard_s": t_rng, "sum_per_shard_s": t_sum}
+        g, wl = _timed_call(torch, stream, lambda: ctx.bsi_range(batch, base, L.BSI_GT, depth, kk)[0].free(), iters)
+        out.append(_entry(f"config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense", "k_bsi_range", plane_bytes * (depth + 3), g, wl, shards=n5,
+                          cpu_baseline=cpu5, parity="shard 0 vs the oracle" if want_cpu else "unchecked"))
+        g, wl = _timed_call(torch, stream, lambda: ctx.bsi_sum(batch, base, depth, rng_out, np.arange(n5)), iters)
+        out.append(_entry("config5: BSI Sum(filter = the Range result)", "k_bsi_sum", plane_bytes * (depth + 3), g, wl, shards=n5))
+        rng_out.free()
+        batch.free()
+    return out
+
+
+def group_in_process(ctx_lib_path, wa, wb, expected, steps):
+    """N = 1 box: the in-library multi-device path with 2 members sharing device 0 (correctness of
+    the G > 1 code path + its per-query latency; not a scaling number)."""
+    from featurebase_amd import lib as L
+    from featurebase_amd.roaring import Group
+
+    grp = Group([0, 0])
+    n = wa.shape[0]
+    plans, keep = [], []
+    for m, c in enumerate(grp.members):
+        A, B = c.upload_dense(np.ascontiguousarray(wa[m::2])), c.upload_dense(np.ascontiguousarray(wb[m::2]))
+        keep += [A, B]
+        plans.append(c.plan(A, np.arange(len(range(m, n, 2))), B, np.arange(len(range(m, n, 2)))))
+    res = {"members": 2, "devices": [0, 0], "note": "both members share device 0: exercises the G > 1 path, not a scaling measurement", "modes": {}}
+    for name, mode in (("host", L.REDUCE_HOST), ("peer", L.REDUCE_PEER)):
+        grp.set_reduce(mode)
+        for _ in range(5):
+            tot = grp.plan_intersection_count_total(plans)
+        assert tot == expected, (name, tot, expected)
+        lat = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            tot = grp.plan_intersection_count_total(plans)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        assert tot == expected
+        res["modes"][name] = {"latency_ms": dist_of(lat), "total_matches_numpy": True}
+    for p in plans:
+        p.free()
+    for b in keep:
+        b.free()
+    grp.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shards", type=int, default=SHARDS_PER_GPU, help="shards per GPU")
+    ap.add_argument("--repeats", type=int, default=50, help="additional timed regions of --steps steps (distribution of the step time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 3, 4, 5 (N = 1 only anyway)")
+    ap.add_argument("--shards3", type=int, default=256)
+    ap.add_argument("--shards4", type=int, default=1024)
+    ap.add_argument("--shards5", type=int, default=96)
+    ap.add_argument("--secondary-iters", type=int, default=20)
     ap.add_argument("--cold-sets", type=int, default=4, help="distinct resident data sets cycled for the L3-cold roofline (1 = skip)")
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    n_gpus = max(world, 1)
-    # one process per GPU.  (FBK_BENCH_BACKEND=gloo lets the N > 1 code path be smoke-tested on
-    # a single-GPU box: every rank then shares device 0 and the collectives go through gloo.)
+    world = int(world_env or "1")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line whose n_gpus differs from what was asked for")
+    n_gpus = world
+
+    # config 3's rows are generated first, in forked worker processes, BEFORE this process touches the
+    # HIP runtime (a fork afterwards would be unsafe)
+    pre3 = None
+    if n_gpus == 1 and not args.no_secondary and args.shards3:
+        import datagen as D0
+
+        t0 = time.perf_counter()
+        r3, g3, f3 = D0.config3_flat(args.shards3, mp="fork")
+        pre3 = (r3, g3, f3, time.perf_counter() - t0)
+
+    import torch  # (first: one HIP runtime per process, see featurebase_amd/lib.py)
+
+    # one process per GPU.  (FBK_BENCH_BACKEND=gloo: fewer devices than ranks, see self_launch.)
     backend = os.environ.get("FBK_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    n_dev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % n_dev if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     from featurebase_amd import dist as fdist
@@ -147,7 +429,7 @@ def main():
         import torch.distributed as dist
 
         fdist.init(backend, dev)  # backend "nccl" IS RCCL on ROCm
-
+        assert dist.get_world_size() == n_gpus
     import datagen as D
     from featurebase_amd import lib as L
     from featurebase_amd.roaring import Context
@@ -186,21 +468,25 @@ def main():
         if n_gpus > 1:
             dist.barrier()
 
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step()
-        red.flush()
+    def timed_region(k):
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(k):
             step()
         reduced = red.flush()  # the tail bucket + every outstanding collective: inside the timed region
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        return time.perf_counter() - t0, reduced
+
+    extra = {}
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        red.flush()
+        dt, reduced = timed_region(args.steps)  # THE timed region: exactly --steps steps
 
         # parity spot check of the timed result (numpy popcount of this rank's shards)
         local_expected = int(np.bitwise_count(wa & wb).sum())
@@ -210,9 +496,72 @@ def main():
         ge = torch.tensor([local_expected], dtype=torch.int64, device=dev)
         if n_gpus > 1:
             dist.all_reduce(ge)
+        global_expected = int(ge.item())
         vals = torch.cat([b for b in reduced]).cpu().numpy()
         vals = vals[vals != 0]
-        assert vals.size > 0 and (vals == int(ge.item())).all(), "reduced totals differ from the sum of the per-shard counts"
+        assert vals.size > 0 and (vals == global_expected).all(), "reduced totals differ from the sum of the per-shard counts"
+
+        # ---- distribution: the same timed region `repeats` more times (median / p10 / p90 of the step time)
+        rep = []
+        for _ in range(args.repeats):
+            d, _r = timed_region(args.steps)
+            if n_gpus > 1:
+                t = torch.tensor([d], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d = float(t.item())
+            rep.append(d / args.steps * 1e3)
+
+        # ---- N > 1: what ONE query pays.  (a) a collective per step, pipelined on the device;
+        # (b) the same with the total read back by the host after every step (per-query latency);
+        # (c) "copy the partials to the host and add": D2H of each rank's partial + a gloo all-reduce
+        if n_gpus > 1:
+            lat_steps = min(args.steps, 200)
+
+            def step_collective():
+                plan.intersection_count_total(total.data_ptr())
+                dist.all_reduce(total)
+
+            for _ in range(5):
+                step_collective()
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(lat_steps):
+                step_collective()
+            torch.cuda.synchronize()
+            barrier()
+            pipelined = (time.perf_counter() - t0) / lat_steps * 1e3
+            assert int(total.item()) == global_expected
+            lat = []
+            for _ in range(lat_steps):
+                t0 = time.perf_counter()
+                step_collective()
+                v = int(total.item())
+                lat.append((time.perf_counter() - t0) * 1e3)
+            assert v == global_expected
+            host_lat = None
+            try:
+                cpu_group = dist.new_group(backend="gloo")
+                pinned = torch.zeros(1, dtype=torch.int64).pin_memory()
+                hl = []
+                for _ in range(lat_steps):
+                    t0 = time.perf_counter()
+                    plan.intersection_count_total(total.data_ptr())
+                    pinned.copy_(total, non_blocking=True)
+                    torch.cuda.synchronize()
+                    dist.all_reduce(pinned, group=cpu_group)
+                    hl.append((time.perf_counter() - t0) * 1e3)
+                assert int(pinned.item()) == global_expected
+                host_lat = dist_of(hl)
+            except Exception as e:  # noqa: BLE001
+                host_lat = {"error": str(e)}
+            extra["per_query"] = {
+                "collective_per_step_pipelined_ms_per_step": pipelined,
+                "collective_per_step_set_ops_per_s": n_gpus * n * 16 / (pipelined * 1e-3),
+                "collective_per_step_host_readback_latency_ms": dist_of(lat),
+                "host_add_latency_ms": host_lat,
+                "note": f"value/ms_per_step reduce {REDUCE_BUCKET} steps per collective (throughput mode); these are the per-query costs: one all-reduce per step",
+            }
 
         # ---- roofline of the dominant kernel: HIP events around back-to-back launches
         # of k_icount_dense alone, on the stream it is launched on
@@ -222,24 +571,28 @@ def main():
         for _ in range(5):
             kernel_step()
         torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(kiters):
-            kernel_step()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        k_ms = e0.elapsed_time(e1) / kiters
+        k_samples = []
+        for _ in range(max(10, min(args.repeats, 50))):
+            e0.record(stream)
+            for _ in range(kiters):
+                kernel_step()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            k_samples.append(e0.elapsed_time(e1) / kiters)
+        k_dist = dist_of(k_samples)
+        k_ms = k_dist["median"]
         alg_bytes = 2 * n * 16 * 8192 + n * 8  # both operands read once + one u64 count per shard
         # ---- the same kernel with the Infinity Cache taken out of the picture: the 256 MiB
         # working set of configs[1] is exactly the size of the 256 MiB L3, so cycle over
         # several distinct resident data sets (cold_sets x 256 MiB) between launches
         cold = None
         if args.cold_sets > 1:
-            extra = []
+            xs = []
             for i in range(1, args.cold_sets):
                 xa = ctx.upload_dense(D.dense_rows(n, 0.5, 5000 + 2 * i + 100 * rank))
                 xb = ctx.upload_dense(D.dense_rows(n, 0.5, 5001 + 2 * i + 100 * rank))
-                extra.append((xa, xb, ctx.plan(xa, rows, xb, rows)))
-            plans = [plan] + [e[2] for e in extra]
+                xs.append((xa, xb, ctx.plan(xa, rows, xb, rows)))
+            plans = [plan] + [e[2] for e in xs]
             for i in range(2 * len(plans)):
                 plans[i % len(plans)].intersection_count()
             torch.cuda.synchronize()
@@ -258,7 +611,7 @@ def main():
                 "frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "kernel_us": c_ms * 1e3,
             }
-            for xa, xb, pl in extra:
+            for xa, xb, pl in xs:
                 pl.free()
                 xa.free()
                 xb.free()
@@ -277,11 +630,38 @@ def main():
         torch.cuda.synchronize()
         assert int(total.item()) == local_expected
 
+        secondary = None
+        if n_gpus == 1 and not args.no_secondary:
+            t_s0 = time.perf_counter()
+            secondary = secondary_configs(torch, dev, ctx, stream, pre3, args, not args.no_cpu_baseline)
+            extra["secondary_wall_s"] = time.perf_counter() - t_s0
+
     # max over ranks
     if n_gpus > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- the in-library multi-device path (one process, fbk_group_*): rank 0 runs it in a child process
+    # over the same devices while the other ranks wait at the barrier below
+    group_api = None
+    if n_gpus > 1 and rank == 0:
+        devs = ",".join(str(r if backend == "nccl" else r % n_dev) for r in range(n_gpus))
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK")}
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "group_bench.py"), "--devices", devs, "--shards", str(n), "--steps", str(min(args.steps, 200))],
+                               capture_output=True, text=True, timeout=300, env=env)
+            line = [x for x in p.stdout.splitlines() if x.startswith("{")]
+            group_api = json.loads(line[-1]) if line else {"error": (p.stderr or "no output")[-400:]}
+        except Exception as e:  # noqa: BLE001
+            group_api = {"error": str(e)}
+    elif n_gpus == 1:
+        try:
+            group_api = group_in_process(None, wa, wb, local_expected, 50)
+        except Exception as e:  # noqa: BLE001
+            group_api = {"error": str(e)}
+    if n_gpus > 1:
+        dist.barrier()
 
     if rank == 0:
         set_ops = n_gpus * n * 16 * args.steps
@@ -304,9 +684,13 @@ def main():
                 "shards_per_gpu": n,
                 "containers_per_gpu": 2 * n * 16,
                 "op": "Count(Intersect(Row,Row)) as IntersectionCount + per-node sum"
-                + (f" + RCCL all-reduce of the partial totals ({REDUCE_BUCKET} steps per collective, async)" if n_gpus > 1 else ""),
+                + (f" + {'RCCL' if backend == 'nccl' else backend} all-reduce of the partial totals ({REDUCE_BUCKET} steps per collective, async)" if n_gpus > 1 else ""),
                 "parallelism": f"shards/{n_gpus}gpu",
+                "backend": (("rccl" if backend == "nccl" else backend) if n_gpus > 1 else None),
+                "ranks": n_gpus,
+                "oversubscribed": bool(n_gpus > 1 and backend != "nccl"),
             },
+            "ms_per_step_distribution": dict(dist_of(rep), note=f"{args.repeats} further timed regions of {args.steps} steps each") if rep else None,
             "bits_scanned_GBps": n_gpus * 2 * n * 16 * 8192 / (dt / args.steps) / 1e9,
             "roofline": {
                 "kernel": "k_icount_dense<16>",
@@ -316,7 +700,9 @@ def main():
                 "unit": "GB/s",
                 "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "traffic": None,
+                "traffic_source": None,
                 "kernel_us": k_ms * 1e3,
+                "kernel_us_distribution": {k: (v * 1e3 if k != "n" else v) for k, v in k_dist.items()},
                 "algorithmic_bytes": alg_bytes,
             },
             "materialized": {
@@ -329,11 +715,16 @@ def main():
             },
             "roofline_l3_cold": cold,
             "h2d_upload_s": t_upload,
+            "group_api": group_api,
         }
+        out.update(extra)
+        if secondary is not None:
+            out["secondary"] = secondary
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             try:
                 out["roofline"]["traffic"] = json.load(open(traffic_file)).get("k_icount_dense_hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc passes of an earlier run of this command, not measured in this run)"
             except Exception:
                 pass
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -7,6 +7,7 @@
 #include <hipcub/hipcub.hpp>  // device radix sort / unique for fbk_bsi_distinct (plumbing, not the hot path)
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -29,12 +30,29 @@ using fbk::u64;
 
 namespace {
 
+// Error reporting.  Every failing call leaves its message in TWO places: a thread-local string
+// (what fbk_last_error(NULL) returns: the only place for failures that have no context, e.g.
+// fbk_open) and the context the call was made on (fbk_last_error_r / fbk_last_error(ctx)).  The
+// per-context copy is what a cgo caller must read: a goroutine may be moved to another OS thread
+// between the failing call and the call that fetches the message, so thread-local state alone is
+// not reliable there.
 thread_local std::string g_err = "";
+thread_local fbk_ctx* g_scope_ctx = nullptr;  // context of the API call running on this thread
+void ctx_record_error(fbk_ctx* ctx, int32_t code, const std::string& msg);  // defined after fbk_ctx
 
 int32_t fail(int32_t code, const std::string& msg) {
   g_err = msg;
+  if (g_scope_ctx) ctx_record_error(g_scope_ctx, code, msg);
   return code;
 }
+
+// first statement of every entry point that takes a context
+struct ApiScope {
+  fbk_ctx* prev;
+  explicit ApiScope(fbk_ctx* c) : prev(g_scope_ctx) { g_scope_ctx = c; }
+  ~ApiScope() { g_scope_ctx = prev; }
+};
+#define FBK_ENTER(ctx) ApiScope api_scope_(ctx)
 
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
@@ -50,11 +68,37 @@ inline uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
 
 }  // namespace
 
+// Tuning / test knobs.  Read from the environment ONCE, in fbk_open (FBK_<NAME>), and changed
+// afterwards only through fbk_set_option: no entry point calls getenv.
+struct FbkOptions {
+  int64_t dense_spb = 16;                // slots per block of k_icount_dense: 1|2|4|8|16
+  int64_t fold_register = 0;             // 1: register-accumulating fold kernel for every op (A/B runs)
+  int64_t matrix_valu = 0;               // 1: vector-ALU count-matrix kernel instead of the matrix cores (A/B runs)
+  int64_t matrix_spb = 0;                // slots per block of the dense count matrix; 0 = chosen per launch
+  int64_t matrix_pass_kb = 1 << 20;      // per-shard matrices are produced in passes of at most this many KiB
+  int64_t matrix_densify = -1;           // encoded rows: 1 densify + dense kernel, 0 generic pair kernel, -1 cost model
+  int64_t matrix_fused = -1;             // encoded rows: 1 decode inside the matrix-core kernel, 0 never, -1 cost model
+  int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
+  int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
+  int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
+};
+
 struct fbk_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::mutex mu;
+  FbkOptions opt;
+  // last failing call on this context (fbk_last_error_r): guarded by err_mu, NOT by mu, so that
+  // a failure recorded before / after the call took the context lock never deadlocks
+  std::mutex err_mu;
+  std::string err_msg;
+  int32_t err_code = 0;
+  uint64_t err_seq = 0;
+  // fbk_ctx_fork: a child context has its own stream, lock, pool and staging (so that concurrent
+  // callers overlap on the device) and shares the fragment cache of the root context
+  fbk_ctx* root = nullptr;  // nullptr: this IS a root context
+  std::atomic<int> children{0};
   // Device-memory pool: every query needs a handful of temporaries (row index arrays, count
   // vectors, the output arena); hipMalloc / hipFree cost 50-200 us each and hipFree
   // synchronises the device, which on a 100-400 us query was most of the wall time
@@ -94,6 +138,13 @@ struct fbk_batch {
 };
 
 namespace {
+
+void ctx_record_error(fbk_ctx* ctx, int32_t code, const std::string& msg) {
+  std::lock_guard<std::mutex> g(ctx->err_mu);
+  ctx->err_msg = msg;
+  ctx->err_code = code;
+  ++ctx->err_seq;
+}
 
 uint64_t pool_bucket(uint64_t bytes) {
   if (bytes <= 256) return 256;
@@ -158,6 +209,21 @@ void ctx_free(fbk_ctx* ctx, void* p) {
   (void)hipFree(p);
 }
 
+// hand a live block from one context's book-keeping to another's (same device)
+void pool_rehome(fbk_ctx* from, fbk_ctx* to, void* p) {
+  if (!p || from == to) return;
+  uint64_t bucket = 0;
+  {
+    std::lock_guard<std::mutex> g(from->pool_mu);
+    auto it = from->pool_live.find(p);
+    if (it == from->pool_live.end()) return;
+    bucket = it->second;
+    from->pool_live.erase(it);
+  }
+  std::lock_guard<std::mutex> g(to->pool_mu);
+  to->pool_live[p] = bucket;
+}
+
 void pool_release_all(fbk_ctx* ctx) {
   std::lock_guard<std::mutex> g(ctx->pool_mu);
   for (auto& kv : ctx->pool_free_lists)
@@ -185,6 +251,7 @@ struct DevBuf {
 };
 
 int32_t set_device(fbk_ctx* ctx) {
+  g_scope_ctx = ctx;  // entry points that take the context from a batch / plan handle (ApiScope restores the caller's)
   HIP_TRY(hipSetDevice(ctx->device));
   ctx->h_stage_used = 0;
   return FBK_OK;
@@ -302,7 +369,37 @@ extern "C" {
 
 int32_t fbk_abi_version(void) { return FBK_ABI_VERSION; }
 
-const char* fbk_last_error(fbk_ctx*) { return g_err.c_str(); }
+const char* fbk_last_error(fbk_ctx* ctx) {
+  if (!ctx) return g_err.c_str();
+  // the context's last message, copied under its lock into this thread's buffer (the pointer stays
+  // valid until this thread's next call into the library)
+  thread_local std::string copy;
+  {
+    std::lock_guard<std::mutex> g(ctx->err_mu);
+    copy = ctx->err_msg;
+  }
+  return copy.c_str();
+}
+
+int32_t fbk_last_error_r(fbk_ctx* ctx, char* buf, uint64_t cap, int32_t* out_code) {
+  FBK_ENTER(ctx);
+  std::string msg;
+  int32_t code = 0;
+  if (ctx) {
+    std::lock_guard<std::mutex> g(ctx->err_mu);
+    msg = ctx->err_msg;
+    code = ctx->err_code;
+  } else {
+    msg = g_err;
+  }
+  if (out_code) *out_code = code;
+  if (buf && cap) {
+    const uint64_t n = std::min<uint64_t>(cap - 1, msg.size());
+    std::memcpy(buf, msg.data(), n);
+    buf[n] = 0;
+  }
+  return FBK_OK;
+}
 
 int32_t fbk_device_count(int32_t* out_n) {
   if (!out_n) return fail(FBK_E_INVALID, "out_n is NULL");
@@ -317,9 +414,49 @@ int32_t fbk_device_count(int32_t* out_n) {
   return FBK_OK;
 }
 
-int32_t fbk_open(int32_t device, uint32_t /*flags*/, fbk_ctx** out_ctx) {
-  if (!out_ctx) return fail(FBK_E_INVALID, "out_ctx is NULL");
-  *out_ctx = nullptr;
+}  // extern "C"
+
+namespace {
+
+struct OptionDesc {
+  const char* name;  // fbk_set_option name; the environment variable is FBK_<NAME in upper case>
+  int64_t FbkOptions::*field;
+  int64_t lo, hi;
+};
+const OptionDesc kOptions[] = {
+    {"dense_spb", &FbkOptions::dense_spb, 1, 16},
+    {"fold_register", &FbkOptions::fold_register, 0, 1},
+    {"matrix_valu", &FbkOptions::matrix_valu, 0, 1},
+    {"matrix_spb", &FbkOptions::matrix_spb, 0, 16},
+    {"matrix_pass_kb", &FbkOptions::matrix_pass_kb, 1, int64_t(1) << 40},
+    {"matrix_densify", &FbkOptions::matrix_densify, -1, 1},
+    {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
+    {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
+    {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
+    {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
+};
+
+int32_t option_set(FbkOptions& o, const char* name, int64_t v) {
+  for (const OptionDesc& d : kOptions)
+    if (std::strcmp(d.name, name) == 0) {
+      if (v < d.lo || v > d.hi) return fail(FBK_E_INVALID, std::string("option ") + name + ": value out of range");
+      if ((d.field == &FbkOptions::dense_spb || (d.field == &FbkOptions::matrix_spb && v)) && (v & (v - 1)))
+        return fail(FBK_E_INVALID, std::string("option ") + name + ": must be a power of two");
+      o.*(d.field) = v;
+      return FBK_OK;
+    }
+  return fail(FBK_E_INVALID, std::string("unknown option ") + name);
+}
+
+void options_from_env(FbkOptions& o) {
+  for (const OptionDesc& d : kOptions) {
+    std::string env = "FBK_";
+    for (const char* c = d.name; *c; ++c) env += char(std::toupper(*c));
+    if (const char* e = getenv(env.c_str())) (void)option_set(o, d.name, strtoll(e, nullptr, 10));
+  }
+}
+
+int32_t open_on_device(int32_t device, fbk_ctx* root, fbk_ctx** out_ctx) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -341,24 +478,77 @@ int32_t fbk_open(int32_t device, uint32_t /*flags*/, fbk_ctx** out_ctx) {
     return fail(FBK_E_HIP, std::string("stream create: ") + hipGetErrorString(e2));
   }
   ctx->stream = ctx->own_stream;
-  if (const char* cap = getenv("FBK_POOL_MAX_BYTES")) ctx->pool_cap_bytes = strtoull(cap, nullptr, 10);
+  if (root) {
+    ctx->root = root;
+    ctx->opt = root->opt;
+    ctx->pool_cap_bytes = root->pool_cap_bytes;
+    root->children.fetch_add(1);
+  } else {
+    // the only place the environment is read
+    if (const char* cap = getenv("FBK_POOL_MAX_BYTES")) ctx->pool_cap_bytes = strtoull(cap, nullptr, 10);
+    options_from_env(ctx->opt);
+  }
   *out_ctx = ctx;
   return FBK_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int32_t fbk_open(int32_t device, uint32_t /*flags*/, fbk_ctx** out_ctx) {
+  if (!out_ctx) return fail(FBK_E_INVALID, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  return open_on_device(device, nullptr, out_ctx);
+}
+
+int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child) {
+  FBK_ENTER(ctx);
+  if (!ctx || !out_child) return fail(FBK_E_INVALID, "NULL argument");
+  *out_child = nullptr;
+  fbk_ctx* root = ctx->root ? ctx->root : ctx;
+  return open_on_device(root->device, root, out_child);
+}
+
 int32_t fbk_close(fbk_ctx* ctx) {
+  FBK_ENTER(ctx);
   if (!ctx) return FBK_OK;
+  if (!ctx->root && ctx->children.load() != 0) {
+    FBK_ENTER(ctx);
+    return fail(FBK_E_INVALID, "fbk_close: forked contexts of this context are still open");
+  }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  cache_release_all(ctx);
+  if (!ctx->root) cache_release_all(ctx);
   pool_release_all(ctx);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  if (ctx->root) ctx->root->children.fetch_sub(1);
   delete ctx;
   return FBK_OK;
 }
 
+int32_t fbk_set_option(fbk_ctx* ctx, const char* name, int64_t value) {
+  FBK_ENTER(ctx);
+  if (!ctx || !name) return fail(FBK_E_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  return option_set(ctx->opt, name, value);
+}
+
+int32_t fbk_get_option(fbk_ctx* ctx, const char* name, int64_t* out_value) {
+  FBK_ENTER(ctx);
+  if (!ctx || !name || !out_value) return fail(FBK_E_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  for (const OptionDesc& d : kOptions)
+    if (std::strcmp(d.name, name) == 0) {
+      *out_value = ctx->opt.*(d.field);
+      return FBK_OK;
+    }
+  return fail(FBK_E_INVALID, std::string("unknown option ") + name);
+}
+
 int32_t fbk_set_stream(fbk_ctx* ctx, void* hip_stream) {
+  FBK_ENTER(ctx);
   if (!ctx) return fail(FBK_E_INVALID, "ctx is NULL");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
@@ -369,6 +559,7 @@ int32_t fbk_set_stream(fbk_ctx* ctx, void* hip_stream) {
 }
 
 int32_t fbk_synchronize(fbk_ctx* ctx) {
+  FBK_ENTER(ctx);
   if (!ctx) return fail(FBK_E_INVALID, "ctx is NULL");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
@@ -377,6 +568,7 @@ int32_t fbk_synchronize(fbk_ctx* ctx) {
 }
 
 int32_t fbk_batch_free(fbk_ctx* ctx, fbk_batch* b) {
+  FBK_ENTER(ctx);
   if (!b) return FBK_OK;
   if (!ctx) ctx = b->ctx;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -436,6 +628,7 @@ static int32_t validate_container(const fbk_container_desc& d, const uint8_t* pa
 
 int32_t fbk_batch_upload(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t n_desc, uint32_t n_rows,
                          const void* payload, uint64_t payload_len, fbk_batch** out_batch) {
+  FBK_ENTER(ctx);
   if (!ctx || !out_batch || (n_desc && (!descs || !payload))) return fail(FBK_E_INVALID, "NULL argument");
   *out_batch = nullptr;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -491,7 +684,9 @@ int32_t fbk_batch_upload(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t
     hs.off = off;
     hs.len = d.len;
     hs.tn = fbk::make_tn(d.type, d.n < 0 ? 0x00FFFFFFu : uint32_t(d.n));
-    if (d.n < 0) need_recount = true;
+    // the caller's n is not trusted for bitmaps and runs (every `n == 65536` shortcut and every
+    // buffer sized from a cardinality depends on it): recounted on the device, as bitmapRepair does
+    if (d.n < 0 || d.type != FBK_TYPE_ARRAY) need_recount = true;
     if (d.type != FBK_TYPE_BITMAP || off != s * 8192ull) dense = false;
     off += align16(nbytes[s]);
   }
@@ -555,6 +750,7 @@ int32_t fbk_batch_upload(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t
 }
 
 int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_rows, fbk_batch** out_batch) {
+  FBK_ENTER(ctx);
   if (!ctx || !out_batch || (n_rows && !words)) return fail(FBK_E_INVALID, "NULL argument");
   *out_batch = nullptr;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -602,6 +798,7 @@ int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_r
 
 int32_t fbk_batch_info(fbk_ctx* ctx, const fbk_batch* batch, uint32_t* n_rows, uint64_t* n_containers,
                        uint64_t* payload_bytes) {
+  FBK_ENTER(ctx);
   if (!batch) return fail(FBK_E_INVALID, "batch is NULL");
   fbk_batch* b = const_cast<fbk_batch*>(batch);
   if (!ctx) ctx = b->ctx;
@@ -623,20 +820,25 @@ int32_t fbk_batch_info(fbk_ctx* ctx, const fbk_batch* batch, uint32_t* n_rows, u
 
 int32_t fbk_batch_download(fbk_ctx* ctx, const fbk_batch* batch, fbk_container_desc* descs_out, uint64_t descs_cap,
                            void* payload_out, uint64_t payload_cap) {
+  FBK_ENTER(ctx);
   if (!batch) return fail(FBK_E_INVALID, "batch is NULL");
   fbk_batch* b = const_cast<fbk_batch*>(batch);
   if (!ctx) ctx = b->ctx;
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   if (int32_t rc = refresh_slots(b)) return rc;
+  // Descriptors come from the host copy of the slot table; the payloads are packed on the device
+  // (k_wire_copy: one wavefront per container, arena -> a contiguous image in download order) and
+  // cross the bus in ONE device-to-host copy.  (One hipMemcpyAsync per container — 16 384 of them
+  // for the result of a 1024-shard set-op — was all launch overhead.)
   uint64_t nc = 0, pb = 0;
-  uint8_t* out = static_cast<uint8_t*>(payload_out);
+  std::vector<fbk::WireDesc> wd;
   for (uint64_t s = 0; s < b->h_slots.size(); ++s) {
     const Slot& hs = b->h_slots[s];
     const uint32_t t = fbk::slot_type(hs);
     if (t == fbk::kTypeNil || fbk::slot_n(hs) == 0) continue;
     const uint64_t bytes = t == fbk::kTypeArray ? uint64_t(hs.len) * 2 : t == fbk::kTypeRun ? uint64_t(hs.len) * 4 : 8192ull;
-    if (nc >= descs_cap || pb + bytes > payload_cap || !descs_out || !out)
+    if (nc >= descs_cap || pb + bytes > payload_cap || !descs_out || !payload_out)
       return fail(FBK_E_CAPACITY, "download buffers too small (use fbk_batch_info)");
     fbk_container_desc& d = descs_out[nc];
     std::memset(&d, 0, sizeof(d));
@@ -646,15 +848,25 @@ int32_t fbk_batch_download(fbk_ctx* ctx, const fbk_batch* batch, fbk_container_d
     d.len = hs.len;
     d.n = int32_t(fbk::slot_n(hs));
     d.type = uint8_t(t);
-    HIP_TRY(hipMemcpyAsync(out + pb, b->d_arena + hs.off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    wd.push_back(fbk::WireDesc{hs.off, pb, uint32_t(bytes), 0u});
     ++nc;
     pb += bytes;
   }
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (nc == 0) return FBK_OK;
+  DevBuf dpack, ddesc;
+  HIP_TRY(dpack.alloc(ctx, std::max<uint64_t>(pb, 16)));
+  HIP_TRY(ddesc.alloc(ctx, nc * sizeof(fbk::WireDesc)));
+  HIP_TRY(hipMemcpyAsync(ddesc.p, wd.data(), nc * sizeof(fbk::WireDesc), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(fbk::k_wire_copy, dim3(uint32_t((nc + 3) / 4)), dim3(256), 0, ctx->stream, b->d_arena, dpack.as<uint8_t>(),
+                     ddesc.as<fbk::WireDesc>(), nc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(payload_out, dpack.p, pb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // (also keeps `wd` alive until the descriptor copy has been made)
   return FBK_OK;
 }
 
 int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n, uint64_t* out_counts) {
+  FBK_ENTER(ctx);
   if (!batch || (n && (!rows || !out_counts))) return fail(FBK_E_INVALID, "NULL argument");
   fbk_batch* b = const_cast<fbk_batch*>(batch);
   if (!ctx) ctx = b->ctx;
@@ -676,6 +888,7 @@ int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, ui
 
 int32_t fbk_count_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n, uint64_t start,
                         uint64_t end, uint64_t* out_counts) {
+  FBK_ENTER(ctx);
   if (!batch || (n && (!rows || !out_counts))) return fail(FBK_E_INVALID, "NULL argument");
   const uint64_t width = uint64_t(fbk::kSlots) << 16;
   if (start > end || end > width) return fail(FBK_E_INVALID, "count_range: need 0 <= start <= end <= 2^20");
@@ -808,11 +1021,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
   if (p->a->dense && p->b->dense) {
     // all-bitmap rows: pure streaming kernel.  slots-per-block 16 = one block per row
     // pair, plain store; smaller groups = more blocks + one atomicAdd per block.
-    static const int spb = [] {
-      const char* e = getenv("FBK_DENSE_SPB");
-      int v = e ? atoi(e) : 16;
-      return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 16;
-    }();
+    const int spb = int(ctx->opt.dense_spb);
     if (spb != 16) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
 #define FBK_LAUNCH_DENSE(S)                                                                                       \
   hipLaunchKernelGGL(fbk::k_icount_dense<S>, dim3(np*(16 / S)), dim3(256), 0, ctx->stream, p->a->d_arena,         \
@@ -840,6 +1049,10 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 int32_t plan_setop_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, int32_t op, bool want_runs) {
   const uint64_t n_slots = p->n_pairs * fbk::kSlots;
   if (!p->out) {
+    // the output keys are derived from the inputs' host slot tables: refresh them if an input is
+    // itself the output of an asynchronous operation
+    if (int32_t rc = refresh_slots(const_cast<fbk_batch*>(p->a))) return rc;
+    if (int32_t rc = refresh_slots(const_cast<fbk_batch*>(p->b))) return rc;
     fbk_batch* o = new (std::nothrow) fbk_batch();
     if (!o) return fail(FBK_E_NOMEM, "host allocation failed");
     o->ctx = ctx;
@@ -887,6 +1100,7 @@ extern "C" {
 
 int32_t fbk_plan_create(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
                         const uint32_t* rows_b, uint64_t n_pairs, void* device_counts_or_null, fbk_plan** out_plan) {
+  FBK_ENTER(ctx);
   if (!ctx || !a || !b || !out_plan || (n_pairs && (!rows_a || !rows_b))) return fail(FBK_E_INVALID, "NULL argument");
   *out_plan = nullptr;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -895,6 +1109,7 @@ int32_t fbk_plan_create(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a
 }
 
 int32_t fbk_plan_free(fbk_ctx* ctx, fbk_plan* plan) {
+  FBK_ENTER(ctx);
   if (!plan) return FBK_OK;
   if (!ctx) ctx = plan->ctx;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -905,6 +1120,7 @@ int32_t fbk_plan_free(fbk_ctx* ctx, fbk_plan* plan) {
 }
 
 int32_t fbk_plan_intersection_count(fbk_ctx* ctx, fbk_plan* plan) {
+  FBK_ENTER(ctx);
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
@@ -912,6 +1128,7 @@ int32_t fbk_plan_intersection_count(fbk_ctx* ctx, fbk_plan* plan) {
 }
 
 int32_t fbk_plan_intersection_count_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null) {
+  FBK_ENTER(ctx);
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
@@ -920,6 +1137,7 @@ int32_t fbk_plan_intersection_count_total(fbk_ctx* ctx, fbk_plan* plan, void* de
 }
 
 int32_t fbk_plan_intersection_count_accumulate(fbk_ctx* ctx, fbk_plan* plan, void* device_accum) {
+  FBK_ENTER(ctx);
   if (!ctx || !plan || !device_accum) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
@@ -927,6 +1145,7 @@ int32_t fbk_plan_intersection_count_accumulate(fbk_ctx* ctx, fbk_plan* plan, voi
 }
 
 int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags) {
+  FBK_ENTER(ctx);
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   if (op < 0 || op > 3) return fail(FBK_E_INVALID, "unknown set operation");
   if (flags & ~FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "unknown flags");
@@ -938,6 +1157,7 @@ int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags)
 }
 
 int32_t fbk_plan_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null) {
+  FBK_ENTER(ctx);
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
@@ -948,6 +1168,7 @@ int32_t fbk_plan_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null)
 }
 
 int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64_t* out_total) {
+  FBK_ENTER(ctx);
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
@@ -959,6 +1180,7 @@ int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64
 }
 
 int32_t fbk_plan_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch) {
+  FBK_ENTER(ctx);
   if (!plan || !out_batch) return fail(FBK_E_INVALID, "NULL argument");
   (void)ctx;
   *out_batch = plan->out;
@@ -967,6 +1189,7 @@ int32_t fbk_plan_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch) {
 }
 
 int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch) {
+  FBK_ENTER(ctx);
   if (!plan || !out_batch) return fail(FBK_E_INVALID, "NULL argument");
   if (!ctx) ctx = plan->ctx;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -980,6 +1203,7 @@ int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_bat
 
 int32_t fbk_intersection_count(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
                                const uint32_t* rows_b, uint64_t n_pairs, uint64_t* out_counts) {
+  FBK_ENTER(ctx);
   if (!ctx || !a || !b || (n_pairs && (!rows_a || !rows_b || !out_counts))) return fail(FBK_E_INVALID, "NULL argument");
   if (n_pairs == 0) return FBK_OK;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -1001,6 +1225,7 @@ int32_t fbk_intersection_count(fbk_ctx* ctx, const fbk_batch* a, const uint32_t*
 int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
                   const uint32_t* rows_b, uint64_t n_pairs, uint32_t flags, fbk_batch** out_batch,
                   uint64_t* out_counts) {
+  FBK_ENTER(ctx);
   if (!ctx || !a || !b || !out_batch || (n_pairs && (!rows_a || !rows_b))) return fail(FBK_E_INVALID, "NULL argument");
   if (op < 0 || op > 3) return fail(FBK_E_INVALID, "unknown set operation");
   if (flags & ~FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "unknown flags");
@@ -1032,3 +1257,4 @@ int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* 
 #include "fbk_query_api.inc"
 #include "fbk_wire_api.inc"
 #include "fbk_cache_api.inc"
+#include "fbk_group_api.inc"

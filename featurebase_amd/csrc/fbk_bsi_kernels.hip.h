@@ -525,7 +525,7 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
 __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ rows,
                                                    uint32_t n_shards, uint32_t depth, const uint8_t* __restrict__ farena,
                                                    const uint32_t* __restrict__ frows, long long* __restrict__ out,
-                                                   u64* __restrict__ cursor) {
+                                                   u64 out_cap, u64* __restrict__ cursor) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t shard = blockIdx.x >> 4, slot = blockIdx.x & 15;
@@ -590,7 +590,10 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
         const u64 below = lane ? (ek & (~0ull >> (64 - lane))) : 0ull;
         // value *= -1 for negative columns (int64 wrap-around as in the reference, executor.go:2123)
         const long long val = ((sk >> lane) & 1ull) ? (long long)(0ull - v) : (long long)v;
-        out[basepos + before + __popcll(below)] = val;
+        // out was sized from the stored cardinalities of the exists row; the cursor still counts
+        // every value, so the host sees an overflow instead of a write past the buffer
+        const u64 at = basepos + before + __popcll(below);
+        if (at < out_cap) out[at] = val;
       }
       }
     }

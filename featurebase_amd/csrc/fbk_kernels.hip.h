@@ -282,6 +282,50 @@ __global__ void __launch_bounds__(256) k_recount(Slot* __restrict__ slots, const
   if (lane == 0) slots[wid].tn = make_tn(t, c);
 }
 
+// Upload-time check of containers that did not pass the host validator (serialised roaring /
+// RBF images are unpacked on the device and never parsed value by value on the host): arrays
+// must be strictly ascending, runs ordered and non-overlapping (roaring.go:53-58; the XOR-toggle
+// run decode and every `n == 65536` shortcut rely on it), and the header's cardinality is not
+// trusted — bitmaps and runs are recounted, as bitmapRepair does (roaring.go:4193-4206).  One wave
+// per slot; *bad receives bit 0 (array order) / bit 1 (run order).
+__global__ void __launch_bounds__(256) k_validate_recount(Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                                         uint64_t n_slots, uint32_t* __restrict__ bad) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= n_slots) return;
+  const Slot s = slots[wid];
+  const uint32_t t = slot_type(s);
+  if (t == kTypeNil) return;
+  const uint8_t* p = arena + s.off;
+  uint32_t c = 0, err = 0;
+  if (t == kTypeBitmap) {
+    u64 w[kWordsPerLane];
+    frag_load_bitmap(p, lane, w);
+    c = frag_popcount(w);
+  } else if (t == kTypeArray) {
+    const uint16_t* q = reinterpret_cast<const uint16_t*>(p);
+    for (uint32_t i = lane; i < s.len; i += kWave) {
+      if (i + 1 < s.len && q[i + 1] <= q[i]) err = 1u;
+      ++c;
+    }
+  } else {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    for (uint32_t i = lane; i < s.len; i += kWave) {
+      const uint32_t iv = q[i], st = iv & 0xFFFFu, la = iv >> 16;
+      if (la < st) err = 2u;
+      else c += la - st + 1u;
+      if (i + 1 < s.len && (q[i + 1] & 0xFFFFu) <= la) err = 2u;
+    }
+  }
+  c = wave_reduce_add(c);
+  const u64 anyerr = __ballot(err != 0);
+  if (anyerr) {
+    if (err) atomicOr(bad, err);
+    return;
+  }
+  if (lane == 0) slots[wid].tn = make_tn(t, c);
+}
+
 // Bits of each row in [start, end) (Bitmap.CountRange, roaring.go:573-615): one wave per
 // (row, slot).  Containers wholly inside the range contribute their stored n (roaring.go:603),
 // the (at most two) boundary containers are loaded and masked (BitmapCountRange :3092,

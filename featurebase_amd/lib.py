@@ -40,6 +40,23 @@ class ContainerDesc(C.Structure):
     ]
 
 
+class MatrixArgs(C.Structure):
+    """Mirror of fbk_matrix_args (include/fbk.h): one group member's count-matrix arguments."""
+
+    _fields_ = [
+        ("a", C.c_void_p),
+        ("rows_a", C.c_void_p),
+        ("b", C.c_void_p),
+        ("rows_b", C.c_void_p),
+        ("filter", C.c_void_p),
+        ("rows_f", C.c_void_p),
+        ("n_shards", C.c_uint32),
+        ("pad", C.c_uint32),
+    ]
+
+
+REDUCE_HOST, REDUCE_PEER, REDUCE_RCCL = 0, 1, 2
+
 _vp, _u32p, _u64p, _i32p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
 _vpp = C.POINTER(C.c_void_p)
 
@@ -48,6 +65,10 @@ _vpp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "fbk_abi_version": (C.c_int32, []),
     "fbk_last_error": (C.c_char_p, [_vp]),
+    "fbk_last_error_r": (C.c_int32, [_vp, C.c_char_p, C.c_uint64, _i32p]),
+    "fbk_ctx_fork": (C.c_int32, [_vp, _vpp]),
+    "fbk_set_option": (C.c_int32, [_vp, C.c_char_p, C.c_int64]),
+    "fbk_get_option": (C.c_int32, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "fbk_device_count": (C.c_int32, [_i32p]),
     "fbk_open": (C.c_int32, [C.c_int32, C.c_uint32, _vpp]),
     "fbk_close": (C.c_int32, [_vp]),
@@ -97,6 +118,14 @@ SIGNATURES = {
     "fbk_bsi_add": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _vpp]),
     "fbk_bsi_range": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_uint32, C.c_int64, C.c_uint32, _vpp, _vp]),
     "fbk_bsi_range_between": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_uint32, _vpp, _vp]),
+    "fbk_group_open": (C.c_int32, [_i32p, C.c_uint32, C.c_uint32, _vpp]),
+    "fbk_group_close": (C.c_int32, [_vp]),
+    "fbk_group_size": (C.c_int32, [_vp, _u32p]),
+    "fbk_group_member": (C.c_int32, [_vp, C.c_uint32, _vpp]),
+    "fbk_group_set_reduce": (C.c_int32, [_vp, C.c_int32]),
+    "fbk_group_plan_intersection_count_total": (C.c_int32, [_vp, _vpp, _u64p]),
+    "fbk_group_count_matrix": (C.c_int32, [_vp, C.POINTER(MatrixArgs), C.c_uint32, C.c_uint32, _vp]),
+    "fbk_group_reduce_u64": (C.c_int32, [_vp, _vpp, C.c_uint64, _vp]),
 }
 
 BSI_EQ, BSI_NEQ, BSI_LT, BSI_LTE, BSI_GT, BSI_GTE = 1, 2, 3, 4, 5, 6

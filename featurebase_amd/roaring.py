@@ -176,16 +176,42 @@ class Plan:
 class Context:
     """One GPU.  Fails loudly when libfbk.so is missing or no gfx950 device is visible."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _handle: Optional[int] = None, _borrowed: bool = False):
         self.lib = L.load()
+        self.borrowed = _borrowed  # a group member: closed by the group
+        if _handle is not None:
+            self.h = C.c_void_p(_handle)
+            return
         h = C.c_void_p()
         L.check(self.lib.fbk_open(device, 0, C.byref(h)))
         self.h = h
 
     def close(self) -> None:
-        if self.h:
+        if self.h and not self.borrowed:
             L.check(self.lib.fbk_close(self.h))
-            self.h = C.c_void_p(None)
+        self.h = C.c_void_p(None)
+
+    def fork(self) -> "Context":
+        """A second context on the same device (own stream / lock / pool) for another calling
+        thread; shares the fragment cache with this one (fbk_ctx_fork)."""
+        h = C.c_void_p()
+        L.check(self.lib.fbk_ctx_fork(self.h, C.byref(h)))
+        return Context(_handle=h.value)
+
+    def set_option(self, name: str, value: int) -> None:
+        L.check(self.lib.fbk_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64()
+        L.check(self.lib.fbk_get_option(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def last_error(self) -> Tuple[int, str]:
+        """(status code, message) of the last failing call on THIS context (fbk_last_error_r)."""
+        buf = C.create_string_buffer(512)
+        code = C.c_int32()
+        L.check(self.lib.fbk_last_error_r(self.h, buf, 512, C.byref(code)))
+        return int(code.value), buf.value.decode()
 
     def set_stream(self, hip_stream: int) -> None:
         L.check(self.lib.fbk_set_stream(self.h, C.c_void_p(hip_stream or None)))
@@ -212,6 +238,20 @@ class Context:
         payload = b"".join(chunks) or b"\0"
         h = C.c_void_p()
         L.check(self.lib.fbk_batch_upload(self.h, descs, n_desc, len(rows), payload, off, C.byref(h)))
+        return Batch(self, h.value)
+
+    def upload_flat(self, descs: np.ndarray, payload: np.ndarray, n_rows: int) -> Batch:
+        """The flattened form directly: `descs` a structured array laid out as fbk_container_desc
+        (32 bytes per record), `payload` the bytes its offsets point into."""
+        d = np.ascontiguousarray(descs)
+        assert d.dtype.itemsize == C.sizeof(L.ContainerDesc)
+        pay = np.ascontiguousarray(payload).view(np.uint8).reshape(-1)
+        h = C.c_void_p()
+        L.check(
+            self.lib.fbk_batch_upload(
+                self.h, C.cast(d.ctypes.data, C.POINTER(L.ContainerDesc)), d.size, n_rows, pay.ctypes.data, pay.size, C.byref(h)
+            )
+        )
         return Batch(self, h.value)
 
     def upload_roaring(self, data: bytes) -> Tuple[Batch, np.ndarray]:
@@ -492,3 +532,67 @@ class Context:
             )
         )
         return Plan(self, h.value, int(ra.size))
+
+
+class Group:
+    """Several GPUs behind one process (fbk_group_*): member m owns the shards s with s % G == m;
+    partial counts are reduced inside the library (mapReduce + reduceFn, executor.go:6449-6533)."""
+
+    def __init__(self, devices: Sequence[int]):
+        self.lib = L.load()
+        dv = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        L.check(self.lib.fbk_group_open(dv, len(devices), 0, C.byref(h)))
+        self.h = h
+        self.members: List[Context] = []
+        for i in range(len(devices)):
+            m = C.c_void_p()
+            L.check(self.lib.fbk_group_member(self.h, i, C.byref(m)))
+            self.members.append(Context(_handle=m.value, _borrowed=True))
+
+    def __len__(self) -> int:
+        return len(self.members)
+
+    def set_reduce(self, mode: int) -> None:
+        L.check(self.lib.fbk_group_set_reduce(self.h, mode))
+
+    def plan_intersection_count_total(self, plans: Sequence[Optional[Plan]]) -> int:
+        arr = (C.c_void_p * len(self.members))(*[(p.h if p is not None else None) for p in plans])
+        tot = C.c_uint64()
+        L.check(self.lib.fbk_group_plan_intersection_count_total(self.h, arr, C.byref(tot)))
+        return int(tot.value)
+
+    def count_matrix(self, per_member: Sequence[Optional[dict]], n_a: int, n_b: int) -> np.ndarray:
+        """per_member[m]: None or dict(a=Batch, rows_a=[n_shards, n_a], b=Batch, rows_b=[n_shards, n_b],
+        filt=Batch|None, rows_f=[n_shards])."""
+        args = (L.MatrixArgs * len(self.members))()
+        keep = []
+        for m, pm in enumerate(per_member):
+            if pm is None:
+                continue
+            ra = np.ascontiguousarray(pm["rows_a"], dtype=np.uint32)
+            rb = np.ascontiguousarray(pm["rows_b"], dtype=np.uint32)
+            assert ra.shape[1] == n_a and rb.shape[1] == n_b and ra.shape[0] == rb.shape[0]
+            rf = np.ascontiguousarray(pm["rows_f"], dtype=np.uint32) if pm.get("filt") is not None else None
+            keep += [ra, rb, rf]
+            args[m].a, args[m].rows_a = pm["a"].h, ra.ctypes.data
+            args[m].b, args[m].rows_b = pm["b"].h, rb.ctypes.data
+            args[m].filter = pm["filt"].h if pm.get("filt") is not None else None
+            args[m].rows_f = rf.ctypes.data if rf is not None else None
+            args[m].n_shards = ra.shape[0]
+        tot = np.zeros((n_a, n_b), dtype=np.uint64)
+        L.check(self.lib.fbk_group_count_matrix(self.h, args, n_a, n_b, tot.ctypes.data))
+        return tot
+
+    def reduce_u64(self, device_ptrs: Sequence[int], words: int) -> np.ndarray:
+        arr = (C.c_void_p * len(self.members))(*[(p or None) for p in device_ptrs])
+        out = np.zeros(words, dtype=np.uint64)
+        L.check(self.lib.fbk_group_reduce_u64(self.h, arr, words, out.ctypes.data))
+        return out
+
+    def close(self) -> None:
+        if self.h:
+            L.check(self.lib.fbk_group_close(self.h))
+            self.h = C.c_void_p(None)
+            for m in self.members:
+                m.h = C.c_void_p(None)

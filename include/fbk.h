@@ -12,19 +12,20 @@
  * Conventions
  *   - C linkage, plain pointers and sizes, no exceptions across the boundary.
  *   - Every function returns an int32 status: FBK_OK (0) or a negative FBK_E_* code;
- *     fbk_last_error(ctx) returns a thread-local human readable message.
+ *     fbk_last_error_r(ctx, ...) returns the context's human readable message (see below).
  *     (roaring set-ops never return errors in Go — invariant breaks panic,
  *     roaring/roaring.go:976,3524 — so every error here is an argument/resource error.)
  *   - The caller owns every input buffer for the duration of the call only: the
  *     library copies/uploads before returning, which matches the lifetime rule of
  *     mmapped containers ("must not retain", roaring/filter.go:179-181, tx.go:66-72).
  *   - Handles (fbk_ctx, fbk_batch) are opaque; one fbk_ctx drives ONE GPU.  A process
- *     that owns several GPUs opens one context per device (one process per GPU is the
- *     deployment model; shards are partitioned over contexts by the caller exactly as
- *     executor.go:6579 `mapper` partitions shards over nodes).
+ *     that owns several GPUs opens a group (fbk_group_open: one member context per device,
+ *     shards partitioned over the members as executor.go:6579 `mapper` partitions shards
+ *     over nodes, partial counts reduced inside the library); one process per GPU with
+ *     torch.distributed / RCCL above the ABI is the other supported deployment.
  *   - Thread safety: calls on one context are serialised by an internal mutex (cgo pins
- *     one OS thread per call; ~NumCPU goroutines may call concurrently,
- *     executor.go:6723-6737).
+ *     one OS thread per call).  Concurrent callers that should overlap on the device
+ *     (~NumCPU goroutines, executor.go:6723-6737) each use their own fbk_ctx_fork.
  *   - There is NO CPU fallback: if no gfx950 device is usable, fbk_open fails.
  *
  * Data model (modelled on roaring/containers_slice.go:5-10 — sorted keys + containers —
@@ -50,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FBK_ABI_VERSION 1
+#define FBK_ABI_VERSION 2
 
 /* status codes */
 #define FBK_OK 0
@@ -108,8 +109,34 @@ int32_t fbk_device_count(int32_t* out_n);
 int32_t fbk_open(int32_t device, uint32_t flags, fbk_ctx** out_ctx);
 int32_t fbk_close(fbk_ctx* ctx);
 
-/* Thread-local message of the last failing call (never NULL). ctx may be NULL. */
+/* Message of the last failing call (never NULL).
+ *   ctx == NULL : the calling THREAD's last failure (the only source for failures that have no
+ *                 context yet: fbk_open, fbk_device_count, fbk_rbf_find_root).
+ *   ctx != NULL : the CONTEXT's last failure, copied into a buffer owned by the calling thread (valid
+ *                 until that thread's next call into the library).
+ * fbk_last_error_r copies the context's message (and its status code) into a caller buffer — the
+ * form a cgo binding must use: a goroutine can be rescheduled onto another OS thread between the
+ * failing call and the call that fetches the message, so nothing thread-local is reliable there.
+ * Semantics are sqlite3_errmsg's: with several callers failing concurrently on ONE context the
+ * message is that of the most recent failure; callers that need their own message use their own
+ * forked context (fbk_ctx_fork). */
 const char* fbk_last_error(fbk_ctx* ctx);
+int32_t fbk_last_error_r(fbk_ctx* ctx, char* buf, uint64_t cap, int32_t* out_code);
+
+/* A second context on the same device for another calling thread: its own stream, lock, staging
+ * area and memory pool, so that concurrent callers overlap on the device instead of serialising on
+ * one context mutex — the analogue of the reference's pool of ~NumCPU shard workers
+ * (executor.go:6723-6737).  Batches are read-only once uploaded and may be used through any context
+ * of the same device; the fragment cache (fbk_cache_*) is shared with the root context.  A fork is
+ * closed with fbk_close, before its root. */
+int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
+
+/* Tuning / test knobs (A/B measurements, forcing code paths in tests).  The environment variables
+ * FBK_<NAME> are read ONCE, by fbk_open; afterwards only these calls change an option.  Names:
+ * dense_spb, fold_register, matrix_valu, matrix_spb, matrix_pass_kb, matrix_densify, matrix_fused,
+ * topk_device_sort, sparse_paths, setop_direct_encode. */
+int32_t fbk_set_option(fbk_ctx* ctx, const char* name, int64_t value);
+int32_t fbk_get_option(fbk_ctx* ctx, const char* name, int64_t* out_value);
 
 int32_t fbk_abi_version(void);
 
@@ -421,12 +448,13 @@ int32_t fbk_shift(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, co
  * (roaring/add.go:12-849), which AddBSI (bsi.go:83-175) uses to merge per-shard TopK counts.
  * Group g of x is the depth_x rows rows_x[g*depth_x + i] (plane i = bit i, no exists / sign
  * planes), likewise y; out row g*(D+1) + i is plane i of the sum, D = max(depth_x, depth_y),
- * plane D holding the final carry.  Output container keys are the slot numbers 0..15. */
+ * plane D holding the final carry.  Output container keys are out_row * 16 + slot (the fragment-storage
+ * form rowID << 4 | slot with the output row ordinal as row id). */
 int32_t fbk_bsi_add(fbk_ctx* ctx, const fbk_batch* x, const uint32_t* rows_x, uint32_t depth_x, const fbk_batch* y,
                     const uint32_t* rows_y, uint32_t depth_y, uint64_t n_groups, uint32_t flags, fbk_batch** out_batch);
 
 /* out row s = columns of shard s whose value satisfies `op predicate` (fragment.rangeOp,
- * fragment.go:937-1208); container keys of the result are the slot numbers 0..15. */
+ * fragment.go:937-1208); the container keys of the result are s * 16 + slot. */
 int32_t fbk_bsi_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards,
                       int32_t op, uint32_t bit_depth, int64_t predicate, uint32_t flags, fbk_batch** out_batch,
                       uint64_t* out_counts);
@@ -435,6 +463,57 @@ int32_t fbk_bsi_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base
 int32_t fbk_bsi_range_between(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows,
                               uint32_t n_shards, uint32_t bit_depth, int64_t lo, int64_t hi, uint32_t flags,
                               fbk_batch** out_batch, uint64_t* out_counts);
+
+/* ---- several GPUs in one process ---------------------------------------------------------------
+ * The reference maps per-shard functions on the node that owns each shard and folds count-valued
+ * results with an associative reduceFn in the same process (mapReduce / mapperLocal,
+ * executor.go:6449-6533, 6742-6790; executeCount's reduceFn :5880; mergeGroupCounts :3728).  A
+ * group is that for the GPUs of one node: one context per device (member m), shard s on member
+ * s mod G, every member's work enqueued on its own stream so that the devices run concurrently, and
+ * the partial counts reduced by one of
+ *   FBK_REDUCE_HOST  G device->pinned-host copies of the partials and an add on the host
+ *   FBK_REDUCE_PEER  one kernel on member 0 loading the other devices' partials over xGMI (peer access)
+ *   FBK_REDUCE_RCCL  ncclAllReduce over single-process communicators (ncclCommInitAll); librccl is
+ *                    dlopen'ed on first use, so libfbk.so itself links only the HIP runtime.
+ * Bitmap-valued results are not exchanged (they stay per shard, executor.go:1767).  Data is made
+ * resident and plans are created through the member contexts (fbk_group_member) with the ordinary
+ * calls.  The same device ordinal may appear several times (members share the device): that is how
+ * the G > 1 path is exercised on a one-GPU box; FBK_REDUCE_RCCL refuses such a group. */
+typedef struct fbk_group fbk_group;
+#define FBK_REDUCE_HOST 0
+#define FBK_REDUCE_PEER 1
+#define FBK_REDUCE_RCCL 2
+int32_t fbk_group_open(const int32_t* devices, uint32_t n_devices, uint32_t flags, fbk_group** out_group);
+int32_t fbk_group_close(fbk_group* group);
+int32_t fbk_group_size(const fbk_group* group, uint32_t* out_n);
+int32_t fbk_group_member(fbk_group* group, uint32_t i, fbk_ctx** out_ctx); /* borrowed: closed by fbk_group_close */
+int32_t fbk_group_set_reduce(fbk_group* group, int32_t mode);
+
+/* One step of Count(Intersect(Row, Row)) over the shards of all members: plans[m] (created on
+ * member m over the shards it owns; NULL = none) runs as one launch per device with the per-device
+ * sum fused, all devices concurrently; *out_total = sum over the members (executor.go:5871-5880). */
+int32_t fbk_group_plan_intersection_count_total(fbk_group* group, fbk_plan* const* plans, uint64_t* out_total);
+
+/* The count matrix of fbk_count_matrix over the shards of all members: per_member[m] are member m's
+ * arguments (n_shards == 0: the member has no shard of this query), out_total[i * n_b + j] the sum
+ * over every shard of every member (mergeGroupCounts across nodes, executor.go:3728). */
+typedef struct fbk_matrix_args {
+  const fbk_batch* a;
+  const uint32_t* rows_a; /* [n_shards][n_a] */
+  const fbk_batch* b;
+  const uint32_t* rows_b; /* [n_shards][n_b] */
+  const fbk_batch* filter; /* may be NULL */
+  const uint32_t* rows_f; /* [n_shards] */
+  uint32_t n_shards;
+  uint32_t pad;
+} fbk_matrix_args;
+int32_t fbk_group_count_matrix(fbk_group* group, const fbk_matrix_args* per_member, uint32_t n_a, uint32_t n_b,
+                               uint64_t* out_total);
+
+/* The reduce alone, for count-valued partials the caller produced with the member contexts (BSI
+ * sums, TopK counts, fold counts): device_partials[m] = `words` uint64 on member m's device (NULL =
+ * zeros), produced on member m's stream. */
+int32_t fbk_group_reduce_u64(fbk_group* group, void* const* device_partials, uint64_t words, uint64_t* out_total);
 
 #ifdef __cplusplus
 }

@@ -185,3 +185,177 @@ def mixed_container_for_density(rng, d: float, run_structured: bool):
         return None
     c = O.OContainer.array(vals) if vals.size < 4096 else O.OContainer.bitmap(words_of(vals))
     return O.optimize(c)
+
+
+# ---- fast flat generators for bench.py's secondary configurations -------------------------
+DESC_DTYPE = np.dtype(
+    [("key", "<u8"), ("off", "<u8"), ("row", "<u4"), ("len", "<u4"), ("n", "<i4"), ("type", "u1"), ("pad", "u1", (3,))]
+)  # == fbk_container_desc (include/fbk.h), 32 bytes
+
+
+class FlatRows:
+    """Rows in the flattened form fbk_batch_upload takes (descriptor table + one payload buffer),
+    built without one Python object per container.  Encodings follow Container.optimize()
+    (roaring.go:3412-3461), as fbk_container_of_vals does."""
+
+    def __init__(self):
+        self.key, self.row, self.len, self.n, self.type, self.off = [], [], [], [], [], []
+        self.chunks: List[np.ndarray] = []
+        self.bytes = 0
+        self.n_rows = 0
+
+    def add(self, row: int, key: int, typ: int, data: np.ndarray, n: int) -> None:
+        self.key.append(key)
+        self.row.append(row)
+        self.type.append(typ)
+        self.n.append(n)
+        self.len.append(1024 if typ == 2 else (data.size if typ == 1 else data.size // 2))
+        self.off.append(self.bytes)
+        b = data.view(np.uint8).reshape(-1)
+        self.chunks.append(b)
+        self.bytes += b.size
+
+    def add_vals(self, row: int, key: int, vals: np.ndarray) -> None:
+        """sorted distinct values (int64) of one container"""
+        n = int(vals.size)
+        if n == 0:
+            return
+        br = np.nonzero(np.diff(vals) != 1)[0]
+        runs = br.size + 1
+        if runs <= 2048 and runs <= n // 2:
+            iv = np.empty((runs, 2), dtype=np.uint16)
+            iv[0, 0] = vals[0]
+            iv[1:, 0] = vals[br + 1]
+            iv[:-1, 1] = vals[br]
+            iv[-1, 1] = vals[-1]
+            self.add(row, key, 3, iv, n)
+        elif n < 4096:
+            self.add(row, key, 1, vals.astype(np.uint16), n)
+        else:
+            self.add(row, key, 2, words_of(vals), n)
+
+    def add_runs(self, row: int, key: int, starts: np.ndarray, lens: np.ndarray) -> None:
+        """disjoint, non-adjacent runs [start, start + len)"""
+        n, runs = int(lens.sum()), int(starts.size)
+        if runs <= 2048 and runs <= n // 2:
+            iv = np.empty((runs, 2), dtype=np.uint16)
+            iv[:, 0] = starts
+            iv[:, 1] = starts + lens - 1
+            self.add(row, key, 3, iv, n)
+        else:
+            first = np.cumsum(lens) - lens  # index of each run's first value in the flattened list
+            self.add_vals(row, key, (np.repeat(starts - first, lens) + np.arange(n)).astype(np.int64))
+
+    def extend(self, other: "FlatRows", row_off: int) -> None:
+        self.key += other.key
+        self.row += [r + row_off for r in other.row]
+        self.len += other.len
+        self.n += other.n
+        self.type += other.type
+        self.off += [o + self.bytes for o in other.off]
+        self.chunks += other.chunks
+        self.bytes += other.bytes
+
+    def descs(self) -> np.ndarray:
+        d = np.zeros(len(self.key), dtype=DESC_DTYPE)
+        d["key"], d["off"], d["row"], d["len"], d["n"], d["type"] = self.key, self.off, self.row, self.len, self.n, self.type
+        return d
+
+    def payload(self) -> np.ndarray:
+        return np.concatenate(self.chunks) if self.chunks else np.zeros(1, dtype=np.uint8)
+
+
+def sparse_positions(rng, d: float, span: int) -> np.ndarray:
+    """Sorted positions in [0, span), each present with probability d: geometric gaps (O(d * span))."""
+    m = int(span * d * 1.2) + 64
+    pos = np.cumsum(rng.geometric(d, size=m)) - 1
+    while pos[-1] < span:  # rare: extend
+        more = np.cumsum(rng.geometric(d, size=m)) + pos[-1]
+        pos = np.concatenate([pos, more])
+    return pos[pos < span]
+
+
+def bernoulli_words(rng, d: float, shape) -> np.ndarray:
+    """uint64 words whose bits are set with probability round(d * 256) / 256 (bit-serial construction)."""
+    k = max(1, min(255, int(round(d * 256))))
+    acc = np.zeros(shape, dtype=np.uint64)
+    for bit in range(8):
+        r = rng.integers(0, 2**64, shape, dtype=np.uint64)
+        acc = (acc | r) if (k >> bit) & 1 else (acc & r)
+    return acc
+
+
+def _config3_chunk(args):
+    s0, s1, k, seed_idx = args
+    rows, _, filt = config3_flat(s1 - s0, k, seed_idx, first_shard=s0, workers=1)
+    return rows, filt
+
+
+def config3_flat(n_shards: int, k: int = 64, seed_idx: int = 3000, first_shard: int = 0, workers: int = 0, mp: str = "spawn"):
+    """BASELINE.json configs[2]: per shard k rows of rank-law density clamp(0.5 (r+1)^-1.1, 0.001, 0.5)
+    — a quarter of the containers run-structured — plus one filter row of density 0.5.
+    Returns (rows FlatRows, groups [n_shards, k], filter FlatRows).  Shard s is seeded by (seed_idx,
+    s), so the data does not depend on how the shards are split over `workers` processes."""
+    rows, filt = FlatRows(), FlatRows()
+    groups = np.arange(n_shards * k, dtype=np.uint32).reshape(n_shards, k)
+    if workers == 0:
+        import os
+
+        workers = max(1, min(16, (os.cpu_count() or 1) // 2, n_shards // 8))
+    if workers > 1:
+        import multiprocessing
+        from concurrent.futures import ProcessPoolExecutor
+
+        per = (n_shards + workers - 1) // workers
+        jobs = [(first_shard + a, first_shard + min(n_shards, a + per), k, seed_idx) for a in range(0, n_shards, per)]
+        # mp="fork" only before the process has initialised the HIP runtime (bench.py generates first)
+        with ProcessPoolExecutor(max_workers=workers, mp_context=multiprocessing.get_context(mp)) as ex:
+            for (a, _, _, _), (r, f) in zip(jobs, ex.map(_config3_chunk, jobs)):
+                rows.extend(r, (a - first_shard) * k)
+                filt.extend(f, a - first_shard)
+        rows.n_rows, filt.n_rows = n_shards * k, n_shards
+        return rows, groups, filt
+    for s_local in range(n_shards):
+        s = first_shard + s_local
+        rng = rng_for(seed_idx, s)
+        for r in range(k):
+            d = zipf_density(r)
+            row = s_local * k + r
+            is_run = rng.random(SLOTS) < 0.25
+            plain = np.nonzero(~is_run)[0]
+            if plain.size:
+                if d >= 0.07:  # bitmaps (n >= 4096 with overwhelming probability)
+                    w = bernoulli_words(rng, d, (plain.size, WORDS))
+                    cnt = np.bitwise_count(w).sum(axis=1)
+                    for i, slot in enumerate(plain):
+                        if cnt[i] >= 4096:
+                            rows.add(row, s * 16 + int(slot), 2, w[i], int(cnt[i]))
+                        else:
+                            rows.add_vals(row, s * 16 + int(slot), np.nonzero(np.unpackbits(w[i].view(np.uint8), bitorder="little"))[0].astype(np.int64))
+                else:
+                    # i.i.d. bits at density d < 0.07: runs ~ n (1 - d) > n / 2, never a run container;
+                    # n ~ 65536 d < 4096 except in the tail of the distribution (checked)
+                    pos = sparse_positions(rng, d, plain.size * 65536)
+                    cut = np.searchsorted(pos, np.arange(1, plain.size + 1) * 65536)
+                    v16 = (pos & 0xFFFF).astype(np.uint16)
+                    lo = 0
+                    for i, slot in enumerate(plain):
+                        hi = int(cut[i])
+                        if hi - lo >= 4096:
+                            rows.add_vals(row, s * 16 + int(slot), pos[lo:hi] - i * 65536)
+                        elif hi > lo:
+                            rows.add(row, s * 16 + int(slot), 1, v16[lo:hi], hi - lo)
+                        lo = hi
+            for slot in np.nonzero(is_run)[0]:
+                nr = int(rng.choice([16, 32, 128, 1024]))
+                fill = min(0.95, max(0.02, d * 2))
+                period = 65536 // nr
+                starts = np.arange(nr) * period + rng.integers(0, max(1, period // 4), nr)
+                lens = np.maximum(1, (period * fill * rng.uniform(0.5, 1.0, nr)).astype(np.int64))
+                lens = np.maximum(np.minimum(lens, period - (starts - np.arange(nr) * period) - 1), 1)
+                rows.add_runs(row, s * 16 + int(slot), starts, lens)
+        w = rng.integers(0, 2**64, (SLOTS, WORDS), dtype=np.uint64)
+        for slot in range(SLOTS):
+            filt.add(s_local, s * 16 + slot, 2, w[slot], int(np.bitwise_count(w[slot]).sum()))
+    rows.n_rows, filt.n_rows = n_shards * k, n_shards
+    return rows, groups, filt

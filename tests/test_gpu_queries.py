@@ -445,20 +445,20 @@ def test_count_matrix_dense_kernel_vs_numpy(gpu_ctx, n_shards, n_a, n_b, use_fil
     # atomic adds of partial matrices), and the vector-ALU kernel kept for A/B measurements
     try:
         for spb in ("16", "8", "4", "2", "1"):
-            os.environ["FBK_MATRIX_SPB"] = spb
+            gpu_ctx.set_option("matrix_spb", int(spb))
             tot2, ps2 = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf if use_filter else None, per_shard=True)
             assert (ps2 == exp).all(), spb
             assert (tot2 == tot).all(), spb
     finally:
-        os.environ.pop("FBK_MATRIX_SPB", None)
+        gpu_ctx.set_option("matrix_spb", 0)
     # the total alone (no per-shard matrices asked for) is reduced in passes over the shards: force
     # passes of one or two shards
     try:
-        os.environ["FBK_MATRIX_PASS_KB"] = str(max(1, (2 * n_a * n_b * 8) // 1024))
+        gpu_ctx.set_option("matrix_pass_kb", int(str(max(1, (2 * n_a * n_b * 8) // 1024))))
         tot3 = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf if use_filter else None)
         assert (tot3 == tot).all()
     finally:
-        os.environ.pop("FBK_MATRIX_PASS_KB", None)
+        gpu_ctx.set_option("matrix_pass_kb", 1048576)
     A.free()
     Bt.free()
     if F is not None:
@@ -581,10 +581,10 @@ def test_count_matrix_mixed_rows_take_the_densify_path(gpu_ctx, oracle, B, a_den
         exp_tot += e
     assert (tot == exp_tot).all()
     try:
-        os.environ["FBK_MATRIX_DENSIFY"] = "0"
+        gpu_ctx.set_option("matrix_densify", int("0"))
         tot_g, ps_g = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
     finally:
-        os.environ.pop("FBK_MATRIX_DENSIFY", None)
+        gpu_ctx.set_option("matrix_densify", -1)
     assert (tot_g == tot).all() and (ps_g == ps).all()
     for b in (A, Bt, F):
         if b is not None:
@@ -898,30 +898,30 @@ def test_topk_on_device_vs_oracle(gpu_ctx, oracle, use_filter):
     fargs = (F, np.arange(n_shards)) if use_filter else (None, None)
     try:
         for mode in ("0", "1"):  # ordered on the host (small fields) / by the device radix sort
-            os.environ["FBK_TOPK_DEVICE_SORT"] = mode
+            gpu_ctx.set_option("topk_device_sort", int(mode))
             for k in (0, 1, 7, 1000):
                 idx, cnt = gpu_ctx.topk(A, ra, k, *fargs)
                 exp = order if k == 0 else order[:k]
                 assert idx.tolist() == exp and cnt.tolist() == tot[exp].tolist(), (mode, k)
     finally:
-        os.environ.pop("FBK_TOPK_DEVICE_SORT", None)
+        gpu_ctx.set_option("topk_device_sort", -1)
     try:  # one shard per pass
-        os.environ["FBK_MATRIX_PASS_KB"] = "1"
+        gpu_ctx.set_option("matrix_pass_kb", int("1"))
         idx, cnt = gpu_ctx.topk(A, ra, 5, *fargs)
         assert idx.tolist() == order[:5] and cnt.tolist() == tot[order[:5]].tolist()
     finally:
-        os.environ.pop("FBK_MATRIX_PASS_KB", None)
+        gpu_ctx.set_option("matrix_pass_kb", 1048576)
     # a buffer smaller than the result: FBK_E_CAPACITY and the needed size
     import ctypes as C
 
     small_i, small_c, n = np.zeros(2, np.uint32), np.zeros(2, np.uint64), C.c_uint32()
     need = len([i for i in range(n_a) if any(rows[ra[s, i]] for s in range(n_shards))])
     for mode in ("0", "1"):
-        os.environ["FBK_TOPK_DEVICE_SORT"] = mode
+        gpu_ctx.set_option("topk_device_sort", int(mode))
         try:
             rc = gpu_ctx.lib.fbk_topk(gpu_ctx.h, A.h, ra.ctypes.data, n_a, None, None, n_shards, 0, small_i.ctypes.data, small_c.ctypes.data, 2, C.byref(n))
         finally:
-            os.environ.pop("FBK_TOPK_DEVICE_SORT", None)
+            gpu_ctx.set_option("topk_device_sort", -1)
         assert rc == L.FBK_E_CAPACITY and n.value == need
     A.free()
     F.free()
@@ -941,11 +941,11 @@ def test_fragment_topn_vectors_through_fbk_topk(gpu_ctx, oracle):
         fargs = (F, np.zeros(1, dtype=np.uint32)) if F is not None else (None, None)
         try:
             for mode in ("0", "1"):
-                os.environ["FBK_TOPK_DEVICE_SORT"] = mode
+                gpu_ctx.set_option("topk_device_sort", int(mode))
                 idx, cnt = gpu_ctx.topk(batch, np.arange(len(ids)).reshape(1, -1), n, *fargs)
                 assert [(ids[i], int(c)) for i, c in zip(idx.tolist(), cnt.tolist())] == want, mode
         finally:
-            os.environ.pop("FBK_TOPK_DEVICE_SORT", None)
+            gpu_ctx.set_option("topk_device_sort", -1)
         batch.free()
         if F is not None:
             F.free()
