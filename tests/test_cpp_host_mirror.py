@@ -13,6 +13,8 @@ SRC_EXEC = os.path.join(ROOT, "tests", "cpp", "test_executor_api.cpp")
 BIN_EXEC = os.path.join(ROOT, "build", "test_executor_api")
 SRC_THR = os.path.join(ROOT, "tests", "cpp", "test_threads.cpp")
 BIN_THR = os.path.join(ROOT, "build", "test_threads")
+SRC_FORK = os.path.join(ROOT, "tests", "cpp", "test_forks.cpp")
+BIN_FORK = os.path.join(ROOT, "build", "test_forks")
 
 
 def compile_it(src=SRC, out=BIN):
@@ -33,6 +35,8 @@ def test_cpp_host_mirror_compiles():
     assert os.path.exists(BIN_EXEC)
     compile_it(SRC_THR, BIN_THR)
     assert os.path.exists(BIN_THR)
+    compile_it(SRC_FORK, BIN_FORK)
+    assert os.path.exists(BIN_FORK)
 
 
 @pytest.mark.gpu
@@ -42,6 +46,16 @@ def test_one_context_many_threads_on_gpu():
     out = subprocess.run([BIN_THR], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "threads ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_forked_contexts_overlap_on_gpu():
+    """8 threads x 8 forked contexts finish the same queries in < 0.5 x the serial wall time;
+    error messages are per context (tests/cpp/test_forks.cpp)."""
+    compile_it(SRC_FORK, BIN_FORK)
+    out = subprocess.run([BIN_FORK], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "forks ok" in out.stdout
 
 
 @pytest.mark.gpu

