@@ -23,6 +23,7 @@
 #include "fbk_bsi_kernels.hip.h"
 #include "fbk_matrix_kernels.hip.h"
 #include "fbk_matrix_mfma.hip.h"
+#include "fbk_matrix_fused.hip.h"
 #include "fbk_wire_kernels.hip.h"
 
 using fbk::Slot;
@@ -78,6 +79,7 @@ struct FbkOptions {
   int64_t matrix_pass_kb = 1 << 20;      // per-shard matrices are produced in passes of at most this many KiB
   int64_t matrix_densify = -1;           // encoded rows: 1 densify + dense kernel, 0 generic pair kernel, -1 cost model
   int64_t matrix_fused = -1;             // encoded rows: 1 decode inside the matrix-core kernel, 0 never, -1 cost model
+  int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
@@ -431,6 +433,7 @@ const OptionDesc kOptions[] = {
     {"matrix_pass_kb", &FbkOptions::matrix_pass_kb, 1, int64_t(1) << 40},
     {"matrix_densify", &FbkOptions::matrix_densify, -1, 1},
     {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
+    {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},

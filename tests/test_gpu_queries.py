@@ -538,7 +538,7 @@ def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("a_dense,b_dense,f_mode", [(False, False, "mixed"), (True, False, "none"), (False, True, "dense"), (False, False, "none")])
-def test_count_matrix_mixed_rows_take_the_densify_path(gpu_ctx, oracle, B, a_dense, b_dense, f_mode):
+def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle, B, a_dense, b_dense, f_mode):
     """nA x nB >= 100 with array / run containers among the rows: fbk_count_matrix densifies the
     referenced rows into temporary bitmap rows and runs the dense matrix kernel; every mix of
     dense and encoded operands, checked against the oracle's groupByIterator counts — and against
@@ -580,10 +580,22 @@ def test_count_matrix_mixed_rows_take_the_densify_path(gpu_ctx, oracle, B, a_den
         assert (ps[k] == e).all(), (k, s)
         exp_tot += e
     assert (tot == exp_tot).all()
+    # the same call on the other two paths for encoded rows: decode inside the matrix-core kernel
+    # (fbk_matrix_fused.hip.h, option matrix_fused=1; every slots-per-block split of its launch) and
+    # the generic pair kernel (matrix_densify=0); the default above densifies + runs the dense kernel
     try:
-        gpu_ctx.set_option("matrix_densify", int("0"))
+        gpu_ctx.set_option("matrix_fused", 1)
+        for spb in (0, 16, 8, 4, 2, 1):
+            gpu_ctx.set_option("matrix_spb", spb)
+            tot_s, ps_s = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
+            assert (tot_s == tot).all() and (ps_s == ps).all(), spb
+        gpu_ctx.set_option("matrix_spb", 0)
+        gpu_ctx.set_option("matrix_fused", 0)
+        gpu_ctx.set_option("matrix_densify", 0)
         tot_g, ps_g = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
     finally:
+        gpu_ctx.set_option("matrix_spb", 0)
+        gpu_ctx.set_option("matrix_fused", -1)
         gpu_ctx.set_option("matrix_densify", -1)
     assert (tot_g == tot).all() and (ps_g == ps).all()
     for b in (A, Bt, F):
