@@ -952,7 +952,7 @@ void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
   else
     hipLaunchKernelGGL(fbk::k_setop<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, p->d_counts);
+                       want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
 }
 
 void free_batch_storage(fbk_batch* b) {
@@ -1040,7 +1040,8 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
   } else {
     HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,
-                       p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts);
+                       p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts,
+                       uint32_t(ctx->opt.sparse_paths));
     if (fused_total)
       hipLaunchKernelGGL(fbk::k_sum_u64, dim3(1), dim3(256), 0, ctx->stream, p->d_counts, p->n_pairs, fused_total);
     if (accum) hipLaunchKernelGGL(fbk::k_sum_u64_add, dim3(1), dim3(256), 0, ctx->stream, p->d_counts, p->n_pairs, accum);

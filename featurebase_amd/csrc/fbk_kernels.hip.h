@@ -475,6 +475,44 @@ __global__ void __launch_bounds__(256) k_setop_dense(const uint8_t* __restrict__
   }
 }
 
+// ---- small-operand fast paths (option sparse_paths) ------------------------------------------
+// The generic pair kernels below decode BOTH operands into an 8 KiB LDS bitmap: zero 8 KiB, scatter,
+// read 8 KiB back — per operand, whatever its size.  For the shapes the reference serves with
+// intersectionCountArrayArray / intersectionCountArrayBitmap (roaring.go:4514-4536, 4596-4609) that
+// is two orders of magnitude more LDS traffic than the operands have bytes; and an array x bitmap
+// pair streams the whole 8 KiB bitmap from HBM to test a handful of values.
+//   array x array, both <= 64 values   all-pairs compare in registers: the shorter array is broadcast
+//                                      value by value (v_readlane), no LDS, no decode
+//   array (<= 128 values) x bitmap     each value probes its dword of the bitmap straight from global
+//                                      memory: <= 128 sectors instead of the whole container
+constexpr uint32_t kSmallArray = 64;
+constexpr uint32_t kProbeArray = 128;
+
+// lanes whose value of the longer array also occurs in the shorter one (both <= 64 values)
+__device__ __forceinline__ u64 small_arrays_match(const uint8_t* __restrict__ pa, uint32_t la, const uint8_t* __restrict__ pb,
+                                                  uint32_t lb, int lane, uint32_t& my_value, bool& a_is_long) {
+  const uint32_t a = (uint32_t)lane < la ? reinterpret_cast<const uint16_t*>(pa)[lane] : 0xFFFFFFFFu;
+  const uint32_t b = (uint32_t)lane < lb ? reinterpret_cast<const uint16_t*>(pb)[lane] : 0xFFFFFFFEu;
+  a_is_long = la >= lb;  // wave-uniform
+  const uint32_t lng = a_is_long ? a : b, sht = a_is_long ? b : a;
+  const uint32_t ns = a_is_long ? lb : la;
+  bool m = false;
+  for (uint32_t k = 0; k < ns; ++k) m |= lng == (uint32_t)__builtin_amdgcn_readlane((int)sht, (int)k);
+  my_value = lng;
+  return __ballot(m);
+}
+
+// lanes (of chunk `base`) whose array value is set in the bitmap container at pb
+__device__ __forceinline__ u64 array_probe_bitmap(const uint8_t* __restrict__ pa, uint32_t la, uint32_t base,
+                                                  const uint8_t* __restrict__ pb, int lane, uint32_t& my_value) {
+  const uint32_t i = base + (uint32_t)lane;
+  const bool on = i < la;
+  const uint32_t a = on ? reinterpret_cast<const uint16_t*>(pa)[i] : 0u;
+  const uint32_t w = on ? reinterpret_cast<const uint32_t*>(pb)[a >> 5] : 0u;
+  my_value = a;
+  return __ballot(on && ((w >> (a & 31u)) & 1u));
+}
+
 // Generic |A ∩ B| over row pairs with any mix of array / bitmap / run / nil containers
 // (intersectionCount and its six kernels, roaring.go:4477-4614).  One wave per
 // (pair, slot).  Short-circuits mirror roaring.go:4478-4486.
@@ -482,7 +520,7 @@ __global__ void __launch_bounds__(256) k_icount(const Slot* __restrict__ slotsA,
                                                const uint32_t* __restrict__ rowsA,
                                                const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB,
                                                const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
-                                               u64* __restrict__ out) {
+                                               u64* __restrict__ out, uint32_t sparse_paths) {
   __shared__ u64 lds[4][kWords];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -493,6 +531,7 @@ __global__ void __launch_bounds__(256) k_icount(const Slot* __restrict__ slotsA,
   const Slot sa = slotsA[(uint64_t)rowsA[pair] * kSlots + slot];
   const Slot sb = slotsB[(uint64_t)rowsB[pair] * kSlots + slot];
   const uint32_t na = slot_n(sa), nb = slot_n(sb);
+  const uint32_t ta = slot_type(sa), tb = slot_type(sb);
   uint32_t c;
   if (na == 0 || nb == 0) {
     return;  // contributes 0
@@ -500,6 +539,18 @@ __global__ void __launch_bounds__(256) k_icount(const Slot* __restrict__ slotsA,
     c = nb;
   } else if (nb == 65536u) {
     c = na;
+  } else if (sparse_paths && ta == kTypeArray && tb == kTypeArray && sa.len <= kSmallArray && sb.len <= kSmallArray) {
+    uint32_t v;
+    bool al;
+    c = (uint32_t)__popcll(small_arrays_match(arenaA + sa.off, sa.len, arenaB + sb.off, sb.len, lane, v, al));
+  } else if (sparse_paths && ta == kTypeArray && tb == kTypeBitmap && sa.len <= kProbeArray) {
+    uint32_t v;
+    c = 0;
+    for (uint32_t base = 0; base < sa.len; base += kWave) c += (uint32_t)__popcll(array_probe_bitmap(arenaA + sa.off, sa.len, base, arenaB + sb.off, lane, v));
+  } else if (sparse_paths && tb == kTypeArray && ta == kTypeBitmap && sb.len <= kProbeArray) {
+    uint32_t v;
+    c = 0;
+    for (uint32_t base = 0; base < sb.len; base += kWave) c += (uint32_t)__popcll(array_probe_bitmap(arenaB + sb.off, sb.len, base, arenaA + sa.off, lane, v));
   } else {
     u64 wa[kWordsPerLane], wb[kWordsPerLane];
     frag_load(sa, arenaA, lane, lds[wv], wa);
@@ -521,7 +572,7 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
                                               const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB,
                                               const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
                                               uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
-                                              uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts) {
+                                              uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts, uint32_t direct) {
   __shared__ u64 lds[4][kWords];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -546,6 +597,42 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
       if (outRuns) outRuns[wslot] = 0;
     }
     return;
+  }
+  if (OP == 0 && direct && outRuns) {
+    // Right-sized output (option setop_direct_encode, only when the caller asked for optimize()):
+    // an intersection with a small array is a subset of that array — written as an ARRAY of <= 64
+    // values into the cell (<= 128 bytes instead of 8 KiB; intersectArrayArray / intersectArrayBitmap,
+    // roaring.go:4778-4830), with the run count optimize() needs taken from the sorted survivors.
+    const uint32_t ta = slot_type(sa), tb = slot_type(sb);
+    u64 mm = 0;
+    uint32_t v = 0;
+    bool handled = true, al;
+    if (ta == kTypeArray && tb == kTypeArray && sa.len <= kSmallArray && sb.len <= kSmallArray)
+      mm = small_arrays_match(arenaA + sa.off, sa.len, arenaB + sb.off, sb.len, lane, v, al);
+    else if (ta == kTypeArray && tb == kTypeBitmap && sa.len <= kSmallArray)
+      mm = array_probe_bitmap(arenaA + sa.off, sa.len, 0, arenaB + sb.off, lane, v);
+    else if (tb == kTypeArray && ta == kTypeBitmap && sb.len <= kSmallArray)
+      mm = array_probe_bitmap(arenaB + sb.off, sb.len, 0, arenaA + sa.off, lane, v);
+    else
+      handled = false;
+    if (handled) {  // wave-uniform
+      const u64 below = lane ? (mm & (~0ull >> (64 - lane))) : 0ull;
+      const bool mine = (mm >> lane) & 1ull;
+      if (mine) reinterpret_cast<uint16_t*>(arenaO + so.off)[__popcll(below)] = (uint16_t)v;
+      // a run starts at every survivor whose predecessor among the survivors is not value - 1
+      const int prev = below ? 63 - __builtin_clzll(below) : 0;
+      const uint32_t vprev = (uint32_t)__shfl((int)v, prev, kWave);
+      const uint32_t r = (uint32_t)__popcll(__ballot(mine && (below == 0 || vprev + 1u != v)));
+      const uint32_t c = (uint32_t)__popcll(mm);
+      if (lane == 0) {
+        so.len = c;
+        so.tn = make_tn(c ? kTypeArray : kTypeNil, c);
+        outSlots[wslot] = so;
+        outRuns[wslot] = r;
+        if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
+      }
+      return;
+    }
   }
   u64 wa[kWordsPerLane], wb[kWordsPerLane];
   frag_load(sa, arenaA, lane, lds[wv], wa);

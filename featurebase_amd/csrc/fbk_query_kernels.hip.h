@@ -478,8 +478,31 @@ __global__ void __launch_bounds__(256) k_encode_plan(const Slot* __restrict__ ce
   enc_bytes[i] = (bytes + 15) & ~15ull;
 }
 
-// Phase 2: exclusive prefix sum of the byte sizes (single block, chunked; n_slots is at most
-// a few million).  total[0] receives the arena size.
+// Phase 2: exclusive prefix sum of the byte sizes, two levels: k_scan_blocks scans chunks of 1024
+// cells in parallel (one block each: local exclusive offsets + the chunk's total), k_exclusive_scan
+// — a single block, chunked — then only scans the per-chunk totals (n_slots / 1024 values; it used
+// to walk all n_slots cells, 3 barriers per 1024 of them: milliseconds at 8 M cells), and
+// k_encode_write adds the two.  total[0] receives the arena size.
+__global__ void __launch_bounds__(1024) k_scan_blocks(const u64* __restrict__ in, u64* __restrict__ out_local, uint64_t n,
+                                                     u64* __restrict__ block_sums) {
+  __shared__ u64 wsum[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  const u64 v = i < n ? in[i] : 0;
+  u64 incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u64 t = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  u64 woff = 0;
+  for (int k = 0; k < wv; ++k) woff += wsum[k];
+  if (i < n) out_local[i] = woff + incl - v;
+  if (threadIdx.x == 1023) block_sums[blockIdx.x] = woff + incl;
+}
+
 __global__ void __launch_bounds__(1024) k_exclusive_scan(const u64* __restrict__ in, u64* __restrict__ out, uint64_t n,
                                                         u64* __restrict__ total) {
   __shared__ u64 wsum[16];
@@ -512,9 +535,10 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan(const u64* __restrict__
 // Phase 3: one wave per cell re-encodes its bitmap cell into the compact arena
 // (bitmapToArray roaring.go:3687, bitmapToRun :3859) or copies it.
 __global__ void __launch_bounds__(256) k_encode_write(const Slot* __restrict__ cells, const uint8_t* __restrict__ cell_arena,
-                                                     const uint32_t* __restrict__ enc_type, const u64* __restrict__ enc_off,
-                                                     const uint32_t* __restrict__ runs, uint64_t n_slots,
-                                                     uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots) {
+                                                     const uint32_t* __restrict__ enc_type, const u64* __restrict__ enc_off_local,
+                                                     const u64* __restrict__ enc_off_block, const uint32_t* __restrict__ runs,
+                                                     uint64_t n_slots, uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots) {
+  __shared__ u64 lds[4][kWords];  // decode scratch: a cell may already be an array (k_setop's right-sized outputs)
   const int lane = threadIdx.x & 63;
   const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_slots) return;
@@ -530,9 +554,10 @@ __global__ void __launch_bounds__(256) k_encode_write(const Slot* __restrict__ c
   const Slot cell = cells[i];
   const uint32_t n = slot_n(cell);
   u64 w[kWordsPerLane];
-  frag_load_bitmap(cell_arena + cell.off, lane, w);
-  uint8_t* dst = arenaO + enc_off[i];
-  so.off = enc_off[i];
+  frag_load(cell, cell_arena, lane, lds[threadIdx.x >> 6], w);
+  const u64 my_off = enc_off_local[i] + enc_off_block[i >> 10];
+  uint8_t* dst = arenaO + my_off;
+  so.off = my_off;
   so.tn = make_tn(t, n);
   if (t == kTypeBitmap) {
     frag_store_bitmap(dst, lane, w);
