@@ -730,4 +730,133 @@ __global__ void __launch_bounds__(256) k_shift(const Slot* __restrict__ slots, c
   }
 }
 
+// ---- Flip: negate the bits of a row inside [start, end] --------------------------------------
+// Bitmap.Flip(start, end) (roaring.go:2769-2799; the container-level flipArray / flipBitmap / flipRun
+// of roaring.go:6259-6274 are the case start = 0, end = 65535 of one slot).  One wavefront per
+// (row, slot): decode, XOR with the slot's share of the range mask, write a bitmap cell.
+__global__ void __launch_bounds__(256) k_flip(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                             const uint32_t* __restrict__ rows, uint64_t n_rows, uint32_t start, uint32_t end_incl,
+                                             uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
+                                             u64* __restrict__ out_counts) {
+  __shared__ u64 lds[4][kWords];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
+  const uint64_t i = wslot >> 4;
+  const uint32_t slot = wslot & 15;
+  if (i >= n_rows) return;
+  const Slot s = slots[(uint64_t)rows[i] * kSlots + slot];
+  const uint32_t base = slot << 16;
+  // the part of [start, end_incl] that falls into this slot, as [lo, hi) relative to the slot
+  const uint32_t lo = start > base ? min(start - base, 65536u) : 0u;
+  const uint32_t hi = end_incl + 1u > base ? min(end_incl + 1u - base, 65536u) : 0u;
+  Slot so;
+  so.off = wslot * 8192ull;
+  so.len = kWords;
+  so.tn = 0;
+  u64 w[kWordsPerLane];
+  if (slot_n(s) == 0) frag_zero(w);
+  else frag_load(s, arena, lane, lds[wv], w);
+  if (lo < hi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t b0 = (128u * j + 2u * lane + h) * 64u;  // first bit of this word
+        u64 m = ~0ull;
+        if (lo > b0) m = (lo - b0 >= 64u) ? 0ull : (m << (lo - b0));
+        if (hi < b0 + 64u) m = (hi <= b0) ? 0ull : (m & (~0ull >> (b0 + 64u - hi)));
+        w[2 * j + h] ^= m;
+      }
+  }
+  const uint32_t c = wave_reduce_add(frag_popcount(w));
+  if (c) frag_store_bitmap(arenaO + so.off, lane, w);
+  uint32_t r = 0;
+  if (outRuns) r = wave_reduce_add(frag_count_runs(w, lane));
+  if (lane == 0) {
+    so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
+    outSlots[wslot] = so;
+    if (outRuns) outRuns[wslot] = r;
+    if (out_counts && c) atomicAdd(&out_counts[i], (u64)c);
+  }
+}
+
+// ---- TopN qualification (fragment.top's threshold rules, fragment.go:1329-1402) ------------------
+// counts[s][i] = |row i of shard s ∩ src_s| (the row's cardinality when there is no source row),
+// cards[s][i] = the row's cardinality, src_counts[s] = |src_s|.  A row that does not qualify in a
+// shard contributes nothing from that shard (its count is zeroed).  Integer forms of the
+// reference's float64 comparisons: cnt <= src*T/100 <=> cnt*100 <= src*T; cnt >= src*100/T <=>
+// cnt*T >= src*100; ceil(count*100 / (cnt + src - count)) is the integer ceiling division.
+__global__ void __launch_bounds__(256) k_topn_filter(u64* __restrict__ counts, const u64* __restrict__ cards,
+                                                    const u64* __restrict__ src_counts, uint64_t n, uint32_t n_a, u64 min_threshold,
+                                                    u64 tanimoto_threshold) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 cnt = cards[i], count = counts[i];
+  bool ok = cnt != 0 && count != 0;
+  if (ok) {
+    if (tanimoto_threshold > 0 && src_counts) {
+      const u64 src = src_counts[i / n_a];
+      if (cnt * 100 <= src * tanimoto_threshold || cnt * tanimoto_threshold >= src * 100) ok = false;
+      else {
+        const u64 den = cnt + src - count;
+        ok = (count * 100 + den - 1) / den > tanimoto_threshold;
+      }
+    } else {
+      ok = cnt >= min_threshold && count >= min_threshold;
+    }
+  }
+  if (!ok) counts[i] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_max_u64(const u64* __restrict__ v, uint64_t n, u64* __restrict__ out) {
+  u64 m = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) m = v[i] > m ? v[i] : m;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 t = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(m >> 32), o, kWave) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)m, o, kWave);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// ---- counts -> BSI planes (bsiBuilder.Insert(rowID, count), bsi.go:251-284) ------------------------
+// totals[i] = count of row i; plane p (output row p) gets bit i iff bit p of totals[i] is set.  One
+// wavefront per 64 row ids: 64 ballots give the 64-bit word of every plane.  Cells are 8 KiB bitmap
+// cells (zeroed by the caller); k_cell_stats fills cardinalities and run counts afterwards.
+__global__ void __launch_bounds__(256) k_counts_to_bsi(const u64* __restrict__ totals, uint32_t n_a, uint32_t depth,
+                                                      uint8_t* __restrict__ arenaO) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wordi = blockIdx.x * 4 + (threadIdx.x >> 6);  // which 64 row ids
+  const uint32_t i = wordi * 64 + lane;
+  if (wordi * 64 >= n_a) return;
+  const u64 v = i < n_a ? totals[i] : 0;
+  for (uint32_t p = 0; p < depth; ++p) {
+    const u64 word = __ballot((v >> p) & 1ull);
+    // plane p = output row p; row-relative bit position = row id: slot = i >> 16, word (i & 65535) >> 6
+    if (lane == 0 && word)
+      reinterpret_cast<u64*>(arenaO + ((uint64_t)p * kSlots + (wordi >> 10)) * 8192ull)[wordi & 1023u] = word;
+  }
+}
+
+// cardinality and run count of bitmap cells (cell layout: slot s at s * 8 KiB)
+__global__ void __launch_bounds__(256) k_cell_stats(uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
+                                                   uint64_t n_slots) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wslot >= n_slots) return;
+  u64 w[kWordsPerLane];
+  frag_load_bitmap(arenaO + wslot * 8192ull, lane, w);
+  const uint32_t c = wave_reduce_add(frag_popcount(w));
+  const uint32_t r = wave_reduce_add(frag_count_runs(w, lane));
+  if (lane == 0) {
+    Slot so;
+    so.off = wslot * 8192ull;
+    so.len = kWords;
+    so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
+    outSlots[wslot] = so;
+    if (outRuns) outRuns[wslot] = r;
+  }
+}
+
 }  // namespace fbk

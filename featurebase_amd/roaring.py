@@ -403,6 +403,42 @@ class Context:
         )
         return idx[: n.value].copy(), cnt[: n.value].copy()
 
+    def topn(self, a: Batch, rows_a, n: int = 0, filt: Optional[Batch] = None, rows_f=None, min_threshold: int = 0,
+             tanimoto_threshold: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        """fbk_topn: topk with fragment.top's MinThreshold / TanimotoThreshold rules (fragment.go:1317)."""
+        ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
+        n_shards, n_a = ra.shape
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        cap = n_a if n == 0 else min(n, n_a)
+        idx = np.zeros(max(cap, 1), dtype=np.uint32)
+        cnt = np.zeros(max(cap, 1), dtype=np.uint64)
+        got = C.c_uint32()
+        L.check(
+            self.lib.fbk_topn(
+                self.h, a.h, ra.ctypes.data, n_a, filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None,
+                n_shards, n, min_threshold, tanimoto_threshold, idx.ctypes.data, cnt.ctypes.data, cap, C.byref(got),
+            )
+        )
+        return idx[: got.value].copy(), cnt[: got.value].copy()
+
+    def topk_bsi(self, a: Batch, rows_a, filt: Optional[Batch] = None, rows_f=None, flags: int = 0) -> Tuple[Batch, int]:
+        """The TopK counts as BSI planes over the row indices (bsiBuilder, bsi.go:251): (batch of depth rows, depth)."""
+        ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
+        n_shards, n_a = ra.shape
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        h, depth = C.c_void_p(), C.c_uint32()
+        L.check(self.lib.fbk_topk_bsi(self.h, a.h, ra.ctypes.data, n_a, filt.h if filt is not None else None,
+                                      rf.ctypes.data if rf is not None else None, n_shards, flags, C.byref(h), C.byref(depth)))
+        return Batch(self, h.value), int(depth.value)
+
+    def flip(self, batch: Batch, rows, start: int, end: int, flags: int = 0) -> Tuple[Batch, np.ndarray]:
+        """out row i = rows[i] with the bits of [start, end] (inclusive, row-relative) negated: Bitmap.Flip (roaring.go:2769)."""
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.zeros(r.size, dtype=np.uint64)
+        h = C.c_void_p()
+        L.check(self.lib.fbk_flip(self.h, batch.h, r.ctypes.data, r.size, start, end, flags, C.byref(h), out.ctypes.data))
+        return Batch(self, h.value), out
+
     NO_ROW = 0xFFFFFFFF
 
     def shift(self, batch: Batch, rows, carry_rows=None, flags: int = 0) -> Tuple[Batch, np.ndarray]:

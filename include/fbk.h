@@ -431,6 +431,39 @@ int32_t fbk_topk(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint3
                  const uint32_t* rows_f, uint32_t n_shards, uint32_t k, uint32_t* out_index, uint64_t* out_count, uint32_t cap,
                  uint32_t* out_n);
 
+/* TopN with the reference's qualification rules (fragment.top, fragment.go:1317-1437; executeTopN's
+ * per-shard map): per shard s and row i, cnt = the row's stored cardinality and count = |row ∩ F_s|
+ * (count = cnt without a filter = the `Src` row).  The row contributes count to totals[i] from that
+ * shard iff cnt != 0, count != 0 and
+ *   tanimoto_threshold > 0 and a filter is given:
+ *       src*T/100 < cnt < src*100/T   and   ceil(count*100 / (cnt + src - count)) > T     (:1334-1391;
+ *       src = |F_s|, T = tanimoto_threshold, a percentage; evaluated in integer arithmetic, which equals
+ *       the reference's float64 comparisons for every count a shard can hold)
+ *   otherwise:  cnt >= min_threshold and count >= min_threshold                              (:1357, :1394)
+ * Every row is counted exactly: the rank cache's early exits (:1404-1422) only skip rows that could
+ * not qualify, its truncation to the first N cached rows is an approximation this path does not
+ * need.  Totals are summed over the shards (Pairs.Add, cache.go:463), ordered count descending /
+ * row index ascending, at most n results (n = 0: all).  fbk_topk is fbk_topn with both thresholds 0. */
+int32_t fbk_topn(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a, const fbk_batch* filter,
+                 const uint32_t* rows_f, uint32_t n_shards, uint32_t n, uint64_t min_threshold, uint64_t tanimoto_threshold,
+                 uint32_t* out_index, uint64_t* out_count, uint32_t cap, uint32_t* out_n);
+
+/* The TopK counts in the form executeTopKShard hands to its reducer: BSI planes over the ROW IDS
+ * (bsiBuilder.Insert(rowID, count), bsi.go:251-284; merged across shards with AddBSI = fbk_bsi_add,
+ * read back with PivotDescending, bsi.go:18-62).  totals[i] as in fbk_topk; out row p (p <
+ * *out_depth = bits of the largest total) holds bit i iff bit p of totals[i] is set; row ids are the
+ * indices i (n_a <= 2^20), container keys p * 16 + slot. */
+int32_t fbk_topk_bsi(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a, const fbk_batch* filter,
+                     const uint32_t* rows_f, uint32_t n_shards, uint32_t flags, fbk_batch** out_batch, uint32_t* out_depth);
+
+/* out row i = rows[i] with the bits of the row-relative positions [start, end] (inclusive, 0 <= start
+ * <= end < 2^20) negated: Bitmap.Flip (roaring/roaring.go:2769-2799); the container-level flip of the
+ * reference's combination table (flipArray / flipBitmap / flipRun, roaring.go:6259-6274) is the
+ * range of one slot.  No PQL call reaches Flip (Not is Difference(existence, row), executor.go:5554);
+ * it completes the container algebra.  out_counts[i] = cardinality of out row i. */
+int32_t fbk_flip(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n_rows, uint64_t start, uint64_t end,
+                 uint32_t flags, fbk_batch** out_batch, uint64_t* out_counts);
+
 /* Shift: out row i = rows[i] with every column moved up by one — Row.Shift (row.go:374-396) /
  * RowSegment.Shift (:613-626) / Bitmap.Shift(1) (roaring/roaring.go:1629-1662; shiftArray,
  * shiftBitmap, shiftRun :6184-6257), which executeShiftShard (executor.go:5818-5836) applies n
