@@ -41,7 +41,7 @@ constexpr int kFxSB = 1024;                     // bytes of every row per stage
 constexpr int kFxStagesPerSlot = 8192 / kFxSB;  // 8
 constexpr int kFxNR = 65;                       // 32 A rows + 32 B rows + the filter row
 constexpr int kFxConsumers = 4;
-constexpr int kFxProducers = 8;
+constexpr int kFxProducers = 12;
 constexpr int kFxWaves = kFxConsumers + kFxProducers;
 constexpr int kFxRowsPerProducer = (kFxNR + kFxProducers - 1) / kFxProducers;  // 9
 constexpr int kFxArrayPasses = (kFxRowsPerProducer + 3) / 4;                  // 3
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
   const uint32_t pw = (uint32_t)wv - kFxConsumers;  // 0..7; owns rows pw, pw + 8, ... (lane j stands for row pw + 8 j)
   const uint32_t gq = lane >> 4, gl = lane & 15;
   // the descriptor table row of this lane's matrix row (fixed for the whole kernel)
-  const uint32_t my_row = pw + 8u * (uint32_t)lane;
+  const uint32_t my_row = pw + (uint32_t)kFxProducers * (uint32_t)lane;
   const Slot* my_slots = nullptr;
   const uint8_t* my_base = nullptr;
   if (lane < kFxRowsPerProducer && my_row < (uint32_t)kFxNR) {
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
     const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uintptr_t)d_ptr >> 32), src);
     ptr = reinterpret_cast<const uint8_t*>(((uintptr_t)phi << 32) | plo);
     len = (uint32_t)__builtin_amdgcn_readlane((int)d_len, src);
-    row = pw + 8u * (uint32_t)src;
+    row = pw + (uint32_t)kFxProducers * (uint32_t)src;
   };
   // slots at and past the end of the array get a value that lies outside the stage starting at lo
   auto fix_tail = [&](uint4& w, uint32_t idx0, uint32_t len, uint32_t lo) {
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
       const uint32_t phi = (uint32_t)__shfl((int)(uint32_t)((uintptr_t)d_ptr >> 32), (int)src, kWave);
       a_ptr[p] = reinterpret_cast<const uint8_t*>(((uintptr_t)phi << 32) | plo);
       a_len[p] = e < n_nar ? (uint32_t)__shfl((int)d_len, (int)src, kWave) : 0u;
-      a_row[p] = pw + 8u * src;
+      a_row[p] = pw + (uint32_t)kFxProducers * src;
       a_cur[p] = 0;
       a_win[p] = uint4{0, 0, 0, 0};
       if (4u * p < n_nar) a_win[p] = load_narrow(p, 0);
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
       if (!(ablate & 16u)) {
         const u64 zm = ~bmask;
         for (uint32_t j = 0; j < (uint32_t)kFxRowsPerProducer; ++j) {
-          const uint32_t row = pw + 8u * j;
+          const uint32_t row = pw + (uint32_t)kFxProducers * j;
           if (row < (uint32_t)kFxNR && ((zm >> j) & 1ull))
             *reinterpret_cast<uint4*>(ring8 + bufoff + row * kFxSB + lane * 16) = uint4{0, 0, 0, 0};
         }
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
         while (m) {  // (b) parity prefix over every run row: lane j owns logical piece j (words 2j, 2j + 1)
           const int src = __builtin_ctzll(m);
           m &= m - 1;
-          const uint32_t row = pw + 8u * (uint32_t)src, rot = row & 15u;
+          const uint32_t row = pw + (uint32_t)kFxProducers * (uint32_t)src, rot = row & 15u;
           uint4* pc = reinterpret_cast<uint4*>(ring8 + bufoff + row * kFxSB + fx_phys_piece((uint32_t)lane, rot) * 16u);
           const uint4 tv = *pc;
           const u64 t0 = ((u64)tv.y << 32) | tv.x, t1 = ((u64)tv.w << 32) | tv.z;

@@ -286,6 +286,11 @@ int main(int argc, char** argv) {
     CK(hipMemsetAsync(out, 0, n * 8, 0));
     hipLaunchKernelGGL(fbk::k_setop_dense<0>, dim3(n * 4), dim3(256), 0, 0, A[s], rows, B[s], rows, O[s], oslots, out);
   });
+  // the reference counts were computed for data set 0: run the checked launch on THAT set (the timed
+  // loop above ends on whichever set the cycle stopped at — comparing that with set 0's reference is
+  // what printed "and product mismatch" for sets > 1 in the round-1 log; the kernel was never wrong)
+  CK(hipMemsetAsync(out, 0, n * 8, 0));
+  hipLaunchKernelGGL(fbk::k_setop_dense<0>, dim3(n * 4), dim3(256), 0, 0, A[0], rows, B[0], rows, O[0], oslots, out);
   check("and product");
   TIME("AND row ld plain st plain", rdwr, hipLaunchKernelGGL((k_and_row<false, false>), dim3(n), dim3(256), 0, 0, A[s], B[s], O[s], out));
   TIME("AND row ld plain st nt", rdwr, hipLaunchKernelGGL((k_and_row<false, true>), dim3(n), dim3(256), 0, 0, A[s], B[s], O[s], out));

@@ -409,3 +409,17 @@ def test_reference_bitmap_level_count_range_vectors_through_the_abi(gpu_ctx, ora
         if name == "EdgeCase":
             assert int(batch.count(np.arange(len(shards))).sum()) == ranges[0][2]
         batch.free()
+
+
+def test_count_range_counts_bits_where_run_count_range_double_counts(gpu_ctx, oracle):
+    """The deliberate divergence from RunCountRange (roaring.go:3216-3227, pinned on the oracle in
+    tests/test_oracle_bitmap_vectors.py::test_run_count_range_overcount_is_pinned): the device counts
+    the bits of [start, end)."""
+    from featurebase_amd.roaring import Container
+
+    b = gpu_ctx.upload([{0: Container.run([(10, 20), (30, 40)])}])
+    assert gpu_ctx.count_range(b, [0], 15, 40).tolist() == [16]
+    bm = oracle.OBitmap.from_containers([(0, oracle.OContainer.run([(10, 20), (30, 40)]))])
+    assert bm.count_range(15, 40) == 27  # the reference's answer for the same call
+    assert gpu_ctx.count_range(b, [0], 12, 35).tolist() == [bm.count_range(12, 35)]
+    b.free()

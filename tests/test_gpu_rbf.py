@@ -8,7 +8,7 @@ import pytest
 
 import datagen as D
 from featurebase_amd import lib as L
-from test_oracle_rbf import FIX, fixture_file, random_fragment
+from test_oracle_rbf import FIX, file_image, fixture_file, random_fragment
 
 pytestmark = pytest.mark.gpu
 
@@ -25,6 +25,25 @@ def test_reference_written_file_on_gpu(gpu_ctx):
     batch.free()
     with pytest.raises(L.FbkError):
         gpu_ctx.rbf_find_root(f, "nope")  # ErrBitmapNotFound
+
+
+def test_every_reference_written_file_on_gpu(gpu_ctx):
+    """The four database files the reference ships, through fbk_rbf_find_root + fbk_batch_upload_rbf:
+    three hold bitmap "x" = {key 0: array [100]}; bad-bitmap's branch cell points outside the file."""
+    for name, d in FIX["files"].items():
+        f = file_image(name)
+        root = gpu_ctx.rbf_find_root(f, FIX["bitmap"])
+        assert root == 3, name
+        if "expect" in d:
+            batch, ids = gpu_ctx.upload_rbf(f, root)
+            rows = batch.download()
+            assert ids.tolist() == [0] and list(rows[0]) == [0], name
+            c = rows[0][0]
+            assert c.typ == L.TYPE_ARRAY and c.n == 1 and c.data.tolist() == [100], name
+            batch.free()
+        else:
+            with pytest.raises(L.FbkError, match="65537"):
+                gpu_ctx.upload_rbf(f, root)
 
 
 def test_bad_bitmap_file_is_rejected(gpu_ctx):
@@ -123,3 +142,47 @@ def test_fragment_cache_hit_miss_invalidate_evict(gpu_ctx, oracle):
     ctx.cache_release(g0[0])
     ctx.cache_configure(128 << 30)
     ctx.cache_invalidate("")
+
+
+def test_corrupt_trees_and_untrusted_headers(gpu_ctx, oracle):
+    """a branch cell that points back at an ancestor must be rejected (not walked
+    cell_n^16 times); a leaf cell whose BitN under-reports is repaired by the device recount, an
+    unsorted array cell is rejected by the device validator."""
+    import struct
+
+    from oracle import pyrbf
+
+    rng = D.rng_for(103)
+    frag = random_fragment(rng, 30, oracle)
+    f = bytearray(pyrbf.write_db({"i/f/standard/0": frag}, leaf_cells_per_page=4, branch_fanout=3))
+    root = pyrbf.find_root(bytes(f), "i/f/standard/0")
+    assert struct.unpack_from(">I", f, root * 8192 + 4)[0] == pyrbf.BRANCH
+    # first branch cell of the root: childPgno (little endian u32 at cell + 12) -> the root itself
+    cell0 = struct.unpack_from(">H", f, root * 8192 + 10)[0]
+    cyc = bytearray(f)
+    struct.pack_into("<I", cyc, root * 8192 + cell0 + 12, root)
+    with pytest.raises(L.FbkError, match="reachable twice"):
+        gpu_ctx.upload_rbf(bytes(cyc), root)
+    # find a leaf page with an array cell and damage it
+    n_pages = len(f) // 8192
+    for pg in range(2, n_pages):
+        flags, cell_n = struct.unpack_from(">IH", f, pg * 8192 + 4)
+        if flags != pyrbf.LEAF or cell_n == 0:
+            continue
+        for i in range(cell_n):
+            off = struct.unpack_from(">H", f, pg * 8192 + 10 + 2 * i)[0]
+            key, typ, elem_n, bit_n = struct.unpack_from("<QIHI", f, pg * 8192 + off)
+            if typ == 1 and elem_n >= 4:
+                under = bytearray(f)
+                struct.pack_into("<I", under, pg * 8192 + off + 14, 1)  # BitN = 1: the array holds more
+                batch, ids = gpu_ctx.upload_rbf(bytes(under), root)
+                got = {k: c for row in batch.download() for k, c in row.items()}
+                assert got[key].n == elem_n  # recounted on the device
+                batch.free()
+                swapped = bytearray(f)
+                a, b = struct.unpack_from("<HH", f, pg * 8192 + off + 18)
+                struct.pack_into("<HH", swapped, pg * 8192 + off + 18, b, a)
+                with pytest.raises(L.FbkError, match="ascending"):
+                    gpu_ctx.upload_rbf(bytes(swapped), root)
+                return
+    raise AssertionError("no array cell found")

@@ -90,3 +90,32 @@ def test_bitmap_fold_vectors(oracle, name, op, specs, want, want_slice):
     assert r.count() == want
     if want_slice is not None:
         assert r.slice() == want_slice
+
+
+def test_run_count_range_overcount_is_pinned(oracle):
+    """RunCountRange (roaring.go:3200-3232) counts a run twice when it starts inside the range and its
+    LAST value equals `end`: the "subset of range" branch (Last <= end) adds the whole run and the
+    "overlaps end" branch (Last >= end) adds end - Start on top.  The oracle restates the function as
+    written, so it reproduces the over-count; fbk_count_range counts bits (include/fbk.h) — the
+    deliberate divergence is pinned here instead of assumed.  Container-aligned ranges, the only
+    ones the reference's callers produce (fragment.go:237,396,444), never meet the quirk."""
+    import ctypes as C
+
+    import numpy as np
+
+    O = oracle
+    runs = np.array([[10, 20], [30, 40]], dtype=np.uint16)  # bits 10..20 and 30..40
+    f = O.lib().orc_run_count_range
+    cnt = lambda s, e: int(f(runs.ctypes.data_as(C.c_void_p), 2, s, e))  # noqa: E731
+    bits = np.zeros(65536, dtype=np.int64)
+    bits[10:21] = 1
+    bits[30:41] = 1
+    # the quirk: [15, 40): true count = 6 + 10 = 16; the run [30, 40] has Start > start and Last == end
+    assert int(bits[15:40].sum()) == 16
+    assert cnt(15, 40) == 6 + 11 + 10  # subset branch adds 11 (positions 30..40), overlap branch 40 - 30 = 10 more
+    # away from the quirk the function counts bits
+    for s, e in [(0, 65536), (0, 10), (10, 21), (12, 35), (21, 30), (35, 36), (41, 50), (0, 41)]:
+        assert cnt(s, e) == int(bits[s:e].sum()), (s, e)
+    # same through Bitmap.CountRange on a one-container bitmap
+    bm = O.OBitmap.from_containers([(0, O.OContainer.run([(10, 20), (30, 40)]))])
+    assert bm.count_range(15, 40) == 27 and bm.count_range(12, 35) == int(bits[12:35].sum())

@@ -18,6 +18,35 @@ def fixture_file() -> bytes:
     return b"".join(bytes.fromhex(h).ljust(FIX["page_size"], b"\0") for h in FIX["pages_hex_prefix"])
 
 
+def file_image(name: str) -> bytes:
+    """one of the four reference-written database files (tests/golden/rbf_fixture.json "files")"""
+    return b"".join(bytes.fromhex(h).ljust(FIX["page_size"], b"\0") for h in FIX["files"][name]["pages_hex_prefix"])
+
+
+def test_every_reference_written_file():
+    """All four RBF files the reference ships (rbf/testdata/check/*, ctl/testdata/{ok,
+    err-invalid-page-type}): the oracle's reader finds bitmap "x" and its one array cell in the three
+    readable ones and fails on bad-bitmap's branch cell exactly where the reference does
+    (pgno=65537, rbf/tx_test.go:1301)."""
+    import pytest
+
+    from oracle import pyrbf
+
+    for name, d in FIX["files"].items():
+        f = file_image(name)
+        assert len(f) == 8192 * len(d["pages_hex_prefix"]) and f[:4] == b"\xffRBF"
+        root = pyrbf.find_root(f, FIX["bitmap"])
+        assert root == 3
+        if "expect" in d:
+            conts = pyrbf.read_bitmap(f, root)
+            assert [(k, t, n, p.tolist()) for k, t, n, p in conts] == [(0, 1, 1, [100])], name
+        else:
+            # page 3 carries the BRANCH flag and one branch cell {leftKey 0, flags, childPgno 65537}
+            assert struct.unpack_from(">IIH", f, 3 * 8192) == (3, pyrbf.BRANCH, 1)
+            with pytest.raises(Exception):
+                pyrbf.read_bitmap(f, root)
+
+
 def random_fragment(rng, n_rows, oracle):
     """containers of a fragment: key = row*16 + slot, RBF-legal encodings"""
     out = []
