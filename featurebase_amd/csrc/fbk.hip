@@ -81,6 +81,7 @@ struct FbkOptions {
   int64_t matrix_fused = -1;             // encoded rows: 1 decode inside the matrix-core kernel, 0 never, -1 cost model
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
+  int64_t bsi_minmax_blocks = 0;         // 1: one block per shard for Min / Max (round-1 kernel, A/B runs); 0: one wavefront per (shard, slot)
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
 };
@@ -435,6 +436,7 @@ const OptionDesc kOptions[] = {
     {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
+    {"bsi_minmax_blocks", &FbkOptions::bsi_minmax_blocks, 0, 1},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
 };

@@ -450,6 +450,94 @@ __global__ void __launch_bounds__(1024) k_bsi_minmax(const Slot* __restrict__ sl
   }
 }
 
+// The same scan per (shard, SLOT): min / max over a shard = min / max over its 16 slots' own minima /
+// maxima (the count of the winning value adds up over the slots that reach it), so the 16 slots
+// need not be scanned in lock step.  k_bsi_minmax above runs 96 blocks for 100 M columns — 96 of
+// 256 CUs, each limited to its own ~33 GB/s share of HBM: 256 us for 830 MB (3.2 TB/s,
+// profiles/r02_misc_kernel_stats.csv).  Here one wavefront owns one (shard, slot): 1536 independent
+// scans fill the chip, the next plane's loads are in flight while the current plane is counted
+// (they do not depend on the decision), and there is no barrier at all.  out2[(shard * 16 + slot)]
+// = {magnitude, count | scan flag}; the host folds the 16 pairs of a shard (fbk_query_api.inc bsi_minmax).
+__global__ void __launch_bounds__(64) k_bsi_minmax_slot(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                                       const uint32_t* __restrict__ base, uint32_t n_shards, uint32_t bit_depth,
+                                                       uint32_t mode, const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,
+                                                       const uint32_t* __restrict__ frows, u64* __restrict__ out2) {
+  __shared__ u64 lds[kWords];
+  const int lane = threadIdx.x;
+  const uint64_t cell = blockIdx.x;
+  const uint64_t shard = cell >> 4;
+  const uint32_t slot = cell & 15;
+  if (shard >= n_shards) return;
+  const uint64_t r0 = base[shard];
+  auto load_plane = [&](uint64_t row, u64 (&w)[kWordsPerLane]) {
+    const Slot sp = slots[row * kSlots + slot];
+    if (slot_n(sp) == 0) frag_zero(w);
+    else frag_load(sp, arena, lane, lds, w);
+  };
+  u64 F[kWordsPerLane], T[kWordsPerLane], N[kWordsPerLane];
+  load_plane(r0 + 0, F);  // consider = exists ∩ filter
+  if (fslots) {
+    const Slot sf = fslots[(uint64_t)frows[shard] * kSlots + slot];
+    if (slot_n(sf) == 0) frag_zero(T);
+    else frag_load(sf, farena, lane, lds, T);
+#pragma unroll
+    for (int q = 0; q < kWordsPerLane; ++q) F[q] &= T[q];
+  }
+  uint32_t cur = wave_reduce_add(frag_popcount(F));
+  if (cur == 0) {
+    if (lane == 0) {
+      out2[cell * 2] = 0;
+      out2[cell * 2 + 1] = 0;
+    }
+    return;
+  }
+  bool scan_max, negate;
+  {
+    load_plane(r0 + 1, T);  // sign
+    u64 G[kWordsPerLane];
+#pragma unroll
+    for (int q = 0; q < kWordsPerLane; ++q) G[q] = mode == 0 ? (F[q] & T[q]) : (F[q] & ~T[q]);
+    const uint32_t g = wave_reduce_add(frag_popcount(G));
+    if (g != 0) {
+      scan_max = true;
+      negate = (mode == 0);
+      cur = g;
+#pragma unroll
+      for (int q = 0; q < kWordsPerLane; ++q) F[q] = G[q];
+    } else {
+      scan_max = false;
+      negate = (mode == 1);
+    }
+  }
+  u64 val = 0;
+  if (bit_depth) load_plane(r0 + 2 + (uint64_t)(bit_depth - 1), T);
+  for (int i = (int)bit_depth - 1; i >= 0; --i) {
+    if (i > 0) load_plane(r0 + 2 + (uint64_t)(i - 1), N);  // the next plane, whatever this one decides
+#pragma unroll
+    for (int q = 0; q < kWordsPerLane; ++q) T[q] = scan_max ? (F[q] & T[q]) : (F[q] & ~T[q]);
+    const uint32_t c = wave_reduce_add(frag_popcount(T));
+    if (c > 0) {
+#pragma unroll
+      for (int q = 0; q < kWordsPerLane; ++q) F[q] = T[q];
+      cur = c;
+      if (scan_max) val += 1ull << i;
+    } else if (!scan_max) {
+      val += 1ull << i;
+    }
+#pragma unroll
+    for (int q = 0; q < kWordsPerLane; ++q) T[q] = N[q];
+  }
+  (void)negate;
+  if (lane == 0) {
+    // the unsigned magnitude and, in bit 63 of the count word, which scan produced it: 1 = maxUnsigned
+    // over the columns whose sign decides the result (negatives for min, positives for max), 0 =
+    // minUnsigned over all considered columns.  The host applies the sign AFTER folding the slots, so
+    // that magnitudes are compared unsigned exactly as fragment.min / max do over the whole row.
+    out2[cell * 2] = val;
+    out2[cell * 2 + 1] = (u64)cur | (scan_max ? (1ull << 63) : 0ull);
+  }
+}
+
 // ---- BSI adder ---------------------------------------------------------------------------------
 // roaring.Add (roaring/add.go:12-849), used by AddBSI (bsi.go:83-175) to merge the per-shard
 // TopK count BSIs: z = x + y over unsigned bit-sliced values, plane i of z = x_i ^ y_i ^ carry,

@@ -8,7 +8,7 @@
 
 constexpr int ITER = 2048;
 
-template <int MODE>  // 0 ds_or random, 1 ds_or conflict-free (lane -> own bank), 2 ds_write_b32 random, 3 ds_or same dword pairs, 4 ds_or_b64 random
+template <int MODE>  // 5/6/7: the address patterns of the bitmap-stage decode (fbk_matrix_fused.hip.h); 0 ds_or random, 1 ds_or conflict-free (lane -> own bank), 2 ds_write_b32 random, 3 ds_or same dword pairs, 4 ds_or_b64 random
 __global__ void __launch_bounds__(512) k(uint32_t* out, uint32_t active_lanes, uint32_t seed) {
   __shared__ uint32_t lds[16384];
   const int lane = threadIdx.x & 63;
@@ -21,6 +21,9 @@ __global__ void __launch_bounds__(512) k(uint32_t* out, uint32_t active_lanes, u
     uint32_t a = (x >> 8) & 16383u;
     if (MODE == 1) a = (a & ~63u) | lane;
     if (MODE == 3) a = (a & ~63u) | (lane >> 1);
+    if (MODE == 5) a = ((x >> 24) & 63u) * 256u + ((x >> 8) & 255u);             // all 64 lanes inside ONE 1 KiB row (row picked per lane: random rows)
+    if (MODE == 6) a = (__builtin_amdgcn_readfirstlane((int)(x >> 24)) & 63u) * 256u + ((x >> 8) & 255u);  // all 64 lanes inside the SAME 1 KiB row
+    if (MODE == 7) a = (__builtin_amdgcn_readfirstlane((int)(x >> 24)) & 63u) * 256u + lane * 4u + ((x >> 8) & 3u);  // same row, lane l -> its own 16-byte piece
     if (on) {
       if (MODE == 2) asm volatile("ds_write_b32 %0, %1" ::"v"(a * 4), "v"(x) : "memory");
       else if (MODE == 4) asm volatile("ds_or_b64 %0, %1" ::"v"((a & ~1u) * 4), "v"((unsigned long long)x) : "memory");
@@ -59,5 +62,8 @@ int main() {
   for (uint32_t lanes : {64u, 16u}) run<2>("ds_write_b32 random dword", d, lanes);
   for (uint32_t lanes : {64u}) run<3>("ds_or_b32 pairs share a dword", d, lanes);
   for (uint32_t lanes : {64u, 16u}) run<4>("ds_or_b64 random qword", d, lanes);
+  for (uint32_t lanes : {64u, 16u}) run<5>("ds_or_b32 random rows, dword in row", d, lanes);
+  for (uint32_t lanes : {64u, 32u, 16u}) run<6>("ds_or_b32 all lanes in ONE 1 KiB row", d, lanes);
+  for (uint32_t lanes : {64u}) run<7>("ds_or_b32 one row, lane owns a piece", d, lanes);
   return 0;
 }

@@ -326,13 +326,18 @@ def test_bsi_minmax_random_multi_shard_vs_oracle(gpu_ctx, B):
             filts.append(B.row_from_columns([int(c) for c in cols[:: 2 + s]] + [5, 70000]))
         batch, base = upload_bsi(gpu_ctx, frags)
         F = gpu_ctx.upload([fbk_row_of_bitmap(f) for f in filts])
-        for fn, ofn in ((gpu_ctx.bsi_min, B.bsi_min), (gpu_ctx.bsi_max, B.bsi_max)):
-            v, c = fn(batch, base, depth)
-            for s, fr in enumerate(frags):
-                assert (int(v[s]), int(c[s])) == ofn(fr, None, depth), (depth, s)
-            v, c = fn(batch, base, depth, F, np.arange(len(frags)))
-            for s, fr in enumerate(frags):
-                assert (int(v[s]), int(c[s])) == ofn(fr, filts[s], depth), (depth, s, "filtered")
+        try:
+            for blocks in (0, 1):  # one wavefront per (shard, slot) + host fold (default) / one block per shard (round-1 kernel)
+                gpu_ctx.set_option("bsi_minmax_blocks", blocks)
+                for fn, ofn in ((gpu_ctx.bsi_min, B.bsi_min), (gpu_ctx.bsi_max, B.bsi_max)):
+                    v, c = fn(batch, base, depth)
+                    for s, fr in enumerate(frags):
+                        assert (int(v[s]), int(c[s])) == ofn(fr, None, depth), (depth, s, blocks)
+                    v, c = fn(batch, base, depth, F, np.arange(len(frags)))
+                    for s, fr in enumerate(frags):
+                        assert (int(v[s]), int(c[s])) == ofn(fr, filts[s], depth), (depth, s, "filtered", blocks)
+        finally:
+            gpu_ctx.set_option("bsi_minmax_blocks", 0)
         batch.free()
         F.free()
 
