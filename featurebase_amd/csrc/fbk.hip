@@ -79,6 +79,7 @@ struct FbkOptions {
   int64_t matrix_pass_kb = 1 << 20;      // per-shard matrices are produced in passes of at most this many KiB
   int64_t matrix_densify = -1;           // encoded rows: 1 densify + dense kernel, 0 generic pair kernel, -1 cost model
   int64_t matrix_fused = -1;             // encoded rows: 1 decode inside the matrix-core kernel, 0 never, -1 cost model
+  int64_t matrix_fp4 = -1;               // dense count matrix on the FP4 matrix instruction: 1 always, 0 never, -1 when it has several tiles
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
   int64_t bsi_minmax_blocks = 0;         // 1: one block per shard for Min / Max (round-1 kernel, A/B runs); 0: one wavefront per (shard, slot)
@@ -434,6 +435,7 @@ const OptionDesc kOptions[] = {
     {"matrix_pass_kb", &FbkOptions::matrix_pass_kb, 1, int64_t(1) << 40},
     {"matrix_densify", &FbkOptions::matrix_densify, -1, 1},
     {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
+    {"matrix_fp4", &FbkOptions::matrix_fp4, -1, 1},
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
     {"bsi_minmax_blocks", &FbkOptions::bsi_minmax_blocks, 0, 1},

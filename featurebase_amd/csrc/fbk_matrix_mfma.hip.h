@@ -53,7 +53,18 @@ typedef uint32_t mm_u4 __attribute__((ext_vector_type(4)));
 // its TM A operands and TN B operands — 2 x 2 halves the VALU, LDS and DMA work per MFMA, which is
 // what bounds a matrix of many tiles (128 x 128 rows x 64 shards: 1256 us with 1 x 1 tiles, where
 // the matrix cores alone would need 437 us).
-template <bool HAS_F, int WAVES = kMmWaves, int DEPTH = kMmDepth, int AUX = kMmAux, int TM = 1, int TN = 1>
+// FP4 = true: the same product on the block-scaled FP4 matrix instruction
+// (v_mfma_scale_f32_32x32x64_f8f6f4, formats E2M1 x E2M1, scales 2^0): a bit becomes a NIBBLE —
+// (x >> k) & 0x11111111 for k = 0..3 puts bit (4 j + k) of the word into nibble j as code 0001 = 0.5
+// — so one instruction covers K = 64 bit positions instead of 32 and every common bit adds
+// 0.5 * 0.5 = 0.25 to an f32 accumulator (exact: at most 2^20 * 0.25 per shard, all partial sums
+// are multiples of 0.25 below 2^24).  Per 16 bytes of every row: 4 matrix instructions instead of
+// 8 and 60 vector-ALU operations instead of 76 — for matrices of several tiles, which the i8
+// version leaves matrix-core bound (58-63 % of the dense i8 rate in round 1).
+typedef int mm_v8i __attribute__((ext_vector_type(8)));
+typedef float mm_v16f __attribute__((ext_vector_type(16)));
+
+template <bool HAS_F, int WAVES = kMmWaves, int DEPTH = kMmDepth, int AUX = kMmAux, int TM = 1, int TN = 1, bool FP4 = false>
 __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
     const uint8_t* __restrict__ arenaA, const uint32_t* __restrict__ rowsA, uint32_t nA, const uint8_t* __restrict__ arenaB,
     const uint32_t* __restrict__ rowsB, uint32_t nBtot, const uint8_t* __restrict__ arenaF,
@@ -122,12 +133,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
   // alternates between two P accumulators so that consecutive MFMAs never chain on one
   constexpr int NP = (TM * TN == 1) ? 2 : 1;
   mm_v16i accP[TM][TN][NP], accN[TM][TN];
+  mm_v16f accF[TM][TN][3];  // FP4 only (the compiler drops whichever set is unused)
 #pragma unroll
   for (int m = 0; m < TM; ++m)
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
 #pragma unroll
       for (int h = 0; h < NP; ++h) accP[m][n][h] = mm_v16i{};
+#pragma unroll
+      for (int h = 0; h < 3; ++h) accF[m][n][h] = mm_v16f{};
       accN[m][n] = mm_v16i{};
     }
 
@@ -170,6 +184,38 @@ __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
   };
   constexpr uint32_t M = 0x01010101u;
   auto octet = [&](const Oct& o) {
+    if (FP4) {
+      // nibble codes of E2M1: 0001 = 0.5, 0010 = 1.0, 0100 = 2.0 (1000 = -0.0: useless).  Masking the
+      // word with 0x11111111 << k (k = 0, 1, 2) leaves bit 4j + k in nibble j with those values — ONE
+      // v_and per operand dword, no shift; only k = 3 needs (x >> 3) & 0x11111111.  The products are
+      // 0.25 (k = 0 and 3), 1 (k = 1) and 4 (k = 2) per common bit, kept in three accumulators:
+      // count = 4 acc0 + acc1 + acc2 / 4, every partial sum exact in f32.
+      constexpr uint32_t M4 = 0x11111111u;
+      uint32_t a[TM][4];
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) a[m][d] = HAS_F ? (o.A[m][d] & o.F[d]) : o.A[m][d];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mm_v8i oa[TM], ob[TN];  // the instruction reads the first four registers of an FP4 operand: the rest stays undefined
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) oa[m][d] = (int)(k < 3 ? (a[m][d] & (M4 << k)) : ((a[m][d] >> 3) & M4));
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) ob[n][d] = (int)(k < 3 ? (o.B[n][d] & (M4 << k)) : ((o.B[n][d] >> 3) & M4));
+        constexpr int kAcc[4] = {0, 1, 2, 0};
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            accF[m][n][kAcc[k]] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa[m], ob[n], accF[m][n][kAcc[k]], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+      return;
+    }
     uint32_t a[TM][4], bb[TN][4];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -243,7 +289,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
     for (int n = 0; n < TN; ++n)
 #pragma unroll
       for (int q = 0; q < 16; ++q)
-        red[((m * TN + n) * 16 + q) * 64 + lane] = (uint32_t)(accP[m][n][0][q] + (NP > 1 ? accP[m][n][NP - 1][q] : 0) - accN[m][n][q]) >> 7;
+        red[((m * TN + n) * 16 + q) * 64 + lane] =
+            FP4 ? (uint32_t)(accF[m][n][0][q] * 4.0f + accF[m][n][1][q] + accF[m][n][2][q] * 0.25f + 0.5f)
+                : (uint32_t)(accP[m][n][0][q] + (NP > 1 ? accP[m][n][NP - 1][q] : 0) - accN[m][n][q]) >> 7;
   __syncthreads();
   constexpr int kRegs = TM * TN * 16;
   static_assert(kRegs % WAVES == 0, "accumulator registers are dealt evenly to the waves");

@@ -448,14 +448,20 @@ def test_count_matrix_dense_kernel_vs_numpy(gpu_ctx, n_shards, n_a, n_b, use_fil
     assert (tot == exp.sum(axis=0)).all()
     # every slots-per-block split of the launch (16 = whole shards with plain stores, smaller =
     # atomic adds of partial matrices), and the vector-ALU kernel kept for A/B measurements
+    # ... on both matrix instructions: v_mfma_i32_32x32x32_i8 (bit -> byte) and the block-scaled FP4
+    # v_mfma_scale_f32_32x32x64_f8f6f4 (bit -> nibble, option matrix_fp4; the default picks it for
+    # matrices of several tiles)
     try:
-        for spb in ("16", "8", "4", "2", "1"):
-            gpu_ctx.set_option("matrix_spb", int(spb))
-            tot2, ps2 = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf if use_filter else None, per_shard=True)
-            assert (ps2 == exp).all(), spb
-            assert (tot2 == tot).all(), spb
+        for fp4 in (0, 1):
+            gpu_ctx.set_option("matrix_fp4", fp4)
+            for spb in ("16", "8", "4", "2", "1"):
+                gpu_ctx.set_option("matrix_spb", int(spb))
+                tot2, ps2 = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf if use_filter else None, per_shard=True)
+                assert (ps2 == exp).all(), (fp4, spb)
+                assert (tot2 == tot).all(), (fp4, spb)
     finally:
         gpu_ctx.set_option("matrix_spb", 0)
+        gpu_ctx.set_option("matrix_fp4", -1)
     # the total alone (no per-shard matrices asked for) is reduced in passes over the shards: force
     # passes of one or two shards
     try:
