@@ -271,16 +271,16 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         out.append(_entry("config3 rows, TopN/TopK shape: 64 rows x 1 filter row per shard", "k_rows_vs_filter", nbytes + 8 * 64 * n3, g, w,
                           set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), **common))
         g, w = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx), max(5, iters // 2))
-        out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: densify + dense matrix-core kernel (default)", "k_densify_rows + k_count_matrix_mfma",
+        out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel (default)", "k_count_matrix_fused",
                           nbytes + 8 * 1024 * n3, g, w, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
-                          hbm_note="1.9 KB of temporary bitmap rows written and read back per KB of encoded rows", **common))
-        ctx.set_option("matrix_fused", 1)
+                          hbm_note="encoded rows are the only HBM traffic (PMC ratio 1.07); instruction-bound decode (DESIGN.md section 9)", **common))
+        ctx.set_option("matrix_fused", 0)
         assert (ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx, per_shard=True)[1] == mat3).all(), "fused and densify paths disagree"
         g, w = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx), max(5, iters // 2))
         ctx.set_option("matrix_fused", -1)
-        out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel (option matrix_fused=1)", "k_count_matrix_fused",
-                          nbytes + 8 * 1024 * n3, g, w, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
-                          hbm_note="encoded rows are the only HBM traffic; instruction-bound decode (DESIGN.md section 9)", **common))
+        out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: densify + dense matrix-core kernel (round 1, option matrix_fused=0)",
+                          "k_densify_rows + k_count_matrix_mfma", nbytes + 8 * 1024 * n3, g, w, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
+                          hbm_note="3.7 bytes of temporary bitmap rows written and read back per byte of encoded rows", **common))
         g, w = _timed_call(torch, stream, lambda: ctx.union_n(batch, groups, L.SETOP_OPTIMIZE)[0].free(), max(5, iters // 2))
         out.append(_entry("config3 rows, Union-of-64 materialised + optimize() re-encode", "k_fold_scatter<OR> + k_encode_*", nbytes, g, w, **common))
         batch.free()

@@ -591,17 +591,19 @@ def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle
         assert (ps[k] == e).all(), (k, s)
         exp_tot += e
     assert (tot == exp_tot).all()
-    # the same call on the other two paths for encoded rows: decode inside the matrix-core kernel
-    # (fbk_matrix_fused.hip.h, option matrix_fused=1; every slots-per-block split of its launch) and
-    # the generic pair kernel (matrix_densify=0); the default above densifies + runs the dense kernel
+    # the default above decodes inside the matrix-core kernel (fbk_matrix_fused.hip.h): every
+    # slots-per-block split of that launch; then the same call on the other two paths for encoded rows:
+    # densify + dense matrix-core kernel (round 1's path, matrix_fused=0) and the generic pair kernel
+    # (matrix_fused=0, matrix_densify=0)
     try:
-        gpu_ctx.set_option("matrix_fused", 1)
-        for spb in (0, 16, 8, 4, 2, 1):
+        for spb in (16, 8, 4, 2, 1):
             gpu_ctx.set_option("matrix_spb", spb)
             tot_s, ps_s = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
             assert (tot_s == tot).all() and (ps_s == ps).all(), spb
         gpu_ctx.set_option("matrix_spb", 0)
         gpu_ctx.set_option("matrix_fused", 0)
+        tot_d, ps_d = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
+        assert (tot_d == tot).all() and (ps_d == ps).all()
         gpu_ctx.set_option("matrix_densify", 0)
         tot_g, ps_g = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
     finally:
