@@ -24,6 +24,7 @@
 #include "fbk_matrix_kernels.hip.h"
 #include "fbk_matrix_mfma.hip.h"
 #include "fbk_matrix_fused.hip.h"
+#include "fbk_matrix_fused2.hip.h"
 #include "fbk_wire_kernels.hip.h"
 
 using fbk::Slot;
@@ -78,7 +79,7 @@ struct FbkOptions {
   int64_t matrix_spb = 0;                // slots per block of the dense count matrix; 0 = chosen per launch
   int64_t matrix_pass_kb = 1 << 20;      // per-shard matrices are produced in passes of at most this many KiB
   int64_t matrix_densify = -1;           // encoded rows: 1 densify + dense kernel, 0 generic pair kernel, -1 cost model
-  int64_t matrix_fused = -1;             // encoded rows: 1 decode inside the matrix-core kernel, 0 never, -1 cost model
+  int64_t matrix_fused = -1;             // encoded rows: 1 decode inside the matrix-core kernel (2: its first version), 0 never, -1 cost model
   int64_t matrix_fp4 = -1;               // dense count matrix on the FP4 matrix instruction: 1 always, 0 never, -1 when it has several tiles
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
@@ -139,6 +140,10 @@ struct fbk_batch {
   bool slots_stale = false;    // host copy must be refreshed from device before use
   std::vector<Slot> h_slots;   // host copy of the descriptors (types, n, offsets)
   std::vector<uint64_t> h_keys;  // container key per slot (carried through to download)
+  // window index (k_window_index): 16 bytes per slot, built on the first count matrix that reads the
+  // batch, dropped whenever the containers are rewritten (plan outputs, optimize)
+  mutable uint4* d_win = nullptr;
+  mutable std::mutex win_mu;
 };
 
 namespace {
@@ -161,7 +166,9 @@ uint64_t pool_bucket(uint64_t bytes) {
 }
 
 hipError_t ctx_malloc(fbk_ctx* ctx, void** out, uint64_t bytes) {
-  const uint64_t bucket = pool_bucket(bytes);
+  // 64 bytes of slack behind every allocation: kernels read array payloads with 16-byte loads at
+  // 2-byte alignment (fbk_matrix_fused.hip.h), up to 14 bytes past the padded end of the last container
+  const uint64_t bucket = pool_bucket(bytes + 64);
   {
     std::lock_guard<std::mutex> g(ctx->pool_mu);
     auto it = ctx->pool_free_lists.find(bucket);
@@ -316,6 +323,39 @@ int32_t refresh_slots(fbk_batch* b) {
   return FBK_OK;
 }
 
+// The containers of `b` were (re)written on the device: the host descriptors are stale and the
+// window index no longer describes the payloads.  (Called with the stream's earlier readers of the
+// index behind the rewrite in stream order, or already synchronised.)
+void slots_rewritten(fbk_batch* b) {
+  b->slots_stale = true;
+  std::lock_guard<std::mutex> g(b->win_mu);
+  if (b->d_win) {
+    (void)ctx_free(b->ctx, b->d_win);
+    b->d_win = nullptr;
+  }
+}
+
+// The window index of `b`, built on first use (one pass over its arrays and run lists) on the
+// calling context's stream and complete when this returns.
+int32_t window_index(fbk_ctx* ctx, const fbk_batch* b, const uint4** out) {
+  std::lock_guard<std::mutex> g(b->win_mu);
+  if (!b->d_win) {
+    const uint64_t n_slots = uint64_t(b->n_rows) * fbk::kSlots;
+    uint4* w = nullptr;
+    HIP_TRY(ctx_malloc(b->ctx, reinterpret_cast<void**>(&w), std::max<uint64_t>(n_slots, 1) * sizeof(uint4)));
+    if (n_slots) hipLaunchKernelGGL(fbk::k_window_index, dim3(uint32_t((n_slots + 3) / 4)), dim3(256), 0, ctx->stream, b->d_slots, b->d_arena, n_slots, w);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      (void)ctx_free(b->ctx, w);
+      return fail(FBK_E_HIP, std::string("window index: ") + hipGetErrorString(e));
+    }
+    b->d_win = w;
+  }
+  *out = b->d_win;
+  return FBK_OK;
+}
+
 int32_t upload_rows(fbk_ctx* ctx, const uint32_t* rows, uint64_t n, uint32_t n_rows_limit, DevBuf& out) {
   for (uint64_t i = 0; n_rows_limit != UINT32_MAX && i < n; ++i)  // UINT32_MAX: the caller has validated the indices
     if (rows[i] >= n_rows_limit)
@@ -434,7 +474,7 @@ const OptionDesc kOptions[] = {
     {"matrix_spb", &FbkOptions::matrix_spb, 0, 16},
     {"matrix_pass_kb", &FbkOptions::matrix_pass_kb, 1, int64_t(1) << 40},
     {"matrix_densify", &FbkOptions::matrix_densify, -1, 1},
-    {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
+    {"matrix_fused", &FbkOptions::matrix_fused, -1, 2},
     {"matrix_fp4", &FbkOptions::matrix_fp4, -1, 1},
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
@@ -583,6 +623,7 @@ int32_t fbk_batch_free(fbk_ctx* ctx, fbk_batch* b) {
   (void)hipStreamSynchronize(ctx->stream);
   if (b->d_arena) (void)ctx_free(b->ctx, b->d_arena);
   if (b->d_slots) (void)ctx_free(b->ctx, b->d_slots);
+  if (b->d_win) (void)ctx_free(b->ctx, b->d_win);
   delete b;
   return FBK_OK;
 }
@@ -963,6 +1004,7 @@ void free_batch_storage(fbk_batch* b) {
   if (!b) return;
   if (b->d_arena) (void)ctx_free(b->ctx, b->d_arena);
   if (b->d_slots) (void)ctx_free(b->ctx, b->d_slots);
+  if (b->d_win) (void)ctx_free(b->ctx, b->d_win);
   delete b;
 }
 
@@ -1098,7 +1140,7 @@ int32_t plan_setop_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, int32_t op, bool wa
   // dense kernels write the dense layout (an all-zero result cell stays an all-zero
   // bitmap in the arena, its slot says nil): the output can feed the dense kernels again
   p->out->dense = dense;
-  p->out->slots_stale = true;
+  slots_rewritten(p->out);
   return FBK_OK;
 }
 

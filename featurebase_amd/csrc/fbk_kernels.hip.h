@@ -326,6 +326,43 @@ __global__ void __launch_bounds__(256) k_validate_recount(Slot* __restrict__ slo
   if (lane == 0) slots[wid].tn = make_tn(t, c);
 }
 
+// Window index of a batch: for every array / run container the position at which each eighth of
+// the value range begins — win[w] (w = 0..7, 16 bits each, one uint4 per (row, slot)) = the index of
+// the first array value >= w * 8192, or of the first run whose LAST value is >= w * 8192 (win[0] = 0;
+// "none" = len).  The count-matrix kernel decodes rows 8192 bit positions at a time
+// (fbk_matrix_fused.hip.h); with the index a stage's values of a row are a known piece of the array
+// and nothing is searched or walked inside that kernel.  16 bytes per container, built once per batch
+// (lazily, on the first count matrix that reads the batch) by streaming the arrays and run lists once.
+// One wave per slot.
+__global__ void __launch_bounds__(256) k_window_index(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                                     uint64_t n_slots, uint4* __restrict__ win) {
+  __shared__ uint16_t sw[4][8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t wid = (uint64_t)blockIdx.x * 4 + wv;
+  if (wid >= n_slots) return;
+  const Slot s = slots[wid];
+  const uint32_t t = slot_n(s) ? slot_type(s) : kTypeNil;
+  if (t != kTypeArray && t != kTypeRun) {
+    if (lane == 0) win[wid] = uint4{0, 0, 0, 0};
+    return;
+  }
+  const uint8_t* p = arena + s.off;
+  if (lane < 8) sw[wv][lane] = (uint16_t)s.len;  // (len <= 65535 whenever some window has no value)
+  wave_lds_sync();
+  const uint32_t shift = t == kTypeArray ? 1u : 2u;  // array: uint16 values; run: {start, last} pairs, the key is `last`
+  for (uint32_t i = lane; i < s.len; i += kWave) {
+    const int k = (int)(*reinterpret_cast<const uint16_t*>(p + ((uint64_t)i << shift) + (t == kTypeRun ? 2u : 0u)) >> 13);
+    const int pk = i ? (int)(*reinterpret_cast<const uint16_t*>(p + ((uint64_t)(i - 1) << shift) + (t == kTypeRun ? 2u : 0u)) >> 13) : -1;
+    for (int w = pk + 1; w <= k; ++w) sw[wv][w] = (uint16_t)i;  // sorted input: each w is written by exactly one i
+  }
+  wave_lds_sync();
+  if (lane == 0) {
+    const uint16_t* q = sw[wv];
+    win[wid] = uint4{(uint32_t)q[0] | ((uint32_t)q[1] << 16), (uint32_t)q[2] | ((uint32_t)q[3] << 16), (uint32_t)q[4] | ((uint32_t)q[5] << 16),
+                     (uint32_t)q[6] | ((uint32_t)q[7] << 16)};
+  }
+}
+
 // Bits of each row in [start, end) (Bitmap.CountRange, roaring.go:573-615): one wave per
 // (row, slot).  Containers wholly inside the range contribute their stored n (roaring.go:603),
 // the (at most two) boundary containers are loaded and masked (BitmapCountRange :3092,

@@ -1,0 +1,488 @@
+// fbk_matrix_fused2.hip.h — the many-row IntersectionCount matrix (GroupBy / TopN shape,
+// executor.go:8880-8934, 2705-2774) for rows in ANY encoding, on the matrix cores, decoding the
+// rows inside the kernel (no decoded row ever goes to HBM).  Second version of the in-kernel decode.
+//
+//   out[shard][i][j] += sum over the block's slots of |A[shard][i] ∩ F[shard] ∩ B[shard][j]|
+//
+// The first version (fbk_matrix_fused.hip.h) was bound by vector-instruction ISSUE, not by memory:
+// a wave64 instruction occupies its SIMD for ~4.75 cycles whatever the number of active lanes, and
+// its decode spent ~185 instructions per (row, stage) on cursor walking, window re-derivation and
+// half-empty passes.  This version is built around the instruction count:
+//
+//   * the batch carries a WINDOW INDEX (k_window_index, 16 bytes per container): where each eighth
+//     of the value range begins inside an array / run list.  Nothing is searched, walked or
+//     re-derived here;
+//   * one block = (shard, slot group, 32 A rows, 32 B rows), 16 wavefronts: 4 CONSUMERS (one per
+//     SIMD; bit -> FP4 nibble by ONE v_and per operand dword, v_mfma_scale_f32_32x32x64_f8f6f4, see
+//     fbk_matrix_mfma.hip.h) and 12 PRODUCERS that decode;
+//   * a stage = the 8192 bit positions [q * 8192, (q + 1) * 8192) of all 65 rows (32 A, 32 B, the
+//     filter) as 1 KiB of bitmap per row in LDS (row stride 1040 bytes: the 16 rows of a
+//     ds_read_b128 lane group fall into 16 different bank groups); two stages alternate, one
+//     barrier per stage;
+//   * once per container slot ONE producer wave turns the 65 descriptors + window indexes into
+//     work lists in LDS: for every stage the list of ARRAY ITEMS (row, first value index, <= 128
+//     values), the bitmap rows, the run rows.  Array items of a stage are dealt out to the 48
+//     16-lane groups of the producers round robin — a heavy row is spread over several groups, four
+//     rows are decoded per wave pass, every lane holds 8 values (one 16-byte load at 2-byte
+//     alignment, exactly the stage's values: no window test, only "k < valid");
+//   * array bits are OR-ed in with LDS atomics, so any group may write any row; the CONSUMERS zero
+//     the piece of every row they have just read (the buffer is clean when the producers get it
+//     back), which removes the ordering "zero before scatter" between producer waves;
+//   * every global load is issued one stage ahead (items, bitmap KiBs, run windows sit in registers
+//     over the barrier), so a stage never waits for HBM latency;
+//   * bitmap rows: the q-th KiB of the container, global -> registers (a stage ahead) -> LDS;
+//     run rows (owned by one wave each): toggles at the clamped start / one past the clamped end,
+//     then a parity prefix over the row's 1 KiB (runToBitmap, roaring.go:3792).
+#pragma once
+#include "fbk_matrix_mfma.hip.h"
+
+namespace fbk {
+
+constexpr int kF2SB = 1024;               // bytes of every row per stage
+constexpr int kF2Stages = 8192 / kF2SB;   // 8 stages per container slot
+constexpr int kF2NR = 65;                 // 32 A rows + 32 B rows + the filter row
+constexpr int kF2Stride = kF2SB + 16;     // LDS row stride
+constexpr int kF2Buf = kF2NR * kF2Stride;  // 67 600 bytes per stage buffer
+constexpr int kF2Consumers = 4;
+constexpr int kF2Producers = 12;
+constexpr int kF2Waves = kF2Consumers + kF2Producers;
+constexpr int kF2Groups = kF2Producers * 4;  // 16-lane groups
+constexpr int kF2Pref = 3;                   // array items per group and stage that are loaded a stage ahead
+constexpr int kF2BmPref = (kF2NR + kF2Producers - 1) / kF2Producers;  // 6: bitmap rows per wave (all of them are loaded ahead)
+constexpr int kF2RunPref = 2;                // run rows per wave whose first 64 runs are loaded a stage ahead
+constexpr int kF2ItemArrayMax = 4096;        // arrays up to this length go through the item lists (ArrayMaxSize, roaring.go:46)
+constexpr int kF2ItemCap = 2624;             // >= 65 rows x (4096 / 128 + 8) items per container slot
+
+struct F2Tab {                      // the work lists of one container slot
+  uint4 row[kF2NR][2];              // [0] = {payload address lo, hi, len, type}; [1] = window index
+  uint32_t pool[kF2ItemCap];        // array items of the 8 stages: row | first value << 7 | (values - 1) << 19
+  uint32_t ibase[kF2Stages], icnt[kF2Stages];
+  uint8_t bml[72], runl[72], bigl[72];  // rows holding bitmaps / runs / arrays longer than kF2ItemArrayMax
+  uint32_t nbm, nrun, nbig, pad;
+};
+
+typedef mm_u4 __attribute__((aligned(2))) f2_u4_unaligned;
+
+__device__ __forceinline__ uint4 f2_ld_global16_u(const uint8_t* p) {  // 16 bytes at 2-byte alignment, global address space
+  const mm_u4 v = *reinterpret_cast<const __attribute__((address_space(1))) f2_u4_unaligned*>((uintptr_t)p);
+  return uint4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ uint32_t f2_win(const uint4& w, int k) {  // k-th 16-bit entry of a window index
+  const uint32_t d = k < 2 ? w.x : k < 4 ? w.y : k < 6 ? w.z : w.w;
+  return (k & 1) ? d >> 16 : d & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t f2_win_dyn(const uint4& w, uint32_t k) {
+  const uint32_t d = k < 2 ? w.x : k < 4 ? w.y : k < 6 ? w.z : w.w;
+  return (k & 1) ? d >> 16 : d & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t f2_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+template <bool HAS_F>
+__global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
+    const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA, const uint4* __restrict__ winA, const uint32_t* __restrict__ rowsA, uint32_t nA,
+    const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB, const uint4* __restrict__ winB, const uint32_t* __restrict__ rowsB, uint32_t nBtot,
+    const Slot* __restrict__ slotsF, const uint8_t* __restrict__ arenaF, const uint4* __restrict__ winF, const uint32_t* __restrict__ rowsF, uint32_t n_shards,
+    uint32_t spb, u64* __restrict__ out_shard, uint32_t ablate) {
+  // `ablate` (option matrix_fused_ablate, timing experiments only — results are wrong when set):
+  // 1 no consumer arithmetic, 2 no array decode, 4 no run decode, 8 no bitmap rows
+  __shared__ uint4 ring[2 * kF2Buf / 16];  // 135 200 bytes
+  __shared__ F2Tab tabs[2];                // 2 x 12 896 bytes
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t agroups = (nA + 31) / 32, btiles = (nBtot + 31) / 32, sgroups = kSlots / spb;
+  uint32_t b = blockIdx.x;
+  const uint32_t bt = b % btiles;
+  b /= btiles;
+  const uint32_t ag = b % agroups;
+  b /= agroups;
+  const uint32_t sg = b % sgroups;
+  const uint32_t shard = b / sgroups;
+  if (shard >= n_shards) return;
+  const uint32_t i0 = ag * 32, j0 = bt * 32;
+
+  // slots of this block at which anything can intersect (a nil filter container annihilates the slot)
+  uint32_t act[kSlots];
+  uint32_t n_act = 0;
+  for (uint32_t s = sg * spb; s < (sg + 1) * spb; ++s) {
+    bool on = true;
+    if (HAS_F) on = slot_n(slotsF[(uint64_t)rowsF[shard] * kSlots + s]) != 0;
+    if (on) act[n_act++] = s;
+  }
+  const uint32_t n_stage = n_act * kF2Stages;
+  uint8_t* const ring8 = reinterpret_cast<uint8_t*>(&ring[0]);
+  // both stage buffers start clean (afterwards the consumers clean what they have read)
+  for (uint32_t i = threadIdx.x; i < (uint32_t)(2 * kF2Buf / 16); i += kF2Waves * 64) ring[i] = uint4{0, 0, 0, 0};
+
+  if (wv < kF2Consumers) {
+    // ============================== consumers ==============================
+    const uint32_t r = lane & 31, g = lane >> 5;
+    mm_v16f acc0{}, acc1{}, acc2{};
+    constexpr uint32_t M4 = 0x11111111u;
+    __syncthreads();  // (the producers' set-up barrier)
+    for (uint32_t it = 0; it <= n_stage; ++it) {
+      if (it >= 1 && !(ablate & 1u)) {
+        // rows as uint4 pieces (row stride 65 pieces): this wave's K range is pieces 16 wv .. 16 wv + 15 of
+        // every row; pair o = pieces 16 wv + 2 o + g
+        uint4* buf = ring + ((it - 1) & 1u) * (uint32_t)(kF2Buf / 16);
+        uint4* rowA = buf + r * (uint32_t)(kF2Stride / 16) + 16u * (uint32_t)wv + g;
+        uint4* rowB = rowA + 32 * (kF2Stride / 16);
+        uint4* rowF = buf + 64 * (kF2Stride / 16) + 16u * (uint32_t)wv;
+        auto ld = [&](int o, uint4& va, uint4& vb, uint4& vf) {
+          va = rowA[2 * o];
+          vb = rowB[2 * o];
+          if (HAS_F) vf = rowF[2 * o + g];
+          // clean behind the read (LDS operations of one wave execute in order)
+          rowA[2 * o] = uint4{0, 0, 0, 0};
+          rowB[2 * o] = uint4{0, 0, 0, 0};
+        };  // (no branch in here: the optimiser sinks the arithmetic of all eight octets below the last conditional block)
+        auto octet = [&](const uint4& va, const uint4& vb, const uint4& vf) {
+          uint32_t a[4] = {va.x, va.y, va.z, va.w};
+          const uint32_t bb[4] = {vb.x, vb.y, vb.z, vb.w};
+          const uint32_t f[4] = {vf.x, vf.y, vf.z, vf.w};
+#pragma unroll
+          for (int d = 0; d < 4; ++d) a[d] = HAS_F ? (a[d] & f[d]) : a[d];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            mm_v8i oa, ob;  // the instruction reads the first four registers of an FP4 operand
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              oa[d] = (int)(k < 3 ? (a[d] & (M4 << k)) : ((a[d] >> 3) & M4));
+              ob[d] = (int)(k < 3 ? (bb[d] & (M4 << k)) : ((bb[d] >> 3) & M4));
+            }
+            if (k == 0 || k == 3) acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            else if (k == 1) acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            else acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc2, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+          }
+        };
+        uint4 xa, xb, xf = uint4{0, 0, 0, 0}, ya, yb, yf = uint4{0, 0, 0, 0};
+        // (the scheduler would otherwise hoist all 24 reads of the stage to the top: 96 registers, spills)
+        ld(0, xa, xb, xf);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int o = 0; o < 8; o += 2) {
+          ld(o + 1, ya, yb, yf);
+          __builtin_amdgcn_sched_barrier(0);
+          octet(xa, xb, xf);
+          __builtin_amdgcn_sched_barrier(0);
+          if (o + 2 < 8) ld(o + 2, xa, xb, xf);
+          __builtin_amdgcn_sched_barrier(0);
+          octet(ya, yb, yf);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the filter row's 16 pieces of this wave's K range
+        // (all lanes, four per piece, the same zeros: a condition here would put the arithmetic above behind it)
+        if (HAS_F) rowF[lane & 15] = uint4{0, 0, 0, 0};
+      }
+      __syncthreads();
+    }
+    // cross-wave reduction through LDS (the ring is free now): [wave][16 regs][64 lanes]
+    uint32_t* red = reinterpret_cast<uint32_t*>(ring8);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[(wv * 16 + q) * 64 + lane] = (uint32_t)(acc0[q] * 4.0f + acc1[q] + acc2[q] * 0.25f + 0.5f);
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 16 / kF2Consumers; ++qq) {
+      const int q = wv * (16 / kF2Consumers) + qq;
+      uint32_t tot = 0;
+#pragma unroll
+      for (int w = 0; w < kF2Consumers; ++w) tot += red[(w * 16 + q) * 64 + lane];
+      const uint32_t i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), j = lane & 31;
+      if (i0 + i < nA && j0 + j < nBtot && tot) atomicAdd(&out_shard[((uint64_t)shard * nA + i0 + i) * nBtot + j0 + j], (u64)tot);
+    }
+    return;
+  }
+
+  // ============================== producers ==============================
+  const uint32_t pw = (uint32_t)wv - kF2Consumers;  // 0..11
+  const uint32_t gq = lane >> 4, gl = lane & 15;
+  const uint32_t first_group = 4u * pw;  // array items of a stage: item x goes to group x mod 48
+  const u64 lane_lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  // ---- descriptor sources of the set-up wave: lane l stands for matrix row l (0..31 A, 32..63 B) ----
+  const Slot* my_slots = nullptr;
+  const uint4* my_win = nullptr;
+  const uint8_t* my_base = lane < 32 ? arenaA : arenaB;
+  if (lane < 32) {
+    if (i0 + lane < nA) {
+      const uint64_t rr = rowsA[(uint64_t)shard * nA + i0 + lane];
+      my_slots = slotsA + rr * kSlots;
+      my_win = winA ? winA + rr * kSlots : nullptr;
+    }
+  } else if (j0 + lane - 32 < nBtot) {
+    const uint64_t rr = rowsB[(uint64_t)shard * nBtot + j0 + lane - 32];
+    my_slots = slotsB + rr * kSlots;
+    my_win = winB ? winB + rr * kSlots : nullptr;
+  }
+  const uint64_t rowF = HAS_F ? (uint64_t)rowsF[shard] * kSlots : 0;
+  struct Desc {
+    Slot d;
+    uint4 w;
+    Slot df;
+    uint4 wf;
+  };
+  auto load_desc = [&](uint32_t slot) {
+    Desc x;
+    x.d.off = 0, x.d.len = 0, x.d.tn = 0;
+    x.df = x.d;
+    x.w = uint4{0, 0, 0, 0};
+    x.wf = x.w;
+    if (my_slots) {
+      x.d = my_slots[slot];
+      if (my_win) x.w = my_win[slot];
+    }
+    if (HAS_F) {
+      x.df = slotsF[rowF + slot];
+      if (winF) x.wf = winF[rowF + slot];
+    }
+    return x;
+  };
+  // ---- the work lists of one container slot (one wave) ----
+  auto build_tab = [&](F2Tab& T, const Desc& x) {
+    const uint32_t type = slot_n(x.d) ? slot_type(x.d) : 0u;
+    const uint32_t typeF = (HAS_F && slot_n(x.df)) ? slot_type(x.df) : 0u;  // wave-uniform
+    {
+      const uintptr_t pa = (uintptr_t)(my_base + x.d.off);
+      T.row[lane][0] = uint4{(uint32_t)pa, (uint32_t)(pa >> 32), x.d.len, type};
+      T.row[lane][1] = x.w;
+      if (HAS_F && lane == 0) {
+        const uintptr_t pf = (uintptr_t)(arenaF + x.df.off);
+        T.row[64][0] = uint4{(uint32_t)pf, (uint32_t)(pf >> 32), x.df.len, typeF};
+        T.row[64][1] = x.wf;
+      }
+    }
+    const bool isarr = type == kTypeArray && x.d.len <= (uint32_t)kF2ItemArrayMax;
+    const bool isbig = type == kTypeArray && !isarr;
+    const bool farr = typeF == kTypeArray && x.df.len <= (uint32_t)kF2ItemArrayMax;
+    {
+      const u64 mb = __ballot(type == kTypeBitmap), mr = __ballot(type == kTypeRun), mg = __ballot(isbig);
+      if (type == kTypeBitmap) T.bml[__popcll(mb & lane_lt)] = (uint8_t)lane;
+      if (type == kTypeRun) T.runl[__popcll(mr & lane_lt)] = (uint8_t)lane;
+      if (isbig) T.bigl[__popcll(mg & lane_lt)] = (uint8_t)lane;
+      uint32_t nb = __popcll(mb), nr = __popcll(mr), ng = __popcll(mg);
+      if (lane == 0) {
+        if (typeF == kTypeBitmap) T.bml[nb++] = 64;
+        if (typeF == kTypeRun) T.runl[nr++] = 64;
+        if (typeF == kTypeArray && !farr) T.bigl[ng++] = 64;
+        T.nbm = nb, T.nrun = nr, T.nbig = ng;
+      }
+    }
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < kF2Stages; ++w) {
+      const uint32_t st = f2_win(x.w, w), en = w + 1 < kF2Stages ? f2_win(x.w, w + 1) : x.d.len;
+      const uint32_t cnt = (isarr && en > st) ? min(en - st, (uint32_t)kF2ItemArrayMax) : 0u;
+      const uint32_t nch = (cnt + 127u) >> 7;
+      uint32_t incl = nch;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, kWave);
+        if (lane >= d) incl += o;
+      }
+      const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      const uint32_t at = base + incl - nch;
+      for (uint32_t c = 0; __ballot(c < nch) != 0; ++c)
+        if (c < nch && at + c < (uint32_t)kF2ItemCap) T.pool[at + c] = (uint32_t)lane | ((st + 128u * c) << 7) | ((min(128u, cnt - 128u * c) - 1u) << 19);
+      // the filter row's items (wave-uniform quantities; lane c writes chunk c: at most 32 chunks + 1)
+      uint32_t nchF = 0;
+      if (HAS_F && farr) {
+        const uint32_t stF = f2_win(x.wf, w), enF = w + 1 < kF2Stages ? f2_win(x.wf, w + 1) : x.df.len;
+        const uint32_t cntF = enF > stF ? min(enF - stF, (uint32_t)kF2ItemArrayMax) : 0u;
+        nchF = (cntF + 127u) >> 7;
+        if ((uint32_t)lane < nchF && base + tot + lane < (uint32_t)kF2ItemCap)
+          T.pool[base + tot + lane] = 64u | ((stF + 128u * lane) << 7) | ((min(128u, cntF - 128u * lane) - 1u) << 19);
+      }
+      const uint32_t n_w = min(tot + nchF, (uint32_t)kF2ItemCap - min(base, (uint32_t)kF2ItemCap));
+      if (lane == 0) T.ibase[w] = base, T.icnt[w] = n_w;
+      base += n_w;
+    }
+  };
+
+  // ---- per-stage state, loaded one stage ahead ----
+  uint4 a_w[kF2Pref];        // array items: 8 values of this lane
+  uint32_t a_nv[kF2Pref];    //   how many of them exist (0: this lane has nothing)
+  uint32_t a_off[kF2Pref];   //   byte offset of the item's row inside a stage buffer
+  uint32_t n_items = 0, item_base = 0;  // of the stage the prefetched items belong to (wave-uniform)
+  uint4 b_w[kF2BmPref];      // bitmap rows: this lane's 16 bytes of the stage's KiB
+  uint32_t b_off[kF2BmPref];  //   (wave-uniform) byte offset of the row; ~0u: none
+  uint32_t r_iv[kF2RunPref];  // run rows: run (first + lane) of the stage
+  uint32_t n_bm = 0, n_run = 0, n_big = 0;
+#pragma unroll
+  for (int k = 0; k < kF2Pref; ++k) a_w[k] = uint4{0, 0, 0, 0}, a_nv[k] = 0, a_off[k] = 0;
+#pragma unroll
+  for (int k = 0; k < kF2BmPref; ++k) b_w[k] = uint4{0, 0, 0, 0}, b_off[k] = ~0u;
+#pragma unroll
+  for (int k = 0; k < kF2RunPref; ++k) r_iv[k] = 0;
+
+  // one array item of group (first_group + gq): fetch the lane's 8 values
+  auto fetch_item = [&](const F2Tab& T, uint32_t idx, uint32_t n, uint32_t ib, uint4& w, uint32_t& nv, uint32_t& off) {
+    w = uint4{0, 0, 0, 0};
+    nv = 0;
+    off = 0;
+    if (idx < n) {
+      const uint32_t it = T.pool[ib + idx];
+      const uint32_t row = it & 127u, start = (it >> 7) & 4095u, nvt = ((it >> 19) & 127u) + 1u;
+      const uint4 rt = T.row[row][0];
+      off = row * (uint32_t)kF2Stride;
+      if (nvt > 8u * gl) {
+        nv = min(nvt - 8u * gl, 8u);
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)rt.y << 32) | rt.x);
+        w = f2_ld_global16_u(p + 2u * (start + 8u * gl));
+      }
+    }
+  };
+  // 8 values of one lane -> bits of a row of the stage buffer (values are inside the stage by construction).
+  // No branches and no exec juggling: a slot past the lane's last value ORs a zero mask into the row
+  // (4 vector instructions + the LDS atomic per value: bfe + shift-add for the address, bfe + shift for the mask).
+  auto scatter8 = [&](const uint4& w, uint32_t nv, uint32_t rowaddr) {
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    const uint32_t valid = (1u << nv) - 1u;  // nv <= 8
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t d = ww[k >> 1];
+      // (value >> 5) & 255 = the dword inside the stage's KiB.  Written as the two instructions it should be:
+      // the compiler turns bfe + shift-add into shift + and + add
+      uint32_t word, addr;
+      if (k & 1) asm("v_bfe_u32 %0, %1, 21, 8" : "=v"(word) : "v"(d));
+      else asm("v_bfe_u32 %0, %1, 5, 8" : "=v"(word) : "v"(d));
+      asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(addr) : "v"(word), "v"(rowaddr));
+      const uint32_t sh = (k & 1) ? d >> 16 : d;  // (the shifter reads the low 5 bits only)
+      atomicOr(reinterpret_cast<uint32_t*>(ring8 + addr), __builtin_amdgcn_ubfe(valid, (uint32_t)k, 1u) << (sh & 31u));
+    }
+  };
+  // loads of stage `it` (slot si, eighth q): array items, bitmap KiBs, the first runs of the run rows
+  auto prefetch = [&](uint32_t it) {
+    const uint32_t si = it / kF2Stages, q = it % kF2Stages;
+    const F2Tab& T = tabs[si & 1u];
+    n_items = f2_uniform(T.icnt[q]);
+    item_base = f2_uniform(T.ibase[q]);
+    n_bm = f2_uniform(T.nbm);
+    n_run = f2_uniform(T.nrun);
+    n_big = f2_uniform(T.nbig);
+#pragma unroll
+    for (int k = 0; k < kF2Pref; ++k) {
+      a_nv[k] = 0;
+      if (first_group + (uint32_t)kF2Groups * k < n_items && !(ablate & 2u))
+        fetch_item(T, first_group + gq + (uint32_t)kF2Groups * k, n_items, item_base, a_w[k], a_nv[k], a_off[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kF2BmPref; ++k) {
+      b_off[k] = ~0u;
+      const uint32_t e = pw + (uint32_t)kF2Producers * k;
+      if (e < n_bm && !(ablate & 8u)) {
+        const uint32_t row = f2_uniform(T.bml[e]);
+        const uint4 rt = T.row[row][0];
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)f2_uniform(rt.y) << 32) | f2_uniform(rt.x));
+        b_w[k] = fx_ld_global16(p + q * (uint32_t)kF2SB + (uint32_t)lane * 16u);
+        b_off[k] = row * (uint32_t)kF2Stride;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kF2RunPref; ++k) {
+      const uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * k;
+      if (e < n_run && !(ablate & 4u)) {
+        const uint32_t row = f2_uniform(T.runl[e]);
+        const uint4 rt = T.row[row][0], rw = T.row[row][1];
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)f2_uniform(rt.y) << 32) | f2_uniform(rt.x));
+        const uint32_t len = f2_uniform(rt.z);
+        const uint32_t first = f2_uniform(f2_win_dyn(rw, q));
+        const uint32_t idx = first + (uint32_t)lane;
+        r_iv[k] = idx < len ? fx_ld_global4(p + 4u * idx) : 0u;
+      }
+    }
+  };
+  // one run row of stage (T, q) into buffer bufoff: toggles, then the parity prefix
+  auto run_row = [&](const F2Tab& T, uint32_t e, uint32_t q, uint32_t bufoff, bool have_first, uint32_t first_iv) {
+    const uint32_t row = f2_uniform(T.runl[e]);
+    const uint4 rt = T.row[row][0], rw = T.row[row][1];
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)f2_uniform(rt.y) << 32) | f2_uniform(rt.x));
+    const uint32_t len = f2_uniform(rt.z);
+    const uint32_t lo = q * (uint32_t)(kF2SB * 8), hi = lo + (uint32_t)(kF2SB * 8);
+    const uint32_t i0 = f2_uniform(f2_win_dyn(rw, q));                                                  // first run whose last value is >= lo
+    const uint32_t i1 = q + 1 < (uint32_t)kF2Stages ? min(f2_uniform(f2_win_dyn(rw, q + 1)) + 1u, len) : len;  // one past the last run that can start below hi
+    const uint32_t rowaddr = bufoff + row * (uint32_t)kF2Stride;
+    for (uint32_t base = i0; base < i1; base += 64u) {
+      const uint32_t idx = base + (uint32_t)lane;
+      uint32_t iv = 0;
+      if (base == i0 && have_first) iv = first_iv;
+      else if (idx < len) iv = fx_ld_global4(p + 4u * idx);
+      const uint32_t s = iv & 0xFFFFu, l = iv >> 16;
+      if (idx < i1 && s < hi && l >= lo) {
+        const uint32_t s2 = (s > lo ? s : lo) - lo;           // 0 .. 8191
+        const uint32_t e2 = (l + 1u < hi ? l + 1u : hi) - lo;  // 1 .. 8192
+        atomicXor(reinterpret_cast<uint32_t*>(ring8 + rowaddr + ((s2 >> 3) & 0x3FCu)), 1u << (s2 & 31u));
+        if (e2 < (uint32_t)(kF2SB * 8)) atomicXor(reinterpret_cast<uint32_t*>(ring8 + rowaddr + ((e2 >> 3) & 0x3FCu)), 1u << (e2 & 31u));
+      }
+    }
+    wave_lds_sync();
+    {  // parity prefix: lane j owns bytes 16 j .. 16 j + 15 of the row
+      uint4* pc = reinterpret_cast<uint4*>(ring8 + rowaddr + (uint32_t)lane * 16u);
+      const uint4 tv = *pc;
+      const u64 t0 = ((u64)tv.y << 32) | tv.x, t1 = ((u64)tv.w << 32) | tv.z;
+      const uint32_t p0 = __popcll(t0) & 1u, p1 = __popcll(t1) & 1u;
+      const u64 mm = __ballot((p0 ^ p1) != 0);
+      const uint32_t in = __popcll(mm & lane_lt) & 1u;
+      const u64 f0 = prefix_xor64(t0) ^ (in ? ~0ull : 0ull);
+      const u64 f1 = prefix_xor64(t1) ^ ((in ^ p0) ? ~0ull : 0ull);
+      *pc = uint4{(uint32_t)f0, (uint32_t)(f0 >> 32), (uint32_t)f1, (uint32_t)(f1 >> 32)};
+    }
+  };
+
+  // ---- set-up of the first slot, then the stage loop ----
+  Desc next_d = load_desc(n_act ? act[0] : 0);  // (every producer wave: the builder of a later slot overwrites its copy)
+  if (n_stage && pw == 0) build_tab(tabs[0], next_d);
+  __syncthreads();  // tabs[0] and the clean ring are visible
+  if (n_stage) prefetch(0);
+  for (uint32_t it = 0; it <= n_stage; ++it) {
+    if (it < n_stage) {
+      const uint32_t si = it / kF2Stages, q = it % kF2Stages;
+      const F2Tab& T = tabs[si & 1u];
+      const uint32_t bufoff = (it & 1u) * (uint32_t)kF2Buf;
+      const uint32_t cur_items = n_items, cur_base = item_base, cur_run = n_run, cur_big = n_big;
+      // ---- 1. bitmap rows: registers -> LDS ----
+#pragma unroll
+      for (int k = 0; k < kF2BmPref; ++k)
+        if (b_off[k] != ~0u) *reinterpret_cast<uint4*>(ring8 + bufoff + b_off[k] + (uint32_t)lane * 16u) = b_w[k];
+      // ---- 2. array items: the prefetched ones, then (long lists only) the rest ----
+#pragma unroll
+      for (int k = 0; k < kF2Pref; ++k)
+        if (first_group + (uint32_t)kF2Groups * k < cur_items && !(ablate & 2u)) scatter8(a_w[k], a_nv[k], bufoff + a_off[k]);
+      for (uint32_t x = first_group + (uint32_t)kF2Groups * kF2Pref; x < cur_items && !(ablate & 2u); x += (uint32_t)kF2Groups) {
+        uint4 w;
+        uint32_t nv, off;
+        fetch_item(T, x + gq, cur_items, cur_base, w, nv, off);
+        scatter8(w, nv, bufoff + off);
+      }
+      // ---- 3. arrays longer than 4096 values (never produced by optimize(); uploads may hold them): one row per wave pass ----
+      for (uint32_t e = pw; e < cur_big && !(ablate & 2u); e += (uint32_t)kF2Producers) {
+        const uint32_t row = f2_uniform(T.bigl[e]);
+        const uint4 rt = T.row[row][0], rw = T.row[row][1];
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)f2_uniform(rt.y) << 32) | f2_uniform(rt.x));
+        const uint32_t len = f2_uniform(rt.z);
+        const uint32_t v0 = f2_uniform(f2_win_dyn(rw, q)), v1 = q + 1 < (uint32_t)kF2Stages ? min(f2_uniform(f2_win_dyn(rw, q + 1)), len) : len;
+        for (uint32_t base = v0; base < v1; base += 512u) {
+          const uint32_t mine = base + 8u * (uint32_t)lane;
+          if (mine < v1) scatter8(f2_ld_global16_u(p + 2u * mine), min(v1 - mine, 8u), bufoff + row * (uint32_t)kF2Stride);
+        }
+      }
+      // ---- 4. run rows (each owned by one wave, so the parity prefix follows this wave's own toggles) ----
+#pragma unroll
+      for (int k = 0; k < kF2RunPref; ++k) {
+        const uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * k;
+        if (e < cur_run && !(ablate & 4u)) run_row(T, e, q, bufoff, true, r_iv[k]);
+      }
+      for (uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * kF2RunPref; e < cur_run && !(ablate & 4u); e += (uint32_t)kF2Producers)
+        run_row(T, e, q, bufoff, false, 0u);
+      // ---- 5. the next slot's work lists (descriptors fetched at q == 1, lists built at q == 3 by one wave) ----
+      if (si + 1 < n_act) {
+        const bool builder = pw == (si + 1) % (uint32_t)kF2Producers;
+        if (q == 1 && builder) next_d = load_desc(act[si + 1]);
+        if (q == 3 && builder) build_tab(tabs[(si + 1) & 1u], next_d);
+      }
+      // ---- 6. the next stage's loads ----
+      if (it + 1 < n_stage) prefetch(it + 1);
+    }
+    __syncthreads();
+  }
+  __syncthreads();  // the consumers' reduction barrier
+}
+
+}  // namespace fbk

@@ -601,6 +601,9 @@ def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle
             tot_s, ps_s = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
             assert (tot_s == tot).all() and (ps_s == ps).all(), spb
         gpu_ctx.set_option("matrix_spb", 0)
+        gpu_ctx.set_option("matrix_fused", 2)  # the first version of the in-kernel decode (cursor-walked arrays)
+        tot_1, ps_1 = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
+        assert (tot_1 == tot).all() and (ps_1 == ps).all()
         gpu_ctx.set_option("matrix_fused", 0)
         tot_d, ps_d = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
         assert (tot_d == tot).all() and (ps_d == ps).all()
@@ -611,6 +614,87 @@ def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle
         gpu_ctx.set_option("matrix_fused", -1)
         gpu_ctx.set_option("matrix_densify", -1)
     assert (tot_g == tot).all() and (ps_g == ps).all()
+    for b in (A, Bt, F):
+        if b is not None:
+            b.free()
+
+
+@pytest.mark.parametrize("f_kind", ["cluster", "run", "bitmap", "none"])
+def test_count_matrix_fused_window_edges(gpu_ctx, oracle, B, f_kind):
+    """The in-kernel decode works through a container in eight windows of 8192 values, from work lists
+    built out of the batch's window index: arrays clustered inside ONE window (up to 32 items of one
+    row in one stage, more than a thousand items per stage: the list loop past the prefetched items),
+    values on both sides of every window edge, runs that straddle edges or cover several windows,
+    a window without any value, the filter itself an array / a run list, tile edges (40 x 33 rows)."""
+    O = oracle
+    rng = D.rng_for(58)
+    n_shards, n_a, n_b = 2, 40, 33
+
+    def container(kind):
+        if kind == "cluster":
+            w = int(rng.integers(0, 8))
+            n = int(rng.choice([1, 7, 8, 9, 127, 128, 129, 1000, 4095]))
+            return O.OContainer.array(np.sort(rng.choice(8192, size=n, replace=False)) + w * 8192)
+        if kind == "edges":
+            v = np.array([0] + [e for w in range(1, 8) for e in (w * 8192 - 1, w * 8192)] + [65535])
+            return O.OContainer.array(v[rng.random(v.size) < 0.8])
+        if kind == "run_straddle":
+            return O.OContainer.run([(8000, 8400), (16383, 16384), (24576, 24576), (30000, 50000), (57343, 57343), (65535, 65535)])
+        if kind == "run_cluster":  # 300 short runs inside one window
+            w = int(rng.integers(0, 8))
+            st = w * 8192 + np.arange(300) * 27 + rng.integers(0, 5, 300)
+            return O.OContainer.run([(int(a), int(a) + int(rng.integers(0, 20))) for a in st])
+        if kind == "two_windows":  # nothing in six of the eight windows
+            return O.OContainer.array(np.concatenate([np.arange(8192 * 2 + 5, 8192 * 2 + 700, 3), np.arange(8192 * 6, 8192 * 6 + 40)]))
+        return D.oracle_container(rng, D.KINDS[int(rng.integers(0, len(D.KINDS)))])
+
+    kinds = ["cluster", "cluster", "edges", "run_straddle", "run_cluster", "two_windows", "any", "any"]
+
+    def row():
+        return {s: container(kinds[int(rng.integers(0, len(kinds)))]) for s in range(16) if rng.random() > 0.1}
+
+    a_rows = [[row() for _ in range(n_a)] for _ in range(n_shards)]
+    b_rows = [[row() for _ in range(n_b)] for _ in range(n_shards)]
+    # one slot where EVERY row is a 4095-value array inside window 3: 73 x 32 items in one stage
+    for s in range(n_shards):
+        for r in a_rows[s] + b_rows[s]:
+            r[5] = O.OContainer.array(np.sort(rng.choice(8192, size=4095, replace=False)) + 3 * 8192)
+    f_rows = None
+    if f_kind != "none":
+        f_rows = []
+        for s in range(n_shards):
+            fr = {}
+            for k in range(16):
+                if f_kind == "cluster":
+                    fr[k] = container("cluster") if k != 5 else O.OContainer.array(np.arange(3 * 8192, 4 * 8192, 2))
+                elif f_kind == "run":
+                    fr[k] = container("run_straddle" if k % 2 else "run_cluster")
+                else:
+                    fr[k] = O.OContainer.bitmap(D.words_of(D.vals_density(rng, 0.5)))
+            f_rows.append(fr)
+
+    def obm(r):
+        return O.OBitmap.from_containers(list(r.items()))
+
+    A = gpu_ctx.upload([D.to_fbk_row(r) for s in a_rows for r in s])
+    Bt = gpu_ctx.upload([D.to_fbk_row(r) for s in b_rows for r in s])
+    F = gpu_ctx.upload([D.to_fbk_row(r) for r in f_rows]) if f_rows else None
+    ra = np.arange(n_shards * n_a).reshape(n_shards, n_a)
+    rb = np.arange(n_shards * n_b).reshape(n_shards, n_b)
+    rf = np.arange(n_shards) if F is not None else None
+    try:
+        gpu_ctx.set_option("matrix_fused", 1)
+        tot, ps = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf, per_shard=True)
+        gpu_ctx.set_option("matrix_fused", 0)
+        gpu_ctx.set_option("matrix_densify", 0)
+        tot_g, ps_g = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf, per_shard=True)
+    finally:
+        gpu_ctx.set_option("matrix_fused", -1)
+        gpu_ctx.set_option("matrix_densify", -1)
+    for s in range(n_shards):
+        e = B.groupby_counts(B.Fragment([obm(r) for r in a_rows[s]]), B.Fragment([obm(r) for r in b_rows[s]]), obm(f_rows[s]) if f_rows else None)
+        assert (ps[s] == e).all(), (s, np.argwhere(ps[s] != e)[:5])
+    assert (ps_g == ps).all() and (tot_g == tot).all()
     for b in (A, Bt, F):
         if b is not None:
             b.free()
