@@ -48,7 +48,7 @@ constexpr int kF2Producers = 12;
 constexpr int kF2Waves = kF2Consumers + kF2Producers;
 constexpr int kF2Groups = kF2Producers * 4;  // 16-lane groups
 constexpr int kF2Pref = 3;                   // array items per group and stage that are loaded a stage ahead
-constexpr int kF2BmPref = (kF2NR + kF2Producers - 1) / kF2Producers;  // 6: bitmap rows per wave (all of them are loaded ahead)
+constexpr int kF2BmPref = 2;                 // bitmap rows per wave whose KiB is loaded a stage ahead (a wave owns at most 6)
 constexpr int kF2RunPref = 2;                // run rows per wave whose first 64 runs are loaded a stage ahead
 constexpr int kF2ItemArrayMax = 4096;        // arrays up to this length go through the item lists (ArrayMaxSize, roaring.go:46)
 constexpr int kF2ItemCap = 2624;             // >= 65 rows x (4096 / 128 + 8) items per container slot
@@ -74,6 +74,18 @@ __device__ __forceinline__ uint32_t f2_win(const uint4& w, int k) {  // k-th 16-
 __device__ __forceinline__ uint32_t f2_win_dyn(const uint4& w, uint32_t k) {
   const uint32_t d = k < 2 ? w.x : k < 4 ? w.y : k < 6 ? w.z : w.w;
   return (k & 1) ? d >> 16 : d & 0xFFFFu;
+}
+// inclusive prefix sum over the 64 lanes on the DPP network (no LDS round trips): Hillis-Steele inside
+// each row of 16 lanes (row_shr 1, 2, 4, 8), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15),
+// then lane 31 into rows 2 and 3 (row_bcast:31)
+__device__ __forceinline__ uint32_t f2_wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);
+  return v;
 }
 __device__ __forceinline__ uint32_t f2_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -271,12 +283,7 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
       const uint32_t st = f2_win(x.w, w), en = w + 1 < kF2Stages ? f2_win(x.w, w + 1) : x.d.len;
       const uint32_t cnt = (isarr && en > st) ? min(en - st, (uint32_t)kF2ItemArrayMax) : 0u;
       const uint32_t nch = (cnt + 127u) >> 7;
-      uint32_t incl = nch;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, kWave);
-        if (lane >= d) incl += o;
-      }
+      const uint32_t incl = f2_wave_incl_scan(nch);
       const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
       const uint32_t at = base + incl - nch;
       for (uint32_t c = 0; __ballot(c < nch) != 0; ++c)
@@ -296,21 +303,32 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
     }
   };
 
-  // ---- per-stage state, loaded one stage ahead ----
-  uint4 a_w[kF2Pref];        // array items: 8 values of this lane
-  uint32_t a_nv[kF2Pref];    //   how many of them exist (0: this lane has nothing)
-  uint32_t a_off[kF2Pref];   //   byte offset of the item's row inside a stage buffer
-  uint32_t n_items = 0, item_base = 0;  // of the stage the prefetched items belong to (wave-uniform)
-  uint4 b_w[kF2BmPref];      // bitmap rows: this lane's 16 bytes of the stage's KiB
-  uint32_t b_off[kF2BmPref];  //   (wave-uniform) byte offset of the row; ~0u: none
-  uint32_t r_iv[kF2RunPref];  // run rows: run (first + lane) of the stage
-  uint32_t n_bm = 0, n_run = 0, n_big = 0;
+  // ---- per-stage state: the loads of a stage, issued a WHOLE stage before they are used ----
+  // (Issued at the end of the previous stage they would be exposed on the slowest wave of every stage
+  // — the one that reaches the barrier last and starts the next stage at once: measured, the first
+  // cut of this kernel spent 2 us per stage that way.)  Two sets alternate.
+  struct Pre {
+    uint4 a_w[kF2Pref];        // array items: 8 values of this lane
+    uint32_t a_nv[kF2Pref];    //   how many of them exist (0: this lane has nothing)
+    uint32_t a_off[kF2Pref];   //   byte offset of the item's row inside a stage buffer
+    uint32_t n_items, item_base;  // the stage's item list (wave-uniform)
+    uint4 b_w[kF2BmPref];      // bitmap rows: this lane's 16 bytes of the stage's KiB
+    uint32_t b_off[kF2BmPref];  //   (wave-uniform) byte offset of the row; ~0u: none
+    uint32_t r_iv[kF2RunPref];  // run rows: run (first + lane) of the stage
+    uint32_t n_bm, n_run, n_big;
+  };
+  Pre P0, P1;
+  auto clear_pre = [&](Pre& P) {
 #pragma unroll
-  for (int k = 0; k < kF2Pref; ++k) a_w[k] = uint4{0, 0, 0, 0}, a_nv[k] = 0, a_off[k] = 0;
+    for (int k = 0; k < kF2Pref; ++k) P.a_w[k] = uint4{0, 0, 0, 0}, P.a_nv[k] = 0, P.a_off[k] = 0;
 #pragma unroll
-  for (int k = 0; k < kF2BmPref; ++k) b_w[k] = uint4{0, 0, 0, 0}, b_off[k] = ~0u;
+    for (int k = 0; k < kF2BmPref; ++k) P.b_w[k] = uint4{0, 0, 0, 0}, P.b_off[k] = ~0u;
 #pragma unroll
-  for (int k = 0; k < kF2RunPref; ++k) r_iv[k] = 0;
+    for (int k = 0; k < kF2RunPref; ++k) P.r_iv[k] = 0;
+    P.n_items = P.item_base = P.n_bm = P.n_run = P.n_big = 0;
+  };
+  clear_pre(P0);
+  clear_pre(P1);
 
   // one array item of group (first_group + gq): fetch the lane's 8 values
   auto fetch_item = [&](const F2Tab& T, uint32_t idx, uint32_t n, uint32_t ib, uint4& w, uint32_t& nv, uint32_t& off) {
@@ -333,6 +351,10 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
   // No branches and no exec juggling: a slot past the lane's last value ORs a zero mask into the row
   // (4 vector instructions + the LDS atomic per value: bfe + shift-add for the address, bfe + shift for the mask).
   auto scatter8 = [&](const uint4& w, uint32_t nv, uint32_t rowaddr) {
+    // Lanes without any value are switched off for the whole pass: left on, their zero-mask atomics all
+    // go to ONE address and the LDS serialises same-address atomics (measured: SQ_LDS_ADDR_CONFLICT
+    // 62.8 M quad-cycles per launch, the LDS 80 % busy, 250 us of 630).
+    if (nv == 0) return;
     const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
     const uint32_t valid = (1u << nv) - 1u;  // nv <= 8
 #pragma unroll
@@ -348,53 +370,57 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
       atomicOr(reinterpret_cast<uint32_t*>(ring8 + addr), __builtin_amdgcn_ubfe(valid, (uint32_t)k, 1u) << (sh & 31u));
     }
   };
+  auto row_ptr = [&](const F2Tab& T, uint32_t row, uint32_t& len) {  // wave-uniform row -> payload address, length
+    const uint4 rt = T.row[row][0];
+    len = f2_uniform(rt.z);
+    return reinterpret_cast<const uint8_t*>(((uintptr_t)f2_uniform(rt.y) << 32) | f2_uniform(rt.x));
+  };
   // loads of stage `it` (slot si, eighth q): array items, bitmap KiBs, the first runs of the run rows
-  auto prefetch = [&](uint32_t it) {
+  auto prefetch = [&](uint32_t it, Pre& P) {
     const uint32_t si = it / kF2Stages, q = it % kF2Stages;
     const F2Tab& T = tabs[si & 1u];
-    n_items = f2_uniform(T.icnt[q]);
-    item_base = f2_uniform(T.ibase[q]);
-    n_bm = f2_uniform(T.nbm);
-    n_run = f2_uniform(T.nrun);
-    n_big = f2_uniform(T.nbig);
+    P.n_items = f2_uniform(T.icnt[q]);
+    P.item_base = f2_uniform(T.ibase[q]);
+    P.n_bm = f2_uniform(T.nbm);
+    P.n_run = f2_uniform(T.nrun);
+    P.n_big = f2_uniform(T.nbig);
 #pragma unroll
     for (int k = 0; k < kF2Pref; ++k) {
-      a_nv[k] = 0;
-      if (first_group + (uint32_t)kF2Groups * k < n_items && !(ablate & 2u))
-        fetch_item(T, first_group + gq + (uint32_t)kF2Groups * k, n_items, item_base, a_w[k], a_nv[k], a_off[k]);
+      P.a_nv[k] = 0;
+      if (first_group + (uint32_t)kF2Groups * k < P.n_items && !(ablate & 2u))
+        fetch_item(T, first_group + gq + (uint32_t)kF2Groups * k, P.n_items, P.item_base, P.a_w[k], P.a_nv[k], P.a_off[k]);
     }
 #pragma unroll
     for (int k = 0; k < kF2BmPref; ++k) {
-      b_off[k] = ~0u;
+      P.b_off[k] = ~0u;
       const uint32_t e = pw + (uint32_t)kF2Producers * k;
-      if (e < n_bm && !(ablate & 8u)) {
+      if (e < P.n_bm && !(ablate & 8u)) {
         const uint32_t row = f2_uniform(T.bml[e]);
-        const uint4 rt = T.row[row][0];
-        const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)f2_uniform(rt.y) << 32) | f2_uniform(rt.x));
-        b_w[k] = fx_ld_global16(p + q * (uint32_t)kF2SB + (uint32_t)lane * 16u);
-        b_off[k] = row * (uint32_t)kF2Stride;
+        uint32_t len;
+        const uint8_t* p = row_ptr(T, row, len);
+        P.b_w[k] = fx_ld_global16(p + q * (uint32_t)kF2SB + (uint32_t)lane * 16u);
+        P.b_off[k] = row * (uint32_t)kF2Stride;
       }
     }
 #pragma unroll
     for (int k = 0; k < kF2RunPref; ++k) {
       const uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * k;
-      if (e < n_run && !(ablate & 4u)) {
+      if (e < P.n_run && !(ablate & 4u)) {
         const uint32_t row = f2_uniform(T.runl[e]);
-        const uint4 rt = T.row[row][0], rw = T.row[row][1];
-        const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)f2_uniform(rt.y) << 32) | f2_uniform(rt.x));
-        const uint32_t len = f2_uniform(rt.z);
-        const uint32_t first = f2_uniform(f2_win_dyn(rw, q));
-        const uint32_t idx = first + (uint32_t)lane;
-        r_iv[k] = idx < len ? fx_ld_global4(p + 4u * idx) : 0u;
+        uint32_t len;
+        const uint8_t* p = row_ptr(T, row, len);
+        const uint4 rw = T.row[row][1];
+        const uint32_t idx = f2_uniform(f2_win_dyn(rw, q)) + (uint32_t)lane;
+        P.r_iv[k] = idx < len ? fx_ld_global4(p + 4u * idx) : 0u;
       }
     }
   };
   // one run row of stage (T, q) into buffer bufoff: toggles, then the parity prefix
   auto run_row = [&](const F2Tab& T, uint32_t e, uint32_t q, uint32_t bufoff, bool have_first, uint32_t first_iv) {
     const uint32_t row = f2_uniform(T.runl[e]);
-    const uint4 rt = T.row[row][0], rw = T.row[row][1];
-    const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)f2_uniform(rt.y) << 32) | f2_uniform(rt.x));
-    const uint32_t len = f2_uniform(rt.z);
+    uint32_t len;
+    const uint8_t* p = row_ptr(T, row, len);
+    const uint4 rw = T.row[row][1];
     const uint32_t lo = q * (uint32_t)(kF2SB * 8), hi = lo + (uint32_t)(kF2SB * 8);
     const uint32_t i0 = f2_uniform(f2_win_dyn(rw, q));                                                  // first run whose last value is >= lo
     const uint32_t i1 = q + 1 < (uint32_t)kF2Stages ? min(f2_uniform(f2_win_dyn(rw, q + 1)) + 1u, len) : len;  // one past the last run that can start below hi
@@ -426,61 +452,92 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
     }
   };
 
-  // ---- set-up of the first slot, then the stage loop ----
-  Desc next_d = load_desc(n_act ? act[0] : 0);  // (every producer wave: the builder of a later slot overwrites its copy)
-  if (n_stage && pw == 0) build_tab(tabs[0], next_d);
-  __syncthreads();  // tabs[0] and the clean ring are visible
-  if (n_stage) prefetch(0);
-  for (uint32_t it = 0; it <= n_stage; ++it) {
-    if (it < n_stage) {
-      const uint32_t si = it / kF2Stages, q = it % kF2Stages;
-      const F2Tab& T = tabs[si & 1u];
-      const uint32_t bufoff = (it & 1u) * (uint32_t)kF2Buf;
-      const uint32_t cur_items = n_items, cur_base = item_base, cur_run = n_run, cur_big = n_big;
-      // ---- 1. bitmap rows: registers -> LDS ----
+  Desc next_d = {};
+  // one stage: `cur` was loaded during the previous stage, `nxt` is loaded now for the next one
+  auto stage = [&](uint32_t it, Pre& cur, Pre& nxt) {
+    const uint32_t si = it / kF2Stages, q = it % kF2Stages;
+    const F2Tab& T = tabs[si & 1u];
+    const uint32_t bufoff = (it & 1u) * (uint32_t)kF2Buf;
+    // ---- 0. the next stage's loads go out first ----
+    if (it + 1 < n_stage) prefetch(it + 1, nxt);
+    // ---- 1. bitmap rows: registers -> LDS; a wave's third and later bitmap rows (more than 24 bitmap rows
+    //         among the 65) are loaded here, all of them before the first is stored ----
 #pragma unroll
-      for (int k = 0; k < kF2BmPref; ++k)
-        if (b_off[k] != ~0u) *reinterpret_cast<uint4*>(ring8 + bufoff + b_off[k] + (uint32_t)lane * 16u) = b_w[k];
-      // ---- 2. array items: the prefetched ones, then (long lists only) the rest ----
+    for (int k = 0; k < kF2BmPref; ++k)
+      if (cur.b_off[k] != ~0u) *reinterpret_cast<uint4*>(ring8 + bufoff + cur.b_off[k] + (uint32_t)lane * 16u) = cur.b_w[k];
+    if (pw + (uint32_t)kF2Producers * kF2BmPref < cur.n_bm && !(ablate & 8u)) {
+      constexpr int kMore = (kF2NR + kF2Producers - 1) / kF2Producers - kF2BmPref;  // 4
+      uint4 t[kMore];
+      uint32_t toff[kMore];
 #pragma unroll
-      for (int k = 0; k < kF2Pref; ++k)
-        if (first_group + (uint32_t)kF2Groups * k < cur_items && !(ablate & 2u)) scatter8(a_w[k], a_nv[k], bufoff + a_off[k]);
-      for (uint32_t x = first_group + (uint32_t)kF2Groups * kF2Pref; x < cur_items && !(ablate & 2u); x += (uint32_t)kF2Groups) {
-        uint4 w;
-        uint32_t nv, off;
-        fetch_item(T, x + gq, cur_items, cur_base, w, nv, off);
-        scatter8(w, nv, bufoff + off);
-      }
-      // ---- 3. arrays longer than 4096 values (never produced by optimize(); uploads may hold them): one row per wave pass ----
-      for (uint32_t e = pw; e < cur_big && !(ablate & 2u); e += (uint32_t)kF2Producers) {
-        const uint32_t row = f2_uniform(T.bigl[e]);
-        const uint4 rt = T.row[row][0], rw = T.row[row][1];
-        const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)f2_uniform(rt.y) << 32) | f2_uniform(rt.x));
-        const uint32_t len = f2_uniform(rt.z);
-        const uint32_t v0 = f2_uniform(f2_win_dyn(rw, q)), v1 = q + 1 < (uint32_t)kF2Stages ? min(f2_uniform(f2_win_dyn(rw, q + 1)), len) : len;
-        for (uint32_t base = v0; base < v1; base += 512u) {
-          const uint32_t mine = base + 8u * (uint32_t)lane;
-          if (mine < v1) scatter8(f2_ld_global16_u(p + 2u * mine), min(v1 - mine, 8u), bufoff + row * (uint32_t)kF2Stride);
+      for (int k = 0; k < kMore; ++k) {
+        const uint32_t e = pw + (uint32_t)kF2Producers * (kF2BmPref + k);
+        toff[k] = ~0u;
+        if (e < cur.n_bm) {
+          const uint32_t row = f2_uniform(T.bml[e]);
+          uint32_t len;
+          const uint8_t* p = row_ptr(T, row, len);
+          t[k] = fx_ld_global16(p + q * (uint32_t)kF2SB + (uint32_t)lane * 16u);
+          toff[k] = row * (uint32_t)kF2Stride;
         }
       }
-      // ---- 4. run rows (each owned by one wave, so the parity prefix follows this wave's own toggles) ----
 #pragma unroll
-      for (int k = 0; k < kF2RunPref; ++k) {
-        const uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * k;
-        if (e < cur_run && !(ablate & 4u)) run_row(T, e, q, bufoff, true, r_iv[k]);
-      }
-      for (uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * kF2RunPref; e < cur_run && !(ablate & 4u); e += (uint32_t)kF2Producers)
-        run_row(T, e, q, bufoff, false, 0u);
-      // ---- 5. the next slot's work lists (descriptors fetched at q == 1, lists built at q == 3 by one wave) ----
-      if (si + 1 < n_act) {
-        const bool builder = pw == (si + 1) % (uint32_t)kF2Producers;
-        if (q == 1 && builder) next_d = load_desc(act[si + 1]);
-        if (q == 3 && builder) build_tab(tabs[(si + 1) & 1u], next_d);
-      }
-      // ---- 6. the next stage's loads ----
-      if (it + 1 < n_stage) prefetch(it + 1);
+      for (int k = 0; k < kMore; ++k)
+        if (toff[k] != ~0u) *reinterpret_cast<uint4*>(ring8 + bufoff + toff[k] + (uint32_t)lane * 16u) = t[k];
     }
+    // ---- 2. array items: the prefetched ones, then (long lists only) the rest ----
+#pragma unroll
+    for (int k = 0; k < kF2Pref; ++k)
+      if (first_group + (uint32_t)kF2Groups * k < cur.n_items && !(ablate & 2u)) scatter8(cur.a_w[k], cur.a_nv[k], bufoff + cur.a_off[k]);
+    for (uint32_t x = first_group + (uint32_t)kF2Groups * kF2Pref; x < cur.n_items && !(ablate & 2u); x += (uint32_t)kF2Groups) {
+      uint4 w;
+      uint32_t nv, off;
+      fetch_item(T, x + gq, cur.n_items, cur.item_base, w, nv, off);
+      scatter8(w, nv, bufoff + off);
+    }
+    // ---- 3. arrays longer than 4096 values (never produced by optimize(); uploads may hold them): one row per wave pass ----
+    for (uint32_t e = pw; e < cur.n_big && !(ablate & 2u); e += (uint32_t)kF2Producers) {
+      const uint32_t row = f2_uniform(T.bigl[e]);
+      uint32_t len;
+      const uint8_t* p = row_ptr(T, row, len);
+      const uint4 rw = T.row[row][1];
+      const uint32_t v0 = f2_uniform(f2_win_dyn(rw, q)), v1 = q + 1 < (uint32_t)kF2Stages ? min(f2_uniform(f2_win_dyn(rw, q + 1)), len) : len;
+      for (uint32_t base = v0; base < v1; base += 512u) {
+        const uint32_t mine = base + 8u * (uint32_t)lane;
+        if (mine < v1) scatter8(f2_ld_global16_u(p + 2u * mine), min(v1 - mine, 8u), bufoff + row * (uint32_t)kF2Stride);
+      }
+    }
+    // ---- 4. run rows (each owned by one wave, so the parity prefix follows this wave's own toggles) ----
+#pragma unroll
+    for (int k = 0; k < kF2RunPref; ++k) {
+      const uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * k;
+      if (e < cur.n_run && !(ablate & 4u)) run_row(T, e, q, bufoff, true, cur.r_iv[k]);
+    }
+    for (uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * kF2RunPref; e < cur.n_run && !(ablate & 4u); e += (uint32_t)kF2Producers)
+      run_row(T, e, q, bufoff, false, 0u);
+    // ---- 5. the work lists of slot si + 1 (those of slots 0 and 1 are built before the loop): descriptors
+    //         fetched at q == 1, lists built at q == 3, by one wave; first read at the start of stage (si, 7) ----
+    if (si + 1 < n_act && si + 1 >= 2u) {
+      const bool builder = pw == (si + 1) % (uint32_t)kF2Producers;
+      if (q == 1 && builder) next_d = load_desc(act[si + 1]);
+      if (q == 3 && builder) build_tab(tabs[(si + 1) & 1u], next_d);
+    }
+  };
+
+  // ---- set-up: the work lists of the first two slots (two waves side by side), then the stage loop ----
+  if (n_stage && pw < 2u && pw < n_act) {
+    next_d = load_desc(act[pw]);
+    build_tab(tabs[pw], next_d);
+  }
+  __syncthreads();  // the work lists and the clean ring are visible
+  if (n_stage) prefetch(0, P0);
+  for (uint32_t it = 0; it <= n_stage; it += 2) {  // (n_stage is a multiple of 8)
+    if (it < n_stage) stage(it, P0, P1);
     __syncthreads();
+    if (it + 1 <= n_stage) {
+      if (it + 1 < n_stage) stage(it + 1, P1, P0);
+      __syncthreads();
+    }
   }
   __syncthreads();  // the consumers' reduction barrier
 }
