@@ -47,7 +47,7 @@ constexpr int kF2Consumers = 4;
 constexpr int kF2Producers = 12;
 constexpr int kF2Waves = kF2Consumers + kF2Producers;
 constexpr int kF2Groups = kF2Producers * 4;  // 16-lane groups
-constexpr int kF2Pref = 3;                   // array items per group and stage that are loaded a stage ahead
+constexpr int kF2Pref = 2;                   // array items per group and stage that are loaded a stage ahead (96 per stage; longer lists load in place)
 constexpr int kF2BmPref = 2;                 // bitmap rows per wave whose KiB is loaded a stage ahead (a wave owns at most 6)
 constexpr int kF2RunPref = 2;                // run rows per wave whose first 64 runs are loaded a stage ahead
 constexpr int kF2ItemArrayMax = 4096;        // arrays up to this length go through the item lists (ArrayMaxSize, roaring.go:46)
@@ -307,15 +307,20 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
   // (Issued at the end of the previous stage they would be exposed on the slowest wave of every stage
   // — the one that reaches the barrier last and starts the next stage at once: measured, the first
   // cut of this kernel spent 2 us per stage that way.)  Two sets alternate.
+  // Wave-uniform quantities (row offsets, run ranges, list lengths) stay in VECTOR registers, the same
+  // value in every lane, and conditions on them are exec masks: moving them to scalar registers costs a
+  // v_readfirstlane each plus v_readlane / v_writelane spills (there are not enough scalar registers
+  // for two sets) — the vector ALU is what bounds this kernel, and that bookkeeping was a third of it.
   struct Pre {
     uint4 a_w[kF2Pref];        // array items: 8 values of this lane
     uint32_t a_nv[kF2Pref];    //   how many of them exist (0: this lane has nothing)
     uint32_t a_off[kF2Pref];   //   byte offset of the item's row inside a stage buffer
-    uint32_t n_items, item_base;  // the stage's item list (wave-uniform)
+    uint32_t n_items, item_base;  // the stage's item list
     uint4 b_w[kF2BmPref];      // bitmap rows: this lane's 16 bytes of the stage's KiB
-    uint32_t b_off[kF2BmPref];  //   (wave-uniform) byte offset of the row; ~0u: none
-    uint32_t r_iv[kF2RunPref];  // run rows: run (first + lane) of the stage
-    uint32_t n_bm, n_run, n_big;
+    uint32_t b_off[kF2BmPref];  //   byte offset of the row; ~0u: none
+    uint32_t r_iv[kF2RunPref];  // run rows: run (i0 + lane) of the stage
+    uint32_t r_i0[kF2RunPref], r_i1[kF2RunPref];  //   the runs [i0, i1) can intersect the stage (i0 == i1: nothing to do)
+    uint32_t r_row[kF2RunPref];
   };
   Pre P0, P1;
   auto clear_pre = [&](Pre& P) {
@@ -324,31 +329,31 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
 #pragma unroll
     for (int k = 0; k < kF2BmPref; ++k) P.b_w[k] = uint4{0, 0, 0, 0}, P.b_off[k] = ~0u;
 #pragma unroll
-    for (int k = 0; k < kF2RunPref; ++k) P.r_iv[k] = 0;
-    P.n_items = P.item_base = P.n_bm = P.n_run = P.n_big = 0;
+    for (int k = 0; k < kF2RunPref; ++k) P.r_iv[k] = 0, P.r_i0[k] = 0, P.r_i1[k] = 0, P.r_row[k] = 0;
+    P.n_items = P.item_base = 0;
   };
   clear_pre(P0);
   clear_pre(P1);
+  const uint32_t gl8 = 8u * gl, gl16 = 16u * gl, lane16 = 16u * (uint32_t)lane;
 
   // one array item of group (first_group + gq): fetch the lane's 8 values
   auto fetch_item = [&](const F2Tab& T, uint32_t idx, uint32_t n, uint32_t ib, uint4& w, uint32_t& nv, uint32_t& off) {
-    w = uint4{0, 0, 0, 0};
     nv = 0;
-    off = 0;
     if (idx < n) {
       const uint32_t it = T.pool[ib + idx];
-      const uint32_t row = it & 127u, start = (it >> 7) & 4095u, nvt = ((it >> 19) & 127u) + 1u;
+      const uint32_t row = it & 127u;
       const uint4 rt = T.row[row][0];
       off = row * (uint32_t)kF2Stride;
-      if (nvt > 8u * gl) {
-        nv = min(nvt - 8u * gl, 8u);
+      const int mine = (int)__builtin_amdgcn_ubfe(it, 19u, 7u) + 1 - (int)gl8;  // values of the item from this lane's first on
+      if (mine > 0) {
+        nv = (uint32_t)min(mine, 8);
         const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)rt.y << 32) | rt.x);
-        w = f2_ld_global16_u(p + 2u * (start + 8u * gl));
+        w = f2_ld_global16_u(p + (((it >> 6) & 0x1FFEu) + gl16));  // 2 * (first value of the item + 8 * lane)
       }
     }
   };
   // 8 values of one lane -> bits of a row of the stage buffer (values are inside the stage by construction).
-  // No branches and no exec juggling: a slot past the lane's last value ORs a zero mask into the row
+  // No branches and no exec juggling per value: a slot past the lane's last value ORs a zero mask into the row
   // (4 vector instructions + the LDS atomic per value: bfe + shift-add for the address, bfe + shift for the mask).
   auto scatter8 = [&](const uint4& w, uint32_t nv, uint32_t rowaddr) {
     // Lanes without any value are switched off for the whole pass: left on, their zero-mask atomics all
@@ -370,66 +375,65 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
       atomicOr(reinterpret_cast<uint32_t*>(ring8 + addr), __builtin_amdgcn_ubfe(valid, (uint32_t)k, 1u) << (sh & 31u));
     }
   };
-  auto row_ptr = [&](const F2Tab& T, uint32_t row, uint32_t& len) {  // wave-uniform row -> payload address, length
+  auto row_ptr = [&](const F2Tab& T, uint32_t row, uint32_t& len) {  // payload address and length of a row (the same in all lanes)
     const uint4 rt = T.row[row][0];
-    len = f2_uniform(rt.z);
-    return reinterpret_cast<const uint8_t*>(((uintptr_t)f2_uniform(rt.y) << 32) | f2_uniform(rt.x));
+    len = rt.z;
+    return reinterpret_cast<const uint8_t*>(((uintptr_t)rt.y << 32) | rt.x);
+  };
+  // k-th entry of a row's window index, straight from the work lists
+  auto win_of = [&](const F2Tab& T, uint32_t row, uint32_t k) {
+    return (uint32_t) reinterpret_cast<const uint16_t*>(&T.row[row][1])[k];
+  };
+  // the runs [i0, i1) of a run row can intersect stage q
+  auto run_range = [&](const F2Tab& T, uint32_t row, uint32_t q, uint32_t len, uint32_t& i0, uint32_t& i1) {
+    i0 = win_of(T, row, q);                                                            // first run whose last value is >= lo
+    i1 = q + 1 < (uint32_t)kF2Stages ? min(win_of(T, row, q + 1) + 1u, len) : len;       // one past the last run that can start below hi
   };
   // loads of stage `it` (slot si, eighth q): array items, bitmap KiBs, the first runs of the run rows
   auto prefetch = [&](uint32_t it, Pre& P) {
     const uint32_t si = it / kF2Stages, q = it % kF2Stages;
     const F2Tab& T = tabs[si & 1u];
-    P.n_items = f2_uniform(T.icnt[q]);
-    P.item_base = f2_uniform(T.ibase[q]);
-    P.n_bm = f2_uniform(T.nbm);
-    P.n_run = f2_uniform(T.nrun);
-    P.n_big = f2_uniform(T.nbig);
+    P.n_items = T.icnt[q];
+    P.item_base = T.ibase[q];
+    const uint32_t nbm = T.nbm, nrun = T.nrun;
 #pragma unroll
     for (int k = 0; k < kF2Pref; ++k) {
       P.a_nv[k] = 0;
-      if (first_group + (uint32_t)kF2Groups * k < P.n_items && !(ablate & 2u))
-        fetch_item(T, first_group + gq + (uint32_t)kF2Groups * k, P.n_items, P.item_base, P.a_w[k], P.a_nv[k], P.a_off[k]);
+      if (!(ablate & 2u)) fetch_item(T, first_group + gq + (uint32_t)kF2Groups * k, P.n_items, P.item_base, P.a_w[k], P.a_nv[k], P.a_off[k]);
     }
 #pragma unroll
     for (int k = 0; k < kF2BmPref; ++k) {
       P.b_off[k] = ~0u;
       const uint32_t e = pw + (uint32_t)kF2Producers * k;
-      if (e < P.n_bm && !(ablate & 8u)) {
-        const uint32_t row = f2_uniform(T.bml[e]);
+      if (e < nbm && !(ablate & 8u)) {
+        const uint32_t row = T.bml[e];
         uint32_t len;
         const uint8_t* p = row_ptr(T, row, len);
-        P.b_w[k] = fx_ld_global16(p + q * (uint32_t)kF2SB + (uint32_t)lane * 16u);
+        P.b_w[k] = fx_ld_global16(p + (q * (uint32_t)kF2SB + lane16));
         P.b_off[k] = row * (uint32_t)kF2Stride;
       }
     }
 #pragma unroll
     for (int k = 0; k < kF2RunPref; ++k) {
       const uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * k;
-      if (e < P.n_run && !(ablate & 4u)) {
-        const uint32_t row = f2_uniform(T.runl[e]);
+      P.r_i0[k] = P.r_i1[k] = 0;
+      if (e < nrun && !(ablate & 4u)) {
+        const uint32_t row = T.runl[e];
         uint32_t len;
         const uint8_t* p = row_ptr(T, row, len);
-        const uint4 rw = T.row[row][1];
-        const uint32_t idx = f2_uniform(f2_win_dyn(rw, q)) + (uint32_t)lane;
+        run_range(T, row, q, len, P.r_i0[k], P.r_i1[k]);
+        const uint32_t idx = P.r_i0[k] + (uint32_t)lane;
         P.r_iv[k] = idx < len ? fx_ld_global4(p + 4u * idx) : 0u;
+        P.r_row[k] = row;
       }
     }
   };
-  // one run row of stage (T, q) into buffer bufoff: toggles, then the parity prefix
-  auto run_row = [&](const F2Tab& T, uint32_t e, uint32_t q, uint32_t bufoff, bool have_first, uint32_t first_iv) {
-    const uint32_t row = f2_uniform(T.runl[e]);
-    uint32_t len;
-    const uint8_t* p = row_ptr(T, row, len);
-    const uint4 rw = T.row[row][1];
+  // one run row of a stage into its row of the stage buffer: toggles at the clamped start and one past the clamped
+  // end of the runs [i0, i1) (the first 64 of them were loaded a stage ahead), then the parity prefix
+  auto run_row = [&](const F2Tab& T, uint32_t row, uint32_t q, uint32_t bufoff, uint32_t i0, uint32_t i1, bool have_first, uint32_t first_iv) {
     const uint32_t lo = q * (uint32_t)(kF2SB * 8), hi = lo + (uint32_t)(kF2SB * 8);
-    const uint32_t i0 = f2_uniform(f2_win_dyn(rw, q));                                                  // first run whose last value is >= lo
-    const uint32_t i1 = q + 1 < (uint32_t)kF2Stages ? min(f2_uniform(f2_win_dyn(rw, q + 1)) + 1u, len) : len;  // one past the last run that can start below hi
     const uint32_t rowaddr = bufoff + row * (uint32_t)kF2Stride;
-    for (uint32_t base = i0; base < i1; base += 64u) {
-      const uint32_t idx = base + (uint32_t)lane;
-      uint32_t iv = 0;
-      if (base == i0 && have_first) iv = first_iv;
-      else if (idx < len) iv = fx_ld_global4(p + 4u * idx);
+    auto toggle = [&](uint32_t idx, uint32_t iv) {
       const uint32_t s = iv & 0xFFFFu, l = iv >> 16;
       if (idx < i1 && s < hi && l >= lo) {
         const uint32_t s2 = (s > lo ? s : lo) - lo;           // 0 .. 8191
@@ -437,10 +441,23 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
         atomicXor(reinterpret_cast<uint32_t*>(ring8 + rowaddr + ((s2 >> 3) & 0x3FCu)), 1u << (s2 & 31u));
         if (e2 < (uint32_t)(kF2SB * 8)) atomicXor(reinterpret_cast<uint32_t*>(ring8 + rowaddr + ((e2 >> 3) & 0x3FCu)), 1u << (e2 & 31u));
       }
+    };
+    uint32_t base = i0;
+    if (have_first) {
+      toggle(i0 + (uint32_t)lane, first_iv);
+      base += 64u;
+    }
+    if (base < i1) {  // more than 64 runs inside one eighth of the container (or a row beyond the prefetched two)
+      uint32_t len;
+      const uint8_t* p = row_ptr(T, row, len);
+      for (; base < i1; base += 64u) {
+        const uint32_t idx = base + (uint32_t)lane;
+        toggle(idx, idx < len ? fx_ld_global4(p + 4u * idx) : 0u);
+      }
     }
     wave_lds_sync();
     {  // parity prefix: lane j owns bytes 16 j .. 16 j + 15 of the row
-      uint4* pc = reinterpret_cast<uint4*>(ring8 + rowaddr + (uint32_t)lane * 16u);
+      uint4* pc = reinterpret_cast<uint4*>(ring8 + rowaddr + lane16);
       const uint4 tv = *pc;
       const u64 t0 = ((u64)tv.y << 32) | tv.x, t1 = ((u64)tv.w << 32) | tv.z;
       const uint32_t p0 = __popcll(t0) & 1u, p1 = __popcll(t1) & 1u;
@@ -464,8 +481,9 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
     //         among the 65) are loaded here, all of them before the first is stored ----
 #pragma unroll
     for (int k = 0; k < kF2BmPref; ++k)
-      if (cur.b_off[k] != ~0u) *reinterpret_cast<uint4*>(ring8 + bufoff + cur.b_off[k] + (uint32_t)lane * 16u) = cur.b_w[k];
-    if (pw + (uint32_t)kF2Producers * kF2BmPref < cur.n_bm && !(ablate & 8u)) {
+      if (cur.b_off[k] != ~0u) *reinterpret_cast<uint4*>(ring8 + (bufoff + lane16) + cur.b_off[k]) = cur.b_w[k];
+    if (cur.b_off[kF2BmPref - 1] != ~0u && !(ablate & 8u)) {
+      const uint32_t nbm = T.nbm;
       constexpr int kMore = (kF2NR + kF2Producers - 1) / kF2Producers - kF2BmPref;  // 4
       uint4 t[kMore];
       uint32_t toff[kMore];
@@ -473,48 +491,58 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
       for (int k = 0; k < kMore; ++k) {
         const uint32_t e = pw + (uint32_t)kF2Producers * (kF2BmPref + k);
         toff[k] = ~0u;
-        if (e < cur.n_bm) {
-          const uint32_t row = f2_uniform(T.bml[e]);
+        if (e < nbm) {
+          const uint32_t row = T.bml[e];
           uint32_t len;
           const uint8_t* p = row_ptr(T, row, len);
-          t[k] = fx_ld_global16(p + q * (uint32_t)kF2SB + (uint32_t)lane * 16u);
+          t[k] = fx_ld_global16(p + (q * (uint32_t)kF2SB + lane16));
           toff[k] = row * (uint32_t)kF2Stride;
         }
       }
 #pragma unroll
       for (int k = 0; k < kMore; ++k)
-        if (toff[k] != ~0u) *reinterpret_cast<uint4*>(ring8 + bufoff + toff[k] + (uint32_t)lane * 16u) = t[k];
+        if (toff[k] != ~0u) *reinterpret_cast<uint4*>(ring8 + (bufoff + lane16) + toff[k]) = t[k];
     }
     // ---- 2. array items: the prefetched ones, then (long lists only) the rest ----
 #pragma unroll
-    for (int k = 0; k < kF2Pref; ++k)
-      if (first_group + (uint32_t)kF2Groups * k < cur.n_items && !(ablate & 2u)) scatter8(cur.a_w[k], cur.a_nv[k], bufoff + cur.a_off[k]);
-    for (uint32_t x = first_group + (uint32_t)kF2Groups * kF2Pref; x < cur.n_items && !(ablate & 2u); x += (uint32_t)kF2Groups) {
-      uint4 w;
-      uint32_t nv, off;
-      fetch_item(T, x + gq, cur.n_items, cur.item_base, w, nv, off);
-      scatter8(w, nv, bufoff + off);
+    for (int k = 0; k < kF2Pref; ++k) scatter8(cur.a_w[k], cur.a_nv[k], bufoff + cur.a_off[k]);
+    if (first_group + (uint32_t)kF2Groups * kF2Pref < cur.n_items && !(ablate & 2u)) {
+      const uint32_t n = f2_uniform(cur.n_items), ib = f2_uniform(cur.item_base);
+      for (uint32_t x = first_group + (uint32_t)kF2Groups * kF2Pref; x < n; x += (uint32_t)kF2Groups) {
+        uint4 w;
+        uint32_t nv, off;
+        fetch_item(T, x + gq, n, ib, w, nv, off);
+        scatter8(w, nv, bufoff + off);
+      }
     }
     // ---- 3. arrays longer than 4096 values (never produced by optimize(); uploads may hold them): one row per wave pass ----
-    for (uint32_t e = pw; e < cur.n_big && !(ablate & 2u); e += (uint32_t)kF2Producers) {
-      const uint32_t row = f2_uniform(T.bigl[e]);
-      uint32_t len;
-      const uint8_t* p = row_ptr(T, row, len);
-      const uint4 rw = T.row[row][1];
-      const uint32_t v0 = f2_uniform(f2_win_dyn(rw, q)), v1 = q + 1 < (uint32_t)kF2Stages ? min(f2_uniform(f2_win_dyn(rw, q + 1)), len) : len;
-      for (uint32_t base = v0; base < v1; base += 512u) {
-        const uint32_t mine = base + 8u * (uint32_t)lane;
-        if (mine < v1) scatter8(f2_ld_global16_u(p + 2u * mine), min(v1 - mine, 8u), bufoff + row * (uint32_t)kF2Stride);
+    if (!(ablate & 2u)) {
+      const uint32_t nbig = f2_uniform(T.nbig);
+      for (uint32_t e = pw; e < nbig; e += (uint32_t)kF2Producers) {
+        const uint32_t row = f2_uniform(T.bigl[e]);
+        uint32_t len;
+        const uint8_t* p = row_ptr(T, row, len);
+        const uint32_t v0 = f2_uniform(win_of(T, row, q)), v1 = q + 1 < (uint32_t)kF2Stages ? f2_uniform(min(win_of(T, row, q + 1), len)) : f2_uniform(len);
+        for (uint32_t base = v0; base < v1; base += 512u) {
+          const uint32_t mine = base + 8u * (uint32_t)lane;
+          if (mine < v1) scatter8(f2_ld_global16_u(p + 2u * mine), min(v1 - mine, 8u), bufoff + row * (uint32_t)kF2Stride);
+        }
       }
     }
     // ---- 4. run rows (each owned by one wave, so the parity prefix follows this wave's own toggles) ----
 #pragma unroll
-    for (int k = 0; k < kF2RunPref; ++k) {
-      const uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * k;
-      if (e < cur.n_run && !(ablate & 4u)) run_row(T, e, q, bufoff, true, cur.r_iv[k]);
+    for (int k = 0; k < kF2RunPref; ++k)
+      if (cur.r_i0[k] < cur.r_i1[k]) run_row(T, cur.r_row[k], q, bufoff, cur.r_i0[k], cur.r_i1[k], true, cur.r_iv[k]);
+    if (cur.r_i1[kF2RunPref - 1] != 0 && !(ablate & 4u)) {  // (a wave with a second run row may have a third)
+      const uint32_t nrun = f2_uniform(T.nrun);
+      for (uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * kF2RunPref; e < nrun; e += (uint32_t)kF2Producers) {
+        const uint32_t row = f2_uniform(T.runl[e]);
+        uint32_t len, i0, i1;
+        (void)row_ptr(T, row, len);
+        run_range(T, row, q, len, i0, i1);
+        if (i0 < i1) run_row(T, row, q, bufoff, i0, i1, false, 0u);
+      }
     }
-    for (uint32_t e = (uint32_t)(kF2Producers - 1) - pw + (uint32_t)kF2Producers * kF2RunPref; e < cur.n_run && !(ablate & 4u); e += (uint32_t)kF2Producers)
-      run_row(T, e, q, bufoff, false, 0u);
     // ---- 5. the work lists of slot si + 1 (those of slots 0 and 1 are built before the loop): descriptors
     //         fetched at q == 1, lists built at q == 3, by one wave; first read at the start of stage (si, 7) ----
     if (si + 1 < n_act && si + 1 >= 2u) {
