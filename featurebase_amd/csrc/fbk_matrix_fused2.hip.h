@@ -63,9 +63,13 @@ struct F2Tab {                      // the work lists of one container slot
 
 typedef mm_u4 __attribute__((aligned(2))) f2_u4_unaligned;
 
-__device__ __forceinline__ uint4 f2_ld_global16_u(const uint8_t* p) {  // 16 bytes at 2-byte alignment, global address space
-  const mm_u4 v = *reinterpret_cast<const __attribute__((address_space(1))) f2_u4_unaligned*>((uintptr_t)p);
-  return uint4{v[0], v[1], v[2], v[3]};
+// (the prefetched 16-byte values stay ext-vector typed end to end: as a struct of four components they are four
+// separate registers to the compiler, which then copies parts of a load's result around — waiting for the load first)
+__device__ __forceinline__ mm_u4 f2_ld_global16_u(const uint8_t* p) {  // 16 bytes at 2-byte alignment, global address space
+  return *reinterpret_cast<const __attribute__((address_space(1))) f2_u4_unaligned*>((uintptr_t)p);
+}
+__device__ __forceinline__ mm_u4 f2_ld_global16(const uint8_t* p) {  // 16-byte aligned
+  return *reinterpret_cast<const __attribute__((address_space(1))) mm_u4*>((uintptr_t)p);
 }
 __device__ __forceinline__ uint32_t f2_win(const uint4& w, int k) {  // k-th 16-bit entry of a window index
   const uint32_t d = k < 2 ? w.x : k < 4 ? w.y : k < 6 ? w.z : w.w;
@@ -89,14 +93,22 @@ __device__ __forceinline__ uint32_t f2_wave_incl_scan(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t f2_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-template <bool HAS_F>
+template <bool HAS_F, bool PROF = false>
 __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
     const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA, const uint4* __restrict__ winA, const uint32_t* __restrict__ rowsA, uint32_t nA,
     const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB, const uint4* __restrict__ winB, const uint32_t* __restrict__ rowsB, uint32_t nBtot,
     const Slot* __restrict__ slotsF, const uint8_t* __restrict__ arenaF, const uint4* __restrict__ winF, const uint32_t* __restrict__ rowsF, uint32_t n_shards,
-    uint32_t spb, u64* __restrict__ out_shard, uint32_t ablate) {
+    uint32_t spb, u64* __restrict__ out_shard, uint32_t ablate, u64* __restrict__ prof = nullptr) {
   // `ablate` (option matrix_fused_ablate, timing experiments only — results are wrong when set):
   // 1 no consumer arithmetic, 2 no array decode, 4 no run decode, 8 no bitmap rows
+  // PROF (ablate & 32): the block in the middle of the grid writes cycle stamps, prof[(wave * 24 + stage) * 8 + k]:
+  // producers k = 0 stage start, 1 this stage's loads settled and bitmap rows stored, 2 next stage's loads issued,
+  // 3 array items done, 4 run rows (and list building) done, 5 past the barrier; consumers k = 0 start,
+  // 1 arithmetic done, 5 past the barrier
+  const bool traced = PROF && blockIdx.x == gridDim.x / 2;
+  auto stamp = [&](uint32_t st, int k) {
+    if (PROF && traced && (threadIdx.x & 63) == 0 && st < 24u) prof[((threadIdx.x >> 6) * 24u + st) * 8u + k] = (u64)__builtin_readcyclecounter();
+  };
   __shared__ uint4 ring[2 * kF2Buf / 16];  // 135 200 bytes
   __shared__ F2Tab tabs[2];                // 2 x 12 896 bytes
   const int lane = threadIdx.x & 63;
@@ -130,8 +142,10 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
     const uint32_t r = lane & 31, g = lane >> 5;
     mm_v16f acc0{}, acc1{}, acc2{};
     constexpr uint32_t M4 = 0x11111111u;
-    __syncthreads();  // (the producers' set-up barrier)
+    __syncthreads();  // (the producers' two set-up barriers)
+    __syncthreads();
     for (uint32_t it = 0; it <= n_stage; ++it) {
+      stamp(it, 0);
       if (it >= 1 && !(ablate & 1u)) {
         // rows as uint4 pieces (row stride 65 pieces): this wave's K range is pieces 16 wv .. 16 wv + 15 of
         // every row; pair o = pieces 16 wv + 2 o + g
@@ -185,7 +199,9 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
         // (all lanes, four per piece, the same zeros: a condition here would put the arithmetic above behind it)
         if (HAS_F) rowF[lane & 15] = uint4{0, 0, 0, 0};
       }
+      stamp(it, 1);
       __syncthreads();
+      stamp(it, 5);
     }
     // cross-wave reduction through LDS (the ring is free now): [wave][16 regs][64 lanes]
     uint32_t* red = reinterpret_cast<uint32_t*>(ring8);
@@ -247,60 +263,71 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
     }
     return x;
   };
-  // ---- the work lists of one container slot (one wave) ----
-  auto build_tab = [&](F2Tab& T, const Desc& x) {
+  // ---- the work lists of one container slot, built by nine waves in three steps a stage apart: (1) the
+  //      descriptors are fetched; (2) wave w < 8 counts the items of eighth w, wave 8 writes the row table
+  //      and the bitmap / run / long-array lists; (3) wave w adds up the counts before it and writes its
+  //      items.  (One wave doing all of it took 9000 cycles — longer than a whole stage of the block.) ----
+  struct Build {
+    uint32_t st, cnt, nch, incl, tot;  // this lane's row in the wave's eighth: first value, values, items, inclusive scan, wave total
+    uint32_t stF, cntF, nchF;          // the filter row (wave-uniform)
+  };
+  auto build_rows = [&](F2Tab& T, const Desc& x) {
     const uint32_t type = slot_n(x.d) ? slot_type(x.d) : 0u;
     const uint32_t typeF = (HAS_F && slot_n(x.df)) ? slot_type(x.df) : 0u;  // wave-uniform
-    {
-      const uintptr_t pa = (uintptr_t)(my_base + x.d.off);
-      T.row[lane][0] = uint4{(uint32_t)pa, (uint32_t)(pa >> 32), x.d.len, type};
-      T.row[lane][1] = x.w;
-      if (HAS_F && lane == 0) {
-        const uintptr_t pf = (uintptr_t)(arenaF + x.df.off);
-        T.row[64][0] = uint4{(uint32_t)pf, (uint32_t)(pf >> 32), x.df.len, typeF};
-        T.row[64][1] = x.wf;
-      }
+    const uintptr_t pa = (uintptr_t)(my_base + x.d.off);
+    T.row[lane][0] = uint4{(uint32_t)pa, (uint32_t)(pa >> 32), x.d.len, type};
+    T.row[lane][1] = x.w;
+    if (HAS_F && lane == 0) {
+      const uintptr_t pf = (uintptr_t)(arenaF + x.df.off);
+      T.row[64][0] = uint4{(uint32_t)pf, (uint32_t)(pf >> 32), x.df.len, typeF};
+      T.row[64][1] = x.wf;
     }
+    const bool isbig = type == kTypeArray && x.d.len > (uint32_t)kF2ItemArrayMax;
+    const u64 mb = __ballot(type == kTypeBitmap), mr = __ballot(type == kTypeRun), mg = __ballot(isbig);
+    if (type == kTypeBitmap) T.bml[__popcll(mb & lane_lt)] = (uint8_t)lane;
+    if (type == kTypeRun) T.runl[__popcll(mr & lane_lt)] = (uint8_t)lane;
+    if (isbig) T.bigl[__popcll(mg & lane_lt)] = (uint8_t)lane;
+    uint32_t nb = __popcll(mb), nr = __popcll(mr), ng = __popcll(mg);
+    if (lane == 0) {
+      if (typeF == kTypeBitmap) T.bml[nb++] = 64;
+      if (typeF == kTypeRun) T.runl[nr++] = 64;
+      if (typeF == kTypeArray && x.df.len > (uint32_t)kF2ItemArrayMax) T.bigl[ng++] = 64;
+      T.nbm = nb, T.nrun = nr, T.nbig = ng;
+    }
+  };
+  auto build_count = [&](F2Tab& T, const Desc& x, uint32_t w, Build& B) {  // w: wave-uniform
+    const uint32_t type = slot_n(x.d) ? slot_type(x.d) : 0u;
+    const uint32_t typeF = (HAS_F && slot_n(x.df)) ? slot_type(x.df) : 0u;
     const bool isarr = type == kTypeArray && x.d.len <= (uint32_t)kF2ItemArrayMax;
-    const bool isbig = type == kTypeArray && !isarr;
     const bool farr = typeF == kTypeArray && x.df.len <= (uint32_t)kF2ItemArrayMax;
-    {
-      const u64 mb = __ballot(type == kTypeBitmap), mr = __ballot(type == kTypeRun), mg = __ballot(isbig);
-      if (type == kTypeBitmap) T.bml[__popcll(mb & lane_lt)] = (uint8_t)lane;
-      if (type == kTypeRun) T.runl[__popcll(mr & lane_lt)] = (uint8_t)lane;
-      if (isbig) T.bigl[__popcll(mg & lane_lt)] = (uint8_t)lane;
-      uint32_t nb = __popcll(mb), nr = __popcll(mr), ng = __popcll(mg);
-      if (lane == 0) {
-        if (typeF == kTypeBitmap) T.bml[nb++] = 64;
-        if (typeF == kTypeRun) T.runl[nr++] = 64;
-        if (typeF == kTypeArray && !farr) T.bigl[ng++] = 64;
-        T.nbm = nb, T.nrun = nr, T.nbig = ng;
-      }
+    B.st = f2_win_dyn(x.w, w);
+    const uint32_t en = w + 1 < (uint32_t)kF2Stages ? f2_win_dyn(x.w, w + 1) : x.d.len;
+    B.cnt = (isarr && en > B.st) ? min(en - B.st, (uint32_t)kF2ItemArrayMax) : 0u;
+    B.nch = (B.cnt + 127u) >> 7;
+    B.incl = f2_wave_incl_scan(B.nch);
+    B.tot = (uint32_t)__builtin_amdgcn_readlane((int)B.incl, 63);
+    B.stF = B.cntF = B.nchF = 0;
+    if (HAS_F && farr) {
+      B.stF = f2_win_dyn(x.wf, w);
+      const uint32_t enF = w + 1 < (uint32_t)kF2Stages ? f2_win_dyn(x.wf, w + 1) : x.df.len;
+      B.cntF = enF > B.stF ? min(enF - B.stF, (uint32_t)kF2ItemArrayMax) : 0u;
+      B.nchF = (B.cntF + 127u) >> 7;
     }
+    if (lane == 0) T.icnt[w] = B.tot + B.nchF;
+  };
+  auto build_items = [&](F2Tab& T, uint32_t w, const Build& B) {
     uint32_t base = 0;
-#pragma unroll
-    for (int w = 0; w < kF2Stages; ++w) {
-      const uint32_t st = f2_win(x.w, w), en = w + 1 < kF2Stages ? f2_win(x.w, w + 1) : x.d.len;
-      const uint32_t cnt = (isarr && en > st) ? min(en - st, (uint32_t)kF2ItemArrayMax) : 0u;
-      const uint32_t nch = (cnt + 127u) >> 7;
-      const uint32_t incl = f2_wave_incl_scan(nch);
-      const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-      const uint32_t at = base + incl - nch;
-      for (uint32_t c = 0; __ballot(c < nch) != 0; ++c)
-        if (c < nch && at + c < (uint32_t)kF2ItemCap) T.pool[at + c] = (uint32_t)lane | ((st + 128u * c) << 7) | ((min(128u, cnt - 128u * c) - 1u) << 19);
-      // the filter row's items (wave-uniform quantities; lane c writes chunk c: at most 32 chunks + 1)
-      uint32_t nchF = 0;
-      if (HAS_F && farr) {
-        const uint32_t stF = f2_win(x.wf, w), enF = w + 1 < kF2Stages ? f2_win(x.wf, w + 1) : x.df.len;
-        const uint32_t cntF = enF > stF ? min(enF - stF, (uint32_t)kF2ItemArrayMax) : 0u;
-        nchF = (cntF + 127u) >> 7;
-        if ((uint32_t)lane < nchF && base + tot + lane < (uint32_t)kF2ItemCap)
-          T.pool[base + tot + lane] = 64u | ((stF + 128u * lane) << 7) | ((min(128u, cntF - 128u * lane) - 1u) << 19);
-      }
-      const uint32_t n_w = min(tot + nchF, (uint32_t)kF2ItemCap - min(base, (uint32_t)kF2ItemCap));
-      if (lane == 0) T.ibase[w] = base, T.icnt[w] = n_w;
-      base += n_w;
-    }
+    for (uint32_t v = 0; v < w; ++v) base += T.icnt[v];  // (counts of the earlier eighths: written a stage / a barrier ago)
+    base = min(base, (uint32_t)kF2ItemCap);
+    const uint32_t at = base + B.incl - B.nch;
+    for (uint32_t c = 0; __ballot(c < B.nch) != 0; ++c)
+      if (c < B.nch && at + c < (uint32_t)kF2ItemCap) T.pool[at + c] = (uint32_t)lane | ((B.st + 128u * c) << 7) | ((min(128u, B.cnt - 128u * c) - 1u) << 19);
+    // the filter row's items (wave-uniform quantities; lane c writes chunk c: at most 32 chunks + 1)
+    if (HAS_F && (uint32_t)lane < B.nchF && base + B.tot + lane < (uint32_t)kF2ItemCap)
+      T.pool[base + B.tot + lane] = 64u | ((B.stF + 128u * lane) << 7) | ((min(128u, B.cntF - 128u * lane) - 1u) << 19);
+    // (the lists fit by construction; the clamps only keep a corrupt index inside the pool.  icnt[w] itself stays
+    // as counted: the waves of the later eighths are reading it)
+    if (lane == 0) T.ibase[w] = base;
   };
 
   // ---- per-stage state: the loads of a stage, issued a WHOLE stage before they are used ----
@@ -312,11 +339,11 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
   // v_readfirstlane each plus v_readlane / v_writelane spills (there are not enough scalar registers
   // for two sets) — the vector ALU is what bounds this kernel, and that bookkeeping was a third of it.
   struct Pre {
-    uint4 a_w[kF2Pref];        // array items: 8 values of this lane
+    mm_u4 a_w[kF2Pref];        // array items: 8 values of this lane
     uint32_t a_nv[kF2Pref];    //   how many of them exist (0: this lane has nothing)
     uint32_t a_off[kF2Pref];   //   byte offset of the item's row inside a stage buffer
     uint32_t n_items, item_base;  // the stage's item list
-    uint4 b_w[kF2BmPref];      // bitmap rows: this lane's 16 bytes of the stage's KiB
+    mm_u4 b_w[kF2BmPref];      // bitmap rows: this lane's 16 bytes of the stage's KiB
     uint32_t b_off[kF2BmPref];  //   byte offset of the row; ~0u: none
     uint32_t r_iv[kF2RunPref];  // run rows: run (i0 + lane) of the stage
     uint32_t r_i0[kF2RunPref], r_i1[kF2RunPref];  //   the runs [i0, i1) can intersect the stage (i0 == i1: nothing to do)
@@ -325,9 +352,9 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
   Pre P0, P1;
   auto clear_pre = [&](Pre& P) {
 #pragma unroll
-    for (int k = 0; k < kF2Pref; ++k) P.a_w[k] = uint4{0, 0, 0, 0}, P.a_nv[k] = 0, P.a_off[k] = 0;
+    for (int k = 0; k < kF2Pref; ++k) P.a_w[k] = mm_u4{0, 0, 0, 0}, P.a_nv[k] = 0, P.a_off[k] = 0;
 #pragma unroll
-    for (int k = 0; k < kF2BmPref; ++k) P.b_w[k] = uint4{0, 0, 0, 0}, P.b_off[k] = ~0u;
+    for (int k = 0; k < kF2BmPref; ++k) P.b_w[k] = mm_u4{0, 0, 0, 0}, P.b_off[k] = ~0u;
 #pragma unroll
     for (int k = 0; k < kF2RunPref; ++k) P.r_iv[k] = 0, P.r_i0[k] = 0, P.r_i1[k] = 0, P.r_row[k] = 0;
     P.n_items = P.item_base = 0;
@@ -337,7 +364,7 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
   const uint32_t gl8 = 8u * gl, gl16 = 16u * gl, lane16 = 16u * (uint32_t)lane;
 
   // one array item of group (first_group + gq): fetch the lane's 8 values
-  auto fetch_item = [&](const F2Tab& T, uint32_t idx, uint32_t n, uint32_t ib, uint4& w, uint32_t& nv, uint32_t& off) {
+  auto fetch_item = [&](const F2Tab& T, uint32_t idx, uint32_t n, uint32_t ib, mm_u4& w, uint32_t& nv, uint32_t& off) {
     nv = 0;
     if (idx < n) {
       const uint32_t it = T.pool[ib + idx];
@@ -355,12 +382,12 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
   // 8 values of one lane -> bits of a row of the stage buffer (values are inside the stage by construction).
   // No branches and no exec juggling per value: a slot past the lane's last value ORs a zero mask into the row
   // (4 vector instructions + the LDS atomic per value: bfe + shift-add for the address, bfe + shift for the mask).
-  auto scatter8 = [&](const uint4& w, uint32_t nv, uint32_t rowaddr) {
+  auto scatter8 = [&](const mm_u4& w, uint32_t nv, uint32_t rowaddr) {
     // Lanes without any value are switched off for the whole pass: left on, their zero-mask atomics all
     // go to ONE address and the LDS serialises same-address atomics (measured: SQ_LDS_ADDR_CONFLICT
     // 62.8 M quad-cycles per launch, the LDS 80 % busy, 250 us of 630).
     if (nv == 0) return;
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    const uint32_t ww[4] = {w[0], w[1], w[2], w[3]};
     const uint32_t valid = (1u << nv) - 1u;  // nv <= 8
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -393,8 +420,8 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
   auto prefetch = [&](uint32_t it, Pre& P) {
     const uint32_t si = it / kF2Stages, q = it % kF2Stages;
     const F2Tab& T = tabs[si & 1u];
-    P.n_items = T.icnt[q];
-    P.item_base = T.ibase[q];
+    P.item_base = T.ibase[q];  // (<= kF2ItemCap)
+    P.n_items = min(T.icnt[q], (uint32_t)kF2ItemCap - P.item_base);  // (fits by construction; the clamp keeps a corrupt window index inside the pool)
     const uint32_t nbm = T.nbm, nrun = T.nrun;
 #pragma unroll
     for (int k = 0; k < kF2Pref; ++k) {
@@ -409,7 +436,7 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
         const uint32_t row = T.bml[e];
         uint32_t len;
         const uint8_t* p = row_ptr(T, row, len);
-        P.b_w[k] = fx_ld_global16(p + (q * (uint32_t)kF2SB + lane16));
+        P.b_w[k] = f2_ld_global16(p + (q * (uint32_t)kF2SB + lane16));
         P.b_off[k] = row * (uint32_t)kF2Stride;
       }
     }
@@ -469,23 +496,39 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
     }
   };
 
+  auto settle = [&](Pre& P) {
+#pragma unroll
+    for (int k = 0; k < kF2Pref; ++k) asm volatile("" : "+v"(P.a_w[k]));
+#pragma unroll
+    for (int k = 0; k < kF2BmPref; ++k) asm volatile("" : "+v"(P.b_w[k]));
+#pragma unroll
+    for (int k = 0; k < kF2RunPref; ++k) asm volatile("" : "+v"(P.r_iv[k]));
+  };
   Desc next_d = {};
+  Build bld = {};
   // one stage: `cur` was loaded during the previous stage, `nxt` is loaded now for the next one
   auto stage = [&](uint32_t it, Pre& cur, Pre& nxt) {
     const uint32_t si = it / kF2Stages, q = it % kF2Stages;
     const F2Tab& T = tabs[si & 1u];
     const uint32_t bufoff = (it & 1u) * (uint32_t)kF2Buf;
-    // ---- 0. the next stage's loads go out first ----
-    if (it + 1 < n_stage) prefetch(it + 1, nxt);
-    // ---- 1. bitmap rows: registers -> LDS; a wave's third and later bitmap rows (more than 24 bitmap rows
-    //         among the 65) are loaded here, all of them before the first is stored ----
+    stamp(it, 0);
+    // ---- 0. this stage's loads (issued a stage ago) have landed: ONE wait for all of them here.  The compiler
+    //         cannot count what is in flight across the conditional loads, so wherever it waits it waits for
+    //         everything — after the next stage's loads have gone out that would be their full latency ----
+    settle(cur);
+    // ---- 1. bitmap rows: registers -> LDS ----
 #pragma unroll
     for (int k = 0; k < kF2BmPref; ++k)
-      if (cur.b_off[k] != ~0u) *reinterpret_cast<uint4*>(ring8 + (bufoff + lane16) + cur.b_off[k]) = cur.b_w[k];
+      if (cur.b_off[k] != ~0u) *reinterpret_cast<mm_u4*>(ring8 + (bufoff + lane16) + cur.b_off[k]) = cur.b_w[k];
+    stamp(it, 1);
+    // ---- 2. the next stage's loads go out ----
+    if (it + 1 < n_stage) prefetch(it + 1, nxt);
+    //      a wave's third and later bitmap rows (more than 24 bitmap rows among the 65) are loaded in place,
+    //      all of them before the first is stored
     if (cur.b_off[kF2BmPref - 1] != ~0u && !(ablate & 8u)) {
       const uint32_t nbm = T.nbm;
       constexpr int kMore = (kF2NR + kF2Producers - 1) / kF2Producers - kF2BmPref;  // 4
-      uint4 t[kMore];
+      mm_u4 t[kMore];
       uint32_t toff[kMore];
 #pragma unroll
       for (int k = 0; k < kMore; ++k) {
@@ -495,27 +538,28 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
           const uint32_t row = T.bml[e];
           uint32_t len;
           const uint8_t* p = row_ptr(T, row, len);
-          t[k] = fx_ld_global16(p + (q * (uint32_t)kF2SB + lane16));
+          t[k] = f2_ld_global16(p + (q * (uint32_t)kF2SB + lane16));
           toff[k] = row * (uint32_t)kF2Stride;
         }
       }
 #pragma unroll
       for (int k = 0; k < kMore; ++k)
-        if (toff[k] != ~0u) *reinterpret_cast<uint4*>(ring8 + (bufoff + lane16) + toff[k]) = t[k];
+        if (toff[k] != ~0u) *reinterpret_cast<mm_u4*>(ring8 + (bufoff + lane16) + toff[k]) = t[k];
     }
-    // ---- 2. array items: the prefetched ones, then (long lists only) the rest ----
+    stamp(it, 2);
+    // ---- 3. array items: the prefetched ones, then (long lists only) the rest ----
 #pragma unroll
     for (int k = 0; k < kF2Pref; ++k) scatter8(cur.a_w[k], cur.a_nv[k], bufoff + cur.a_off[k]);
     if (first_group + (uint32_t)kF2Groups * kF2Pref < cur.n_items && !(ablate & 2u)) {
       const uint32_t n = f2_uniform(cur.n_items), ib = f2_uniform(cur.item_base);
       for (uint32_t x = first_group + (uint32_t)kF2Groups * kF2Pref; x < n; x += (uint32_t)kF2Groups) {
-        uint4 w;
+        mm_u4 w;
         uint32_t nv, off;
         fetch_item(T, x + gq, n, ib, w, nv, off);
         scatter8(w, nv, bufoff + off);
       }
     }
-    // ---- 3. arrays longer than 4096 values (never produced by optimize(); uploads may hold them): one row per wave pass ----
+    // ---- 3b. arrays longer than 4096 values (never produced by optimize(); uploads may hold them): one row per wave pass ----
     if (!(ablate & 2u)) {
       const uint32_t nbig = f2_uniform(T.nbig);
       for (uint32_t e = pw; e < nbig; e += (uint32_t)kF2Producers) {
@@ -529,6 +573,7 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
         }
       }
     }
+    stamp(it, 3);
     // ---- 4. run rows (each owned by one wave, so the parity prefix follows this wave's own toggles) ----
 #pragma unroll
     for (int k = 0; k < kF2RunPref; ++k)
@@ -543,28 +588,37 @@ __global__ void __launch_bounds__(kF2Waves * 64) k_count_matrix_fused2(
         if (i0 < i1) run_row(T, row, q, bufoff, i0, i1, false, 0u);
       }
     }
-    // ---- 5. the work lists of slot si + 1 (those of slots 0 and 1 are built before the loop): descriptors
-    //         fetched at q == 1, lists built at q == 3, by one wave; first read at the start of stage (si, 7) ----
-    if (si + 1 < n_act && si + 1 >= 2u) {
-      const bool builder = pw == (si + 1) % (uint32_t)kF2Producers;
-      if (q == 1 && builder) next_d = load_desc(act[si + 1]);
-      if (q == 3 && builder) build_tab(tabs[(si + 1) & 1u], next_d);
+    // ---- 5. the work lists of slot si + 1 (see build_*): read from the start of stage (si, 7) on ----
+    if (si + 1 < n_act && pw <= 8u) {
+      F2Tab& N = tabs[(si + 1) & 1u];
+      if (q == 1) next_d = load_desc(act[si + 1]);
+      if (q == 2) {
+        if (pw < 8u) build_count(N, next_d, pw, bld);
+        else build_rows(N, next_d);
+      }
+      if (q == 3 && pw < 8u) build_items(N, pw, bld);
     }
+    stamp(it, 4);
   };
 
-  // ---- set-up: the work lists of the first two slots (two waves side by side), then the stage loop ----
-  if (n_stage && pw < 2u && pw < n_act) {
-    next_d = load_desc(act[pw]);
-    build_tab(tabs[pw], next_d);
+  // ---- set-up: the work lists of the first slot (the same three steps, a barrier apart), then the stage loop ----
+  if (n_stage && pw <= 8u) {
+    next_d = load_desc(act[0]);
+    if (pw < 8u) build_count(tabs[0], next_d, pw, bld);
+    else build_rows(tabs[0], next_d);
   }
+  __syncthreads();
+  if (n_stage && pw < 8u) build_items(tabs[0], pw, bld);
   __syncthreads();  // the work lists and the clean ring are visible
   if (n_stage) prefetch(0, P0);
   for (uint32_t it = 0; it <= n_stage; it += 2) {  // (n_stage is a multiple of 8)
     if (it < n_stage) stage(it, P0, P1);
     __syncthreads();
+    stamp(it, 5);
     if (it + 1 <= n_stage) {
       if (it + 1 < n_stage) stage(it + 1, P1, P0);
       __syncthreads();
+      stamp(it + 1, 5);
     }
   }
   __syncthreads();  // the consumers' reduction barrier

@@ -1,0 +1,25 @@
+"""Cycle stamps of one block of k_count_matrix_fused2 (option matrix_fused_ablate = 32: the instrumented
+build prints them to stderr).   python scripts/fused2_prof.py [shards=256] [ablate bits=0]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import datagen as D  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ab = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rows, groups, filt = D.config3_flat(n, mp="fork")
+from featurebase_amd.roaring import Context  # noqa: E402
+
+ctx = Context(0)
+batch = ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
+F = ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
+ctx.set_option("matrix_fused", 1)
+for _ in range(2):
+    ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, np.arange(n))
+ctx.set_option("matrix_fused_ablate", 32 | ab)
+ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, np.arange(n))
