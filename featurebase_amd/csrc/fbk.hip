@@ -24,7 +24,6 @@
 #include "fbk_matrix_kernels.hip.h"
 #include "fbk_matrix_mfma.hip.h"
 #include "fbk_matrix_fused.hip.h"
-#include "fbk_matrix_fused2.hip.h"
 #include "fbk_wire_kernels.hip.h"
 
 using fbk::Slot;
@@ -79,7 +78,7 @@ struct FbkOptions {
   int64_t matrix_spb = 0;                // slots per block of the dense count matrix; 0 = chosen per launch
   int64_t matrix_pass_kb = 1 << 20;      // per-shard matrices are produced in passes of at most this many KiB
   int64_t matrix_densify = -1;           // encoded rows: 1 densify + dense kernel, 0 generic pair kernel, -1 cost model
-  int64_t matrix_fused = -1;             // encoded rows: 1 decode inside the matrix-core kernel (2: its first version), 0 never, -1 cost model
+  int64_t matrix_fused = -1;             // encoded rows: 1 decode inside the matrix-core kernel, 0 never, -1 cost model
   int64_t matrix_fp4 = -1;               // dense count matrix on the FP4 matrix instruction: 1 always, 0 never, -1 when it has several tiles
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
@@ -474,7 +473,7 @@ const OptionDesc kOptions[] = {
     {"matrix_spb", &FbkOptions::matrix_spb, 0, 16},
     {"matrix_pass_kb", &FbkOptions::matrix_pass_kb, 1, int64_t(1) << 40},
     {"matrix_densify", &FbkOptions::matrix_densify, -1, 1},
-    {"matrix_fused", &FbkOptions::matrix_fused, -1, 2},
+    {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
     {"matrix_fp4", &FbkOptions::matrix_fp4, -1, 1},
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
@@ -1200,7 +1199,7 @@ int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags)
   if (op < 0 || op > 3) return fail(FBK_E_INVALID, "unknown set operation");
   if (flags & ~FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "unknown flags");
   if (flags & FBK_SETOP_OPTIMIZE)
-    return fail(FBK_E_INVALID, "FBK_SETOP_OPTIMIZE needs a synchronisation point: use fbk_setop or fbk_batch_optimize");
+    return fail(FBK_E_INVALID, "FBK_SETOP_OPTIMIZE needs a synchronisation point (the re-encode sizes its output on the host): use fbk_setop");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   return plan_setop_enqueue_locked(ctx, plan, op, false);

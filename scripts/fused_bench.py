@@ -1,8 +1,8 @@
-"""k_count_matrix_fused2 on config 3's mixed rows (GroupBy 32 x 32 + filter): parity against the
+"""k_count_matrix_fused on config 3's mixed rows (GroupBy 32 x 32 + filter): parity against the
 densify path, time per launch, parts of the kernel switched off (option matrix_fused_ablate; the
 counts are wrong then), and the first version of the kernel / the two-kernel path beside it.
 
-    python scripts/fused2_bench.py [shards=256]
+    python scripts/fused_bench.py [shards=256]
 """
 import os
 import sys
@@ -50,23 +50,20 @@ print(f"{n} shards, {nbytes/1e6:.1f} MB encoded (one-shot call: ~45 us of row up
 ctx.set_option("matrix_fused", 0)
 ref = gb()
 print(f"densify + dense kernel      {t(gb):8.1f} us")
-ctx.set_option("matrix_fused", 2)
-ok1 = bool((gb() == ref).all())
-print(f"fused, first version        {t(gb):8.1f} us  parity {ok1}")
 ctx.set_option("matrix_fused", 1)
 got = gb()
 ok2 = bool((got == ref).all())
-print(f"fused2                      {t(gb):8.1f} us  parity {ok2}  ({nbytes / t(gb) / 1e6:.2f} TB/s)")
+print(f"fused                      {t(gb):8.1f} us  parity {ok2}  ({nbytes / t(gb) / 1e6:.2f} TB/s)")
 if not ok2:
     bad = np.argwhere(got != ref)
     print("mismatches:", len(bad), bad[:10].tolist(), got[got != ref][:10].tolist(), ref[got != ref][:10].tolist())
 for spb in (16, 8, 4, 2, 1):
     ctx.set_option("matrix_spb", spb)
-    print(f"fused2 spb={spb:2d}               {t(gb):8.1f} us")
+    print(f"fused spb={spb:2d}               {t(gb):8.1f} us")
 ctx.set_option("matrix_spb", 0)
 for ab, what in [(1, "no consumer math"), (2, "no arrays"), (4, "no runs"), (8, "no bitmap rows"), (6, "no arrays, no runs"), (14, "no decode at all"),
                  (15, "barriers + work lists only"), (3, "no math, no arrays"), (5, "no math, no runs")]:
     ctx.set_option("matrix_fused_ablate", ab)
-    print(f"fused2 ablate={ab:2d} {what:28s} {t(gb):8.1f} us")
+    print(f"fused ablate={ab:2d} {what:28s} {t(gb):8.1f} us")
 ctx.set_option("matrix_fused_ablate", 0)
 assert (gb() == ref).all() or not ok2

@@ -1,5 +1,5 @@
-"""Cycle stamps of one block of k_count_matrix_fused2 (option matrix_fused_ablate = 32: the instrumented
-build prints them to stderr).   python scripts/fused2_prof.py [shards=256] [ablate bits=0]"""
+"""Cycle stamps of one block of k_count_matrix_fused (option matrix_fused_ablate = 32: the instrumented
+build prints them to stderr).   python scripts/fused_prof.py [shards=256] [ablate bits=0]"""
 import os
 import sys
 

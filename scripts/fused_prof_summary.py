@@ -1,4 +1,4 @@
-"""Summarise the cycle stamps printed by scripts/fused2_prof.py (stderr of the instrumented kernel)."""
+"""Summarise the cycle stamps printed by scripts/fused_prof.py (stderr of the instrumented kernel)."""
 import collections
 import re
 import sys

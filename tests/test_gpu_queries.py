@@ -601,9 +601,6 @@ def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle
             tot_s, ps_s = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
             assert (tot_s == tot).all() and (ps_s == ps).all(), spb
         gpu_ctx.set_option("matrix_spb", 0)
-        gpu_ctx.set_option("matrix_fused", 2)  # the first version of the in-kernel decode (cursor-walked arrays)
-        tot_1, ps_1 = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
-        assert (tot_1 == tot).all() and (ps_1 == ps).all()
         gpu_ctx.set_option("matrix_fused", 0)
         tot_d, ps_d = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
         assert (tot_d == tot).all() and (ps_d == ps).all()
@@ -698,6 +695,45 @@ def test_count_matrix_fused_window_edges(gpu_ctx, oracle, B, f_kind):
     for b in (A, Bt, F):
         if b is not None:
             b.free()
+
+
+def test_count_matrix_window_index_follows_rewritten_batches(gpu_ctx, oracle, B):
+    """The in-kernel decode reads a per-batch window index that is built on first use.  A plan's output batch
+    is rewritten by every run of the plan (8 KiB cells, a different set of them nil each time): used as the
+    GroupBy filter after each run, the index is dropped with the rewrite and rebuilt on the next use."""
+    O = oracle
+    rng = D.rng_for(59)
+    n_shards, n_a, n_b = 3, 34, 33
+
+    def obm(r):
+        return O.OBitmap.from_containers(list(r.items()))
+
+    a_rows = [[D.random_row(rng, 0, p_missing=0.2) for _ in range(n_a)] for _ in range(n_shards)]
+    b_rows = [[D.random_row(rng, 0, p_missing=0.2) for _ in range(n_b)] for _ in range(n_shards)]
+    x_rows = [D.random_row(rng, 0, p_missing=0.1) for _ in range(n_shards)]
+    y_rows = [D.random_row(rng, 0, p_missing=0.1) for _ in range(n_shards)]
+    A = gpu_ctx.upload([D.to_fbk_row(r) for s in a_rows for r in s])
+    Bt = gpu_ctx.upload([D.to_fbk_row(r) for s in b_rows for r in s])
+    X = gpu_ctx.upload([D.to_fbk_row(r) for r in x_rows])
+    Y = gpu_ctx.upload([D.to_fbk_row(r) for r in y_rows])
+    idx = np.arange(n_shards)
+    ra = np.arange(n_shards * n_a).reshape(n_shards, n_a)
+    rb = np.arange(n_shards * n_b).reshape(n_shards, n_b)
+    plan = gpu_ctx.plan(X, idx, Y, idx)
+    try:
+        gpu_ctx.set_option("matrix_fused", 1)
+        for op, name in ((L.OP_AND, "intersect"), (L.OP_XOR, "xor"), (L.OP_ANDNOT, "difference"), (L.OP_AND, "intersect")):
+            plan.setop(op)
+            _, ps = gpu_ctx.count_matrix(A, ra, Bt, rb, plan.output(), idx, per_shard=True)
+            for s in range(n_shards):
+                f = getattr(obm(x_rows[s]), name)(obm(y_rows[s]))
+                e = B.groupby_counts(B.Fragment([obm(r) for r in a_rows[s]]), B.Fragment([obm(r) for r in b_rows[s]]), f)
+                assert (ps[s] == e).all(), (name, s)
+    finally:
+        gpu_ctx.set_option("matrix_fused", -1)
+        plan.free()
+    for b in (A, Bt, X, Y):
+        b.free()
 
 
 def test_rows_vs_filter_many_rows(gpu_ctx, oracle):
