@@ -77,13 +77,17 @@ __device__ __forceinline__ void scatter_chunk(const uint32_t (&d)[4], uint32_t t
         lds_acc32<OP>(&acc32[d[q] >> 21], 1u << ((d[q] >> 16) & 31));
       }
     } else {
-      // the ragged last row: lanes past the end sit out (a dummy OR would not be free — the LDS
-      // serialises same-address atomics, measured)
+      // the ragged last row: lanes past the end sit out as a whole (ONE change of EXEC; a dummy OR would not
+      // be free — the LDS serialises same-address atomics, measured).  The one lane that holds the end of the
+      // array ORs zero masks for the slots past it (those hold real values: whatever follows the payload)
       const uint32_t e0 = row0 + lane * 8u;
+      if (e0 < len) {
+        const uint32_t valid = (1u << min(len - e0, 8u)) - 1u;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (e0 + 2 * q < len) lds_acc32<OP>(&acc32[(d[q] >> 5) & 0x7FFu], 1u << (d[q] & 31));
-        if (e0 + 2 * q + 1 < len) lds_acc32<OP>(&acc32[d[q] >> 21], 1u << ((d[q] >> 16) & 31));
+        for (int q = 0; q < 4; ++q) {
+          lds_acc32<OP>(&acc32[(d[q] >> 5) & 0x7FFu], __builtin_amdgcn_ubfe(valid, 2u * q, 1u) << (d[q] & 31));
+          lds_acc32<OP>(&acc32[d[q] >> 21], __builtin_amdgcn_ubfe(valid, 2u * q + 1u, 1u) << ((d[q] >> 16) & 31));
+        }
       }
     }
     return;
@@ -160,7 +164,7 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const uint64_t cell = blockIdx.x;  // (group, slot)
+  const uint64_t cell = xcd_swizzle(blockIdx.x, gridDim.x);  // (group, slot): the 16 slots of a group on one XCD
   const uint64_t g = cell >> 4;
   const uint32_t slot = cell & 15;
   if (g >= n_groups) return;  // block-uniform

@@ -38,12 +38,32 @@ __host__ __device__ inline uint32_t make_tn(uint32_t type, uint32_t n) { return 
 
 typedef unsigned long long u64;
 
+// XCD-aware block index.  The dispatcher places block b on XCD b % 8, each XCD with its own L2: blocks with
+// CONSECUTIVE indexes share nothing in cache.  Kernels whose neighbouring blocks read the same lines — the 16
+// slots of one row's descriptor table (256 bytes = two lines per row, one block per slot), the rows of one
+// shard — take their work item from this remap instead: XCD x gets the contiguous range of items
+// [x * nwg / 8, (x + 1) * nwg / 8) (bijective for any nwg).
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t bid, uint32_t nwg) {
+  const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (bid >> 3);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS instructions of one wavefront are issued and retired in order; this only stops
   // the compiler from moving LDS accesses of other lanes' data across the point.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum over the 16 lanes of each DPP row, left in every lane of the row: quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_half_mirror, row_mirror — no LDS round trip (a ds_bpermute shuffle costs one)
+__device__ __forceinline__ uint32_t wave_rows_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+  return v;
 }
 
 __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
   // producers k = 0 stage start, 1 this stage's loads settled and bitmap rows stored, 2 next stage's loads issued,
   // 3 array items done, 4 run rows (and list building) done, 5 past the barrier; consumers k = 0 start,
   // 1 arithmetic done, 5 past the barrier
-  const bool traced = PROF && blockIdx.x == gridDim.x / 2;
+  const bool traced = PROF && blockIdx.x == (gridDim.x / 2 | 1u);
   auto stamp = [&](uint32_t st, int k) {
     if (PROF && traced && (threadIdx.x & 63) == 0 && st < 24u) prof[((threadIdx.x >> 6) * 24u + st) * 8u + k] = (u64)__builtin_readcyclecounter();
   };
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t agroups = (nA + 31) / 32, btiles = (nBtot + 31) / 32, sgroups = kSlots / spb;
-  uint32_t b = blockIdx.x;
+  uint32_t b = xcd_swizzle(blockIdx.x, gridDim.x);  // (a shard's slot groups and tiles on one XCD: they share the descriptor lines)
   const uint32_t bt = b % btiles;
   b /= btiles;
   const uint32_t ag = b % agroups;

@@ -35,12 +35,21 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
   const int lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const uint32_t chunks = (nA + rows_per_block - 1) / rows_per_block;
-  uint32_t b = blockIdx.x;
+  uint32_t b = xcd_swizzle(blockIdx.x, gridDim.x);  // (shard, slot, chunk of rows): a shard's blocks on one XCD
   const uint32_t chunk = b % chunks;
   b /= chunks;
   const uint32_t slot = b & 15u;
   const uint32_t shard = b >> 4;
   if (shard >= n_shards) return;
+  // The descriptors of the block's first 64 rows hang off a chain of dependent loads (row index -> descriptor)
+  // just like the filter container (row index -> descriptor -> payload): both chains start here, side by side.
+  const uint32_t i_begin = chunk * rows_per_block, i_end = min(nA, i_begin + rows_per_block);
+  const uint32_t* arow = rowsA + (uint64_t)shard * nA;
+  Slot first_mine;
+  first_mine.off = 0;
+  first_mine.len = 0;
+  first_mine.tn = 0;
+  if (i_begin + lane < i_end) first_mine = slotsA[(uint64_t)arow[i_begin + lane] * kSlots + slot];
   const Slot sf = slotsF[(uint64_t)rowsF[shard] * kSlots + slot];
   const uint32_t nf = slot_n(sf);
   if (nf == 0) return;  // nothing can intersect at this slot (block-uniform)
@@ -85,14 +94,14 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
     return bpos ? r + __popcll(F[w] & (~0ull >> (64 - bpos))) : r;
   };
 
-  const uint32_t i_begin = chunk * rows_per_block, i_end = min(nA, i_begin + rows_per_block);
-  const uint32_t* arow = rowsA + (uint64_t)shard * nA;
   for (uint32_t base = i_begin; base < i_end; base += 64) {
-    Slot mine;  // lane l holds the descriptor of row base+l
-    mine.off = 0;
-    mine.len = 0;
-    mine.tn = 0;
-    if (base + lane < i_end) mine = slotsA[(uint64_t)arow[base + lane] * kSlots + slot];
+    Slot mine = first_mine;  // lane l holds the descriptor of row base+l
+    if (base != i_begin) {
+      mine.off = 0;
+      mine.len = 0;
+      mine.tn = 0;
+      if (base + lane < i_end) mine = slotsA[(uint64_t)arow[base + lane] * kSlots + slot];
+    }
     const uint32_t cnt = min(64u, i_end - base);
     auto meta = [&](uint32_t i, u64& off, uint32_t& len, uint32_t& tn) {
       const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mine.off, (int)(i & 63));
@@ -202,19 +211,22 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
             c += ((F32[a >> 5] >> (a & 31)) & 1u) + ((F32[bb >> 5] >> (bb & 31)) & 1u);
           }
         } else {
+          // the ragged last row, without a branch: slots past the end hold readable values (lanes past the payload
+          // re-read its first 16 bytes, the lane with the end reads on into the padding / the next payload) whose
+          // probe is simply not counted
           const uint32_t e0 = row0 + lane * 8u;
+          const uint32_t valid = e0 < len ? (1u << min(len - e0, 8u)) - 1u : 0u;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const uint32_t a = d[q] & 0xFFFFu, bb = d[q] >> 16;
-            if (e0 + 2 * q < len) c += (F32[a >> 5] >> (a & 31)) & 1u;
-            if (e0 + 2 * q + 1 < len) c += (F32[bb >> 5] >> (bb & 31)) & 1u;
+            c += ((F32[a >> 5] >> (a & 31)) & (valid >> (2 * q)) & 1u) + ((F32[bb >> 5] >> (bb & 31)) & (valid >> (2 * q + 1)) & 1u);
           }
         }
       } else {  // run: 4 intervals per 16-byte chunk
+        // (no branch: a slot past the last run holds some readable interval whose count is masked away)
         const uint32_t i0 = (j * kWave + lane) * 4u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (i0 + q < len) c += rank_of((d[q] >> 16) + 1u) - rank_of(d[q] & 0xFFFFu);
+        for (int q = 0; q < 4; ++q) c += (rank_of((d[q] >> 16) + 1u) - rank_of(d[q] & 0xFFFFu)) & (i0 + q < len ? ~0u : 0u);
       }
       return c;
     };
@@ -230,8 +242,12 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
           c += count_chunk(d, Q.tn >> 24, Q.len, Q.j);
           const uint32_t row = Q.i;
           if (advance(Q)) {
-            c = wave_reduce_add(c);
-            if (lane == 0 && c) atomicAdd(&out_shard[(uint64_t)shard * nA + base + row], (u64)c);
+            // the container's count: sums of the four 16-lane rows on the DPP network, then four scalar reads
+            // (a shuffle reduction is six dependent LDS round trips on the wave's critical path)
+            c = wave_rows_sum(c);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)c, 0) + (uint32_t)__builtin_amdgcn_readlane((int)c, 16) +
+                                 (uint32_t)__builtin_amdgcn_readlane((int)c, 32) + (uint32_t)__builtin_amdgcn_readlane((int)c, 48);
+            if (lane == 0 && tot) atomicAdd(&out_shard[(uint64_t)shard * nA + base + row], (u64)tot);
             c = 0;
           }
           load_chunk(C[q]);
