@@ -170,26 +170,38 @@ def _cpu_time(fn, min_s=1.0):
             return dt / n
 
 
-def _timed_call(torch, stream, fn, iters, warm=2):
+def _timed_call(torch, stream, fn, iters, warm=2, ctx=None):
     """One C-ABI call end to end: GPU time between the first and the last operation it enqueues (HIP
-    events on the library's stream) and host wall time, over `iters` calls."""
+    events on the library's stream) and host wall time, over `iters` calls; with `ctx`, also the
+    duration of the call's dominant kernel (library option time_kernels: HIP events recorded on the
+    library's stream right before and after that launch)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    gpu, wall = [], []
-    for _ in range(iters):
-        e0.record(stream)
-        t0 = time.perf_counter()
-        fn()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        wall.append((time.perf_counter() - t0) * 1e6)
-        gpu.append(e0.elapsed_time(e1) * 1e3)
+    gpu, wall, kern = [], [], []
+    if ctx is not None:
+        ctx.set_option("time_kernels", 1)
+    try:
+        for _ in range(iters):
+            e0.record(stream)
+            t0 = time.perf_counter()
+            fn()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            wall.append((time.perf_counter() - t0) * 1e6)
+            gpu.append(e0.elapsed_time(e1) * 1e3)
+            if ctx is not None:
+                kern.append(ctx.get_option("last_kernel_ns") / 1e3)
+    finally:
+        if ctx is not None:
+            ctx.set_option("time_kernels", 0)
+    if ctx is not None:
+        return dist_of(gpu), dist_of(wall), dist_of(kern)
     return dist_of(gpu), dist_of(wall)
 
 
-def _entry(name, kernel, alg_bytes, gpu_us, wall_us, **extra):
+def _entry(name, kernel, alg_bytes, gpu_us, wall_us, kernel_us=None, **extra):
     t = gpu_us["median"] * 1e-6
     out = {
         "name": name,
@@ -199,8 +211,14 @@ def _entry(name, kernel, alg_bytes, gpu_us, wall_us, **extra):
         "wall_us": wall_us,
         "achieved_GBps": alg_bytes / t / 1e9,
         "frac": alg_bytes / t / 1e9 / HBM_PEAK_GBPS,
-        "timing": "one C-ABI call end to end (index upload, launches, result download): HIP events on the stream; kernel-only times are in profiles/",
+        "timing": "gpu_us / wall_us / achieved_GBps / frac: one C-ABI call end to end (index upload, memsets, launches, reduce, result download), "
+                  "HIP events on the stream; kernel_us / kernel_GBps / kernel_frac: the named kernel(s) alone, HIP events recorded by the library "
+                  "around the launch (option time_kernels); rocprofv3 summaries of the same kernels are in profiles/",
     }
+    if kernel_us is not None:
+        out["kernel_us"] = kernel_us
+        out["kernel_GBps"] = alg_bytes / (kernel_us["median"] * 1e-6) / 1e9
+        out["kernel_frac"] = out["kernel_GBps"] / HBM_PEAK_GBPS
     out.update(extra)
     return out
 
@@ -264,22 +282,22 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             cpu3 = {"kind": "port", "cores": 1, "sample": "shard 0 (64 mixed rows + filter), oracle Bitmap.Union(63 others) + IntersectionCount, one host thread",
                     "per_shard_s": t_cpu, "value": 16 * k / t_cpu, "unit": "set-ops/s", "groupby_32x32_per_shard_s": t_cpu_gb}
         common = {"shards": n3, "containers": ncont, "host_gen_s": gen_s, "upload_s": up_s, "parity": "shard 0 checked against the oracle" if want_cpu else "unchecked (--no-cpu-baseline)"}
-        g, w = _timed_call(torch, stream, lambda: ctx.union_n_intersection_count(batch, groups, F, fidx), iters)
+        g, w, kq = _timed_call(torch, stream, lambda: ctx.union_n_intersection_count(batch, groups, F, fidx), iters, ctx=ctx)
         out.append(_entry("config3: Union-of-64 rows then IntersectionCount(filter), fused, mixed array/run/bitmap rows (rank-law density 0.001-0.5)",
-                          "k_fold_scatter<OR>", nbytes + 8 * n3, g, w, set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), cpu_baseline=cpu3, **common))
-        g, w = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1)), iters)
-        out.append(_entry("config3 rows, TopN/TopK shape: 64 rows x 1 filter row per shard", "k_rows_vs_filter", nbytes + 8 * 64 * n3, g, w,
+                          "k_fold_scatter<OR>", nbytes + 8 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), cpu_baseline=cpu3, **common))
+        g, w, kq = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1)), iters, ctx=ctx)
+        out.append(_entry("config3 rows, TopN/TopK shape: 64 rows x 1 filter row per shard", "k_rows_vs_filter", nbytes + 8 * 64 * n3, g, w, kq,
                           set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), **common))
-        g, w = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx), max(5, iters // 2))
+        g, w, kq = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx), max(5, iters // 2), ctx=ctx)
         out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel (default)", "k_count_matrix_fused",
-                          nbytes + 8 * 1024 * n3, g, w, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
-                          hbm_note="encoded rows are the only HBM traffic (PMC ratio 1.07); instruction-bound decode (DESIGN.md section 9)", **common))
+                          nbytes + 8 * 1024 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
+                          hbm_note="encoded rows are the only HBM traffic (PMC fetch / algorithmic bytes in profiles/); the kernel is bound by instruction issue, not by HBM (DESIGN.md section 9)", **common))
         ctx.set_option("matrix_fused", 0)
         assert (ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx, per_shard=True)[1] == mat3).all(), "fused and densify paths disagree"
-        g, w = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx), max(5, iters // 2))
+        g, w, kq = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx), max(5, iters // 2), ctx=ctx)
         ctx.set_option("matrix_fused", -1)
         out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: densify + dense matrix-core kernel (round 1, option matrix_fused=0)",
-                          "k_densify_rows + k_count_matrix_mfma", nbytes + 8 * 1024 * n3, g, w, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
+                          "k_densify_rows + k_count_matrix_mfma", nbytes + 8 * 1024 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
                           hbm_note="3.7 bytes of temporary bitmap rows written and read back per byte of encoded rows", **common))
         g, w = _timed_call(torch, stream, lambda: ctx.union_n(batch, groups, L.SETOP_OPTIMIZE)[0].free(), max(5, iters // 2))
         out.append(_entry("config3 rows, Union-of-64 materialised + optimize() re-encode", "k_fold_scatter<OR> + k_encode_*", nbytes, g, w, **common))
@@ -309,9 +327,9 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             cpu4 = {"kind": "port", "cores": 1, "sample": "shard 0 (32 x 32 dense rows + filter), oracle groupByIterator counts, one host thread",
                     "per_shard_s": t_cpu, "value": 16 * n_a * n_b / t_cpu, "unit": "set-ops/s"}
         nbytes = n4 * (n_a + n_b + 1) * 16 * 8192
-        g, w = _timed_call(torch, stream, lambda: ctx.count_matrix(A, ra, B, rb, F, rf), max(5, iters // 2))
+        g, w, kq = _timed_call(torch, stream, lambda: ctx.count_matrix(A, ra, B, rb, F, rf), max(5, iters // 2), ctx=ctx)
         out.append(_entry(f"config4 slice: {n4} shards x (32 x 32 rows + filter), dense bitmaps, IntersectionCount matrix", "k_count_matrix_mfma",
-                          nbytes + 8 * n_a * n_b * n4, g, w, shards=n4, host_gen_s=gen_s, set_ops_per_s=n4 * 16 * n_a * n_b / (g["median"] * 1e-6),
+                          nbytes + 8 * n_a * n_b * n4, g, w, kq, shards=n4, host_gen_s=gen_s, set_ops_per_s=n4 * 16 * n_a * n_b / (g["median"] * 1e-6),
                           pair_bits_scanned_GBps=n4 * n_a * n_b * 2 * 16 * 8192 / (g["median"] * 1e-6) / 1e9, cpu_baseline=cpu4,
                           parity=f"cell (3,5) vs numpy over all shards" + ("; shard 0 vs the oracle" if want_cpu else "")))
         for b in (A, B, F):
@@ -343,11 +361,11 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             t_rng = _cpu_time(lambda: PB.bsi_range(fr, PB.GT, depth, kk))
             cpu5 = {"kind": "port", "cores": 1, "sample": "shard 0 (66 dense rows), oracle fragment.rangeOp(GT) / fragment.sum, one host thread",
                     "range_per_shard_s": t_rng, "sum_per_shard_s": t_sum}
-        g, wl = _timed_call(torch, stream, lambda: ctx.bsi_range(batch, base, L.BSI_GT, depth, kk)[0].free(), iters)
-        out.append(_entry(f"config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense", "k_bsi_range", plane_bytes * (depth + 3), g, wl, shards=n5,
+        g, wl, kq = _timed_call(torch, stream, lambda: ctx.bsi_range(batch, base, L.BSI_GT, depth, kk)[0].free(), iters, ctx=ctx)
+        out.append(_entry(f"config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense", "k_bsi_range", plane_bytes * (depth + 3), g, wl, kq, shards=n5,
                           cpu_baseline=cpu5, parity="shard 0 vs the oracle" if want_cpu else "unchecked"))
-        g, wl = _timed_call(torch, stream, lambda: ctx.bsi_sum(batch, base, depth, rng_out, np.arange(n5)), iters)
-        out.append(_entry("config5: BSI Sum(filter = the Range result)", "k_bsi_sum", plane_bytes * (depth + 3), g, wl, shards=n5))
+        g, wl, kq = _timed_call(torch, stream, lambda: ctx.bsi_sum(batch, base, depth, rng_out, np.arange(n5)), iters, ctx=ctx)
+        out.append(_entry("config5: BSI Sum(filter = the Range result)", "k_bsi_sum", plane_bytes * (depth + 3), g, wl, kq, shards=n5))
         rng_out.free()
         batch.free()
     return out

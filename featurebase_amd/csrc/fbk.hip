@@ -80,6 +80,8 @@ struct FbkOptions {
   int64_t matrix_densify = -1;           // encoded rows: 1 densify + dense kernel, 0 generic pair kernel, -1 cost model
   int64_t matrix_fused = -1;             // encoded rows: 1 decode inside the matrix-core kernel, 0 never, -1 cost model
   int64_t matrix_fp4 = -1;               // dense count matrix on the FP4 matrix instruction: 1 always, 0 never, -1 when it has several tiles
+  int64_t time_kernels = 0;              // 1: HIP events around the dominant kernel of a query-level call (count matrix, fold, BSI range / sum)
+  int64_t last_kernel_ns = 0;            //    ... read its duration back here (fbk_get_option) after the call
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
   int64_t bsi_minmax_blocks = 0;         // 1: one block per shard for Min / Max (round-1 kernel, A/B runs); 0: one wavefront per (shard, slot)
@@ -120,6 +122,9 @@ struct fbk_ctx {
   // uses it synchronises the stream before returning).
   uint8_t* h_stage = nullptr;
   uint64_t h_stage_cap = 0, h_stage_used = 0;
+  // option time_kernels: events around the dominant kernel of the last query-level call
+  hipEvent_t kt0 = nullptr, kt1 = nullptr;
+  bool kt_armed = false;
   // device fragment cache (fbk_cache_api.inc)
   std::unordered_map<std::string, struct fbk_cache_entry*> cache;
   std::unordered_map<const fbk_batch*, struct fbk_cache_entry*> cache_by_batch;  // release() looks entries up by handle
@@ -355,6 +360,26 @@ int32_t window_index(fbk_ctx* ctx, const fbk_batch* b, const uint4** out) {
   return FBK_OK;
 }
 
+// Option time_kernels: events on the context's stream right before and after the dominant kernel(s) of a
+// query-level call, so that a caller (bench.py's secondary configurations) can separate the kernel from the
+// row-index upload, memsets, reduce and download around it.  The last span of a call wins.
+struct KernelSpan {
+  fbk_ctx* c;
+  explicit KernelSpan(fbk_ctx* ctx) : c(ctx->opt.time_kernels ? ctx : nullptr) {
+    if (!c) return;
+    if (!c->kt0 && (hipEventCreate(&c->kt0) != hipSuccess || hipEventCreate(&c->kt1) != hipSuccess)) {
+      c = nullptr;
+      return;
+    }
+    (void)hipEventRecord(c->kt0, c->stream);
+  }
+  ~KernelSpan() {
+    if (!c) return;
+    (void)hipEventRecord(c->kt1, c->stream);
+    c->kt_armed = true;
+  }
+};
+
 int32_t upload_rows(fbk_ctx* ctx, const uint32_t* rows, uint64_t n, uint32_t n_rows_limit, DevBuf& out) {
   for (uint64_t i = 0; n_rows_limit != UINT32_MAX && i < n; ++i)  // UINT32_MAX: the caller has validated the indices
     if (rows[i] >= n_rows_limit)
@@ -476,6 +501,8 @@ const OptionDesc kOptions[] = {
     {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
     {"matrix_fp4", &FbkOptions::matrix_fp4, -1, 1},
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
+    {"time_kernels", &FbkOptions::time_kernels, 0, 1},
+    {"last_kernel_ns", &FbkOptions::last_kernel_ns, 0, INT64_MAX},
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
     {"bsi_minmax_blocks", &FbkOptions::bsi_minmax_blocks, 0, 1},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
@@ -585,6 +612,14 @@ int32_t fbk_get_option(fbk_ctx* ctx, const char* name, int64_t* out_value) {
   FBK_ENTER(ctx);
   if (!ctx || !name || !out_value) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
+  if (ctx->kt_armed && std::strcmp(name, "last_kernel_ns") == 0) {
+    if (int32_t rc = set_device(ctx)) return rc;
+    float ms = 0;
+    HIP_TRY(hipEventSynchronize(ctx->kt1));
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->kt0, ctx->kt1));
+    ctx->opt.last_kernel_ns = int64_t(double(ms) * 1e6);
+    ctx->kt_armed = false;
+  }
   for (const OptionDesc& d : kOptions)
     if (std::strcmp(d.name, name) == 0) {
       *out_value = ctx->opt.*(d.field);

@@ -736,6 +736,29 @@ def test_count_matrix_window_index_follows_rewritten_batches(gpu_ctx, oracle, B)
         b.free()
 
 
+def test_time_kernels_option_reports_the_dominant_kernel(gpu_ctx):
+    """Option time_kernels: after a query-level call, last_kernel_ns is the duration of its dominant kernel
+    (HIP events recorded by the library around the launch) — what bench.py reports as kernel_us."""
+    import time
+
+    w = D.dense_rows(2 * 40, 0.4, 77)
+    A = gpu_ctx.upload_dense(w)
+    rows = np.arange(80).reshape(2, 40)
+    try:
+        gpu_ctx.set_option("time_kernels", 1)
+        t0 = time.perf_counter()
+        gpu_ctx.count_matrix(A, rows[:, :20], A, rows[:, 20:])
+        wall_ns = (time.perf_counter() - t0) * 1e9
+        k1 = gpu_ctx.get_option("last_kernel_ns")
+        assert 0 < k1 < wall_ns
+        assert gpu_ctx.get_option("last_kernel_ns") == k1  # stays until the next timed call
+        gpu_ctx.union_n_intersection_count(A, rows, A, np.zeros(2, dtype=np.uint32))
+        assert gpu_ctx.get_option("last_kernel_ns") > 0
+    finally:
+        gpu_ctx.set_option("time_kernels", 0)
+    A.free()
+
+
 def test_rows_vs_filter_many_rows(gpu_ctx, oracle):
     """TopK over a field with more rows than the matrix limit (5000 sparse rows x 2 shards)."""
     O = oracle
