@@ -859,4 +859,75 @@ __global__ void __launch_bounds__(256) k_cell_stats(uint8_t* __restrict__ arenaO
   }
 }
 
+
+// ---- fragment.rows: which rows hold anything / hold a given column ----------------------------
+// The reference walks a fragment's containers in key order through the filter protocol of
+// roaring/filter.go (BitmapRowFilter over an optional BitmapColumnFilter and BitmapRowLimitFilter,
+// ApplyFilterToIterator :1062-1085): a container with n != 0 makes its row a candidate, a column
+// filter opens the ONE container of the row that can hold the column and skips the other fifteen by
+// key (YesKey / NoKey), a limit filter stops the scan.  On the device every row is looked at at once:
+// 16 lanes per row, lane = slot, read the row's 16 descriptors (one 256-byte line) and vote;
+// the lane of the column's slot probes its container (bitmap: one word; array / run: a binary search
+// in the payload) — the same one container per row that the protocol would open.
+//   flags[i] bit 0: the row holds a container with n != 0; bit 1: ... and contains `column`
+//   (column == ~0: no column filter, bit 1 = bit 0).
+__global__ void __launch_bounds__(256) k_rows_flags(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                                   const uint32_t* __restrict__ rows, uint64_t n, uint64_t column,
+                                                   uint8_t* __restrict__ flags) {
+  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t i = gid >> 4;
+  const uint32_t slot = gid & 15u;
+  const int lane = threadIdx.x & 63;
+  Slot s;
+  s.off = 0, s.len = 0, s.tn = 0;
+  if (i < n) s = slots[(uint64_t)rows[i] * kSlots + slot];
+  const uint32_t cnt = slot_n(s);
+  bool hit = false;
+  if (column != ~0ull && cnt != 0 && slot == (uint32_t)((column >> 16) & 15u)) {
+    const uint32_t v = (uint32_t)(column & 0xFFFFu);
+    const uint8_t* p = arena + s.off;
+    const uint32_t t = slot_type(s);
+    if (t == kTypeBitmap) {
+      hit = (reinterpret_cast<const u64*>(p)[v >> 6] >> (v & 63)) & 1ull;
+    } else if (t == kTypeArray) {  // Container.Contains -> search64 over the sorted values
+      const uint16_t* a = reinterpret_cast<const uint16_t*>(p);
+      uint32_t lo = 0, hi = s.len;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+      }
+      hit = lo < s.len && a[lo] == v;
+    } else if (t == kTypeRun) {  // first run whose last value is >= v
+      const uint32_t* r = reinterpret_cast<const uint32_t*>(p);
+      uint32_t lo = 0, hi = s.len;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((r[mid] >> 16) < v) lo = mid + 1;
+        else hi = mid;
+      }
+      hit = lo < s.len && (r[lo] & 0xFFFFu) <= v;
+    }
+  }
+  const u64 ne = __ballot(cnt != 0), hm = __ballot(hit);
+  const uint32_t sh = (uint32_t)lane & 48u;  // this row's 16 lanes inside the ballot
+  const bool nonempty = ((ne >> sh) & 0xFFFFull) != 0, contains = ((hm >> sh) & 0xFFFFull) != 0;
+  if (slot == 0 && i < n) flags[i] = (uint8_t)((nonempty ? 1u : 0u) | ((nonempty && (column == ~0ull || contains)) ? 2u : 0u));
+}
+
+// limit filter (BitmapRowLimitFilter, filter.go:471-509, as executeRowsShard appends it AFTER the column filter,
+// executor.go:4139-4155): the limit filter is consulted for every row the scan visits, whether or not the column
+// filter goes on to match it — the first `limit` non-empty rows stay candidates, everything later is rejected.
+// rank[i] = number of non-empty rows before i (exclusive scan of bit 0).
+__global__ void __launch_bounds__(256) k_rows_select(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ rank, uint64_t n,
+                                                    uint64_t limit, uint8_t* __restrict__ keep) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  keep[i] = (uint8_t)(((flags[i] & 2u) != 0 && (limit == 0 || rank[i] < limit)) ? 1 : 0);
+}
+
+struct RowFlagBit0 {
+  __host__ __device__ uint32_t operator()(uint8_t f) const { return f & 1u; }
+};
+
 }  // namespace fbk

@@ -439,6 +439,18 @@ class Context:
         L.check(self.lib.fbk_flip(self.h, batch.h, r.ctypes.data, r.size, start, end, flags, C.byref(h), out.ctypes.data))
         return Batch(self, h.value), out
 
+    NO_COLUMN = 0xFFFFFFFFFFFFFFFF
+
+    def rows(self, batch: Batch, rows, column: Optional[int] = None, limit: int = 0) -> np.ndarray:
+        """fragment.rows (fragment.go:2465): positions (into `rows`, the fragment's rows in ascending row-id
+        order) of the rows that hold anything / hold `column`, under the reference's limit rule."""
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.zeros(max(r.size, 1), dtype=np.uint32)
+        n = C.c_uint64()
+        L.check(self.lib.fbk_rows(self.h, batch.h, r.ctypes.data, r.size, self.NO_COLUMN if column is None else int(column), int(limit),
+                                  out.ctypes.data, out.size, C.byref(n)))
+        return out[: n.value].copy()
+
     NO_ROW = 0xFFFFFFFF
 
     def shift(self, batch: Batch, rows, carry_rows=None, flags: int = 0) -> Tuple[Batch, np.ndarray]:

@@ -500,6 +500,24 @@ int32_t fbk_bsi_range_between(fbk_ctx* ctx, const fbk_batch* batch, const uint32
                               uint32_t n_shards, uint32_t bit_depth, int64_t lo, int64_t hi, uint32_t flags,
                               fbk_batch** out_batch, uint64_t* out_counts);
 
+
+/* fragment.rows(start, filters...) (fragment.go:2465-2486; executeRowsShard, executor.go:4077-4182): which of
+ * the rows rows[0 .. n_rows) — the fragment's rows from `start` on, in ascending row-id order, one device row each
+ * — hold anything, hold `column`, and fall under `limit`.  The reference streams the fragment's containers in key
+ * order through the filter protocol of roaring/filter.go (BitmapRowFilter :371-469 over BitmapColumnFilter :226-249
+ * and BitmapRowLimitFilter :471-509, ApplyFilterToIterator :1062-1085: skip-ahead by YesKey / NoKey so that a column
+ * filter opens one container per row); here every row is examined at once (16 lanes read a row's 16 descriptors,
+ * one lane probes the column's container) and the survivors are compacted in order.
+ *   column  FBK_NO_COLUMN, or a column of the shard (0 .. 2^20 - 1): the row must contain it
+ *   limit   0 = none; else the reference's composition [column filter, limit filter]: the limit filter counts every
+ *           NON-EMPTY row the scan visits, matching or not, so the result is "rows among the first `limit` non-empty
+ *           rows that contain the column" (without a column: the first `limit` non-empty rows)
+ *   out_idx[cap]  positions (into rows[]) of the matching rows, ascending; *out_n = how many (FBK_E_CAPACITY when
+ *           cap is too small: *out_n says how many there are). */
+#define FBK_NO_COLUMN (~0ull)
+int32_t fbk_rows(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n_rows, uint64_t column, uint64_t limit,
+                 uint32_t* out_idx, uint64_t cap, uint64_t* out_n);
+
 /* ---- several GPUs in one process ---------------------------------------------------------------
  * The reference maps per-shard functions on the node that owns each shard and folds count-valued
  * results with an associative reduceFn in the same process (mapReduce / mapperLocal,

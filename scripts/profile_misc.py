@@ -6,7 +6,7 @@ algorithmic bytes (encoded payload read once + bytes written) for the roofline c
 
 Kernels reached: k_setop<OP> (generic pairs), k_encode_plan / k_scan_blocks / k_exclusive_scan /
 k_encode_write (optimize), k_count_range, k_fold_n<AND>, k_fold_scatter<XOR/ANDNOT>, k_shift, k_flip,
-k_bsi_add, k_bsi_values (+ hipcub sort), k_bsi_minmax, k_bsi_range / k_bsi_sum, k_wire_copy (roaring
+k_bsi_add, k_bsi_values (+ hipcub sort), k_bsi_minmax, k_bsi_range / k_bsi_sum, k_rows_flags, k_wire_copy (roaring
 upload + download), k_validate_recount, k_recount, k_rows_vs_filter + k_topn_filter,
 k_counts_to_bsi / k_cell_stats, k_count_matrix_fused, k_count_matrix<4>."""
 import json
@@ -62,6 +62,7 @@ rec("fbk_fold_n ANDNOT of 64 rows (k_fold_scatter<ANDNOT>)", nbytes, lambda: ctx
 rec("fbk_fold_n_intersection_count OR + filter (k_fold_scatter<OR>)", nbytes, lambda: ctx.union_n_intersection_count(batch, groups, F, fidx))
 rec(f"fbk_shift (k_shift), {allrows.size} rows", nbytes + allrows.size * 16 * 8192, lambda: ctx.shift(batch, allrows))
 rec(f"fbk_flip [123, 900000] (k_flip), {allrows.size} rows", nbytes + allrows.size * 16 * 8192, lambda: ctx.flip(batch, allrows, 123, 900000))
+rec(f"fbk_rows column filter (k_rows_flags + scan / select), {allrows.size} rows", allrows.size * 16 * 16, lambda: ctx.rows(batch, allrows, (3 << 16) + 77))
 rec("fbk_topn MinThreshold + Tanimoto (k_rows_vs_filter, k_row_cardinality, k_topn_filter)", nbytes, lambda: ctx.topn(batch, groups, 10, F, fidx, tanimoto_threshold=2))
 rec("fbk_topk_bsi (k_rows_vs_filter, k_counts_to_bsi, k_cell_stats)", nbytes, lambda: ctx.topk_bsi(batch, groups, F, fidx))
 rec("fbk_count_matrix 32 x 32 + filter, densify + dense kernel (k_densify_rows, k_count_matrix_mfma)", nbytes, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx))
