@@ -24,6 +24,7 @@ constexpr int kSlots = 16;          // containers per shard row (fragment.go:47)
 constexpr int kWords = 1024;        // bitmapN (roaring.go:44)
 constexpr int kWordsPerLane = 16;   // 1024 / 64
 constexpr uint32_t kTypeNil = 0, kTypeArray = 1, kTypeBitmap = 2, kTypeRun = 3;
+constexpr uint32_t kDirectArrayMax = 1024;  // set-op results up to this many values are written as arrays when optimize() follows (4095: the peeling of large arrays into 8 KiB-strided cells triples the kernel time, measured)
 
 // Device-side container descriptor: one 16-byte record per (row, slot), loaded with a
 // single scalar dwordx4 load because it is wave-uniform.  type==0 means nil container.
@@ -63,6 +64,19 @@ __device__ __forceinline__ uint32_t wave_rows_sum(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+  return v;
+}
+
+// inclusive prefix sum over the 64 lanes on the DPP network (no LDS round trips): Hillis-Steele inside
+// each row of 16 lanes (row_shr 1, 2, 4, 8), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15),
+// then lane 31 into rows 2 and 3 (row_bcast:31)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);
   return v;
 }
 
@@ -696,12 +710,35 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
   frag_load(sb, arenaB, lane, lds[wv], wb);
 #pragma unroll
   for (int i = 0; i < kWordsPerLane; ++i) wa[i] = apply_op<OP>(wa[i], wb[i]);
-  frag_store_bitmap(arenaO + so.off, lane, wa);
   uint32_t c = wave_reduce_add(frag_popcount(wa));
   uint32_t r = 0;
   if (outRuns) r = wave_reduce_add(frag_count_runs(wa, lane));
+  bool as_array = false;
+  if (direct && outRuns && c != 0 && c <= kDirectArrayMax) {
+    // Right-sized output for ANY operation (only when the caller asked for optimize()): a result of at most
+    // kDirectArrayMax values leaves the kernel as an ARRAY of 2 c bytes in its cell instead of as an 8 KiB bitmap
+    // that the re-encode pass would read back only to shrink it.  Values in word order: word 128 j + 2 lane + h
+    // sits in this lane's register 2 j + h, so the position of a lane's first value in group j is the count of
+    // all earlier groups plus an exclusive scan over the lanes (DPP network), then each lane peels its bits.
+    as_array = true;
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(arenaO + so.off);
+    uint32_t before = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t mine = (uint32_t)__popcll(wa[2 * j]) + (uint32_t)__popcll(wa[2 * j + 1]);
+      const uint32_t incl = wave_incl_scan(mine);
+      uint32_t pos = before + incl - mine;
+      const uint32_t base = (128u * j + 2u * (uint32_t)lane) * 64u;
+      for (u64 x = wa[2 * j]; x; x &= x - 1) o16[pos++] = (uint16_t)(base + (uint32_t)__builtin_ctzll(x));
+      for (u64 x = wa[2 * j + 1]; x; x &= x - 1) o16[pos++] = (uint16_t)(base + 64u + (uint32_t)__builtin_ctzll(x));
+      before += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+  } else {
+    frag_store_bitmap(arenaO + so.off, lane, wa);
+  }
   if (lane == 0) {
-    so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
+    if (as_array) so.len = c;
+    so.tn = make_tn(c ? (as_array ? kTypeArray : kTypeBitmap) : kTypeNil, c);
     outSlots[wslot] = so;
     if (outRuns) outRuns[wslot] = r;
     if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);

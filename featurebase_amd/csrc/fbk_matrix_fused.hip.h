@@ -88,18 +88,7 @@ __device__ __forceinline__ uint32_t fx_win_dyn(const uint4& w, uint32_t k) {
   const uint32_t d = k < 2 ? w.x : k < 4 ? w.y : k < 6 ? w.z : w.w;
   return (k & 1) ? d >> 16 : d & 0xFFFFu;
 }
-// inclusive prefix sum over the 64 lanes on the DPP network (no LDS round trips): Hillis-Steele inside
-// each row of 16 lanes (row_shr 1, 2, 4, 8), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15),
-// then lane 31 into rows 2 and 3 (row_bcast:31)
-__device__ __forceinline__ uint32_t fx_wave_incl_scan(uint32_t v) {
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);
-  return v;
-}
+__device__ __forceinline__ uint32_t fx_wave_incl_scan(uint32_t v) { return wave_incl_scan(v); }
 __device__ __forceinline__ uint32_t fx_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 template <bool HAS_F, bool PROF = false>

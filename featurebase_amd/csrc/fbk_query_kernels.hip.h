@@ -553,12 +553,22 @@ __global__ void __launch_bounds__(256) k_encode_write(const Slot* __restrict__ c
   }
   const Slot cell = cells[i];
   const uint32_t n = slot_n(cell);
-  u64 w[kWordsPerLane];
-  frag_load(cell, cell_arena, lane, lds[threadIdx.x >> 6], w);
   const u64 my_off = enc_off_local[i] + enc_off_block[i >> 10];
   uint8_t* dst = arenaO + my_off;
   so.off = my_off;
   so.tn = make_tn(t, n);
+  if (t == kTypeArray && slot_type(cell) == kTypeArray) {
+    // the cell already holds the array (k_setop's right-sized outputs): the re-encode is a copy of 2 n bytes
+    // (cells and encoded payloads are 16-byte aligned and padded)
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(cell_arena + cell.off);
+    ulonglong2* d16 = reinterpret_cast<ulonglong2*>(dst);
+    for (uint32_t k = lane; k < (2u * n + 15u) / 16u; k += kWave) d16[k] = src[k];
+    so.len = n;
+    if (lane == 0) outSlots[i] = so;
+    return;
+  }
+  u64 w[kWordsPerLane];
+  frag_load(cell, cell_arena, lane, lds[threadIdx.x >> 6], w);
   if (t == kTypeBitmap) {
     frag_store_bitmap(dst, lane, w);
     so.len = kWords;
@@ -569,12 +579,7 @@ __global__ void __launch_bounds__(256) k_encode_write(const Slot* __restrict__ c
     for (int j = 0; j < 8; ++j) {
       u64 w0 = w[2 * j], w1 = w[2 * j + 1];
       const uint32_t c0 = __popcll(w0), c = c0 + __popcll(w1);
-      uint32_t incl = c;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        uint32_t tt = __shfl_up(incl, o, kWave);
-        if (lane >= o) incl += tt;
-      }
+      const uint32_t incl = wave_incl_scan(c);
       uint32_t at = basecnt + incl - c;
       const uint32_t v0 = (128u * j + 2u * lane) * 64u;
       while (w0) {
@@ -585,7 +590,7 @@ __global__ void __launch_bounds__(256) k_encode_write(const Slot* __restrict__ c
         out[at++] = (uint16_t)(v0 + 64u + __builtin_ctzll(w1));
         w1 &= w1 - 1;
       }
-      basecnt += __shfl(incl, 63, kWave);
+      basecnt += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     so.len = n;
   } else {  // run
@@ -608,15 +613,7 @@ __global__ void __launch_bounds__(256) k_encode_write(const Slot* __restrict__ c
       u64 en0 = w0 & ~((w0 >> 1) | ((w1 & 1ull) << 63));
       u64 en1 = w1 & ~((w1 >> 1) | ((u64)next0 << 63));
       const uint32_t cs = __popcll(st0) + __popcll(st1), ce = __popcll(en0) + __popcll(en1);
-      uint32_t is = cs, ie = ce;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        uint32_t ts = __shfl_up(is, o, kWave), te = __shfl_up(ie, o, kWave);
-        if (lane >= o) {
-          is += ts;
-          ie += te;
-        }
-      }
+      const uint32_t is = wave_incl_scan(cs), ie = wave_incl_scan(ce);
       uint32_t as = sbase + is - cs, ae = ebase + ie - ce;
       const uint32_t v0 = (128u * j + 2u * lane) * 64u;
       while (st0) {
@@ -635,8 +632,8 @@ __global__ void __launch_bounds__(256) k_encode_write(const Slot* __restrict__ c
         out[2 * (ae++) + 1] = (uint16_t)(v0 + 64u + __builtin_ctzll(en1));
         en1 &= en1 - 1;
       }
-      sbase += __shfl(is, 63, kWave);
-      ebase += __shfl(ie, 63, kWave);
+      sbase += (uint32_t)__builtin_amdgcn_readlane((int)is, 63);
+      ebase += (uint32_t)__builtin_amdgcn_readlane((int)ie, 63);
       prev_top = __shfl(top1, 63, kWave);
     }
     so.len = runs[i];
