@@ -1124,12 +1124,11 @@ def test_bsi_add_reference_cases(gpu_ctx, oracle):
     with counts up to 9 023 592 401, and the two-position case — through fbk_bsi_add; every
     position decodes to a + b."""
     O = oracle
-    cases = [
-        ([161311, 611110, 82544, 996022, 836077, 64964, 480737, 156534, 240525, 580896, 239236, 54607, 1019438, 894260, 17570, 884645, 936658, 682651, 987695, 390274],
-         [17, 1, 2846, 45437619, 23781, 36, 88, 168691, 13417, 1301, 10, 71, 0, 176, 1010, 21, 1, 509, 17, 4],
-         [24, 288, 12737, 14, 150, 21, 24, 354, 0, 19, 5, 150, 3940, 121, 25, 621, 7, 9023592401, 6033, 7]),
-        ([17570, 54607], [1010, 71], [25, 150]),
-    ]
+    import json
+    import os
+
+    lit = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "literal_vectors.json")))  # extracted mechanically from bsi_test.go
+    cases = [(c["positions"], c["a"], c["b"]) for c in lit["bsi_add_cases"]]
     depth = 34  # 9023592401 < 2^34
 
     def planes_of(vals):
