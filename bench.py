@@ -676,9 +676,14 @@ def main():
         try:
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK")}
             p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "group_bench.py"), "--devices", devs, "--shards", str(n), "--steps", str(min(args.steps, 200))],
-                               capture_output=True, text=True, timeout=300, env=env)
+                               capture_output=True, text=True, timeout=180, env=env)
             line = [x for x in p.stdout.splitlines() if x.startswith("{")]
             group_api = json.loads(line[-1]) if line else {"error": (p.stderr or "no output")[-400:]}
+        except subprocess.TimeoutExpired as e:  # a reduce mode hung (the script prints a line per finished mode: keep those)
+            so = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+            line = [x for x in so.splitlines() if x.startswith("{")]
+            group_api = json.loads(line[-1]) if line else {}
+            group_api["error"] = "scripts/group_bench.py did not finish within 180 s (killed); modes listed are the ones that completed"
         except Exception as e:  # noqa: BLE001
             group_api = {"error": str(e)}
     elif n_gpus == 1:

@@ -12,8 +12,9 @@ per-query latency a caller sees (the total is back on the host after every step)
     python scripts/group_bench.py --devices 0,1,2,3,4,5,6,7 [--shards 1024] [--steps 200]
 
 The same device may be listed several times (members share it): that exercises the complete G > 1
-path on a one-GPU box; RCCL is skipped then.  Prints ONE JSON line.  bench.py runs this script from
-rank 0 (N > 1) and embeds the line as "group_api".
+path on a one-GPU box; RCCL is skipped then.  Prints one JSON line per finished reduce mode, each a superset of
+the one before (the LAST line is the result).  bench.py runs this script from rank 0 (N > 1) and embeds
+the last line as "group_api".
 """
 import argparse
 import json
@@ -99,6 +100,7 @@ def main():
             "bits_scanned_GBps": 2 * set_ops_per_step * 8192 * args.steps / dt / 1e9,
             "total_matches_numpy": True,
         }
+        print(json.dumps(out), flush=True)  # (a line per finished mode: a caller that has to kill a hung mode keeps the earlier ones)
     for p in plans:
         if p is not None:
             p.free()
