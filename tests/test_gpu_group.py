@@ -48,6 +48,30 @@ def test_group_of_two_members_matches_single_context(gpu_ctx, oracle):
     B.free()
 
 
+def test_group_rccl_reduce_one_member(gpu_ctx):
+    """The RCCL reduce on the hardware this box has: a group of ONE member — librccl found by dlopen (the copy
+    PyTorch already loaded), ncclCommInitAll over its device, ncclAllReduce of the partials on the member's
+    stream inside ncclGroupStart / End, result read back.  (More than one distinct device: 8-GPU nodes only.)"""
+    w = D.dense_rows(2 * 6, 0.5, 2230)
+    grp = Group([0])
+    c = grp.members[0]
+    A = c.upload_dense(w)
+    plan = c.plan(A, np.arange(6) * 2, A, np.arange(6) * 2 + 1)
+    exp = int(sum(np.bitwise_count(w[2 * i] & w[2 * i + 1]).sum() for i in range(6)))
+    grp.set_reduce(L.REDUCE_HOST)
+    assert grp.plan_intersection_count_total([plan]) == exp
+    grp.set_reduce(L.REDUCE_RCCL)
+    for _ in range(3):
+        assert grp.plan_intersection_count_total([plan]) == exp
+    rows = np.arange(12).reshape(2, 6)
+    tot = grp.count_matrix([dict(a=A, rows_a=rows[:, :3], b=A, rows_b=rows[:, 3:], filt=None, rows_f=None)], 3, 3)
+    ref = c.count_matrix(A, rows[:, :3], A, rows[:, 3:])
+    assert (tot == ref).all()
+    plan.free()
+    A.free()
+    grp.close()
+
+
 @pytest.mark.parametrize("dense", [True, False])
 def test_group_count_matrix_matches_single_context(gpu_ctx, dense):
     rng = D.rng_for(2202)
