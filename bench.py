@@ -424,6 +424,11 @@ def main():
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
         raise SystemExit(self_launch(args))
+    # stdout carries exactly ONE line, the JSON: libraries below print to file descriptor 1 on their own (RCCL its
+    # version banner at communicator creation, gloo its connection notes).  Everything but that line goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(world_env or "1")
@@ -762,7 +767,8 @@ def main():
             cb = cpu_baseline(wa, wb)
             assert cb.pop("total_count") == local_expected, "oracle and GPU disagree"
             out["cpu_baseline"] = cb
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     plan.free()
     A.free()
