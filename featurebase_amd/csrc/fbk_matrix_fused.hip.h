@@ -453,9 +453,11 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
       }
     }
   };
-  // one run row of a stage into its row of the stage buffer: toggles at the clamped start and one past the clamped
-  // end of the runs [i0, i1) (the first 64 of them were loaded a stage ahead), then the parity prefix
-  auto run_row = [&](const FxTab& T, uint32_t row, uint32_t q, uint32_t bufoff, uint32_t i0, uint32_t i1, bool have_first, uint32_t first_iv) {
+  // A run row of a stage, in two steps: (1) toggles at the clamped start and one past the clamped end of the runs
+  // [i0, i1) (the first 64 of them were loaded a stage ahead); (2) the parity prefix over the row's 1 KiB.  The two
+  // steps are issued apart — toggles of all the wave's run rows, then the array items, then the prefixes — so that
+  // the LDS round trip between a row's atomics and the read-back of its words is covered by other work.
+  auto run_toggles = [&](const FxTab& T, uint32_t row, uint32_t q, uint32_t bufoff, uint32_t i0, uint32_t i1, bool have_first, uint32_t first_iv) {
     const uint32_t lo = q * (uint32_t)(kFxSB * 8), hi = lo + (uint32_t)(kFxSB * 8);
     const uint32_t rowaddr = bufoff + row * (uint32_t)kFxStride;
     auto toggle = [&](uint32_t idx, uint32_t iv) {
@@ -480,20 +482,20 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
         toggle(idx, idx < len ? fx_ld_global4(p + 4u * idx) : 0u);
       }
     }
-    wave_lds_sync();
-    {  // parity prefix: lane j owns bytes 16 j .. 16 j + 15 of the row
-      uint4* pc = reinterpret_cast<uint4*>(ring8 + rowaddr + lane16);
-      const uint4 tv = *pc;
-      const u64 t0 = ((u64)tv.y << 32) | tv.x, t1 = ((u64)tv.w << 32) | tv.z;
-      const uint32_t p0 = __popcll(t0) & 1u, p1 = __popcll(t1) & 1u;
-      const u64 mm = __ballot((p0 ^ p1) != 0);
-      const uint32_t in = __popcll(mm & lane_lt) & 1u;
-      const u64 f0 = prefix_xor64(t0) ^ (in ? ~0ull : 0ull);
-      const u64 f1 = prefix_xor64(t1) ^ ((in ^ p0) ? ~0ull : 0ull);
-      *pc = uint4{(uint32_t)f0, (uint32_t)(f0 >> 32), (uint32_t)f1, (uint32_t)(f1 >> 32)};
-    }
   };
-
+  auto prefix_of = [&](const uint4& tv) {  // parity prefix over the row, lane j holding its bytes 16 j .. 16 j + 15
+    const u64 t0 = ((u64)tv.y << 32) | tv.x, t1 = ((u64)tv.w << 32) | tv.z;
+    const uint32_t p0 = __popcll(t0) & 1u, p1 = __popcll(t1) & 1u;
+    const u64 mm = __ballot((p0 ^ p1) != 0);
+    const uint32_t in = __popcll(mm & lane_lt) & 1u;
+    const u64 f0 = prefix_xor64(t0) ^ (in ? ~0ull : 0ull);
+    const u64 f1 = prefix_xor64(t1) ^ ((in ^ p0) ? ~0ull : 0ull);
+    return uint4{(uint32_t)f0, (uint32_t)(f0 >> 32), (uint32_t)f1, (uint32_t)(f1 >> 32)};
+  };
+  auto run_prefix = [&](uint32_t row, uint32_t bufoff) {
+    uint4* pc = reinterpret_cast<uint4*>(ring8 + (bufoff + row * (uint32_t)kFxStride) + lane16);
+    *pc = prefix_of(*pc);
+  };
   auto settle = [&](Pre& P) {
 #pragma unroll
     for (int k = 0; k < kFxPref; ++k) asm volatile("" : "+v"(P.a_w[k]));
@@ -545,6 +547,10 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
         if (toff[k] != ~0u) *reinterpret_cast<mm_u4*>(ring8 + (bufoff + lane16) + toff[k]) = t[k];
     }
     stamp(it, 2);
+    // ---- 3a. run rows, step 1 (each run row is owned by one wave, so its parity prefix follows this wave's own toggles) ----
+#pragma unroll
+    for (int k = 0; k < kFxRunPref; ++k)
+      if (cur.r_i0[k] < cur.r_i1[k]) run_toggles(T, cur.r_row[k], q, bufoff, cur.r_i0[k], cur.r_i1[k], true, cur.r_iv[k]);
     // ---- 3. array items: the prefetched ones, then (long lists only) the rest ----
 #pragma unroll
     for (int k = 0; k < kFxPref; ++k) scatter8(cur.a_w[k], cur.a_nv[k], bufoff + cur.a_off[k]);
@@ -572,18 +578,24 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
       }
     }
     stamp(it, 3);
-    // ---- 4. run rows (each owned by one wave, so the parity prefix follows this wave's own toggles) ----
+    // ---- 4. run rows, step 2: the parity prefixes; then (a wave with a second run row may have a third) the rest ----
+    wave_lds_sync();
+    // (reading both rows back before computing either prefix was tried: 25 us slower)
 #pragma unroll
     for (int k = 0; k < kFxRunPref; ++k)
-      if (cur.r_i0[k] < cur.r_i1[k]) run_row(T, cur.r_row[k], q, bufoff, cur.r_i0[k], cur.r_i1[k], true, cur.r_iv[k]);
-    if (cur.r_i1[kFxRunPref - 1] != 0 && !(ablate & 4u)) {  // (a wave with a second run row may have a third)
+      if (cur.r_i0[k] < cur.r_i1[k]) run_prefix(cur.r_row[k], bufoff);
+    if (cur.r_i1[kFxRunPref - 1] != 0 && !(ablate & 4u)) {
       const uint32_t nrun = fx_uniform(T.nrun);
       for (uint32_t e = (uint32_t)(kFxProducers - 1) - pw + (uint32_t)kFxProducers * kFxRunPref; e < nrun; e += (uint32_t)kFxProducers) {
         const uint32_t row = fx_uniform(T.runl[e]);
         uint32_t len, i0, i1;
         (void)row_ptr(T, row, len);
         run_range(T, row, q, len, i0, i1);
-        if (i0 < i1) run_row(T, row, q, bufoff, i0, i1, false, 0u);
+        if (i0 < i1) {
+          run_toggles(T, row, q, bufoff, i0, i1, false, 0u);
+          wave_lds_sync();
+          run_prefix(row, bufoff);
+        }
       }
     }
     // ---- 5. the work lists of slot si + 1 (see build_*): read from the start of stage (si, 7) on ----
