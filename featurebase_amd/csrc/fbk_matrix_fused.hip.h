@@ -8,7 +8,7 @@
 // cycles over its four waves whatever the number of active lanes (rocprofv3 counters and the kernel's own
 // cycle stamps, profiles/r02_pmc_fused2_*.txt, profiles/r02_fused2_*_cycle_stamps.txt).  The first version of
 // the in-kernel decode (round 2, 863 us on 256 shards of config 3's rows) walked every array with a cursor,
-// re-derived its windows and ran half-empty passes: ~185 instructions per (row, stage).  This one (441 us) is
+// re-derived its windows and ran half-empty passes: ~185 instructions per (row, stage).  This one (394 us) is
 // built around the instruction count:
 //
 //   * the batch carries a WINDOW INDEX (k_window_index, 16 bytes per container): where each eighth
@@ -21,8 +21,8 @@
 //     filter) as 1 KiB of bitmap per row in LDS (row stride 1040 bytes: the 16 rows of a
 //     ds_read_b128 lane group fall into 16 different bank groups); two stages alternate, one
 //     barrier per stage;
-//   * once per container slot ONE producer wave turns the 65 descriptors + window indexes into
-//     work lists in LDS: for every stage the list of ARRAY ITEMS (row, first value index, <= 128
+//   * once per container slot nine producer waves (one per eighth + one for the row table) turn the 65
+//     descriptors + window indexes into work lists in LDS: for every stage the list of ARRAY ITEMS (row, first value index, <= 128
 //     values), the bitmap rows, the run rows.  Array items of a stage are dealt out to the 48
 //     16-lane groups of the producers round robin — a heavy row is spread over several groups, four
 //     rows are decoded per wave pass, every lane holds 8 values (one 16-byte load at 2-byte
@@ -30,11 +30,12 @@
 //   * array bits are OR-ed in with LDS atomics, so any group may write any row; the CONSUMERS zero
 //     the piece of every row they have just read (the buffer is clean when the producers get it
 //     back), which removes the ordering "zero before scatter" between producer waves;
-//   * every global load is issued one stage ahead (items, bitmap KiBs, run windows sit in registers
-//     over the barrier), so a stage never waits for HBM latency;
+//   * every global load is issued a WHOLE stage ahead (two register sets alternate: items, bitmap KiBs
+//     and run windows of stage t + 1 go out at the start of stage t), so a stage never waits for HBM;
 //   * bitmap rows: the q-th KiB of the container, global -> registers (a stage ahead) -> LDS;
-//     run rows (owned by one wave each): toggles at the clamped start / one past the clamped end,
-//     then a parity prefix over the row's 1 KiB (runToBitmap, roaring.go:3792).
+//     run rows (owned by one wave each): toggles at the clamped start / one past the clamped end
+//     (issued before the wave's array items), then a parity prefix over the row's 1 KiB (issued after
+//     them: the LDS round trip in between is covered) — runToBitmap, roaring.go:3792.
 #pragma once
 #include "fbk_matrix_mfma.hip.h"
 
