@@ -190,7 +190,15 @@ int32_t fbk_batch_download(fbk_ctx* ctx, const fbk_batch* batch, fbk_container_d
  * (ImportRoaringBits, fragment.go:2038-2165): the blob crosses PCIe once and is unpacked by a
  * device kernel.  Batch row i holds the containers whose key >> 4 equals out_row_ids[i]
  * (ascending; for fragment storage that is the row ID, for a serialised Row the shard number);
- * slot = key & 15.  out_row_ids may be NULL; *out_n_rows is always set. */
+ * slot = key & 15.  out_row_ids may be NULL; *out_n_rows is always set.
+ * An ops log behind the containers of a Pilosa-format FILE image is replayed as
+ * Bitmap.UnmarshalBinary does (unmarshal_binary.go:66-95; op layout and FNV-1a checksum
+ * roaring.go:6325-6431): every op's checksum is verified on the host, consecutive add / remove /
+ * addN / removeN ops collapse to the last op per position and are applied as one union and one
+ * difference on the device, addRoaring / removeRoaring ops upload their nested image from the
+ * same blob and fold it in; the containers that come out are Optimize()d.  The row list then
+ * also names every row an op touches (such a row may end up empty).  A truncated or corrupt op
+ * is FBK_E_INVALID (the reference's FileShouldBeTruncatedError), nothing is uploaded. */
 int32_t fbk_batch_upload_roaring(fbk_ctx* ctx, const void* data, uint64_t len, fbk_batch** out_batch,
                                  uint64_t* out_row_ids, uint32_t row_cap, uint32_t* out_n_rows);
 

@@ -6,6 +6,7 @@
     in source order.  (The bitmaps these tests build with loops cannot be extracted: tests/golden/go_bitmap_vectors.py
     restates the loops; tests/test_golden_transcriptions.py checks its literals against this extraction.)
   * TestBSIAddCases (bsi_test.go): the positions / a / b slices of every case.
+  * TestOpLogWriteUnmarshal (roaring/roaring_internal_test.go): the twelve ops it writes to an ops log and reads back.
 
     python tests/golden/extract_literal_vectors.py [/root/reference]  ->  tests/golden/literal_vectors.json
 """
@@ -40,5 +41,13 @@ for name in ("ArrayArray", "ArrayRun", "RunRun", "BitmapRun", "ArrayBitmap", "Bi
 body = func_body(open(os.path.join(REF, "bsi_test.go")).read(), "TestBSIAddCases")
 for m in re.finditer(r"positions:\s*\[\]uint64\{([^}]*)\},\s*a:\s*\[\]uint64\{([^}]*)\},\s*b:\s*\[\]uint64\{([^}]*)\}", body):
     out["bsi_add_cases"].append({"positions": ints(m.group(1)), "a": ints(m.group(2)), "b": ints(m.group(3))})
+# TestOpLogWriteUnmarshal (roaring/roaring_internal_test.go): the ops it writes and reads back, in order
+body = func_body(open(os.path.join(REF, "roaring", "roaring_internal_test.go")).read(), "TestOpLogWriteUnmarshal")
+body = body[: body.index("// test each one separately")]
+TYPES = {"opTypeAdd": 0, "opTypeRemove": 1, "opTypeAddBatch": 2, "opTypeRemoveBatch": 3}
+out["op_log_ops"] = []
+for m in re.finditer(r"typ:\s*(opType\w+),\s*(value:\s*(\d+)|values:\s*\[\]uint64\{([^}]*)\})", body):
+    typ = TYPES[m.group(1)]
+    out["op_log_ops"].append({"type": typ, "value": int(m.group(3))} if m.group(3) is not None else {"type": typ, "values": ints(m.group(4))})
 json.dump(out, open(os.path.join(HERE, "literal_vectors.json"), "w"), indent=1)
 print({k: len(v["new_file_bitmap_literals"]) for k, v in out["intersection_count"].items()}, len(out["bsi_add_cases"]), "bsi add cases")

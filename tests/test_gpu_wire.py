@@ -130,3 +130,109 @@ def test_unoptimized_and_large_images(gpu_ctx, oracle):
     rows = batch.download()
     assert rows[0][5].typ == L.TYPE_ARRAY and rows[0][5].n == 5000 and rows[1][17].n == 65536
     batch.free()
+
+
+# ---- ops log behind the containers (Bitmap.UnmarshalBinary replays it, unmarshal_binary.go:66-95) ----
+def _replay_case(gpu_ctx, oracle, base_raw, ops):
+    """image + encoded ops through fbk_batch_upload_roaring vs the set model of oracle/pywire_ops.py."""
+    from oracle import pywire_ops as W
+
+    to_set = lambda img: set(oracle.OBitmap.unmarshal(img).slice())
+    model = W.apply_ops(to_set(base_raw), ops, to_set)
+    raw = base_raw + b"".join(W.op_encode(t, p) for t, p in ops)
+    assert W.ops_parse(raw[len(raw) - sum(len(W.op_encode(t, p)) for t, p in ops):]) == list(ops)
+    batch, ids = gpu_ctx.upload_roaring(raw)
+    touched = {p >> 20 for p in to_set(base_raw)}
+    for t, p in ops:
+        touched |= {v >> 20 for v in ([p] if t < 2 else p if t < 4 else to_set(p))}
+    assert ids.tolist() == sorted(touched)
+    assert batch_bits(batch, ids) == sorted(model)
+    assert int(batch.count(np.arange(len(ids))).sum()) == len(model)
+    # every container comes out Optimize()d: the re-serialised bytes are WriteTo of the replayed bitmap
+    assert batch.to_roaring() == oracle.bitmap_from_values(sorted(model)).marshal(True)
+    batch.free()
+    return model
+
+
+def test_ops_log_reference_ops(gpu_ctx, oracle):
+    """The twelve ops of TestOpLogWriteUnmarshal (roaring_internal_test.go:4007), behind an empty bitmap and behind a
+    bitmap that already holds some of their positions."""
+    ops = [(o["type"], o["value"] if "value" in o else o["values"])
+           for o in json.load(open(os.path.join(HERE, "golden", "literal_vectors.json")))["op_log_ops"]]
+    empty = oracle.OBitmap().marshal(True)
+    assert _replay_case(gpu_ctx, oracle, empty, ops) == {27}
+    for i in range(len(ops)):  # "test each one separately"
+        _replay_case(gpu_ctx, oracle, empty, ops[i : i + 1])
+    base = oracle.bitmap_from_values([0, 1, 2, 28, 44, 100, 51234567890, (3 << 20) + 5]).marshal(True)
+    _replay_case(gpu_ctx, oracle, base, ops)
+
+
+def test_ops_log_replay_mixed(gpu_ctx, oracle):
+    """Point, batch and roaring ops in one log over a fragment-shaped image: order of operations on the same position,
+    rows that only the log names, containers emptied by removals, nested images in Pilosa and official format."""
+    from oracle import pywire_ops as W
+
+    O = oracle
+    rng = D.rng_for(97)
+    items = []
+    for r in (0, 2, 5):
+        row = D.random_row(rng, 0)
+        items.extend(((r * 16 + (k & 15)), c) for k, c in row.items())
+    items = [kv for kv in items if kv[0] != 2 * 16 + 3] + [(2 * 16 + 3, O.OContainer.array([10, 11, 12]))]
+    base = O.OBitmap.from_containers(items)
+    raw = base.marshal(True)
+    have = base.slice()
+    pick = lambda n: [int(v) for v in rng.choice(have, size=n, replace=False)]
+    nested_add = O.OBitmap.from_containers([
+        (2 * 16 + 3, O.OContainer.run([(0, 9), (13, 5000)])),  # joins the small array into one long run
+        (7 * 16 + 1, O.OContainer.array([1, 2, 3])),  # a row nothing else names
+        (5 * 16 + 0, O.OContainer.bitmap(rng.integers(0, 1 << 63, size=1024, dtype=np.uint64))),
+    ])
+    nested_rm = O.OBitmap.from_containers([
+        (2 * 16 + 3, O.OContainer.run([(0, 65535)])),  # empties the container again
+        (0 * 16 + 1, O.OContainer.run([(100, 40000)])),
+        (9 * 16 + 0, O.OContainer.array([5])),  # removal from a row that does not exist
+    ])
+    official = bytes.fromhex(FIX["ok"][0]["hex"])
+    p0 = (11 << 20) + 77
+    ops = [
+        (W.ADD, p0), (W.REMOVE, p0), (W.ADD, p0),  # last one wins
+        (W.REMOVE_N, pick(500)),
+        (W.ADD_N, [int(v) for v in rng.integers(0, 6 << 20, size=3000)]),
+        (W.ADD, (2 << 20) + (3 << 16) + 12), (W.REMOVE, (2 << 20) + (3 << 16) + 10),
+        (W.ADD_ROARING, nested_add.marshal(True)),
+        (W.REMOVE, (7 << 20) + (1 << 16) + 2),  # after the image that created it
+        (W.ADD_N, [(7 << 20) + (1 << 16) + 2, (7 << 20) + (1 << 16) + 2]),  # duplicates in one batch
+        (W.REMOVE_ROARING, nested_rm.marshal(False)),
+        (W.ADD, (2 << 20) + (3 << 16) + 40000),  # into the container the image just emptied
+        (W.ADD_ROARING, official),
+        (W.REMOVE_N, pick(200) + [p0 + 1]),
+        (W.ADD_N, []), (W.REMOVE_N, []),
+    ]
+    model = _replay_case(gpu_ctx, oracle, raw, ops)
+    assert p0 in model and (7 << 20) + (1 << 16) + 2 in model and (2 << 20) + (3 << 16) + 40000 in model
+    # prefixes of the log: every intermediate state
+    for cut in (1, 3, 4, 5, 8, 9, 11, 12):
+        _replay_case(gpu_ctx, oracle, raw, ops[:cut])
+
+
+def test_ops_log_errors(gpu_ctx, oracle):
+    from oracle import pywire_ops as W
+
+    raw = oracle.bitmap_from_values([1, 2, 3, 1 << 21]).marshal(True)
+    good = W.op_encode(W.ADD_N, [9, 10])
+    for bad in (good[:-1],  # truncated batch
+                good[:9] + bytes([good[9] ^ 1]) + good[10:],  # checksum
+                b"\x07" + good[1:],  # unknown type
+                good[:12],  # shorter than an op header
+                W.op_encode(W.ADD, 5) + good[:5],  # a valid op, then garbage
+                W.op_encode(W.ADD_ROARING, b"\x3c\x30\x01\x00\x00\x00\x00\x00")):  # nested image announces a container it lacks
+        with pytest.raises(L.FbkError):
+            gpu_ctx.upload_roaring(raw + bad)
+    # the same ops behind a row id buffer that is too small
+    import ctypes as C
+    h, n = C.c_void_p(), C.c_uint32()
+    ids = np.zeros(1, dtype=np.uint64)
+    data = raw + W.op_encode(W.ADD, 40 << 20)
+    assert gpu_ctx.lib.fbk_batch_upload_roaring(gpu_ctx.h, data, len(data), C.byref(h), ids.ctypes.data, 1, C.byref(n)) == L.FBK_E_CAPACITY
+    assert n.value == 3 and not h.value
