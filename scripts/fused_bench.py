@@ -57,12 +57,15 @@ print(f"fused                      {t(gb):8.1f} us  parity {ok2}  ({nbytes / t(g
 if not ok2:
     bad = np.argwhere(got != ref)
     print("mismatches:", len(bad), bad[:10].tolist(), got[got != ref][:10].tolist(), ref[got != ref][:10].tolist())
-for spb in (16, 8, 4, 2, 1):
+quick = os.environ.get("FUSED_QUICK") == "1"  # the fused line and the 'no runs' / 'no arrays' ablations only
+for spb in () if quick else (16, 8, 4, 2, 1):
     ctx.set_option("matrix_spb", spb)
     print(f"fused spb={spb:2d}               {t(gb):8.1f} us")
 ctx.set_option("matrix_spb", 0)
 for ab, what in [(1, "no consumer math"), (2, "no arrays"), (4, "no runs"), (8, "no bitmap rows"), (6, "no arrays, no runs"), (14, "no decode at all"),
                  (15, "barriers + work lists only"), (3, "no math, no arrays"), (5, "no math, no runs")]:
+    if quick and ab not in (2, 4):
+        continue
     ctx.set_option("matrix_fused_ablate", ab)
     print(f"fused ablate={ab:2d} {what:28s} {t(gb):8.1f} us")
 ctx.set_option("matrix_fused_ablate", 0)
