@@ -867,7 +867,8 @@ __global__ void __launch_bounds__(256) k_cell_stats(uint8_t* __restrict__ arenaO
 // the lane of the column's slot probes its container (bitmap: one word; array / run: a binary search
 // in the payload) — the same one container per row that the protocol would open.
 //   flags[i] bit 0: the row holds a container with n != 0; bit 1: ... and contains `column`
-//   (column == ~0: no column filter, bit 1 = bit 0).
+//   (column == ~0: no column filter, bit 1 = bit 0); bit 2: it holds a container with n != 0 in the column's slot
+//   or a later one (what the scan still sees of a row when it arrives by a skip to the column's slot).
 __global__ void __launch_bounds__(256) k_rows_flags(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
                                                    const uint32_t* __restrict__ rows, uint64_t n, uint64_t column,
                                                    uint8_t* __restrict__ flags) {
@@ -906,16 +907,23 @@ __global__ void __launch_bounds__(256) k_rows_flags(const Slot* __restrict__ slo
       hit = lo < s.len && (r[lo] & 0xFFFFu) <= v;
     }
   }
+  const uint32_t cslot = column == ~0ull ? 0u : (uint32_t)((column >> 16) & 15u);
   const u64 ne = __ballot(cnt != 0), hm = __ballot(hit);
   const uint32_t sh = (uint32_t)lane & 48u;  // this row's 16 lanes inside the ballot
-  const bool nonempty = ((ne >> sh) & 0xFFFFull) != 0, contains = ((hm >> sh) & 0xFFFFull) != 0;
-  if (slot == 0 && i < n) flags[i] = (uint8_t)((nonempty ? 1u : 0u) | ((nonempty && (column == ~0ull || contains)) ? 2u : 0u));
+  const uint32_t nes = (uint32_t)((ne >> sh) & 0xFFFFull);
+  const bool nonempty = nes != 0, contains = ((hm >> sh) & 0xFFFFull) != 0, tail = (nes >> cslot) != 0;
+  if (slot == 0 && i < n) flags[i] = (uint8_t)((nonempty ? 1u : 0u) | ((nonempty && (column == ~0ull || contains)) ? 2u : 0u) | (tail ? 4u : 0u));
 }
 
 // limit filter (BitmapRowLimitFilter, filter.go:471-509, as executeRowsShard appends it AFTER the column filter,
-// executor.go:4139-4155): the limit filter is consulted for every row the scan visits, whether or not the column
-// filter goes on to match it — the first `limit` non-empty rows stay candidates, everything later is rejected.
-// rank[i] = number of non-empty rows before i (exclusive scan of bit 0).
+// executor.go:4139-4155).  BitmapRowFilterMultiFilter.ConsiderKey (filter.go:603-622) consults every undecided
+// filter for the key the scan is at, so the limit filter spends one of its rows on every row in which the scan
+// LOOKS AT a container, whether or not the column filter goes on to match the row.  Which rows are those: after a
+// row r whose container in the column's slot c (or a later slot) was looked at, the column filter's answer skips
+// the scan to key (r + 1, c) — the containers of row r + 1 in slots below c are never presented.  So a row counts
+// unless ALL its containers lie below slot c AND the row with the directly preceding id is a candidate with a
+// container in slot >= c.  (Such a row cannot hold the column either.)  Without a column filter every non-empty row
+// counts.  rank[i] = number of counted rows before i (exclusive scan of RowCounted).
 __global__ void __launch_bounds__(256) k_rows_select(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ rank, uint64_t n,
                                                     uint64_t limit, uint8_t* __restrict__ keep) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -923,8 +931,15 @@ __global__ void __launch_bounds__(256) k_rows_select(const uint8_t* __restrict__
   keep[i] = (uint8_t)(((flags[i] & 2u) != 0 && (limit == 0 || rank[i] < limit)) ? 1 : 0);
 }
 
-struct RowFlagBit0 {
-  __host__ __device__ uint32_t operator()(uint8_t f) const { return f & 1u; }
+struct RowCounted {
+  const uint8_t* flags;
+  const uint64_t* ids;  // ids of the candidate rows (NULL without a column filter: adjacency does not matter then)
+  __host__ __device__ uint32_t operator()(uint32_t i) const {
+    const uint32_t f = flags[i];
+    if (!(f & 1u)) return 0u;
+    if (ids && i > 0 && !(f & 4u) && (flags[i - 1] & 4u) && ids[i - 1] + 1 == ids[i]) return 0u;
+    return 1u;
+  }
 };
 
 }  // namespace fbk

@@ -117,7 +117,7 @@ SIGNATURES = {
     "fbk_topn": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint32, _vp]),
     "fbk_topk_bsi": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, _vpp, _u32p]),
     "fbk_flip": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _vpp, _vp]),
-    "fbk_rows": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp, C.c_uint64, _vp]),
+    "fbk_rows": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp, C.c_uint64, _vp]),
     "fbk_shift": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vpp, _vp]),
     "fbk_bsi_add": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _vpp]),
     "fbk_bsi_range": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_uint32, C.c_int64, C.c_uint32, _vpp, _vp]),

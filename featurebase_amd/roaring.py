@@ -441,14 +441,18 @@ class Context:
 
     NO_COLUMN = 0xFFFFFFFFFFFFFFFF
 
-    def rows(self, batch: Batch, rows, column: Optional[int] = None, limit: int = 0) -> np.ndarray:
+    def rows(self, batch: Batch, rows, column: Optional[int] = None, limit: int = 0, row_ids=None) -> np.ndarray:
         """fragment.rows (fragment.go:2465): positions (into `rows`, the fragment's rows in ascending row-id
-        order) of the rows that hold anything / hold `column`, under the reference's limit rule."""
+        order) of the rows that hold anything / hold `column`, under the reference's limit rule (row_ids: the
+        fragment row ids of `rows`, needed when a column and a limit are both given)."""
         r = np.ascontiguousarray(rows, dtype=np.uint32)
+        ids = np.ascontiguousarray(row_ids, dtype=np.uint64) if row_ids is not None else None
+        if ids is not None and ids.size != r.size:
+            raise ValueError("row_ids must name every row")
         out = np.zeros(max(r.size, 1), dtype=np.uint32)
         n = C.c_uint64()
-        L.check(self.lib.fbk_rows(self.h, batch.h, r.ctypes.data, r.size, self.NO_COLUMN if column is None else int(column), int(limit),
-                                  out.ctypes.data, out.size, C.byref(n)))
+        L.check(self.lib.fbk_rows(self.h, batch.h, r.ctypes.data, ids.ctypes.data if ids is not None else None, r.size,
+                                  self.NO_COLUMN if column is None else int(column), int(limit), out.ctypes.data, out.size, C.byref(n)))
         return out[: n.value].copy()
 
     NO_ROW = 0xFFFFFFFF

@@ -517,14 +517,19 @@ int32_t fbk_bsi_range_between(fbk_ctx* ctx, const fbk_batch* batch, const uint32
  * filter opens one container per row); here every row is examined at once (16 lanes read a row's 16 descriptors,
  * one lane probes the column's container) and the survivors are compacted in order.
  *   column  FBK_NO_COLUMN, or a column of the shard (0 .. 2^20 - 1): the row must contain it
- *   limit   0 = none; else the reference's composition [column filter, limit filter]: the limit filter counts every
- *           NON-EMPTY row the scan visits, matching or not, so the result is "rows among the first `limit` non-empty
- *           rows that contain the column" (without a column: the first `limit` non-empty rows)
+ *   limit   0 = none; else the reference's composition [column filter, limit filter]: the limit filter spends one
+ *           of its rows on every row in which the scan looks at a container, matching or not.  Without a column
+ *           that is every non-empty row (result: the first `limit` non-empty rows).  With a column the scan leaves a
+ *           row r in which it saw the column's slot c (or a later one) by skipping to key (r + 1, c), so a row whose
+ *           containers all lie below slot c is not counted when it directly follows (id + 1) such a row — the result
+ *           is "the rows among the first `limit` COUNTED rows that contain the column".
+ *   row_ids the fragment row ids of rows[0 .. n_rows), strictly ascending; required when a column AND a limit are
+ *           given (the rule above needs to know which rows follow each other directly), otherwise may be NULL
  *   out_idx[cap]  positions (into rows[]) of the matching rows, ascending; *out_n = how many (FBK_E_CAPACITY when
  *           cap is too small: *out_n says how many there are). */
 #define FBK_NO_COLUMN (~0ull)
-int32_t fbk_rows(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n_rows, uint64_t column, uint64_t limit,
-                 uint32_t* out_idx, uint64_t cap, uint64_t* out_n);
+int32_t fbk_rows(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, const uint64_t* row_ids, uint64_t n_rows, uint64_t column,
+                 uint64_t limit, uint32_t* out_idx, uint64_t cap, uint64_t* out_n);
 
 /* ---- several GPUs in one process ---------------------------------------------------------------
  * The reference maps per-shard functions on the node that owns each shard and folds count-valued

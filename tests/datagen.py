@@ -8,11 +8,13 @@ here are our own (numpy PCG64 seeded from SEED + index).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
 
-SEED = 0x5EED0001
+# every seeded generator derives from this; FBK_TEST_SEED=<int> re-rolls all randomised tests (scripts/fuzz_parity.sh)
+SEED = int(os.environ.get("FBK_TEST_SEED", "0x5EED0001"), 0)
 SLOTS = 16
 WORDS = 1024
 

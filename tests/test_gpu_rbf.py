@@ -164,11 +164,18 @@ def test_corrupt_trees_and_untrusted_headers(gpu_ctx, oracle):
     with pytest.raises(L.FbkError, match="reachable twice"):
         gpu_ctx.upload_rbf(bytes(cyc), root)
     # find a leaf page with an array cell and damage it
-    n_pages = len(f) // 8192
-    for pg in range(2, n_pages):
+    # (walk the tree: a bitmap data page has no header and its bytes can look like one)
+    leaves, todo = [], [root]
+    while todo:
+        pg = todo.pop()
         flags, cell_n = struct.unpack_from(">IH", f, pg * 8192 + 4)
-        if flags != pyrbf.LEAF or cell_n == 0:
-            continue
+        if flags == pyrbf.BRANCH:
+            todo.extend(struct.unpack_from("<I", f, pg * 8192 + struct.unpack_from(">H", f, pg * 8192 + 10 + 2 * i)[0] + 12)[0] for i in range(cell_n))
+        else:
+            assert flags == pyrbf.LEAF
+            leaves.append(pg)
+    for pg in sorted(leaves):
+        cell_n = struct.unpack_from(">H", f, pg * 8192 + 8)[0]
         for i in range(cell_n):
             off = struct.unpack_from(">H", f, pg * 8192 + 10 + 2 * i)[0]
             key, typ, elem_n, bit_n = struct.unpack_from("<QIHI", f, pg * 8192 + off)

@@ -87,30 +87,55 @@ def test_start_row_and_limit():
     assert PF.fragment_rows(data, 0, [PF.RowLimitFilter(7)]) == list(range(0, 400, 3))[:7]
 
 
+def limit_rule(rows, slots_of, holds, start, col, limit):
+    """The closed form fbk_rows implements (include/fbk.h): the limit filter spends one row on every row in which the
+    scan looks at a container; a row all of whose containers lie below the column's slot is not looked at when it
+    directly follows (id + 1) a candidate row with a container in that slot or a later one."""
+    c = col >> 16
+    out, counted, prev = [], 0, None
+    for r in (r for r in rows if r >= start):
+        tail = any(s >= c for s in slots_of[r])
+        if tail or not (prev is not None and prev[0] + 1 == r and prev[1]):
+            if counted >= limit:
+                break
+            counted += 1
+        if r in holds:
+            out.append(r)
+        prev = (r, tail)
+    return out
+
+
 def test_limit_filter_counts_rows_it_is_asked_about():
     """A property of the reference worth pinning (BitmapRowFilterMultiFilter.ConsiderKey, filter.go:603-622,
     consults EVERY undecided filter for a key, so BitmapRowLimitFilter :481-498 spends one of its rows on each
-    non-empty row the scan visits, whether or not the other filters go on to match it): with executeRowsShard's
-    composition [column filter, limit filter] (executor.go:4139-4155) the result is "the rows among the first
-    `limit` non-empty rows that hold the column" — NOT "the first `limit` rows that hold the column".  fbk_rows
-    reproduces exactly this."""
+    row in which the scan looks at a container, whether or not the other filters go on to match it): with
+    executeRowsShard's composition [column filter, limit filter] (executor.go:4139-4155) the result is "the rows
+    among the first `limit` COUNTED rows that hold the column" — NOT "the first `limit` rows that hold the column";
+    and the column filter's skip to (next row, column's slot) hides a following row whose containers all lie in
+    lower slots.  fbk_rows reproduces exactly this (limit_rule above is its closed form); sparse and dense row ids."""
     rng = np.random.default_rng(11)
-    for _ in range(30):
-        rows = sorted(rng.choice(500, size=int(rng.integers(1, 120)), replace=False).tolist())
-        data, holds = {}, set()
+    for trial in range(200):
+        span = int(rng.choice([40, 500]))
+        rows = sorted(rng.choice(span, size=int(rng.integers(1, min(span, 120))), replace=False).tolist())
+        data, holds, slots_of = {}, set(), {}
         for r in rows:
-            for s in rng.choice(16, size=int(rng.integers(1, 4)), replace=False):
-                data[r * 16 + int(s)] = PF.SetContainer(rng.integers(0, 64, 4))
-        col = (int(rng.integers(0, 16)) << 16) + int(rng.integers(0, 64))
+            slots_of[r] = [int(s) for s in rng.choice(16, size=int(rng.integers(1, 4)), replace=False)]
+            for s in slots_of[r]:
+                data[r * 16 + s] = PF.SetContainer(rng.integers(0, 8, 4))
+        col = (int(rng.integers(0, 16)) << 16) + int(rng.integers(0, 8))
         for r in rows:
             c = data.get(r * 16 + (col >> 16))
             if c is not None and c.contains(col & 0xFFFF):
                 holds.add(r)
-        start = int(rng.integers(0, 300))
-        visited = [r for r in rows if r >= start]
+        start = int(rng.integers(0, span))
         for limit in (1, 2, 5, 1000):
-            exp = [r for r in visited[:limit] if r in holds]
-            assert PF.fragment_rows(data, start, [PF.ColumnFilter(col), PF.RowLimitFilter(limit)]) == exp
+            exp = limit_rule(rows, slots_of, holds, start, col, limit)
+            assert PF.fragment_rows(data, start, [PF.ColumnFilter(col), PF.RowLimitFilter(limit)]) == exp, (trial, start, col, limit)
+    # rows far apart: every non-empty row is looked at, the rule is "among the first `limit` non-empty rows"
+    data = {r * 16 + int(s): PF.SetContainer([1]) for r in range(0, 300, 2) for s in (r % 16, (r + 5) % 16)}
+    col = (3 << 16) + 1
+    holds = [r for r in range(0, 300, 2) if 3 in (r % 16, (r + 5) % 16)]
+    assert PF.fragment_rows(data, 10, [PF.ColumnFilter(col), PF.RowLimitFilter(20)]) == [r for r in range(10, 50, 2) if r in holds]
     # the same rule with a rows filter in front: row 51 (not in the set, but the first key of the scan) costs one
     data = {r * 16 + (r % 16): PF.SetContainer([3]) for r in range(0, 400, 3)}
     assert PF.fragment_rows(data, 50, [PF.RowsFilter([60, 61, 63, 66, 300]), PF.RowLimitFilter(2)]) == [60]
