@@ -362,10 +362,10 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             cpu5 = {"kind": "port", "cores": 1, "sample": "shard 0 (66 dense rows), oracle fragment.rangeOp(GT) / fragment.sum, one host thread",
                     "range_per_shard_s": t_rng, "sum_per_shard_s": t_sum}
         g, wl, kq = _timed_call(torch, stream, lambda: ctx.bsi_range(batch, base, L.BSI_GT, depth, kk)[0].free(), iters, ctx=ctx)
-        out.append(_entry(f"config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense", "k_bsi_range", plane_bytes * (depth + 3), g, wl, kq, shards=n5,
+        out.append(_entry(f"config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense", "k_bsi_range_slot", plane_bytes * (depth + 3), g, wl, kq, shards=n5,
                           cpu_baseline=cpu5, parity="shard 0 vs the oracle" if want_cpu else "unchecked"))
         g, wl, kq = _timed_call(torch, stream, lambda: ctx.bsi_sum(batch, base, depth, rng_out, np.arange(n5)), iters, ctx=ctx)
-        out.append(_entry("config5: BSI Sum(filter = the Range result)", "k_bsi_sum", plane_bytes * (depth + 3), g, wl, kq, shards=n5))
+        out.append(_entry("config5: BSI Sum(filter = the Range result)", "k_bsi_sum_slot", plane_bytes * (depth + 3), g, wl, kq, shards=n5))
         rng_out.free()
         batch.free()
     return out

@@ -85,6 +85,8 @@ struct FbkOptions {
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
   int64_t bsi_minmax_blocks = 0;         // 1: one block per shard for Min / Max (round-1 kernel, A/B runs); 0: one wavefront per (shard, slot)
+  int64_t bsi_sum_blocks = 0;            // 1: one 256-thread block per (shard, slot) for Sum (round-1 kernel, A/B runs); 0: one wavefront
+  int64_t bsi_range_blocks = 0;          // 1: one 256-thread block per (shard, slot) for Range (round-1 kernel, A/B runs); 0: one wavefront
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
 };
@@ -505,6 +507,8 @@ const OptionDesc kOptions[] = {
     {"last_kernel_ns", &FbkOptions::last_kernel_ns, 0, INT64_MAX},
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
     {"bsi_minmax_blocks", &FbkOptions::bsi_minmax_blocks, 0, 1},
+    {"bsi_sum_blocks", &FbkOptions::bsi_sum_blocks, 0, 1},
+    {"bsi_range_blocks", &FbkOptions::bsi_range_blocks, 0, 1},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
 };

@@ -106,6 +106,18 @@ __device__ __forceinline__ u64 block_reduce_add_u64(u64 v, u64* part) {
   return part[0] + part[1] + part[2] + part[3];
 }
 
+// The descriptors of one slot of a BSI fragment's rows (exists, sign, planes: at most 66) staged in LDS by one
+// wavefront, one parallel round of loads: a plane's descriptor is then an LDS read instead of a global load that the
+// plane's own load has to wait for (descriptor -> payload is a dependent chain; it halves the effective prefetch depth).
+constexpr int kBsiDescCap = 128;
+__device__ __forceinline__ void bsi_stage_descs(const Slot* __restrict__ slots, uint64_t r0, uint32_t slot, uint32_t n_rows, int lane, Slot* tab) {
+  for (uint32_t r = (uint32_t)lane; r < n_rows && r < (uint32_t)kBsiDescCap; r += kWave) tab[r] = slots[(r0 + r) * kSlots + slot];
+  wave_lds_sync();
+}
+__device__ __forceinline__ Slot bsi_desc(const Slot* __restrict__ slots, uint64_t r0, uint32_t slot, uint32_t r, const Slot* tab) {
+  return r < (uint32_t)kBsiDescCap ? tab[r] : slots[(r0 + r) * kSlots + slot];
+}
+
 // ---- BSI Sum ---------------------------------------------------------------------------------
 // positive = filter ∩ exists \ sign, negative = filter ∩ exists ∩ sign stay in registers while
 // the bit planes stream past once, U planes in flight:
@@ -199,6 +211,83 @@ __global__ void __launch_bounds__(256) k_bsi_sum(const Slot* __restrict__ slots,
   }
 }
 
+// The same sum with one WAVEFRONT per (shard, slot) (round 2; k_bsi_sum above stays behind option bsi_sum_blocks=1):
+// the planes of a slot do not depend on each other, so a wavefront keeps positive / negative (16 words per lane each)
+// in registers and streams the planes with kAhead of them in flight — 1536 independent streams for 100 M columns,
+// no LDS staging for bitmap planes, no barrier, and ONE wave reduction at the very end: a lane adds its own
+// (popcount << i) terms in uint64 (wrap-around is linear, so the order of additions does not matter).
+__global__ void __launch_bounds__(64) k_bsi_sum_slot(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                                    const uint32_t* __restrict__ base, uint32_t n_shards, uint32_t bit_depth,
+                                                    const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,
+                                                    const uint32_t* __restrict__ frows, u64* __restrict__ out3) {
+  __shared__ u64 lds[kWords];
+  __shared__ Slot tab[kBsiDescCap];
+  const int lane = threadIdx.x;
+  const uint64_t shard = blockIdx.x >> 4;
+  const uint32_t slot = blockIdx.x & 15;
+  if (shard >= n_shards) return;
+  const uint64_t r0 = base[shard];
+  bsi_stage_descs(slots, r0, slot, bit_depth + 2, lane, tab);
+  const Slot se = tab[0];
+  if (slot_n(se) == 0) return;  // no existence bits: positive stays nil (filter.go:1135)
+  u64 pos[kWordsPerLane], neg[kWordsPerLane];
+  constexpr int kAhead = 3;
+  u64 T[kAhead][kWordsPerLane];
+  frag_load(se, arena, lane, lds, pos);
+  if (fslots) {
+    const Slot sf = fslots[(uint64_t)frows[shard] * kSlots + slot];
+    if (slot_n(sf) == 0) return;  // ConsiderKey rejects: no filter container here (filter.go:1112)
+    frag_load(sf, farena, lane, lds, T[0]);
+#pragma unroll
+    for (int q = 0; q < kWordsPerLane; ++q) pos[q] &= T[0][q];
+  }
+  const uint32_t cnt = wave_reduce_add(frag_popcount(pos));
+  if (cnt == 0) return;  // (wave-uniform) nothing considered in this slot: every term below is zero
+  auto load_plane = [&](uint32_t i, u64 (&w)[kWordsPerLane]) {
+    const Slot sp = bsi_desc(slots, r0, slot, 2 + i, tab);
+    if (slot_n(sp) == 0) frag_zero(w);
+    else frag_load(sp, arena, lane, lds, w);
+  };
+  {
+    const Slot ss = tab[1];
+    if (slot_n(ss) == 0) frag_zero(T[0]);  // nil sign row => zeros
+    else frag_load(ss, arena, lane, lds, T[0]);
+#pragma unroll
+    for (int q = 0; q < kWordsPerLane; ++q) {
+      neg[q] = pos[q] & T[0][q];
+      pos[q] &= ~T[0][q];
+    }
+  }
+  u64 psum = 0, nsum = 0;
+#pragma unroll
+  for (int u = 0; u < kAhead; ++u)
+    if ((uint32_t)u < bit_depth) load_plane((uint32_t)u, T[u]);
+  for (uint32_t i0 = 0; i0 < bit_depth; i0 += kAhead) {
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const uint32_t i = i0 + (uint32_t)u;
+      if (i < bit_depth) {  // (wave-uniform)
+        uint32_t pc = 0, nc = 0;
+#pragma unroll
+        for (int q = 0; q < kWordsPerLane; ++q) {
+          pc += __popcll(pos[q] & T[u][q]);
+          nc += __popcll(neg[q] & T[u][q]);
+        }
+        psum += (u64)pc << i;
+        nsum += (u64)nc << i;
+        if (i + kAhead < bit_depth) load_plane(i + kAhead, T[u]);  // this register set is free again
+      }
+    }
+  }
+  psum = wave_reduce_add_u64(psum);
+  nsum = wave_reduce_add_u64(nsum);
+  if (lane == 0) {
+    if (psum) atomicAdd(&out3[shard * 3 + 0], psum);
+    if (nsum) atomicAdd(&out3[shard * 3 + 1], nsum);
+    atomicAdd(&out3[shard * 3 + 2], (u64)cnt);
+  }
+}
+
 // ---- BSI Range: plane-program interpreter -----------------------------------------------------
 // The host walks the reference's control flow (rangeEQ/LT/GT/Between, fragment.go:963-1303)
 // ONCE per query and emits a short straight-line program over three fragment registers
@@ -221,47 +310,77 @@ enum BsiOp : uint32_t {
   kNop = 255
 };
 
-__device__ __forceinline__ void bsi_apply(uint32_t op, u64 (&X)[kBW], u64 (&M)[kBW], u64 (&S)[kBW], const u64 (&T)[kBW]) {
+template <int NW>
+__device__ __forceinline__ void bsi_apply(uint32_t op, u64 (&X)[NW], u64 (&M)[NW], u64 (&S)[NW], const u64 (&T)[NW]) {
   switch (op) {
     case kLoadX:
 #pragma unroll
-      for (int q = 0; q < kBW; ++q) X[q] = T[q];
+      for (int q = 0; q < NW; ++q) X[q] = T[q];
       break;
     case kAndX:
 #pragma unroll
-      for (int q = 0; q < kBW; ++q) X[q] &= T[q];
+      for (int q = 0; q < NW; ++q) X[q] &= T[q];
       break;
     case kAndnX:
 #pragma unroll
-      for (int q = 0; q < kBW; ++q) X[q] &= ~T[q];
+      for (int q = 0; q < NW; ++q) X[q] &= ~T[q];
       break;
     case kMorXA:
 #pragma unroll
-      for (int q = 0; q < kBW; ++q) M[q] |= X[q] & T[q];
+      for (int q = 0; q < NW; ++q) M[q] |= X[q] & T[q];
       break;
     case kMorXAn:
 #pragma unroll
-      for (int q = 0; q < kBW; ++q) M[q] |= X[q] & ~T[q];
+      for (int q = 0; q < NW; ++q) M[q] |= X[q] & ~T[q];
       break;
-    case kMZero: bfrag_zero(M); break;
+    case kMZero:
+#pragma unroll
+      for (int q = 0; q < NW; ++q) M[q] = 0;
+      break;
     case kXFromM:
 #pragma unroll
-      for (int q = 0; q < kBW; ++q) X[q] = M[q];
+      for (int q = 0; q < NW; ++q) X[q] = M[q];
       break;
-    case kZeroX: bfrag_zero(X); break;
+    case kZeroX:
+#pragma unroll
+      for (int q = 0; q < NW; ++q) X[q] = 0;
+      break;
     case kSaveX:
 #pragma unroll
-      for (int q = 0; q < kBW; ++q) S[q] = X[q];
+      for (int q = 0; q < NW; ++q) S[q] = X[q];
       break;
     case kOrXS:
 #pragma unroll
-      for (int q = 0; q < kBW; ++q) X[q] |= S[q];
+      for (int q = 0; q < NW; ++q) X[q] |= S[q];
       break;
     case kAndnXS:
 #pragma unroll
-      for (int q = 0; q < kBW; ++q) X[q] &= ~S[q];
+      for (int q = 0; q < NW; ++q) X[q] &= ~S[q];
       break;
     default: break;
+  }
+}
+
+// the instructions that do not touch S (k_bsi_range_slot keeps S in LDS)
+template <int NW>
+__device__ __forceinline__ void bsi_apply2(uint32_t op, u64 (&X)[NW], u64 (&M)[NW], const u64 (&T)[NW]) {
+  if (op <= kAndnX) {
+    const u64 inv = op == kAndnX ? ~0ull : 0ull, keep = op == kLoadX ? ~0ull : 0ull;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) X[q] = (X[q] | keep) & (T[q] ^ inv);
+  } else if (op <= kMorXAn) {
+    const u64 inv = op == kMorXAn ? ~0ull : 0ull;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) M[q] |= X[q] & (T[q] ^ inv);
+  } else if (op == kMZero) {
+#pragma unroll
+    for (int q = 0; q < NW; ++q) M[q] = 0;
+  } else if (op == kXFromM) {
+#pragma unroll
+    for (int q = 0; q < NW; ++q) X[q] = M[q];
+  } else if (op == kZeroX) {
+#pragma unroll
+    for (int q = 0; q < NW; ++q) X[q] = 0;
   }
 }
 
@@ -306,7 +425,7 @@ __global__ void __launch_bounds__(256) k_bsi_range(const Slot* __restrict__ slot
 #pragma unroll
       for (int u = 0; u < U; ++u) bfrag_load_fast(sd[u], arena, t, T[u]);
 #pragma unroll
-      for (int u = 0; u < U; ++u) bsi_apply(ops[u], X, M, S, T[u]);
+      for (int u = 0; u < U; ++u) bsi_apply<kBW>(ops[u], X, M, S, T[u]);
     } else {  // an array / run container among them: one instruction at a time
 #pragma unroll 1
       for (uint32_t pc = pc0; pc < min(pc0 + U, prog_len); ++pc) {
@@ -315,7 +434,7 @@ __global__ void __launch_bounds__(256) k_bsi_range(const Slot* __restrict__ slot
         u64 T1[kBW];
         bfrag_zero(T1);
         if (op <= kMorXAn) bfrag_load(slots[(r0 + (ins & 0xFFFFFFu)) * kSlots + slot], arena, t, scratch, T1);
-        bsi_apply(op, X, M, S, T1);
+        bsi_apply<kBW>(op, X, M, S, T1);
       }
     }
   }
@@ -338,6 +457,81 @@ __global__ void __launch_bounds__(256) k_bsi_range(const Slot* __restrict__ slot
     rr = (uint32_t)block_reduce_add_u64(r, part);
   }
   if (t == 0) {
+    outSlots[cell] = so;
+    if (outRuns) outRuns[cell] = rr;
+    if (c && out_counts) atomicAdd(&out_counts[shard], (u64)c);
+  }
+}
+
+// The same interpreter with one WAVEFRONT per (shard, slot) (round 2; the block form above stays behind option
+// bsi_range_blocks=1): X / M / S are 16 words per lane, the planes of the next kAhead instructions are in flight while
+// the current one is applied (a load never depends on X / M / S; k_bsi_range issues U loads, waits for all of them,
+// applies, and only then reads the next U descriptors — the chip idles through every descriptor round trip).
+__global__ void __launch_bounds__(64) k_bsi_range_slot(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                                      const uint32_t* __restrict__ base, uint32_t n_shards,
+                                                      const uint32_t* __restrict__ prog, uint32_t prog_len, uint32_t n_rows_frag,
+                                                      uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
+                                                      uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts) {
+  __shared__ u64 lds[kWords];
+  __shared__ Slot tab[kBsiDescCap];
+  __shared__ u64 save[kWords];  // S lives in LDS (only BETWEEN programs use it): 32 registers fewer, two wavefronts per SIMD
+  const int lane = threadIdx.x;
+  const uint64_t cell = blockIdx.x;
+  const uint64_t shard = cell >> 4;
+  const uint32_t slot = cell & 15;
+  if (shard >= n_shards) return;
+  const uint64_t r0 = base[shard];
+  bsi_stage_descs(slots, r0, slot, n_rows_frag, lane, tab);
+  constexpr int kAhead = 2;  // (3 would need 300 registers: one wavefront per SIMD, and 1536 wavefronts do not fit 1024 SIMDs in one round)
+  u64 X[kWordsPerLane], M[kWordsPerLane], T[kAhead][kWordsPerLane];
+  frag_zero(X);
+  frag_zero(M);
+#pragma unroll
+  for (int q = 0; q < kWordsPerLane; ++q) save[q * kWave + lane] = 0;
+  auto issue = [&](uint32_t pc, u64 (&w)[kWordsPerLane]) {
+    if (pc >= prog_len) return;
+    const uint32_t ins = prog[pc];
+    if ((ins >> 24) > kMorXAn) return;  // no operand
+    const Slot sp = bsi_desc(slots, r0, slot, ins & 0xFFFFFFu, tab);
+    if (slot_n(sp) == 0) frag_zero(w);
+    else frag_load(sp, arena, lane, lds, w);
+  };
+#pragma unroll
+  for (int u = 0; u < kAhead; ++u) {
+    frag_zero(T[u]);
+    issue((uint32_t)u, T[u]);
+  }
+  for (uint32_t pc0 = 0; pc0 < prog_len; pc0 += kAhead) {
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const uint32_t pc = pc0 + (uint32_t)u;
+      if (pc < prog_len) {  // (wave-uniform)
+        const uint32_t op = prog[pc] >> 24;
+        if (op == kSaveX) {
+#pragma unroll
+          for (int q = 0; q < kWordsPerLane; ++q) save[q * kWave + lane] = X[q];
+        } else if (op == kOrXS) {
+#pragma unroll
+          for (int q = 0; q < kWordsPerLane; ++q) X[q] |= save[q * kWave + lane];
+        } else if (op == kAndnXS) {
+#pragma unroll
+          for (int q = 0; q < kWordsPerLane; ++q) X[q] &= ~save[q * kWave + lane];
+        } else {
+          bsi_apply2<kWordsPerLane>(op, X, M, T[u]);
+        }
+        issue(pc + kAhead, T[u]);
+      }
+    }
+  }
+  const uint32_t c = wave_reduce_add(frag_popcount(X));
+  Slot so;
+  so.off = cell * 8192ull;
+  so.len = kWords;
+  so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
+  if (c) frag_store_bitmap(arenaO + so.off, lane, X);
+  uint32_t rr = 0;
+  if (outRuns) rr = wave_reduce_add(frag_count_runs(X, lane));  // bitmapCountRuns (roaring.go:3372-3380)
+  if (lane == 0) {
     outSlots[cell] = so;
     if (outRuns) outRuns[cell] = rr;
     if (c && out_counts) atomicAdd(&out_counts[shard], (u64)c);
@@ -463,14 +657,16 @@ __global__ void __launch_bounds__(64) k_bsi_minmax_slot(const Slot* __restrict__
                                                        uint32_t mode, const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,
                                                        const uint32_t* __restrict__ frows, u64* __restrict__ out2) {
   __shared__ u64 lds[kWords];
+  __shared__ Slot tab[kBsiDescCap];
   const int lane = threadIdx.x;
   const uint64_t cell = blockIdx.x;
   const uint64_t shard = cell >> 4;
   const uint32_t slot = cell & 15;
   if (shard >= n_shards) return;
   const uint64_t r0 = base[shard];
+  bsi_stage_descs(slots, r0, slot, bit_depth + 2, lane, tab);
   auto load_plane = [&](uint64_t row, u64 (&w)[kWordsPerLane]) {
-    const Slot sp = slots[row * kSlots + slot];
+    const Slot sp = bsi_desc(slots, r0, slot, (uint32_t)(row - r0), tab);
     if (slot_n(sp) == 0) frag_zero(w);
     else frag_load(sp, arena, lane, lds, w);
   };

@@ -1,0 +1,77 @@
+"""The BSI kernels on config 5's shape (96 shards x (64 planes + exists + sign), dense): kernel time by the
+library's own HIP events (option time_kernels), both forms of Sum / Range / Min-Max side by side.
+
+    python scripts/bsi_bench.py [shards=96]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from featurebase_amd import lib as L  # noqa: E402
+from featurebase_amd.roaring import Context  # noqa: E402
+
+n5, depth = int(sys.argv[1]) if len(sys.argv) > 1 else 96, 64
+ctx = Context(0)
+st = torch.cuda.Stream()
+ctx.set_stream(st.cuda_stream)
+g = torch.Generator(device="cuda:0").manual_seed(51)
+w = torch.randint(-(1 << 63), (1 << 63) - 1, (n5, depth + 2, 16, 1024), dtype=torch.int64, device="cuda:0", generator=g).cpu().numpy().view(np.uint64)
+w[:, 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+w[-1, 0, 6:] = 0
+batch = ctx.upload_dense(w.reshape(-1))
+base = np.arange(n5, dtype=np.uint32) * (depth + 2)
+plane_bytes = n5 * 16 * 8192
+filt, _ = ctx.bsi_range(batch, base, L.BSI_GT, depth, 1 << 62)
+fidx = np.arange(n5)
+
+
+def kernel_us(fn, iters=15):
+    for _ in range(3):
+        fn()
+    ctx.set_option("time_kernels", 1)
+    ts = []
+    for _ in range(iters):
+        fn()
+        ts.append(ctx.get_option("last_kernel_ns") / 1e3)
+    ctx.set_option("time_kernels", 0)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def line(what, nbytes, fn):
+    med, lo = kernel_us(fn)
+    print(f"{what:58s} {med:8.1f} us (min {lo:6.1f})  {nbytes / med / 1e6:6.2f} TB/s = {nbytes / med / 1e6 / 8:.2f}")
+
+
+ref = None
+for blocks in (1, 0):
+    ctx.set_option("bsi_sum_blocks", blocks)
+    got = ctx.bsi_sum(batch, base, depth, filt, fidx)
+    got_nf = ctx.bsi_sum(batch, base, depth)
+    if ref is None:
+        ref = (got, got_nf)
+    else:
+        assert all((a == b).all() for a, b in zip(ref[0], got)) and all((a == b).all() for a, b in zip(ref[1], got_nf)), "Sum: the two kernels disagree"
+    name = "k_bsi_sum (block per (shard, slot))" if blocks else "k_bsi_sum_slot (wavefront per (shard, slot))"
+    line(f"Sum(filter)  {name}", plane_bytes * (depth + 3), lambda: ctx.bsi_sum(batch, base, depth, filt, fidx))
+    line(f"Sum()        {name}", plane_bytes * (depth + 2), lambda: ctx.bsi_sum(batch, base, depth))
+ctx.set_option("bsi_sum_blocks", 0)
+for op, pred, what in ((L.BSI_GT, 1 << 62, "Range(> 2^62)"), (L.BSI_LT, -5, "Range(< -5)"), (L.BSI_EQ, 12345, "Range(== 12345)")):
+    outs = []
+    for blocks in (1, 0):
+        ctx.set_option("bsi_range_blocks", blocks)
+        o, c = ctx.bsi_range(batch, base, op, depth, pred, L.SETOP_OPTIMIZE)
+        outs.append((o.to_roaring(), c.tolist()))
+        o.free()
+        line(f"{what:16s} {'k_bsi_range (block)' if blocks else 'k_bsi_range_slot (wavefront)'}", plane_bytes * (depth + 3), lambda: ctx.bsi_range(batch, base, op, depth, pred)[0].free())
+    assert outs[0] == outs[1], "Range: the two kernels disagree"
+ctx.set_option("bsi_range_blocks", 0)
+for blocks in (1, 0):
+    ctx.set_option("bsi_minmax_blocks", blocks)
+    line(f"Min          {'k_bsi_minmax (block per shard)' if blocks else 'k_bsi_minmax_slot (wavefront per (shard, slot))'}", plane_bytes * (depth + 2), lambda: ctx.bsi_min(batch, base, depth))
+    line(f"Max(filter)  {'k_bsi_minmax (block per shard)' if blocks else 'k_bsi_minmax_slot (wavefront per (shard, slot))'}", plane_bytes * (depth + 3), lambda: ctx.bsi_max(batch, base, depth, filt, fidx))
+ctx.set_option("bsi_minmax_blocks", 0)

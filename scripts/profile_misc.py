@@ -6,7 +6,7 @@ algorithmic bytes (encoded payload read once + bytes written) for the roofline c
 
 Kernels reached: k_setop<OP> (generic pairs), k_encode_plan / k_scan_blocks / k_exclusive_scan /
 k_encode_write (optimize), k_count_range, k_fold_n<AND>, k_fold_scatter<XOR/ANDNOT>, k_shift, k_flip,
-k_bsi_add, k_bsi_values (+ hipcub sort), k_bsi_minmax, k_bsi_range / k_bsi_sum, k_rows_flags, k_wire_copy (roaring
+k_bsi_add, k_bsi_values (+ hipcub sort), k_bsi_minmax_slot, k_bsi_range_slot / k_bsi_sum_slot, k_rows_flags, k_wire_copy (roaring
 upload + download), k_validate_recount, k_recount, k_rows_vs_filter + k_topn_filter,
 k_counts_to_bsi / k_cell_stats, k_count_matrix_fused, k_count_matrix<4>."""
 import json
@@ -88,8 +88,8 @@ w[:, 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
 bsi = ctx.upload_dense(w.reshape(-1))
 base = np.arange(n5, dtype=np.uint32) * (depth + 2)
 pl = n5 * 16 * 8192
-rec("fbk_bsi_range GT 2^62 (k_bsi_range)", pl * (depth + 3), lambda: ctx.bsi_range(bsi, base, L.BSI_GT, depth, 1 << 62))
-rec("fbk_bsi_sum (k_bsi_sum)", pl * (depth + 2), lambda: ctx.bsi_sum(bsi, base, depth))
+rec("fbk_bsi_range GT 2^62 (k_bsi_range_slot)", pl * (depth + 3), lambda: ctx.bsi_range(bsi, base, L.BSI_GT, depth, 1 << 62))
+rec("fbk_bsi_sum (k_bsi_sum_slot)", pl * (depth + 2), lambda: ctx.bsi_sum(bsi, base, depth))
 rec("fbk_bsi_min (k_bsi_minmax)", pl * (depth + 2), lambda: ctx.bsi_min(bsi, base, depth))
 rec("fbk_bsi_max (k_bsi_minmax)", pl * (depth + 2), lambda: ctx.bsi_max(bsi, base, depth))
 px = np.arange(n5 * 16, dtype=np.uint32).reshape(n5, 16) + 2  # 16 planes of each shard as one unsigned operand (rows base + 2 ..)

@@ -205,7 +205,7 @@ def check_range(gpu_ctx, B, frags, depth, batch, base, op, pred, flags=0):
 
 
 @pytest.mark.parametrize("case", CASES["range_cases"], ids=lambda c: c["test"])
-def test_bsi_range_reference_cases_on_gpu(gpu_ctx, B, case):
+def test_bsi_range_reference_cases_on_gpu(gpu_ctx, B, case, bsi_kernel_form):
     """The reference's TestFragment_Range literals evaluated by the HIP plane-program kernel."""
     depth = max(v[1] for v in case["values"])
     fr = B.bsi_fragment_from_values({v[0]: v[2] for v in case["values"]}, depth)
@@ -227,7 +227,7 @@ def test_bsi_range_reference_cases_on_gpu(gpu_ctx, B, case):
     batch.free()
 
 
-def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B):
+def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B, bsi_kernel_form):
     """TestFragmentBSIUnsigned / Signed (fragment_internal_test.go:3768-4275) on the GPU."""
     k = 6
     fu = B.bsi_fragment_from_values({i: i for i in range(1 << k)}, k)
@@ -248,7 +248,17 @@ def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B):
     batch.free()
 
 
-def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle):
+@pytest.fixture(params=[0, 1], ids=["wavefront-kernels", "block-kernels"])
+def bsi_kernel_form(request, gpu_ctx):
+    """Sum / Range / Between run as one wavefront per (shard, slot) (default) or as round 1's block per (shard, slot)."""
+    for name in ("bsi_sum_blocks", "bsi_range_blocks"):
+        gpu_ctx.set_option(name, request.param)
+    yield request.param
+    for name in ("bsi_sum_blocks", "bsi_range_blocks"):
+        gpu_ctx.set_option(name, 0)
+
+
+def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle, bsi_kernel_form):
     O = oracle
     rng = D.rng_for(61)
     depth = 64
