@@ -1,6 +1,6 @@
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2n
+O=$R/gpurun_out/r2q
 mkdir -p $O
 cd $R
 (timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > $O/pytest.log
@@ -12,6 +12,7 @@ timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o b -- python $R/bench.py --steps 20 --warmup 2 --repeats 2 --no-cpu-baseline --cold-sets 1 --shards4 128 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/misc -o misc -- python $R/scripts/profile_misc.py 64 > $O/misc.json 2> /dev/null
 cd $R
-timeout 300 python scripts/bench_ctops.py --rows 1024 --iters 20 --out $O/ctops.json --only Ary1,Ary16,Ary256,BM4096,Run16,Run1024 2>&1 | grep -v amdgpu.ids | tail -30 > $O/ctops_small.txt
+timeout 120 python scripts/bsi_bench.py 2>&1 | grep -v amdgpu.ids > $O/bsi_bench.txt
+if [ "$CTOPS" = 1 ]; then timeout 300 python scripts/bench_ctops.py --rows 1024 --iters 20 --out $O/ctops.json --only Ary1,Ary16,Ary256,BM4096,Run16,Run1024 2>&1 | grep -v amdgpu.ids | tail -30 > $O/ctops_small.txt; fi
 ls $O $O/kt $O/pmc_fetch | head -30
 tail -3 $O/pytest.log
