@@ -1,10 +1,10 @@
-"""Structural fuzz of the C ABI: random batches (every encoding, missing slots, empty rows), random row index lists
-(repeats, both operands from one batch or from two), random group shapes / matrix shapes / options, every entry point
-of the hot path — compared with set algebra on the oracle containers' bit content (the per-container semantics are
-pinned elsewhere: golden tables, test_gpu_parity.py; this file goes after indexing, scheduling and path-selection
-bugs).  FBK_FUZZ_ITERS=<n> runs more iterations, FBK_TEST_SEED re-rolls them (scripts/fuzz_parity.sh)."""
-import os
-
+"""Differential fuzzing of chained operations, in the spirit of the reference's roaring/fuzzer.go
+(:26-120: random op sequences checked against roaring/naive.go): a population of device
+batches (uploaded flat, dense, from a serialised image, or produced by earlier operations, with
+and without optimize()) is mutated by random set-ops / folds / serialisation round trips, and
+after every step compared bit for bit with an independent numpy bitset model.  Catches state
+bugs the per-kernel tests cannot: stale descriptor copies, the dense flag surviving a sparse
+result, recycled pool blocks, keys carried through chains."""
 import numpy as np
 import pytest
 
@@ -12,212 +12,116 @@ import datagen as D
 from featurebase_amd import lib as L
 
 pytestmark = pytest.mark.gpu
-ITERS = int(os.environ.get("FBK_FUZZ_ITERS", "6"))
-WIDTH = 1 << 20
-popc = lambda w: int(np.bitwise_count(w).sum())  # noqa: E731
+
+N_ROWS = 6  # rows per batch; row r is "shard r": keys r*16 + slot
 
 
-def make_batch(ctx, rng, n_rows):
-    """-> (batch, words [n_rows, 16, 1024])"""
-    p_missing = float(rng.choice([0.0, 0.15, 0.6, 0.95]))
-    rows = [D.random_row(rng, 0, p_missing) if rng.random() > 0.05 else {} for _ in range(n_rows)]
-    W = np.zeros((n_rows, 16, 1024), dtype=np.uint64)
+def model_of_rows(rows):
+    """[n_rows][16][1024] uint64 bitset model of a list of {key: oracle container} rows"""
+    m = np.zeros((len(rows), 16, 1024), dtype=np.uint64)
     for r, row in enumerate(rows):
         for k, c in row.items():
-            W[r, k & 15] = c.words()
-    return ctx.upload([D.to_fbk_row(r) for r in rows]), W
+            m[r, k & 15] = c.words()
+    return m
 
 
-def out_words(batch, n):
-    res = batch.download()
-    assert len(res) == n
-    W = np.zeros((n, 16, 1024), dtype=np.uint64)
-    for r, row in enumerate(res):
+def check(batch, model, what):
+    rows = batch.download()
+    assert len(rows) == model.shape[0], what
+    got = np.zeros_like(model)
+    for r, row in enumerate(rows):
         for k, c in row.items():
-            assert c.n == popc(c.words()) and c.n > 0, (r, k)  # empty results are nil slots
-            W[r, k & 15] = c.words()
-    return W, res
+            assert k >> 4 == r, (what, "key moved", k, r)
+            assert c.n == int(np.bitwise_count(c.words()).sum()) and c.n > 0, (what, "stored n", k)
+            got[r, k & 15] = c.words()
+    assert (got == model).all(), what
+    cnt = batch.count(np.arange(model.shape[0]))
+    assert cnt.tolist() == np.bitwise_count(model).sum(axis=(1, 2)).tolist(), what
 
 
-def check_optimized(O, res):
-    """FBK_SETOP_OPTIMIZE: every container has the encoding Container.optimize() picks for its content."""
-    for row in res:
-        for c in row.values():
-            oc = O.optimize(O.OContainer.bitmap(c.words()))
-            assert c.n and c.typ == oc.typ and c.n == oc.n
-            assert np.array_equal(np.asarray(c.data).reshape(-1), np.asarray(oc.data()).reshape(-1))
-
-
-NP_OPS = {L.OP_AND: np.bitwise_and, L.OP_OR: np.bitwise_or, L.OP_XOR: np.bitwise_xor, L.OP_ANDNOT: lambda a, b: a & ~b}
-
-
-def fold(op, W, ids):
-    acc = W[ids[0]].copy()
-    for i in ids[1:]:
-        acc = NP_OPS[op](acc, W[i])
-    return acc
-
-
-def as_int(w):
-    """[16, 1024] words -> python int (bit i = column i of the row)"""
-    return int.from_bytes(w.tobytes(), "little")
-
-
-@pytest.mark.parametrize("it", range(ITERS))
-def test_fuzz_pairwise_and_folds(gpu_ctx, oracle, it):
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_chained_ops_vs_bitset_model(gpu_ctx, oracle, seed):
     O = oracle
-    rng = D.rng_for(7000, it)
-    X, WX = make_batch(gpu_ctx, rng, int(rng.integers(1, 50)))
-    Y, WY = (X, WX) if rng.random() < 0.3 else make_batch(gpu_ctx, rng, int(rng.integers(1, 50)))
-    n = int(rng.integers(1, 120))
-    ia, ib = rng.integers(0, len(WX), n), rng.integers(0, len(WY), n)
-    for name, val in (("sparse_paths", int(rng.integers(0, 2))), ("setop_direct_encode", int(rng.integers(0, 2))), ("dense_spb", int(rng.choice([1, 2, 4, 8, 16])))):
-        gpu_ctx.set_option(name, val)
-    try:
-        got = gpu_ctx.intersection_count(X, ia, Y, ib)
-        assert got.tolist() == [popc(WX[a] & WY[b]) for a, b in zip(ia, ib)]
-        assert X.count(ia).tolist() == [popc(WX[a]) for a in ia]
-        for op in NP_OPS:
+    ctx = gpu_ctx
+    rng = D.rng_for(seed)
+    pop = []  # (batch, model)
+
+    def add(batch, model, what):
+        check(batch, model, what)
+        pop.append((batch, model))
+        if len(pop) > 8:  # retire the oldest: its blocks go back to the pool and get reused
+            old, _ = pop.pop(int(rng.integers(0, 3)))
+            old.free()
+
+    # seed population: flat upload (mixed encodings), dense upload, serialised image
+    rows = [{r * 16 + (k & 15): c for k, c in D.random_row(rng, 0).items()} for r in range(N_ROWS)]
+    add(ctx.upload([D.to_fbk_row(r) for r in rows]), model_of_rows(rows), "flat")
+    w = D.dense_rows(N_ROWS, 0.4, 700 + seed)
+    add(ctx.upload_dense(w), w.reshape(N_ROWS, 16, 1024).copy(), "dense")
+    rows2 = [{r * 16 + (k & 15): c for k, c in D.random_row(rng, 0).items()} for r in range(N_ROWS)]
+    for r in rows2:
+        r.setdefault((rows2.index(r)) * 16, O.OContainer.array([1]))  # every row id present
+    img = O.OBitmap.from_containers([kv for r in rows2 for kv in r.items()]).marshal(True)
+    b, ids = ctx.upload_roaring(img)
+    assert ids.tolist() == list(range(N_ROWS))
+    add(b, model_of_rows(rows2), "roaring image")
+    w2 = D.dense_rows(N_ROWS, 0.5, 800 + seed)
+    add(ctx.upload_dense(w2), w2.reshape(N_ROWS, 16, 1024).copy(), "dense2")
+
+    npop = {L.OP_AND: np.bitwise_and, L.OP_OR: np.bitwise_or, L.OP_XOR: np.bitwise_xor, L.OP_ANDNOT: lambda a, b: a & ~b}
+    idx = np.arange(N_ROWS)
+    for step in range(60):
+        kind = rng.integers(0, 10)
+        ia, ib = rng.integers(0, len(pop), size=2)
+        (A, ma), (B, mb) = pop[ia], pop[ib]
+        if kind < 5:  # pairwise set-op, random row permutation on the B side
+            op = int(rng.integers(0, 4))
             flags = L.SETOP_OPTIMIZE if rng.random() < 0.5 else 0
-            out, cnt = gpu_ctx.setop(op, X, ia, Y, ib, flags)
-            W, res = out_words(out, n)
-            exp = NP_OPS[op](WX[ia], WY[ib])
-            assert np.array_equal(W, exp), (op, flags)
-            assert cnt.tolist() == [popc(e) for e in exp]
-            if flags:
-                check_optimized(O, res)
-            # a result is an ordinary batch: feed it back in
-            if rng.random() < 0.5:
-                again = gpu_ctx.intersection_count(out, np.arange(n), Y, ib)
-                assert again.tolist() == [popc(e & WY[b]) for e, b in zip(exp, ib)]
+            out, cnt = ctx.setop(op, A, idx, B, idx, flags)
+            m = npop[op](ma, mb)
+            assert cnt.tolist() == np.bitwise_count(m).sum(axis=(1, 2)).tolist(), ("setop counts", step)
+            ic = ctx.intersection_count(A, idx, B, idx)
+            assert ic.tolist() == np.bitwise_count(ma & mb).sum(axis=(1, 2)).tolist(), ("icount", step)
+            add(out, m, f"step {step}: setop {op} flags {flags}")
+        elif kind < 8:  # n-way fold over rows of ONE batch: group g = rows (g, g+1, g+2) mod N
+            op = int(rng.integers(0, 4))
+            k = int(rng.integers(1, 4))
+            groups = np.array([[(g + j) % N_ROWS for j in range(k)] for g in range(N_ROWS)], dtype=np.uint32)
+            out, cnt = ctx.fold_n(op, A, groups, L.SETOP_OPTIMIZE if rng.random() < 0.5 else 0)
+            m = ma[groups[:, 0]].copy()
+            if op == L.OP_ANDNOT:
+                for j in range(1, k):
+                    m &= ~ma[groups[:, j]]
+            else:
+                for j in range(1, k):
+                    m = npop[op](m, ma[groups[:, j]])
+            assert cnt.tolist() == np.bitwise_count(m).sum(axis=(1, 2)).tolist(), ("fold counts", step, op, k)
+            # fold outputs carry the key high bits of each group's first row: re-key to row order
+            rows_out = out.download()
+            got = np.zeros_like(m)
+            for r, row in enumerate(rows_out):
+                for kk, c in row.items():
+                    got[r, kk & 15] = c.words()
+            assert (got == m).all(), ("fold", step, op, k)
             out.free()
-        # plans: the same pairs, count / total / accumulate forms
-        plan = gpu_ctx.plan(X, ia, Y, ib)
-        plan.intersection_count_total()
-        counts, total = plan.read(want_total=True)
-        assert counts.tolist() == got.tolist() and int(total) == int(got.sum())
-        plan.free()
-        # n-way folds over random groups
-        g, k = int(rng.integers(1, 40)), int(rng.integers(1, 9 if rng.random() < 0.8 else 80))
-        groups = rng.integers(0, len(WX), (g, k))
-        F, WF = make_batch(gpu_ctx, rng, g)
-        for op in NP_OPS:
-            flags = L.SETOP_OPTIMIZE if rng.random() < 0.5 else 0
-            gpu_ctx.set_option("fold_register", int(rng.integers(0, 2)))
-            out, cnt = gpu_ctx.fold_n(op, X, groups, flags)
-            W, res = out_words(out, g)
-            exp = np.stack([fold(op, WX, ids) for ids in groups])
-            assert np.array_equal(W, exp), (op, g, k)
-            assert cnt.tolist() == [popc(e) for e in exp]
-            if flags:
-                check_optimized(O, res)
-            out.free()
-            assert gpu_ctx.fold_n_intersection_count(op, X, groups).tolist() == [popc(e) for e in exp]
-            rf = rng.permutation(g)
-            assert gpu_ctx.fold_n_intersection_count(op, X, groups, F, rf).tolist() == [popc(e & WF[f]) for e, f in zip(exp, rf)]
-        out, cnt = gpu_ctx.union_n(X, groups)
-        assert np.array_equal(out_words(out, g)[0], np.stack([fold(L.OP_OR, WX, ids) for ids in groups]))
-        out.free()
-        F.free()
-    finally:
-        for name, val in (("sparse_paths", 1), ("setop_direct_encode", 1), ("dense_spb", 16), ("fold_register", 0)):
-            gpu_ctx.set_option(name, val)
-        if Y is not X:
-            Y.free()
-        X.free()
-
-
-@pytest.mark.parametrize("it", range(ITERS))
-def test_fuzz_count_matrix_and_topk(gpu_ctx, it):
-    rng = D.rng_for(7100, it)
-    n_shards = int(rng.integers(1, 7))
-    n_a = int(rng.integers(1, 40)) if rng.random() < 0.8 else int(rng.integers(40, 80))
-    n_b = int(rng.integers(1, 40))
-    X, WX = make_batch(gpu_ctx, rng, int(rng.integers(1, 90)))
-    dense = rng.random() < 0.25  # bitmap-only operands take the dense kernels
-    if dense:
-        X.free()
-        WX = rng.integers(0, 1 << 63, (int(rng.integers(1, 60)), 16, 1024), dtype=np.uint64) & rng.integers(0, 1 << 63, (1, 16, 1024), dtype=np.uint64)
-        X = gpu_ctx.upload_dense(WX.reshape(-1))
-    ra, rb = rng.integers(0, len(WX), (n_shards, n_a)), rng.integers(0, len(WX), (n_shards, n_b))
-    use_f = rng.random() < 0.7
-    F, WF = make_batch(gpu_ctx, rng, n_shards) if use_f else (None, None)
-    rf = rng.permutation(n_shards) if use_f else None
-    opts = {"matrix_fused": int(rng.integers(-1, 2)), "matrix_densify": int(rng.integers(-1, 2)), "matrix_fp4": int(rng.integers(-1, 2)),
-            "matrix_spb": int(rng.choice([0, 1, 2, 4, 8, 16])), "matrix_valu": int(rng.random() < 0.15),
-            "matrix_pass_kb": int(rng.choice([1 << 20, 64, 4]))}
-    for name, val in opts.items():
-        gpu_ctx.set_option(name, val)
-    try:
-        tot, ps = gpu_ctx.count_matrix(X, ra, X, rb, F, rf, per_shard=True)
-        exp = np.zeros((n_shards, n_a, n_b), dtype=np.uint64)
-        for s in range(n_shards):
-            a = WX[ra[s]].reshape(n_a, -1)
-            if use_f:
-                a = a & WF[rf[s]].reshape(1, -1)
-            b = WX[rb[s]].reshape(n_b, -1)
-            for j in range(n_b):
-                exp[s, :, j] = np.bitwise_count(a & b[j]).sum(axis=1)
-        assert np.array_equal(ps, exp), opts
-        assert np.array_equal(tot, exp.sum(axis=0))
-        assert np.array_equal(gpu_ctx.count_matrix(X, ra, X, rb, F, rf), exp.sum(axis=0))
-        # TopK over the same rows: |row ∩ filter| summed over the shards, count descending, index ascending, zeros dropped
-        gpu_ctx.set_option("topk_device_sort", int(rng.integers(-1, 2)))
-        per_row = np.zeros(n_a, dtype=np.uint64)
-        for s in range(n_shards):
-            a = WX[ra[s]].reshape(n_a, -1)
-            per_row += np.bitwise_count(a & WF[rf[s]].reshape(1, -1) if use_f else a).sum(axis=1).astype(np.uint64)
-        order = sorted((i for i in range(n_a) if per_row[i]), key=lambda i: (-int(per_row[i]), i))
-        for k in (0, 1, int(rng.integers(1, n_a + 1))):
-            idx, cnt = gpu_ctx.topk(X, ra, k, F, rf)
-            e = order[:k] if k else order
-            assert idx.tolist() == e and cnt.tolist() == [int(per_row[i]) for i in e], (k, opts)
-    finally:
-        for name, val in (("matrix_fused", -1), ("matrix_densify", -1), ("matrix_fp4", -1), ("matrix_spb", 0), ("matrix_valu", 0), ("matrix_pass_kb", 1 << 20), ("topk_device_sort", -1)):
-            gpu_ctx.set_option(name, val)
-        if F is not None:
-            F.free()
-        X.free()
-
-
-@pytest.mark.parametrize("it", range(ITERS))
-def test_fuzz_row_transforms(gpu_ctx, oracle, it):
-    """CountRange, Flip, Shift on random rows and random index lists, as arithmetic on 2^20-bit integers."""
-    O = oracle
-    rng = D.rng_for(7200, it)
-    X, WX = make_batch(gpu_ctx, rng, int(rng.integers(1, 40)))
-    n = int(rng.integers(1, 60))
-    rows = rng.integers(0, len(WX), n)
-    ints = [as_int(WX[r]) for r in rows]
-    try:
-        for _ in range(4):
-            a, b = sorted(int(v) for v in rng.integers(0, WIDTH + 1, 2))
-            if rng.random() < 0.3:
-                a, b = (a >> 16) << 16, (b >> 16) << 16
-            got = gpu_ctx.count_range(X, rows, a, b)
-            mask = ((1 << b) - 1) ^ ((1 << a) - 1)
-            assert got.tolist() == [bin(v & mask).count("1") for v in ints], (a, b)
-        for _ in range(3):
-            a, b = sorted(int(v) for v in rng.integers(0, WIDTH, 2))
-            flags = L.SETOP_OPTIMIZE if rng.random() < 0.5 else 0
-            out, cnt = gpu_ctx.flip(X, rows, a, b, flags)
-            W, res = out_words(out, n)
-            mask = ((1 << (b + 1)) - 1) ^ ((1 << a) - 1)
-            assert [as_int(w) for w in W] == [v ^ mask for v in ints], (a, b)
-            assert cnt.tolist() == [bin(v ^ mask).count("1") for v in ints]
-            if flags:
-                check_optimized(O, res)
-            out.free()
-        carry = rng.integers(0, len(WX), n).astype(np.uint32)
-        carry[rng.random(n) < 0.4] = gpu_ctx.NO_ROW
-        for flags in (0, L.SETOP_OPTIMIZE):
-            out, cnt = gpu_ctx.shift(X, rows, carry, flags)
-            W, res = out_words(out, n)
-            exp = [((v << 1) & ((1 << WIDTH) - 1)) | (0 if c == gpu_ctx.NO_ROW else as_int(WX[c]) >> (WIDTH - 1)) for v, c in zip(ints, carry)]
-            assert [as_int(w) for w in W] == exp
-            assert cnt.tolist() == [bin(e).count("1") for e in exp]
-            if flags:
-                check_optimized(O, res)
-            out.free()
-    finally:
-        X.free()
+        elif kind < 9:  # serialise -> upload again (only batches whose keys are row-ordered)
+            img = A.to_roaring()
+            b2, ids = ctx.upload_roaring(img)
+            keep = [r for r in range(N_ROWS) if np.bitwise_count(ma[r]).sum() > 0]
+            assert ids.tolist() == keep, ("roundtrip rows", step)
+            m2 = ma[keep]
+            rows_out = b2.download()
+            got = np.zeros_like(m2)
+            for r, row in enumerate(rows_out):
+                for kk, c in row.items():
+                    got[r, kk & 15] = c.words()
+            assert (got == m2).all(), ("roundtrip", step)
+            assert O.OBitmap.unmarshal(img).count() == int(np.bitwise_count(ma).sum())
+            b2.free()
+        else:  # count ranges
+            s, e = sorted(int(x) for x in rng.integers(0, (1 << 20) + 1, size=2))
+            got = ctx.count_range(A, idx, s, e)
+            bits = np.unpackbits(ma.reshape(N_ROWS, -1).view(np.uint8), axis=1, bitorder="little")
+            assert got.tolist() == bits[:, s:e].sum(axis=1).tolist(), ("count_range", step, s, e)
+    for b, _ in pop:
+        b.free()
