@@ -366,6 +366,12 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
                           cpu_baseline=cpu5, parity="shard 0 vs the oracle" if want_cpu else "unchecked"))
         g, wl, kq = _timed_call(torch, stream, lambda: ctx.bsi_sum(batch, base, depth, rng_out, np.arange(n5)), iters, ctx=ctx)
         out.append(_entry("config5: BSI Sum(filter = the Range result)", "k_bsi_sum_slot", plane_bytes * (depth + 3), g, wl, kq, shards=n5))
+        # the same query in ONE pass over the planes (SURVEY §8d "fused"): must give the two-pass totals
+        fsum, fcnt = ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, kk)
+        assert (fsum == sums).all() and (fcnt == cnts).all(), "config 5 fused Range+Sum: differs from Range then Sum"
+        g, wl, kq = _timed_call(torch, stream, lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, kk), iters, ctx=ctx)
+        out.append(_entry("config5 fused: Sum(Range(> 2^62)) of the same field, one pass over the planes", "k_bsi_range_sum_half", plane_bytes * (depth + 2), g, wl, kq, shards=n5,
+                          parity="equal to the Range-then-Sum totals of the two entries above, every shard"))
         rng_out.free()
         batch.free()
     return out

@@ -87,6 +87,8 @@ struct FbkOptions {
   int64_t bsi_minmax_blocks = 0;         // 1: one block per shard for Min / Max (round-1 kernel, A/B runs); 0: one wavefront per (shard, slot)
   int64_t bsi_sum_blocks = 0;            // 1: one 256-thread block per (shard, slot) for Sum (round-1 kernel, A/B runs); 0: one wavefront
   int64_t bsi_range_blocks = 0;          // 1: one 256-thread block per (shard, slot) for Range (round-1 kernel, A/B runs); 0: one wavefront
+  int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)
+  int64_t bsi_half_waves = 1;            // dense BSI batches: the one-pass Range + Sum runs half a container per wavefront; 0: one wavefront per container (A/B runs)
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
 };
@@ -509,6 +511,8 @@ const OptionDesc kOptions[] = {
     {"bsi_minmax_blocks", &FbkOptions::bsi_minmax_blocks, 0, 1},
     {"bsi_sum_blocks", &FbkOptions::bsi_sum_blocks, 0, 1},
     {"bsi_range_blocks", &FbkOptions::bsi_range_blocks, 0, 1},
+    {"bsi_range_sum_two_pass", &FbkOptions::bsi_range_sum_two_pass, 0, 1},
+    {"bsi_half_waves", &FbkOptions::bsi_half_waves, 0, 1},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
 };

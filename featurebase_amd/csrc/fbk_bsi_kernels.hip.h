@@ -538,6 +538,257 @@ __global__ void __launch_bounds__(64) k_bsi_range_slot(const Slot* __restrict__ 
   }
 }
 
+// ---- Sum over a Range of the SAME field, one pass ("fused") ---------------------
+// Sum(Row(v op k), field = v): the reference runs the range scan (a Row), then fragment.sum with that Row as the
+// filter — every plane is read twice.  The scans of rangeLTUnsigned / rangeGTUnsigned (fragment.go:1070-1208) walk the
+// planes MSB -> LSB with `remaining` X and `matched` M, and a column that ENTERS M at plane i has, above i, exactly the
+// predicate's bits (it survived every X &= (~)plane_j and was not matched earlier) and at i the opposite bit — so its
+// contribution above and at plane i is a constant per plane (vhi[i]), and its bits below i are still to come:
+//     sum over M = Σ_i |newly matched at i| · vhi[i]  +  Σ_i 2^i · |M_before_i ∩ plane_i|
+// — both terms available while plane i is in registers.  The other sign class, where the signed comparison takes it
+// whole (v > k with k < 0 takes every positive column), is a plain sum over the same planes.  uint64 wrap-around is
+// linear, so the totals equal the reference's Σ 2^i · count_i.  plan.action[i]: what the reference's loop does at plane
+// i (it may stop early; the planes below are still read here, for the sums); the host builds it from the same
+// predicate transformations as the plane programs above and falls back to the two-pass path for the special forms.
+// one plane of the one-pass Range + Sum; branch-free over the five actions (uniform masks: specialising the body per
+// action through a switch costs the register allocator 260+ spills at two wavefronts per SIMD, and the kernel waits for
+// memory, not for the vector ALU)
+template <bool OTHER>
+__device__ __forceinline__ void range_sum_plane(uint32_t act, u64 (&X)[kWordsPerLane], u64 (&M)[kWordsPerLane], const u64 (&O)[OTHER ? kWordsPerLane : 1],
+                                                const u64 (&T)[kWordsPerLane], uint32_t& a, uint32_t& o, uint32_t& d) {
+  const u64 inv = (act == 2u || act == 4u) ? ~0ull : 0ull;
+  const u64 keep_x = (act == 1u || act == 2u) ? 0ull : ~0ull;  // X &= tx only for actions 1 / 2
+  const u64 match = act >= 3u ? ~0ull : 0ull;
+#pragma unroll
+  for (int q = 0; q < kWordsPerLane; ++q) {
+    const u64 t = T[q];
+    a += __popcll(M[q] & t);
+    if (OTHER) o += __popcll(O[OTHER ? q : 0] & t);
+    const u64 tx = t ^ inv;
+    const u64 nw = X[q] & tx & ~M[q] & match;
+    d += __popcll(nw);
+    M[q] |= nw;
+    X[q] &= tx | keep_x;
+  }
+}
+
+struct RangeSumPlan {
+  u64 vhi[64];
+  uint8_t action[64];  // 0: sums only; 1: X &= T; 2: X &= ~T; 3: D = X & T & ~M; 4: D = X & ~T & ~M  (D: newly matched)
+  uint32_t depth;
+  uint32_t scan_positive;  // the scanned class: 1 = exists \ sign, 0 = exists ∩ sign
+  uint32_t take_other;     // the other class belongs to the result as a whole
+};
+
+// OTHER: the other sign class is part of the result (one more fragment in registers: two planes in flight instead of three)
+template <bool OTHER>
+__global__ void __launch_bounds__(64) k_bsi_range_sum_slot(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
+                                                          const uint32_t* __restrict__ base, uint32_t n_shards, const RangeSumPlan* __restrict__ planp,
+                                                          const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,
+                                                          const uint32_t* __restrict__ frows, u64* __restrict__ out4) {
+  __shared__ u64 lds[kWords];
+  __shared__ Slot tab[kBsiDescCap];
+  const int lane = threadIdx.x;
+  const uint64_t shard = blockIdx.x >> 4;
+  const uint32_t slot = blockIdx.x & 15;
+  if (shard >= n_shards) return;
+  const uint64_t r0 = base[shard];
+  const RangeSumPlan& plan = *planp;  // (uniform: scalar loads)
+  const uint32_t depth = plan.depth;
+  bsi_stage_descs(slots, r0, slot, depth + 2, lane, tab);
+  if (slot_n(tab[0]) == 0) return;
+  constexpr int kAhead = OTHER ? 2 : 3;
+  u64 X[kWordsPerLane], M[kWordsPerLane], O[OTHER ? kWordsPerLane : 1], T[kAhead][kWordsPerLane];
+  frag_load(tab[0], arena, lane, lds, X);  // consider = exists (∩ filter)
+  if (fslots) {
+    const Slot sf = fslots[(uint64_t)frows[shard] * kSlots + slot];
+    if (slot_n(sf) == 0) return;
+    frag_load(sf, farena, lane, lds, T[0]);
+#pragma unroll
+    for (int q = 0; q < kWordsPerLane; ++q) X[q] &= T[0][q];
+  }
+  if (slot_n(tab[1]) == 0) frag_zero(T[0]);
+  else frag_load(tab[1], arena, lane, lds, T[0]);
+  {
+    const u64 sp = plan.scan_positive ? ~0ull : 0ull;
+#pragma unroll
+    for (int q = 0; q < kWordsPerLane; ++q) {
+      const u64 e = X[q], sg = T[0][q];
+      X[q] = e & (sg ^ sp);          // scan_positive: e & ~sg; else e & sg
+      if (OTHER) O[q] = e & ~(sg ^ sp);  // the other class
+      M[q] = 0;
+    }
+  }
+  auto load_plane = [&](uint32_t i, u64 (&w)[kWordsPerLane]) {
+    const Slot sp = tab[2 + i];
+    if (slot_n(sp) == 0) frag_zero(w);
+    else frag_load(sp, arena, lane, lds, w);
+  };
+  u64 sum_m = 0, sum_o = 0;
+  uint32_t cnt_m = 0;
+#pragma unroll
+  for (int u = 0; u < kAhead; ++u)
+    if ((uint32_t)u < depth) load_plane(depth - 1 - (uint32_t)u, T[u]);
+  for (uint32_t j0 = 0; j0 < depth; j0 += kAhead) {  // j counts planes from the most significant one down
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const uint32_t j = j0 + (uint32_t)u;
+      if (j < depth) {  // (wave-uniform)
+        const uint32_t i = depth - 1 - j;
+        const uint32_t act = plan.action[i];
+        uint32_t a = 0, o = 0, d = 0;
+        range_sum_plane<OTHER>(act, X, M, O, T[u], a, o, d);
+        sum_m += ((u64)a << i) + (u64)d * plan.vhi[i];
+        sum_o += (u64)o << i;
+        cnt_m += d;
+        if (j + kAhead < depth) load_plane(depth - 1 - (j + kAhead), T[u]);
+      }
+    }
+  }
+  uint32_t cnt_o = 0;
+  if (OTHER) {
+#pragma unroll
+    for (int q = 0; q < (OTHER ? kWordsPerLane : 1); ++q) cnt_o += __popcll(O[q]);
+    cnt_o = wave_reduce_add(cnt_o);
+  }
+  cnt_m = wave_reduce_add(cnt_m);
+  sum_m = wave_reduce_add_u64(sum_m);
+  sum_o = wave_reduce_add_u64(sum_o);
+  if (lane == 0) {
+    if (sum_m) atomicAdd(&out4[shard * 4 + 0], sum_m);
+    if (sum_o) atomicAdd(&out4[shard * 4 + 1], sum_o);
+    if (cnt_m) atomicAdd(&out4[shard * 4 + 2], (u64)cnt_m);
+    if (cnt_o) atomicAdd(&out4[shard * 4 + 3], (u64)cnt_o);
+  }
+}
+
+// ---- dense BSI batches: HALF a container per wavefront ---------------------------------------------------------
+// One wavefront per (shard, slot) is 1536 wavefronts for 100 M columns: 6 per CU, i.e. two SIMDs of every CU carry two
+// and two carry one, and at 200+ registers no more fit.  When the batch is in the dense layout (every container a bitmap
+// at (row * 16 + slot) * 8192 — fbk_batch_upload_dense, the bit planes of any field with enough values) the payload of a
+// plane needs no descriptor and no decode, and a (shard, slot) splits into two independent halves of 4 KiB per plane:
+// 3072 wavefronts, 3 per SIMD everywhere, 8 words per lane, four planes in flight.  Sums and counts are reductions, the
+// two halves just add into the same totals.  Used by the one-pass Range + Sum, whose plane step is the heaviest (150 ->
+// 136 us on config 5); the plain Sum gains nothing from it (133 vs 136 us, scripts/bsi_bench.py) and stays with one
+// wavefront per container, as do the Range OUTPUT rows, whose run count crosses the middle.
+constexpr int kHalfWords = 8;
+
+__device__ __forceinline__ void half_load(const uint8_t* __restrict__ p, int lane, u64 (&w)[kHalfWords]) {
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const ulonglong2 v = ld_stream(&q[j * kWave + lane]);
+    w[2 * j] = v.x;
+    w[2 * j + 1] = v.y;
+  }
+}
+
+// half `h` of any container (the filter row may come from anywhere): bitmaps directly, the rest through the full decode
+__device__ __forceinline__ void half_load_any(const Slot& s, const uint8_t* __restrict__ arena, int lane, uint32_t h, u64* lds, u64 (&w)[kHalfWords]) {
+  if (slot_n(s) == 0) {
+#pragma unroll
+    for (int q = 0; q < kHalfWords; ++q) w[q] = 0;
+  } else if (slot_type(s) == kTypeBitmap) {
+    half_load(arena + s.off + h * 4096u, lane, w);
+  } else {
+    u64 full[kWordsPerLane];
+    frag_load(s, arena, lane, lds, full);
+#pragma unroll
+    for (int q = 0; q < kHalfWords; ++q) w[q] = h ? full[kHalfWords + q] : full[q];
+  }
+}
+
+template <bool OTHER>
+__global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ base, uint32_t n_shards,
+                                                          const RangeSumPlan* __restrict__ planp, const Slot* __restrict__ fslots,
+                                                          const uint8_t* __restrict__ farena, const uint32_t* __restrict__ frows, u64* __restrict__ out4) {
+  __shared__ u64 lds[kWords];
+  const int lane = threadIdx.x;
+  const uint32_t h = blockIdx.x & 1u;
+  const uint64_t cell = blockIdx.x >> 1;
+  const uint64_t shard = cell >> 4;
+  const uint32_t slot = cell & 15;
+  if (shard >= n_shards) return;
+  const RangeSumPlan& plan = *planp;
+  const uint32_t depth = plan.depth;
+  const uint8_t* const row0 = arena + ((uint64_t)base[shard] * kSlots + slot) * 8192ull + h * 4096u;
+  constexpr uint64_t kRow = (uint64_t)kSlots * 8192ull;
+  constexpr int kAhead = 4;
+  u64 X[kHalfWords], M[kHalfWords], O[OTHER ? kHalfWords : 1], T[kAhead][kHalfWords];
+  half_load(row0, lane, X);
+  if (fslots) {
+    half_load_any(fslots[(uint64_t)frows[shard] * kSlots + slot], farena, lane, h, lds, T[0]);
+#pragma unroll
+    for (int q = 0; q < kHalfWords; ++q) X[q] &= T[0][q];
+  }
+  {
+    uint32_t any = 0;
+#pragma unroll
+    for (int q = 0; q < kHalfWords; ++q) any |= (uint32_t)(X[q] != 0);
+    if (__ballot(any != 0) == 0) return;  // nothing to consider in this half
+  }
+  half_load(row0 + kRow, lane, T[0]);
+  {
+    const u64 sp = plan.scan_positive ? ~0ull : 0ull;
+#pragma unroll
+    for (int q = 0; q < kHalfWords; ++q) {
+      const u64 e = X[q], sg = T[0][q];
+      X[q] = e & (sg ^ sp);
+      if (OTHER) O[q] = e & ~(sg ^ sp);
+      M[q] = 0;
+    }
+  }
+  u64 sum_m = 0, sum_o = 0;
+  uint32_t cnt_m = 0;
+#pragma unroll
+  for (int u = 0; u < kAhead; ++u)
+    if ((uint32_t)u < depth) half_load(row0 + kRow * (2u + depth - 1 - (uint32_t)u), lane, T[u]);
+  for (uint32_t j0 = 0; j0 < depth; j0 += kAhead) {
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const uint32_t j = j0 + (uint32_t)u;
+      if (j < depth) {
+        const uint32_t i = depth - 1 - j;
+        const uint32_t act = plan.action[i];
+        const u64 inv = (act == 2u || act == 4u) ? ~0ull : 0ull;
+        const u64 keep_x = (act == 1u || act == 2u) ? 0ull : ~0ull;
+        const u64 match = act >= 3u ? ~0ull : 0ull;
+        uint32_t a = 0, o = 0, d = 0;
+#pragma unroll
+        for (int q = 0; q < kHalfWords; ++q) {
+          const u64 t = T[u][q];
+          a += __popcll(M[q] & t);
+          if (OTHER) o += __popcll(O[OTHER ? q : 0] & t);
+          const u64 tx = t ^ inv;
+          const u64 nw = X[q] & tx & ~M[q] & match;
+          d += __popcll(nw);
+          M[q] |= nw;
+          X[q] &= tx | keep_x;
+        }
+        sum_m += ((u64)a << i) + (u64)d * plan.vhi[i];
+        sum_o += (u64)o << i;
+        cnt_m += d;
+        if (j + kAhead < depth) half_load(row0 + kRow * (2u + depth - 1 - (j + kAhead)), lane, T[u]);
+      }
+    }
+  }
+  uint32_t cnt_o = 0;
+  if (OTHER) {
+#pragma unroll
+    for (int q = 0; q < (OTHER ? kHalfWords : 1); ++q) cnt_o += __popcll(O[q]);
+    cnt_o = wave_reduce_add(cnt_o);
+  }
+  cnt_m = wave_reduce_add(cnt_m);
+  sum_m = wave_reduce_add_u64(sum_m);
+  sum_o = wave_reduce_add_u64(sum_o);
+  if (lane == 0) {
+    if (sum_m) atomicAdd(&out4[shard * 4 + 0], sum_m);
+    if (sum_o) atomicAdd(&out4[shard * 4 + 1], sum_o);
+    if (cnt_m) atomicAdd(&out4[shard * 4 + 2], (u64)cnt_m);
+    if (cnt_o) atomicAdd(&out4[shard * 4 + 3], (u64)cnt_o);
+  }
+}
+
 // ---- BSI Min / Max ------------------------------------------------------------------------------
 // fragment.min / fragment.max / minUnsigned / maxUnsigned (fragment.go:754-853).  The scan
 // over the bit planes is sequential and every step needs the cardinality of a whole ROW

@@ -566,6 +566,18 @@ class Context:
         L.check(self.lib.fbk_bsi_range(self.h, batch.h, base.ctypes.data, base.size, op, bit_depth, predicate, flags, C.byref(h), counts.ctypes.data))
         return Batch(self, h.value), counts
 
+    def bsi_range_sum(self, batch: Batch, base_rows, op: int, bit_depth: int, predicate: int, filt: Optional[Batch] = None, rows_f=None):
+        """Sum(Row(v op predicate), field = v) in one pass over the planes: (sums int64[n_shards], counts uint64[n_shards]),
+        equal to bsi_sum with filter = bsi_range(op, predicate) (∩ filt)."""
+        b = np.ascontiguousarray(base_rows, dtype=np.uint32)
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        sums = np.zeros(b.size, dtype=np.int64)
+        counts = np.zeros(b.size, dtype=np.uint64)
+        L.check(self.lib.fbk_bsi_range_sum(self.h, batch.h, b.ctypes.data, b.size, op, bit_depth, C.c_int64(predicate),
+                                           filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None,
+                                           sums.ctypes.data, counts.ctypes.data))
+        return sums, counts
+
     def bsi_range_between(self, batch: Batch, base_rows, bit_depth: int, lo: int, hi: int, flags: int = 0) -> Tuple[Batch, np.ndarray]:
         base = np.ascontiguousarray(base_rows, dtype=np.uint32)
         counts = np.zeros(base.size, dtype=np.uint64)

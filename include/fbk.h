@@ -135,7 +135,7 @@ int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
  * FBK_<NAME> are read ONCE, by fbk_open; afterwards only these calls change an option.  Names:
  * dense_spb, fold_register, matrix_valu, matrix_spb, matrix_pass_kb, matrix_densify, matrix_fused,
  * matrix_fp4, bsi_minmax_blocks, bsi_sum_blocks,
- * bsi_range_blocks, topk_device_sort, sparse_paths, setop_direct_encode.
+ * bsi_range_blocks, bsi_range_sum_two_pass, bsi_half_waves, topk_device_sort, sparse_paths, setop_direct_encode.
  * Measurement: time_kernels = 1 makes the query-level calls (count matrix, n-way fold, BSI range /
  * sum / min / max) record HIP events on the context's stream right before and after their dominant kernel;
  * fbk_get_option("last_kernel_ns") then returns that kernel's duration for the last such call. */
@@ -503,6 +503,28 @@ int32_t fbk_bsi_add(fbk_ctx* ctx, const fbk_batch* x, const uint32_t* rows_x, ui
 int32_t fbk_bsi_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards,
                       int32_t op, uint32_t bit_depth, int64_t predicate, uint32_t flags, fbk_batch** out_batch,
                       uint64_t* out_counts);
+
+/* Sum(Row(v op predicate), field = v) — the values of the columns that satisfy a range predicate on the SAME BSI
+ * field, summed: executeSumCountShard (executor.go:2155) with the filter that executeRowBSIGroupShard (:5249) builds
+ * from fragment.rangeOp.  The reference computes the range as a Row and then runs fragment.sum with that Row as the
+ * filter (fragment.go:724-750): every bit plane is read twice.  Here one pass: a column that the MSB -> LSB scan
+ * matches at plane i has the predicate's bits above i, so its high part is a constant per plane and its low planes
+ * are still to come (k_bsi_range_sum_slot).  `filter` (optional, rows_f[s] per shard) restricts the
+ * columns first, as Sum(Intersect(Row(v op k), <filter>), field = v).  out_sums[s] / out_counts[s] equal fbk_bsi_sum
+ * with filter = fbk_bsi_range(op, predicate) (∩ filter) bit for bit; the reference's special forms (predicate 0,
+ * saturated predicates, EQ / NEQ) run as exactly those two calls. */
+int32_t fbk_bsi_range_sum(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards, int32_t op,
+                          uint32_t bit_depth, int64_t predicate, const fbk_batch* filter, const uint32_t* rows_f,
+                          int64_t* out_sums, uint64_t* out_counts);
+
+/* The per-plane schedule fbk_bsi_range_sum runs for (op, bit_depth, predicate) — host arithmetic only, no device:
+ * out_actions[i] (64 entries) = what happens at plane i (0 sums only, 1 remaining &= plane, 2 remaining &= ~plane,
+ * 3 matched |= remaining & plane, 4 matched |= remaining & ~plane), out_vhi[i] (64) = value of a column matched at
+ * plane i above and at that plane, *out_scan_positive = the scanned sign class, *out_take_other = the other class
+ * belongs to the result as a whole.  Returns 1 (not an error) when this predicate takes the two-pass path.  For
+ * tests and for callers that want to know which path a query will take. */
+int32_t fbk_bsi_range_sum_plan(int32_t op, uint32_t bit_depth, int64_t predicate, uint8_t* out_actions, uint64_t* out_vhi,
+                               uint32_t* out_scan_positive, uint32_t* out_take_other);
 
 /* lo <= value <= hi (fragment.rangeBetween, fragment.go:1213-1303). */
 int32_t fbk_bsi_range_between(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows,

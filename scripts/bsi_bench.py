@@ -70,6 +70,21 @@ for op, pred, what in ((L.BSI_GT, 1 << 62, "Range(> 2^62)"), (L.BSI_LT, -5, "Ran
         line(f"{what:16s} {'k_bsi_range (block)' if blocks else 'k_bsi_range_slot (wavefront)'}", plane_bytes * (depth + 3), lambda: ctx.bsi_range(batch, base, op, depth, pred)[0].free())
     assert outs[0] == outs[1], "Range: the two kernels disagree"
 ctx.set_option("bsi_range_blocks", 0)
+for two_pass in (1, 0):
+    ctx.set_option("bsi_range_sum_two_pass", two_pass)
+    r = ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, 1 << 62)
+    if two_pass:
+        ref_rs = r
+        continue
+    for hw in (0, 1):
+        ctx.set_option("bsi_half_waves", hw)
+        r = ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, 1 << 62)
+        assert (ref_rs[0] == r[0]).all() and (ref_rs[1] == r[1]).all(), "Range+Sum: one pass and two passes disagree"
+        print("  bsi_half_waves =", hw)
+        line("Sum(Range(> 2^62)) one pass  k_bsi_range_sum_slot / _half", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, 1 << 62))
+        line("Sum(Range(< -5)) one pass    k_bsi_range_sum_slot / _half", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_LT, depth, -5))
+        line("Sum(Range(> -5)) one pass    ..<other class>", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, -5))
+print("  (two passes: the Range and the Sum(filter) lines above, one after the other)")
 for blocks in (1, 0):
     ctx.set_option("bsi_minmax_blocks", blocks)
     line(f"Min          {'k_bsi_minmax (block per shard)' if blocks else 'k_bsi_minmax_slot (wavefront per (shard, slot))'}", plane_bytes * (depth + 2), lambda: ctx.bsi_min(batch, base, depth))

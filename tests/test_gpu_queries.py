@@ -297,6 +297,96 @@ def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle, bsi_kernel_for
     F.free()
 
 
+def test_bsi_range_sum_one_pass_equals_range_then_sum(gpu_ctx, B, oracle):
+    """fbk_bsi_range_sum (one pass over the planes) == fbk_bsi_sum over fbk_bsi_range == the oracle's fragment.sum over
+    fragment.rangeOp, per shard, bit for bit: every operation, predicates around the reference's special forms and
+    around stored values, with and without an extra filter row, mixed plane encodings, a shard without values."""
+    rng = D.rng_for(63)
+    depth = 64
+    frags, filts, vals_all = [], [], []
+    for s in range(6):
+        ncol = [30000, 2500, 150, 1 << 15, 9, 0][s]
+        cols = rng.choice(1 << 20, size=ncol, replace=False)
+        mag = rng.integers(0, 1 << 62, size=ncol) * (1 if s != 3 else 0) + rng.integers(0, 1000, size=ncol)
+        sign = np.where(rng.random(ncol) < 0.45, -1, 1)
+        vals = {int(c): int(m) * int(g) for c, m, g in zip(cols, mag, sign)}
+        vals_all.append(vals)
+        frags.append(B.bsi_fragment_from_values(vals, depth))
+        filts.append(B.row_from_columns([int(c) for c in cols[:: 2 + s]] + [5, 70000]))
+    batch, base = upload_bsi(gpu_ctx, frags)
+    F = gpu_ctx.upload([fbk_row_of_bitmap(f) for f in filts])
+    rf = np.arange(len(frags))
+    svals = sorted(vals_all[0].values())
+    preds = [svals[len(svals) // 2], svals[len(svals) // 4], svals[0], svals[-1], 0, 1, -1, 2, -2, 500, -500, (1 << 63) - 1, -(1 << 63), 1 << 62, -(1 << 62)]
+    try:
+        for two_pass in (0, 1):
+            gpu_ctx.set_option("bsi_range_sum_two_pass", two_pass)
+            for name, op in B.OPS.items():
+                for p in preds if not two_pass else preds[:3]:
+                    sums, cnts = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p)
+                    fs, fc = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p, F, rf)
+                    for s, fr in enumerate(frags):
+                        e = B.bsi_range(fr, op, depth, p)
+                        assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(fr, e, True), (name, p, s, two_pass)
+                        assert (int(fs[s]), int(fc[s])) == B.bsi_sum(fr, e.intersect(filts[s]), True), (name, p, s, "filter", two_pass)
+    finally:
+        gpu_ctx.set_option("bsi_range_sum_two_pass", 0)
+    # a shallower field, whose predicates saturate
+    d2 = 10
+    v2 = {int(c): int(v) for c, v in zip(rng.choice(1 << 20, size=4000, replace=False), rng.integers(-1023, 1024, size=4000))}
+    fr2 = B.bsi_fragment_from_values(v2, d2)
+    b2, base2 = upload_bsi(gpu_ctx, [fr2])
+    for name, op in B.OPS.items():
+        for p in (-1024, -1023, -1022, -512, -3, 3, 511, 512, 1022, 1023, 1024, 5000):
+            sums, cnts = gpu_ctx.bsi_range_sum(b2, base2, L.BSI_OPS[name], d2, p)
+            assert (int(sums[0]), int(cnts[0])) == B.bsi_sum(fr2, B.bsi_range(fr2, op, d2, p), True), (name, p)
+    for b in (batch, F, b2):
+        b.free()
+
+
+def test_bsi_dense_batches_half_container_kernels(gpu_ctx, B, oracle):
+    """A BSI batch in the dense layout (fbk_batch_upload_dense) takes the half-container-per-wavefront kernel for the
+    one-pass Range + Sum: same totals as one wavefront per container (option bsi_half_waves=0) and as the oracle, with
+    filters of every encoding, empty halves, a shard whose exists row is empty (Sum on the dense batch alongside)."""
+    O = oracle
+    rng = D.rng_for(64)
+    n_sh, depth = 4, 13
+    w = rng.integers(0, 1 << 63, (n_sh, depth + 2, 16, 1024), dtype=np.uint64) * 2 + rng.integers(0, 2, (n_sh, depth + 2, 16, 1024), dtype=np.uint64)
+    w[:, 0] &= rng.integers(0, 1 << 63, (n_sh, 16, 1024), dtype=np.uint64)  # exists: about half of the columns
+    w[:, 0, 3, 512:] = 0   # second half of a container without values
+    w[:, 0, 4, :512] = 0   # first half
+    w[:, 0, 5] = 0         # a whole container
+    w[2, 0] = 0            # a shard without values
+    w[:, 5] = 0            # an empty plane
+    batch = gpu_ctx.upload_dense(w.reshape(-1))
+    base = np.arange(n_sh, dtype=np.uint32) * (depth + 2)
+    frags = [B.Fragment([O.OBitmap.from_containers([(sl, O.OContainer.bitmap(w[s, r, sl])) for sl in range(16) if w[s, r, sl].any()]) for r in range(depth + 2)]) for s in range(n_sh)]
+    filt_rows = [D.random_row(rng, 0, p_missing=0.2) for _ in range(n_sh)]
+    F = gpu_ctx.upload([D.to_fbk_row(r) for r in filt_rows])
+    fbms = [O.OBitmap.from_containers(list(r.items())) for r in filt_rows]
+    rf = np.arange(n_sh)
+    try:
+        for hw in (1, 0):
+            gpu_ctx.set_option("bsi_half_waves", hw)
+            sums, cnts = gpu_ctx.bsi_sum(batch, base, depth)
+            fs, fc = gpu_ctx.bsi_sum(batch, base, depth, F, rf)
+            for s in range(n_sh):
+                assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(frags[s], None, False), (s, hw)
+                assert (int(fs[s]), int(fc[s])) == B.bsi_sum(frags[s], fbms[s], True), (s, hw)
+            for name, op in B.OPS.items():
+                for p in (100, -100, 4000, -4000, 8191, -8191, 1, -1, 0):
+                    sums, cnts = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p)
+                    fs, fc = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p, F, rf)
+                    for s in range(n_sh):
+                        e = B.bsi_range(frags[s], op, depth, p)
+                        assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(frags[s], e, True), (name, p, s, hw)
+                        assert (int(fs[s]), int(fc[s])) == B.bsi_sum(frags[s], e.intersect(fbms[s]), True), (name, p, s, hw, "filter")
+    finally:
+        gpu_ctx.set_option("bsi_half_waves", 1)
+    batch.free()
+    F.free()
+
+
 def test_bsi_minmax_reference_cases_on_gpu(gpu_ctx, B):
     """TestFragment_MinMax (fragment_internal_test.go:524-604) through fbk_bsi_min / fbk_bsi_max."""
     mc = CASES["minmax_case"]

@@ -1,0 +1,98 @@
+"""fbk_bsi_range_sum's per-plane schedule (host arithmetic, exported as fbk_bsi_range_sum_plan) against the oracle:
+the schedule is executed here on Python sets exactly as k_bsi_range_sum_slot executes it on bit planes — matched /
+remaining, the constant high part of a column at the plane where it is matched, the low planes added as they come —
+and the totals must equal fragment.sum over fragment.rangeOp (oracle/pybsi.py), for every operation, predicates around
+every special form of the reference (0, +-1, saturated, beyond the bit depth), several depths."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import datagen as D
+from featurebase_amd import lib as L
+
+U64 = (1 << 64) - 1
+
+
+def plan(op, depth, pred):
+    lib = L.load()
+    act = (C.c_uint8 * 64)()
+    vhi = (C.c_uint64 * 64)()
+    sp, to = C.c_uint32(), C.c_uint32()
+    rc = lib.fbk_bsi_range_sum_plan(op, depth, C.c_int64(pred), act, vhi, C.byref(sp), C.byref(to))
+    assert rc in (0, 1), rc
+    return None if rc else (list(act), list(vhi), bool(sp.value), bool(to.value))
+
+
+def run_plan(values, depth, pl):
+    """values: column -> signed value (sign-magnitude planes, fragment.go:62-65).  -> (sum mod 2^64 as int64, count)"""
+    act, vhi, scan_positive, take_other = pl
+    pos = {c for c, v in values.items() if v >= 0}
+    neg = set(values) - pos
+    X = set(pos if scan_positive else neg)
+    O = set(neg if scan_positive else pos) if take_other else set()
+    M = set()
+    sum_m = sum_o = 0
+    for i in range(depth - 1, -1, -1):
+        plane = {c for c, v in values.items() if (abs(v) >> i) & 1}
+        sum_m += len(M & plane) << i
+        sum_o += len(O & plane) << i
+        a = act[i]
+        if a == 1:
+            X &= plane
+        elif a == 2:
+            X -= plane
+        elif a in (3, 4):
+            new = ((X & plane) if a == 3 else (X - plane)) - M
+            sum_m += len(new) * vhi[i]
+            M |= new
+    total = (sum_m - sum_o) if scan_positive else (sum_o - sum_m)
+    total &= U64
+    return total - (1 << 64) if total >> 63 else total, len(M) + len(O)
+
+
+def oracle_range_sum(B, frag, op, depth, pred):
+    rng = B.bsi_range(frag, op, depth, pred)
+    return B.bsi_sum(frag, rng, True)
+
+
+@pytest.mark.parametrize("depth", [1, 5, 12, 63, 64])
+def test_schedule_equals_range_then_sum(oracle, depth):
+    from oracle import pybsi as B
+
+    B._lib()
+    rng = D.rng_for(8100, depth)
+    lim = (1 << depth) - 1
+    ncol = 300
+    cols = rng.choice(1 << 20, size=ncol, replace=False)
+    mags = [int(rng.integers(0, lim + 1)) if depth < 63 else int(rng.integers(0, 1 << 62)) * 2 + int(rng.integers(0, 2)) for _ in range(ncol)]
+    mags[:6] = [0, 0, lim, lim, 1, min(lim, 2)]  # zeros (of both signs below), the all-ones magnitude
+    if depth == 64:
+        mags = [min(m, (1 << 63) - 1) for m in mags]  # int64 values
+        lim = (1 << 63) - 1
+    signs = [1 if rng.random() < 0.5 else -1 for _ in range(ncol)]
+    values = {int(c): m * s for c, m, s in zip(cols, mags, signs)}
+    frag = B.bsi_fragment_from_values(values, depth)
+    some = [int(abs(v)) for v in list(values.values())[:12]]
+    preds = {0, 1, -1, 2, -2, lim, -lim, lim - 1, -(lim - 1), lim + 1 if lim < (1 << 63) - 1 else lim, -(lim + 1), (1 << 63) - 1, -(1 << 63)}
+    for m in some:
+        preds |= {m, -m, m + 1, -(m + 1), max(m - 1, 0)}
+    fused = two_pass = 0
+    for name, op in B.OPS.items():
+        for pred in sorted(p for p in preds if -(1 << 63) <= p < (1 << 63)):
+            pl = plan(L.BSI_OPS[name], depth, pred)
+            if pl is None:
+                two_pass += 1
+                continue
+            fused += 1
+            exp = oracle_range_sum(B, frag, op, depth, pred)
+            assert run_plan(values, depth, pl) == (int(exp[0]), int(exp[1])), (name, pred, depth)
+    assert fused > (20 if depth > 1 else 0) and two_pass > 0
+
+
+def test_special_forms_take_the_two_pass_path():
+    for name, pred in (("EQ", 5), ("NEQ", 5), ("GT", 0), ("GTE", 0), ("LT", 0), ("LTE", 0), ("GT", -1), ("LT", 1)):
+        assert plan(L.BSI_OPS[name], 16, pred) is None, (name, pred)
+    assert plan(L.BSI_OPS["LT"], 8, 255) is None and plan(L.BSI_OPS["LT"], 8, 300) is None  # saturated / beyond the depth
+    assert plan(L.BSI_OPS["GT"], 8, 300) is None
+    assert plan(L.BSI_OPS["GT"], 8, 7) is not None and plan(L.BSI_OPS["LTE"], 8, -7) is not None
