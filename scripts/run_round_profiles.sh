@@ -1,6 +1,6 @@
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2q
+O=$R/gpurun_out/r2t
 mkdir -p $O
 cd $R
 (timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > $O/pytest.log
