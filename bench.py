@@ -670,7 +670,12 @@ def main():
         secondary = None
         if n_gpus == 1 and not args.no_secondary:
             t_s0 = time.perf_counter()
-            secondary = secondary_configs(torch, dev, ctx, stream, pre3, args, not args.no_cpu_baseline)
+            try:
+                secondary = secondary_configs(torch, dev, ctx, stream, pre3, args, not args.no_cpu_baseline)
+            except Exception as e:  # the headline above is measured already: a failing secondary entry must not cost the bench line
+                import traceback
+
+                secondary = [{"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc().splitlines()[-6:]}]
             extra["secondary_wall_s"] = time.perf_counter() - t_s0
 
     # max over ranks
