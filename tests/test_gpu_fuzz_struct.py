@@ -222,3 +222,105 @@ def test_fuzz_row_transforms(gpu_ctx, oracle, it):
             out.free()
     finally:
         X.free()
+
+
+@pytest.mark.parametrize("it", range(ITERS))
+def test_fuzz_bsi(gpu_ctx, oracle, it):
+    """BSI fragments of random depth (every remainder of the kernels' plane pipelines), shard count, value distribution
+    (so that planes come out as arrays, runs, bitmaps or nothing) — or dense-layout batches — with random filters and
+    predicates: Sum, Range (all operations), Between, Min, Max and the one-pass Range + Sum, every kernel form, against
+    the oracle's fragment.sum / rangeOp / rangeBetween / min / max."""
+    from oracle import pybsi as B
+
+    B._lib()
+    O = oracle
+    rng = D.rng_for(7300, it)
+    depth = int(rng.integers(1, 65))
+    n_sh = int(rng.integers(1, 5))
+    lim = (1 << min(depth, 63)) - 1
+    frags, filts = [], []
+    dense = rng.random() < 0.3
+    for s in range(n_sh):
+        ncol = int(rng.choice([0, 3, 200, 5000, 20000]))
+        span = int(rng.choice([1 << 20, 1 << 16, 70000]))
+        cols = rng.choice(span, size=min(ncol, span), replace=False)
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            mag = [int(rng.integers(0, lim + 1)) if lim < (1 << 62) else int(rng.integers(0, 1 << 62)) * 2 + int(rng.integers(0, 2)) for _ in cols]
+        elif kind == 1:  # few distinct small values: sparse upper planes, run-structured lower ones
+            mag = [min(lim, int(v)) for v in rng.integers(0, 7, size=len(cols))]
+        else:  # clustered around one value
+            c0 = int(rng.integers(0, lim + 1)) if lim < (1 << 62) else int(rng.integers(0, 1 << 62))
+            mag = [min(lim, max(0, c0 + int(d))) for d in rng.integers(-50, 50, size=len(cols))]
+        sign = np.where(rng.random(len(cols)) < rng.choice([0.0, 0.4, 1.0]), -1, 1)
+        vals = {int(c): int(m) * int(g) for c, m, g in zip(cols, mag, sign)}
+        frags.append(B.bsi_fragment_from_values(vals, depth))
+        fr = D.random_row(rng, 0, p_missing=float(rng.choice([0.0, 0.5])))
+        if len(cols) and rng.random() < 0.7:  # make sure the filter meets the values somewhere
+            fr[int(cols[0]) >> 16] = O.OContainer.array(sorted({int(c) & 0xFFFF for c in cols if (int(c) >> 16) == (int(cols[0]) >> 16)})[:4000])
+        filts.append(O.OBitmap.from_containers(list(fr.items())))
+    if dense:
+        w = np.zeros((n_sh, depth + 2, 16, 1024), dtype=np.uint64)
+        for s, fr in enumerate(frags):
+            for r, bm in enumerate(fr.rows):
+                if bm is not None:
+                    for k, c in bm.items():
+                        w[s, r, k & 15] = c.words()
+        batch = gpu_ctx.upload_dense(w.reshape(-1))
+        base = np.arange(n_sh, dtype=np.uint32) * (depth + 2)
+    else:
+        rows, base = [], []
+        for fr in frags:
+            base.append(len(rows))
+            for r, bm in enumerate(fr.rows):
+                rows.append({r * 16 + (k & 15): D.to_fbk(c) for k, c in bm.items() if c.n} if bm is not None else {})
+        batch, base = gpu_ctx.upload(rows), np.array(base, dtype=np.uint32)
+    F = gpu_ctx.upload([{k & 15: D.to_fbk(c) for k, c in f.items() if c.n} for f in filts])
+    rf = np.arange(n_sh)
+    form = int(rng.integers(0, 2))
+    for name in ("bsi_sum_blocks", "bsi_range_blocks", "bsi_minmax_blocks"):
+        gpu_ctx.set_option(name, form)
+    gpu_ctx.set_option("bsi_half_waves", int(rng.integers(0, 2)))
+    try:
+        for use_f in (False, True):
+            fa = (F, rf) if use_f else (None, None)
+            sums, cnts = gpu_ctx.bsi_sum(batch, base, depth, *fa)
+            mn, mnc = gpu_ctx.bsi_min(batch, base, depth, *fa)
+            mx, mxc = gpu_ctx.bsi_max(batch, base, depth, *fa)
+            for s, fr in enumerate(frags):
+                f = filts[s] if use_f else None
+                assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(fr, f, use_f), ("sum", s, use_f, depth)
+                assert (int(mn[s]), int(mnc[s])) == B.bsi_min(fr, f, depth), ("min", s, use_f, depth)
+                assert (int(mx[s]), int(mxc[s])) == B.bsi_max(fr, f, depth), ("max", s, use_f, depth)
+        some = [0, 1, -1, lim, -lim, lim + 1 if lim < (1 << 62) else lim, int(rng.integers(-lim, lim + 1)) if lim < (1 << 62) else int(rng.integers(-(1 << 62), 1 << 62))]
+        for name, op in B.OPS.items():
+            for p in [some[int(j)] for j in rng.choice(len(some), size=3, replace=False)]:
+                flags = L.SETOP_OPTIMIZE if rng.random() < 0.5 else 0
+                out, cnt = gpu_ctx.bsi_range(batch, base, L.BSI_OPS[name], depth, p, flags)
+                res = out.download()
+                rs, rc = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p)
+                fs, fc = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p, F, rf)
+                for s, fr in enumerate(frags):
+                    e = B.bsi_range(fr, op, depth, p)
+                    got = {k & 15: c for k, c in res[s].items()}
+                    exp = {k & 15: c for k, c in e.items() if c.n}
+                    assert set(got) == set(exp) and all((got[k].words() == exp[k].words()).all() for k in exp), (name, p, s, depth)
+                    assert int(cnt[s]) == e.count()
+                    assert (int(rs[s]), int(rc[s])) == B.bsi_sum(fr, e, True), ("range_sum", name, p, s, depth)
+                    assert (int(fs[s]), int(fc[s])) == B.bsi_sum(fr, e.intersect(filts[s]), True), ("range_sum+filter", name, p, s, depth)
+                out.free()
+        lo, hi = sorted(int(v) for v in (rng.integers(-lim, lim + 1, 2) if lim < (1 << 62) else rng.integers(-(1 << 62), 1 << 62, 2)))
+        out, cnt = gpu_ctx.bsi_range_between(batch, base, depth, lo, hi)
+        res = out.download()
+        for s, fr in enumerate(frags):
+            e = B.bsi_range_between(fr, depth, lo, hi)
+            assert int(cnt[s]) == e.count(), ("between", lo, hi, s, depth)
+            got = {k & 15: c for k, c in res[s].items()}
+            assert all((got[k & 15].words() == c.words()).all() for k, c in e.items() if c.n)
+        out.free()
+    finally:
+        for name in ("bsi_sum_blocks", "bsi_range_blocks", "bsi_minmax_blocks"):
+            gpu_ctx.set_option(name, 0)
+        gpu_ctx.set_option("bsi_half_waves", 1)
+        batch.free()
+        F.free()
