@@ -540,7 +540,8 @@ int32_t fbk_bsi_range_between(fbk_ctx* ctx, const fbk_batch* batch, const uint32
  * filter opens one container per row); here every row is examined at once (16 lanes read a row's 16 descriptors,
  * one lane probes the column's container) and the survivors are compacted in order.
  *   column  FBK_NO_COLUMN, or a column of the shard (0 .. 2^20 - 1): the row must contain it
- *   limit   0 = none; else the reference's composition [column filter, limit filter]: the limit filter spends one
+ *   limit   0 = none (a PQL `limit=0` is NewBitmapRowLimitFilter(0), which ends the scan at once: the caller returns no
+ *           rows without calling); else the reference's composition [column filter, limit filter]: the limit filter spends one
  *           of its rows on every row in which the scan looks at a container, matching or not.  Without a column
  *           that is every non-empty row (result: the first `limit` non-empty rows).  With a column the scan leaves a
  *           row r in which it saw the column's slot c (or a later one) by skipping to key (r + 1, c), so a row whose
