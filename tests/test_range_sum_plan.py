@@ -96,3 +96,29 @@ def test_special_forms_take_the_two_pass_path():
     assert plan(L.BSI_OPS["LT"], 8, 255) is None and plan(L.BSI_OPS["LT"], 8, 300) is None  # saturated / beyond the depth
     assert plan(L.BSI_OPS["GT"], 8, 300) is None
     assert plan(L.BSI_OPS["GT"], 8, 7) is not None and plan(L.BSI_OPS["LTE"], 8, -7) is not None
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5, 6])
+def test_schedule_exhaustive_small_depths(oracle, depth):
+    """Every magnitude of the depth with both signs (one column each), every operation, every predicate from below
+    -(2^depth) to above 2^depth: the schedule (where there is one) gives the oracle's Range-then-Sum totals."""
+    from oracle import pybsi as B
+
+    B._lib()
+    top = 1 << depth
+    values, col = {}, 0
+    for m in range(top):
+        for sgn in (1, -1):
+            values[col * 37 + (col % 5) * 70000] = m * sgn  # spread over several containers
+            col += 1
+    frag = B.bsi_fragment_from_values(values, depth)
+    fused = 0
+    for name, op in B.OPS.items():
+        for pred in range(-top - 3, top + 4):
+            pl = plan(L.BSI_OPS[name], depth, pred)
+            if pl is None:
+                continue
+            fused += 1
+            exp = oracle_range_sum(B, frag, op, depth, pred)
+            assert run_plan(values, depth, pl) == (int(exp[0]), int(exp[1])), (name, pred, depth)
+    assert fused >= 4 * (top - 2)  # LT / LTE / GT / GTE, most predicates inside the depth
