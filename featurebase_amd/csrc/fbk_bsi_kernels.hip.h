@@ -789,6 +789,180 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __rest
   }
 }
 
+// ---- Sum over lo <= v <= hi of the same field, one pass ---------------------------------------------------------
+// Two scan lanes, each with its own remaining set X and matched set M.  lo < 0 <= hi: lane 0 = the positive columns with
+// magnitude <= hi, lane 1 = the negative ones with magnitude <= |lo| (two "less or equal" scans from the top plane).
+// Bounds of one sign, mn < mx: the planes above the highest bit t where mn and mx differ filter lane 0 down to the columns
+// that share the common prefix; plane t SPLITS them — bit 1 (already above mn) goes to lane 1 and goes on as "<= mx", bit
+// 0 (already below mx) stays in lane 0 and goes on as ">= mn".  A scan step either drops columns (X &= (~)plane) or
+// MATCHES the columns whose bit decides the comparison; a column matched at plane i carries the bound's bits above i and
+// the deciding bit (vhi), its lower planes are added as they stream past (|M ∩ plane| << i); what is left in a lane
+// after plane 0 equals its bound (vfin).  Unlike the plane programs this is not a transcription of the reference's loops
+// (rangeBetweenUnsigned runs its two scans one after the other, fragment.go:1262-1303) but the same sets by the
+// definition of the comparison; tests/test_range_sum_plan.py executes the schedule for every pair of bounds at small depths.
+struct BetweenSumPlan {
+  u64 vhi[2][64];
+  u64 vfin[2];
+  uint8_t action[2][64];  // 0 none; 1 X &= T; 2 X &= ~T; 3 match X & T (X keeps the rest); 4 match X & ~T
+  uint8_t split[64];      // 1: lane 1 takes X0 & T, lane 0 keeps X0 & ~T (before nothing else happens at this plane)
+  uint32_t depth;
+  uint32_t class_pos[2];  // lane l scans exists \ sign (1) or exists ∩ sign (0)
+  uint32_t init_b;        // lane 1 starts as its whole class (two sign classes); else empty until the split
+  uint32_t whole[2];      // the lane's class belongs to the result as a whole (bound beyond the bit depth): M = class, X = ∅
+};
+
+// NW = words per lane (kHalfWords: dense batches, half a container per wavefront; other batches take the two-pass path —
+// four fragments of 16 words plus the planes in flight do not fit two wavefronts per SIMD)
+// one lane's step, specialised on its action
+template <int ACT, int NW>
+__device__ __forceinline__ void between_lane(u64 (&X)[NW], u64 (&M)[NW], const u64 (&T)[NW], uint32_t& low, uint32_t& d) {
+#pragma unroll
+  for (int q = 0; q < NW; ++q) {
+    const u64 t = T[q];
+    low += __popcll(M[q] & t);
+    if (ACT == 1) X[q] &= t;
+    if (ACT == 2) X[q] &= ~t;
+    if (ACT == 3 || ACT == 4) {
+      const u64 n = ACT == 3 ? (X[q] & t) : (X[q] & ~t);
+      d += __popcll(n);
+      M[q] |= n;
+      X[q] ^= n;
+    }
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void between_lane_any(uint32_t act, u64 (&X)[NW], u64 (&M)[NW], const u64 (&T)[NW], uint32_t& low, uint32_t& d) {
+  switch (act) {  // (wave-uniform)
+    case 1: between_lane<1, NW>(X, M, T, low, d); break;
+    case 2: between_lane<2, NW>(X, M, T, low, d); break;
+    case 3: between_lane<3, NW>(X, M, T, low, d); break;
+    case 4: between_lane<4, NW>(X, M, T, low, d); break;
+    default: between_lane<0, NW>(X, M, T, low, d); break;
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void between_sum_plane(uint32_t a0, uint32_t a1, uint32_t sp, u64 (&X0)[NW], u64 (&X1)[NW], u64 (&M0)[NW], u64 (&M1)[NW],
+                                                  const u64 (&T)[NW], uint32_t (&low)[2], uint32_t (&d)[2]) {
+  if (sp) {  // the split plane: nothing else happens at it
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const u64 t = T[q];
+      low[0] += __popcll(M0[q] & t);
+      low[1] += __popcll(M1[q] & t);
+      X1[q] |= X0[q] & t;
+      X0[q] &= ~t;
+    }
+    return;
+  }
+  between_lane_any<NW>(a0, X0, M0, T, low[0], d[0]);
+  between_lane_any<NW>(a1, X1, M1, T, low[1], d[1]);
+}
+
+template <int NW, typename LoadPlane, typename LoadRow>
+__device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int lane, LoadRow&& load_row, LoadPlane&& load_plane, bool has_filter,
+                                                 u64* __restrict__ out4, uint64_t shard) {
+  constexpr int kAhead = NW == kHalfWords ? 4 : 2;
+  const uint32_t depth = plan.depth;
+  u64 X0[NW], X1[NW], M0[NW], M1[NW], T[kAhead][NW];
+  load_row(0u, X0);  // exists
+  if (has_filter) {
+    load_row(~0u, T[0]);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) X0[q] &= T[0][q];
+  }
+  {
+    uint32_t any = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) any |= (uint32_t)(X0[q] != 0);
+    if (__ballot(any != 0) == 0) return;  // nothing to consider here
+  }
+  load_row(1u, T[0]);  // sign
+  {
+    const u64 p0 = plan.class_pos[0] ? ~0ull : 0ull, p1 = plan.class_pos[1] ? ~0ull : 0ull;
+    const u64 ib = plan.init_b ? ~0ull : 0ull, w0 = plan.whole[0] ? ~0ull : 0ull, w1 = plan.whole[1] ? ~0ull : 0ull;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const u64 e = X0[q], sg = T[0][q];
+      const u64 c0 = e & (sg ^ p0), c1 = e & (sg ^ p1) & ib;
+      X0[q] = c0 & ~w0;
+      M0[q] = c0 & w0;
+      X1[q] = c1 & ~w1;
+      M1[q] = c1 & w1;
+    }
+  }
+  u64 sum[2] = {0, 0};
+  uint32_t cnt[2] = {0, 0};
+#pragma unroll
+  for (int q = 0; q < NW; ++q) {  // whole classes are matched from the start
+    cnt[0] += __popcll(M0[q]);
+    cnt[1] += __popcll(M1[q]);
+  }
+#pragma unroll
+  for (int u = 0; u < kAhead; ++u)
+    if ((uint32_t)u < depth) load_plane(depth - 1 - (uint32_t)u, T[u]);
+  for (uint32_t j0 = 0; j0 < depth; j0 += kAhead) {
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const uint32_t j = j0 + (uint32_t)u;
+      if (j < depth) {  // (wave-uniform)
+        const uint32_t i = depth - 1 - j;
+        uint32_t low[2] = {0, 0}, d[2] = {0, 0};
+        between_sum_plane<NW>(plan.action[0][i], plan.action[1][i], plan.split[i], X0, X1, M0, M1, T[u], low, d);
+        sum[0] += ((u64)low[0] << i) + (u64)d[0] * plan.vhi[0][i];
+        sum[1] += ((u64)low[1] << i) + (u64)d[1] * plan.vhi[1][i];
+        cnt[0] += d[0];
+        cnt[1] += d[1];
+        if (j + kAhead < depth) load_plane(depth - 1 - (j + kAhead), T[u]);
+      }
+    }
+  }
+  {  // what is left in a lane equals its bound
+    uint32_t r0 = 0, r1 = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      r0 += __popcll(X0[q]);
+      r1 += __popcll(X1[q]);
+    }
+    sum[0] += (u64)r0 * plan.vfin[0];
+    sum[1] += (u64)r1 * plan.vfin[1];
+    cnt[0] += r0;
+    cnt[1] += r1;
+  }
+  const u64 s0 = wave_reduce_add_u64(sum[0]), s1 = wave_reduce_add_u64(sum[1]);
+  const uint32_t c0 = wave_reduce_add(cnt[0]), c1 = wave_reduce_add(cnt[1]);
+  if (lane == 0) {
+    if (s0) atomicAdd(&out4[shard * 4 + 0], s0);
+    if (s1) atomicAdd(&out4[shard * 4 + 1], s1);
+    if (c0) atomicAdd(&out4[shard * 4 + 2], (u64)c0);
+    if (c1) atomicAdd(&out4[shard * 4 + 3], (u64)c1);
+  }
+}
+
+__global__ void __launch_bounds__(64) k_bsi_between_sum_half(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ base, uint32_t n_shards,
+                                                            const BetweenSumPlan* __restrict__ planp, const Slot* __restrict__ fslots,
+                                                            const uint8_t* __restrict__ farena, const uint32_t* __restrict__ frows, u64* __restrict__ out4) {
+  __shared__ u64 lds[kWords];
+  const int lane = threadIdx.x;
+  const uint32_t h = blockIdx.x & 1u;
+  const uint64_t cell = blockIdx.x >> 1;
+  const uint64_t shard = cell >> 4;
+  const uint32_t slot = cell & 15;
+  if (shard >= n_shards) return;
+  const uint8_t* const row0 = arena + ((uint64_t)base[shard] * kSlots + slot) * 8192ull + h * 4096u;
+  constexpr uint64_t kRow = (uint64_t)kSlots * 8192ull;
+  Slot sf;
+  sf.off = 0, sf.len = 0, sf.tn = 0;
+  if (fslots) sf = fslots[(uint64_t)frows[shard] * kSlots + slot];
+  auto load_row = [&](uint32_t r, u64 (&w)[kHalfWords]) {
+    if (r == ~0u) half_load_any(sf, farena, lane, h, lds, w);
+    else half_load(row0 + kRow * r, lane, w);
+  };
+  auto load_plane = [&](uint32_t i, u64 (&w)[kHalfWords]) { half_load(row0 + kRow * (2u + i), lane, w); };
+  between_sum_body<kHalfWords>(*planp, lane, load_row, load_plane, fslots != nullptr, out4, shard);
+}
+
 // ---- BSI Min / Max ------------------------------------------------------------------------------
 // fragment.min / fragment.max / minUnsigned / maxUnsigned (fragment.go:754-853).  The scan
 // over the bit planes is sequential and every step needs the cardinality of a whole ROW

@@ -121,6 +121,8 @@ SIGNATURES = {
     "fbk_shift": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vpp, _vp]),
     "fbk_bsi_add": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _vpp]),
     "fbk_bsi_range": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_uint32, C.c_int64, C.c_uint32, _vpp, _vp]),
+    "fbk_bsi_between_sum_plan": (C.c_int32, [C.c_uint32, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "fbk_bsi_range_between_sum": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp]),
     "fbk_bsi_range_sum_plan": (C.c_int32, [C.c_int32, C.c_uint32, C.c_int64, _vp, _vp, _vp, _vp]),
     "fbk_bsi_range_sum": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_uint32, C.c_int64, _vp, _vp, _vp, _vp]),
     "fbk_bsi_range_between": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_uint32, _vpp, _vp]),

@@ -578,6 +578,17 @@ class Context:
                                            sums.ctypes.data, counts.ctypes.data))
         return sums, counts
 
+    def bsi_range_between_sum(self, batch: Batch, base_rows, bit_depth: int, lo: int, hi: int, filt: Optional[Batch] = None, rows_f=None):
+        """Sum(Row(lo <= v <= hi), field = v): (sums, counts) per shard, equal to bsi_sum over bsi_range_between (∩ filt)."""
+        b = np.ascontiguousarray(base_rows, dtype=np.uint32)
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        sums = np.zeros(b.size, dtype=np.int64)
+        counts = np.zeros(b.size, dtype=np.uint64)
+        L.check(self.lib.fbk_bsi_range_between_sum(self.h, batch.h, b.ctypes.data, b.size, bit_depth, C.c_int64(lo), C.c_int64(hi),
+                                                   filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None,
+                                                   sums.ctypes.data, counts.ctypes.data))
+        return sums, counts
+
     def bsi_range_between(self, batch: Batch, base_rows, bit_depth: int, lo: int, hi: int, flags: int = 0) -> Tuple[Batch, np.ndarray]:
         base = np.ascontiguousarray(base_rows, dtype=np.uint32)
         counts = np.zeros(base.size, dtype=np.uint64)

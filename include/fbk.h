@@ -526,6 +526,20 @@ int32_t fbk_bsi_range_sum(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* 
 int32_t fbk_bsi_range_sum_plan(int32_t op, uint32_t bit_depth, int64_t predicate, uint8_t* out_actions, uint64_t* out_vhi,
                                uint32_t* out_scan_positive, uint32_t* out_take_other);
 
+/* Sum(Row(lo <= v <= hi), field = v): fbk_bsi_range_sum's two-sided form (fragment.rangeBetween + fragment.sum on the same
+ * field; `filter` as there).  One pass over the planes for batches in the dense layout (fbk_batch_upload_dense) and
+ * lo < hi within the field's range: two scan lanes — the positives up to hi and the negatives up to |lo|, or, for bounds of
+ * one sign, the columns sharing the bounds' common prefix split at the highest differing bit into ">= lower" and
+ * "<= upper" (k_bsi_between_sum_half); otherwise fbk_bsi_range_between + fbk_bsi_sum.  Totals equal those
+ * two calls bit for bit.  fbk_bsi_between_sum_plan: the schedule (host arithmetic only; returns 1 for the two-pass path):
+ * out_actions[2][64], out_vhi[2][64], out_split[64], out_vfin[2], out_flags[5] = {lane 0 positive, lane 1 positive,
+ * lane 1 starts as its class, lane 0 whole class, lane 1 whole class}. */
+int32_t fbk_bsi_range_between_sum(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards,
+                                  uint32_t bit_depth, int64_t lo, int64_t hi, const fbk_batch* filter, const uint32_t* rows_f,
+                                  int64_t* out_sums, uint64_t* out_counts);
+int32_t fbk_bsi_between_sum_plan(uint32_t bit_depth, int64_t lo, int64_t hi, uint8_t* out_actions, uint64_t* out_vhi,
+                                 uint8_t* out_split, uint64_t* out_vfin, uint32_t* out_flags);
+
 /* lo <= value <= hi (fragment.rangeBetween, fragment.go:1213-1303). */
 int32_t fbk_bsi_range_between(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows,
                               uint32_t n_shards, uint32_t bit_depth, int64_t lo, int64_t hi, uint32_t flags,

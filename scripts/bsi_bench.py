@@ -85,6 +85,15 @@ for two_pass in (1, 0):
         line("Sum(Range(< -5)) one pass    k_bsi_range_sum_slot / _half", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_LT, depth, -5))
         line("Sum(Range(> -5)) one pass    ..<other class>", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, -5))
 print("  (two passes: the Range and the Sum(filter) lines above, one after the other)")
+ctx.set_option("bsi_range_sum_two_pass", 1)
+ref_b = ctx.bsi_range_between_sum(batch, base, depth, -(1 << 61), 1 << 62)
+ref_c = ctx.bsi_range_between_sum(batch, base, depth, 1 << 60, 1 << 62)
+ctx.set_option("bsi_range_sum_two_pass", 0)
+for (lo, hi), ref_x, what in (((-(1 << 61), 1 << 62), ref_b, "both signs"), ((1 << 60, 1 << 62), ref_c, "one sign, split lanes")):
+    r = ctx.bsi_range_between_sum(batch, base, depth, lo, hi)
+    assert (ref_x[0] == r[0]).all() and (ref_x[1] == r[1]).all(), "Between+Sum: one pass and two passes disagree"
+    line(f"Sum(Between) one pass, {what:22s} k_bsi_between_sum_half", plane_bytes * (depth + 2), lambda: ctx.bsi_range_between_sum(batch, base, depth, lo, hi))
+line("Between (row output)                     k_bsi_range_slot", plane_bytes * (depth + 2), lambda: ctx.bsi_range_between(batch, base, depth, 1 << 60, 1 << 62)[0].free())
 for blocks in (1, 0):
     ctx.set_option("bsi_minmax_blocks", blocks)
     line(f"Min          {'k_bsi_minmax (block per shard)' if blocks else 'k_bsi_minmax_slot (wavefront per (shard, slot))'}", plane_bytes * (depth + 2), lambda: ctx.bsi_min(batch, base, depth))

@@ -312,6 +312,12 @@ def test_fuzz_bsi(gpu_ctx, oracle, it):
         lo, hi = sorted(int(v) for v in (rng.integers(-lim, lim + 1, 2) if lim < (1 << 62) else rng.integers(-(1 << 62), 1 << 62, 2)))
         out, cnt = gpu_ctx.bsi_range_between(batch, base, depth, lo, hi)
         res = out.download()
+        bs, bc = gpu_ctx.bsi_range_between_sum(batch, base, depth, lo, hi)
+        fs, fc = gpu_ctx.bsi_range_between_sum(batch, base, depth, lo, hi, F, rf)
+        for s, fr in enumerate(frags):
+            e = B.bsi_range_between(fr, depth, lo, hi)
+            assert (int(bs[s]), int(bc[s])) == B.bsi_sum(fr, e, True), ("between_sum", lo, hi, s, depth, dense)
+            assert (int(fs[s]), int(fc[s])) == B.bsi_sum(fr, e.intersect(filts[s]), True), ("between_sum+filter", lo, hi, s, depth, dense)
         for s, fr in enumerate(frags):
             e = B.bsi_range_between(fr, depth, lo, hi)
             assert int(cnt[s]) == e.count(), ("between", lo, hi, s, depth)

@@ -381,6 +381,15 @@ def test_bsi_dense_batches_half_container_kernels(gpu_ctx, B, oracle):
                         e = B.bsi_range(frags[s], op, depth, p)
                         assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(frags[s], e, True), (name, p, s, hw)
                         assert (int(fs[s]), int(fc[s])) == B.bsi_sum(frags[s], e.intersect(fbms[s]), True), (name, p, s, hw, "filter")
+            # lo <= v <= hi: two lanes of one sign class (split at the highest differing bit), two sign classes, bounds beyond
+            # the field; lo >= hi and hw = 0 take the two-pass path
+            for lo, hi in ((100, 4000), (-4000, -100), (-300, 500), (0, 8191), (-8191, 0), (-9000, 9000), (1, 2), (4095, 4096), (-1, 0), (7, 7), (9, 3), (5000, 20000)):
+                bs, bc = gpu_ctx.bsi_range_between_sum(batch, base, depth, lo, hi)
+                fs, fc = gpu_ctx.bsi_range_between_sum(batch, base, depth, lo, hi, F, rf)
+                for s in range(n_sh):
+                    e = B.bsi_range_between(frags[s], depth, lo, hi)
+                    assert (int(bs[s]), int(bc[s])) == B.bsi_sum(frags[s], e, True), ("between", lo, hi, s, hw)
+                    assert (int(fs[s]), int(fc[s])) == B.bsi_sum(frags[s], e.intersect(fbms[s]), True), ("between", lo, hi, s, hw, "filter")
     finally:
         gpu_ctx.set_option("bsi_half_waves", 1)
     batch.free()
