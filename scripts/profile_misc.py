@@ -90,8 +90,10 @@ base = np.arange(n5, dtype=np.uint32) * (depth + 2)
 pl = n5 * 16 * 8192
 rec("fbk_bsi_range GT 2^62 (k_bsi_range_slot)", pl * (depth + 3), lambda: ctx.bsi_range(bsi, base, L.BSI_GT, depth, 1 << 62))
 rec("fbk_bsi_sum (k_bsi_sum_slot)", pl * (depth + 2), lambda: ctx.bsi_sum(bsi, base, depth))
-rec("fbk_bsi_min (k_bsi_minmax)", pl * (depth + 2), lambda: ctx.bsi_min(bsi, base, depth))
-rec("fbk_bsi_max (k_bsi_minmax)", pl * (depth + 2), lambda: ctx.bsi_max(bsi, base, depth))
+rec("fbk_bsi_range_sum GT 2^62, one pass (k_bsi_range_sum_half)", pl * (depth + 2), lambda: ctx.bsi_range_sum(bsi, base, L.BSI_GT, depth, 1 << 62))
+rec("fbk_bsi_range_between_sum 2^60 .. 2^62, one pass (k_bsi_between_sum_half)", pl * (depth + 2), lambda: ctx.bsi_range_between_sum(bsi, base, depth, 1 << 60, 1 << 62))
+rec("fbk_bsi_min (k_bsi_minmax_slot)", pl * (depth + 2), lambda: ctx.bsi_min(bsi, base, depth))
+rec("fbk_bsi_max (k_bsi_minmax_slot)", pl * (depth + 2), lambda: ctx.bsi_max(bsi, base, depth))
 px = np.arange(n5 * 16, dtype=np.uint32).reshape(n5, 16) + 2  # 16 planes of each shard as one unsigned operand (rows base + 2 ..)
 px = (base[:, None] + 2 + np.arange(16)[None, :]).astype(np.uint32)
 py = (base[:, None] + 18 + np.arange(16)[None, :]).astype(np.uint32)
