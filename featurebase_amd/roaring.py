@@ -21,6 +21,11 @@ SLOTS = 16
 BITMAP_WORDS = 1024
 
 
+DESC_DTYPE = np.dtype(
+    [("key", "<u8"), ("off", "<u8"), ("row", "<u4"), ("len", "<u4"), ("n", "<i4"), ("type", "u1"), ("pad", "u1", (3,))]
+)  # == fbk_container_desc (include/fbk.h), 32 bytes
+
+
 @dataclass
 class Container:
     """One roaring container in its wire encoding (roaring.go:53-58)."""
@@ -97,6 +102,15 @@ class Batch:
         out = np.zeros(r.size, dtype=np.uint64)
         L.check(self.ctx.lib.fbk_count(self.ctx.h, self.h, r.ctypes.data, r.size, out.ctypes.data))
         return out
+
+    def download_flat(self) -> Tuple[np.ndarray, np.ndarray, int]:
+        """(descs, payload, n_rows): the batch in the flattened layout fbk_batch_upload takes — descs a
+        structured array with the fields of fbk_container_desc, payload uint8."""
+        n_rows, nc, pb = self.info()
+        descs = np.zeros(max(nc, 1), dtype=DESC_DTYPE)
+        payload = np.zeros(max(pb, 1), dtype=np.uint8)
+        L.check(self.ctx.lib.fbk_batch_download(self.ctx.h, self.h, descs.ctypes.data_as(C.POINTER(L.ContainerDesc)), nc, payload.ctypes.data, pb))
+        return descs[:nc], payload, n_rows
 
     def download(self) -> List[Row]:
         n_rows, nc, pb = self.info()

@@ -22,7 +22,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("roaring_oracle.c", "bsi_oracle.c", "wire_oracle.c", "roaring_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("roaring_oracle.c", "bsi_oracle.c", "wire_oracle.c", "batch_oracle.c", "roaring_oracle.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libroaring_oracle.so"])
     return LIB_PATH

@@ -361,3 +361,29 @@ def config3_flat(n_shards: int, k: int = 64, seed_idx: int = 3000, first_shard: 
             filt.add(s_local, s * 16 + slot, 2, w[slot], int(np.bitwise_count(w[slot]).sum()))
     rows.n_rows, filt.n_rows = n_shards * k, n_shards
     return rows, groups, filt
+
+
+def config3_flat_subprocess(n_shards: int, k: int = 64, seed_idx: int = 3000):
+    """config3_flat run in a child process (which forks its generator workers): for callers that have
+    already initialised the HIP runtime, where a fork of THIS process would be unsafe and a spawn would
+    re-import the caller's main module.  Returns (descs, payload, n_rows, groups, fdescs, fpayload,
+    encoded_bytes)."""
+    import subprocess
+    import sys
+    import tempfile
+
+    with tempfile.TemporaryDirectory(prefix="fbk_cfg3_") as tmp:
+        code = (
+            "import sys, numpy as np\n"
+            f"sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})\n"
+            "import datagen as D\n"
+            f"rows, groups, filt = D.config3_flat({n_shards}, {k}, {seed_idx}, mp='fork')\n"
+            f"np.save({tmp!r} + '/d.npy', rows.descs()); np.save({tmp!r} + '/p.npy', rows.payload())\n"
+            f"np.save({tmp!r} + '/fd.npy', filt.descs()); np.save({tmp!r} + '/fp.npy', filt.payload())\n"
+        )
+        env = dict(os.environ, FBK_TEST_SEED=hex(SEED))
+        subprocess.check_call([sys.executable, "-c", code], env=env)
+        d, p = np.load(tmp + "/d.npy"), np.load(tmp + "/p.npy")
+        fd, fp = np.load(tmp + "/fd.npy"), np.load(tmp + "/fp.npy")
+    groups = np.arange(n_shards * k, dtype=np.uint32).reshape(n_shards, k)
+    return d, p, n_shards * k, groups, fd, fp, int(p.size + fp.size)
