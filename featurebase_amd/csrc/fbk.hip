@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "fbk_kernels.hip.h"
+#include "fbk_pair_kernels.hip.h"
 #include "fbk_query_kernels.hip.h"
 #include "fbk_fold_kernels.hip.h"
 #include "fbk_topk_kernels.hip.h"
@@ -91,6 +92,7 @@ struct FbkOptions {
   int64_t bsi_half_waves = 1;            // dense BSI batches: the one-pass Range + Sum runs half a container per wavefront; 0: one wavefront per container (A/B runs)
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
+  int64_t pair_kernels = 2;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels (A/B runs)
 };
 
 struct fbk_ctx {
@@ -515,6 +517,7 @@ const OptionDesc kOptions[] = {
     {"bsi_half_waves", &FbkOptions::bsi_half_waves, 0, 1},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
+    {"pair_kernels", &FbkOptions::pair_kernels, 1, 2},
 };
 
 int32_t option_set(FbkOptions& o, const char* name, int64_t v) {
@@ -1036,6 +1039,10 @@ void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
                        p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, p->d_counts);
+  else if (p->ctx->opt.pair_kernels >= 2)
+    hipLaunchKernelGGL(fbk::k_setop2<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
+                       p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
+                       want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
   else
     hipLaunchKernelGGL(fbk::k_setop<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
@@ -1127,9 +1134,14 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #undef FBK_LAUNCH_DENSE
   } else {
     HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
-    hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,
-                       p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts,
-                       uint32_t(ctx->opt.sparse_paths));
+    if (ctx->opt.pair_kernels >= 2)
+      hipLaunchKernelGGL(fbk::k_icount2, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,
+                         p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts,
+                         uint32_t(ctx->opt.sparse_paths));
+    else
+      hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,
+                         p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts,
+                         uint32_t(ctx->opt.sparse_paths));
     if (fused_total)
       hipLaunchKernelGGL(fbk::k_sum_u64, dim3(1), dim3(256), 0, ctx->stream, p->d_counts, p->n_pairs, fused_total);
     if (accum) hipLaunchKernelGGL(fbk::k_sum_u64_add, dim3(1), dim3(256), 0, ctx->stream, p->d_counts, p->n_pairs, accum);

@@ -1,0 +1,23 @@
+# one gpurun call of round 3: STEPS is a space-separated list of step names (default: all)
+set -x
+R=$GRAFT_REPO_ROOT
+TAG=${TAG:-r3a}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+STEPS=${STEPS:-"pytest pairs ctops"}
+for s in $STEPS; do
+case $s in
+pytest) (timeout ${PYTEST_TIMEOUT:-900} python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} 2>&1 | tail -25) > $O/pytest.log ;;
+pytest_full) (timeout 600 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q --durations=10 2>&1 | tail -40) > $O/pytest_full.log ;;
+pairs) timeout 300 python scripts/bench_pairs.py --out $O/pairs.json ${PAIRS_ARGS:-} > $O/pairs.txt 2> $O/pairs.err ;;
+ctops) timeout 600 python scripts/bench_ctops.py --rows 1024 --iters 20 --out $O/ctops.json 2>&1 | grep -v amdgpu.ids | tail -80 > $O/ctops.txt ;;
+bench) timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err ;;
+bench2) timeout 400 python bench.py --gpus 2 --steps 100 > $O/bench_n2.json 2> $O/bench_n2.err ;;
+misc) (cd /tmp; export TMPDIR=/tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/misc -o misc -- python $R/scripts/profile_misc.py 64 > $O/misc.json 2> /dev/null) ;;
+benchprof) (cd /tmp; export TMPDIR=/tmp; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --repeats 5 --no-cpu-baseline > $O/bench_prof.json 2> /dev/null) ;;
+*) echo "unknown step $s" ;;
+esac
+done
+ls -R $O | head -40
+for f in $O/pytest.log $O/pytest_full.log $O/pairs.txt; do [ -f $f ] && tail -60 $f; done
