@@ -40,11 +40,14 @@ namespace {
 // not reliable there.
 thread_local std::string g_err = "";
 thread_local fbk_ctx* g_scope_ctx = nullptr;  // context of the API call running on this thread
+thread_local fbk_group* g_scope_group = nullptr;  // group of the fbk_group_* call running on this thread
 void ctx_record_error(fbk_ctx* ctx, int32_t code, const std::string& msg);  // defined after fbk_ctx
+void group_record_error(fbk_group* g, int32_t code, const std::string& msg);  // fbk_group_api.inc
 
 int32_t fail(int32_t code, const std::string& msg) {
   g_err = msg;
   if (g_scope_ctx) ctx_record_error(g_scope_ctx, code, msg);
+  if (g_scope_group) group_record_error(g_scope_group, code, msg);
   return code;
 }
 
@@ -92,6 +95,8 @@ struct FbkOptions {
   int64_t bsi_half_waves = 1;            // dense BSI batches: the one-pass Range + Sum runs half a container per wavefront; 0: one wavefront per container (A/B runs)
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
+  int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
+  int64_t pair_spw = 2;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4): next slot's payload in flight while the current one is decoded
   int64_t pair_kernels = 2;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels (A/B runs)
 };
 
@@ -518,6 +523,8 @@ const OptionDesc kOptions[] = {
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 1, 2},
+    {"pair_spw", &FbkOptions::pair_spw, 1, 4},
+    {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
 };
 
 int32_t option_set(FbkOptions& o, const char* name, int64_t v) {
@@ -996,7 +1003,8 @@ int32_t fbk_count_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* ro
   HIP_TRY(dcnt.alloc(ctx, n * 8));
   HIP_TRY(hipMemsetAsync(dcnt.p, 0, n * 8, ctx->stream));
   hipLaunchKernelGGL(fbk::k_count_range, dim3(uint32_t(n * fbk::kSlots / 4)), dim3(256), 0, ctx->stream, b->d_slots,
-                     b->d_arena, drows.as<uint32_t>(), n, uint32_t(start), uint32_t(end), dcnt.as<u64>());
+                     b->d_arena, drows.as<uint32_t>(), n, uint32_t(start), uint32_t(end), dcnt.as<u64>(),
+                     uint32_t(ctx->opt.count_range_reference_quirk));
   HIP_TRY(hipGetLastError());
   D2H back(ctx);
   HIP_TRY(back.add(out_counts, dcnt.p, n * 8));
@@ -1134,10 +1142,18 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #undef FBK_LAUNCH_DENSE
   } else {
     HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
-    if (ctx->opt.pair_kernels >= 2)
-      hipLaunchKernelGGL(fbk::k_icount2, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,
-                         p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts,
-                         uint32_t(ctx->opt.sparse_paths));
+    if (ctx->opt.pair_kernels >= 2) {
+#define FBK_LAUNCH_ICOUNT2(S)                                                                                                  \
+  hipLaunchKernelGGL(fbk::k_icount2<S>, dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + 3) / 4)), dim3(256), 0, ctx->stream, \
+                     p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,       \
+                     p->d_counts, uint32_t(ctx->opt.sparse_paths))
+      switch (int(ctx->opt.pair_spw)) {
+        case 1: FBK_LAUNCH_ICOUNT2(1); break;
+        case 4: FBK_LAUNCH_ICOUNT2(4); break;
+        default: FBK_LAUNCH_ICOUNT2(2); break;
+      }
+#undef FBK_LAUNCH_ICOUNT2
+    }
     else
       hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,
                          p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts,

@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(256) k_window_index(const Slot* __restrict__ s
 // ArrayCountRange :3074, RunCountRange :3200 — here all three are "decode, mask, popcount").
 __global__ void __launch_bounds__(256) k_count_range(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
                                                     const uint32_t* __restrict__ rows, uint64_t n_rows, uint32_t start,
-                                                    uint32_t end, u64* __restrict__ out) {
+                                                    uint32_t end, u64* __restrict__ out, uint32_t run_quirk) {
   __shared__ u64 lds[4][kWords];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -421,6 +421,29 @@ __global__ void __launch_bounds__(256) k_count_range(const Slot* __restrict__ sl
   uint32_t c;
   if (lo == 0 && hi == 65536u) {
     c = n;
+  } else if (run_quirk && slot_type(s) == kTypeRun) {
+    // option count_range_reference_quirk: RunCountRange AS WRITTEN (roaring.go:3200-3232).  Its tests mix an
+    // exclusive range end with inclusive run ends: a run whose last value equals `end` is a "subset of the
+    // range" (all of it counted, one value past the range) AND, when it starts after `start`, also "overlaps
+    // the end" (counted again up to `end`).  Every run's contribution is a closed form of (start, last, lo, hi)
+    // — the early `return end - start` is the only contribution when it fires, earlier runs end before `start`
+    // — so the runs are summed lane-parallel.
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(arena + s.off);
+    const int32_t st = (int32_t)lo, en = (int32_t)hi;
+    int32_t part = 0;
+    for (uint32_t i = lane; i < s.len; i += kWave) {
+      const uint32_t iv = q[i];
+      const int32_t rs = (int32_t)(iv & 0xFFFFu), rl = (int32_t)(iv >> 16);
+      if (rl < st || en < rs) continue;
+      if (rs <= st && rl >= en) {
+        part += en - st;
+        continue;
+      }
+      if (rs >= st && rl <= en) part += rl - rs + 1;
+      if (rs < st && rl < en) part += rl - st + 1;
+      if (rs > st && rl >= en) part += en - rs;
+    }
+    c = wave_reduce_add((uint32_t)part);
   } else {
     u64 w[kWordsPerLane];
     frag_load(s, arena, lane, lds[wv], w);

@@ -173,111 +173,205 @@ __device__ __forceinline__ void frag_load_pair(const Slot& sa, const uint8_t* __
   if (tb == kTypeRun) frag_parity_prefix(wb, lane);
 }
 
-// |A ∩ B| over row pairs, any mix of encodings (intersectionCount, roaring.go:4477-4614).  One wave per
-// (pair, slot); short-circuits as roaring.go:4478-4486.
-__global__ void __launch_bounds__(256, 5) k_icount2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
-                                                const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
-                                                const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
-                                                u64* __restrict__ out, uint32_t sparse_paths) {
-  __shared__ u64 lds[4][kWords];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
-  const uint64_t pair = wslot >> 4;
-  const uint32_t slot = wslot & 15;
-  if (pair >= n_pairs) return;
-  const Slot sa = slotsA[(uint64_t)rowsA[pair] * kSlots + slot];
-  const Slot sb = slotsB[(uint64_t)rowsB[pair] * kSlots + slot];
+// ---- |A ∩ B| over row pairs, any mix of encodings (intersectionCount, roaring.go:4477-4614) -------------
+//
+// One WAVE = SPW consecutive slots of one row pair.  Everything that decides control flow is wave-uniform
+// and held in SCALAR registers: the wave index comes from v_readfirstlane, so the row indexes and the 2 x SPW
+// descriptors are s_loads (the round-2 kernel computed them per lane: four dependent VECTOR round trips —
+// row index, cardinality, offset / length, payload — before the first payload byte arrived, ~10 us of a
+// wave's life at five waves per SIMD; that chain, not the LDS, was what the 70 us of k_icount were made of)
+// and every loop has a uniform trip count.  The first payload batch of slot k + 1 is in flight while slot k
+// is worked on, and the wave adds ONE count to out[pair].
+
+// batch 0 of both operands of an item, if the item will be decoded at all
+__device__ __forceinline__ void item_prefetch(const Slot& sa, const uint8_t* __restrict__ arenaA, const Slot& sb,
+                                              const uint8_t* __restrict__ arenaB, int lane, uint32_t (&va)[kPairBatch],
+                                              uint32_t (&vb)[kPairBatch]) {
+  const uint32_t na = slot_n(sa), nb = slot_n(sb);
+  if (na == 0 || nb == 0 || na == 65536u || nb == 65536u) return;
+  const uint32_t ta = slot_type(sa), tb = slot_type(sb);
+  if (ta == kTypeArray || ta == kTypeRun) sparse_load(ta, arenaA + sa.off, sa.len, 0, lane, va);
+  if (tb == kTypeArray || tb == kTypeRun) sparse_load(tb, arenaB + sb.off, sb.len, 0, lane, vb);
+}
+
+// shorter array -> table, longer array probes it; returns this lane's hits
+__device__ __forceinline__ uint32_t arrays_table_probe(const uint8_t* __restrict__ pt, uint32_t lt, uint32_t (&vt)[kPairBatch],
+                                                       const uint8_t* __restrict__ pp, uint32_t lp, uint32_t (&vp)[kPairBatch], int lane,
+                                                       u64* table) {
+  uint32_t* s32 = reinterpret_cast<uint32_t*>(table);
+  lds_zero(table, lane);
+  wave_lds_sync();
+  sparse_xor_all(kTypeArray, pt, lt, lane, s32, vt);
+  wave_lds_sync();
+  const uint32_t h = array_probe_all(pp, lp, lane, s32, vp);
+  wave_lds_sync();
+  return h;
+}
+
+// bitmap -> table (no clear), array probes it; returns this lane's hits
+__device__ __forceinline__ uint32_t bitmap_table_probe(const uint8_t* __restrict__ pbm, const uint8_t* __restrict__ parr, uint32_t larr,
+                                                       uint32_t (&vp)[kPairBatch], int lane, u64* table) {
+  u64 wb[kWordsPerLane];
+  frag_load_bitmap(pbm, lane, wb);
+  ulonglong2* q = reinterpret_cast<ulonglong2*>(table);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ulonglong2 x;
+    x.x = wb[2 * j];
+    x.y = wb[2 * j + 1];
+    q[j * kWave + lane] = x;  // fragment layout -> natural word order in the table
+  }
+  wave_lds_sync();
+  const uint32_t h = array_probe_all(parr, larr, lane, reinterpret_cast<const uint32_t*>(table), vp);
+  wave_lds_sync();
+  return h;
+}
+
+// values (<= 128, in v[0..1]) of an array that are set in a bitmap container in global memory
+__device__ __forceinline__ uint32_t array_probe_global(const uint32_t (&v)[kPairBatch], uint32_t len, const uint8_t* __restrict__ pbm, int lane) {
+  uint32_t h = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t i = (uint32_t)k * kWave + (uint32_t)lane;
+    if (i < len) h += (reinterpret_cast<const uint32_t*>(pbm)[v[k] >> 5] >> (v[k] & 31u)) & 1u;
+  }
+  return h;
+}
+
+// one (pair, slot): adds to `part` (per lane) or `spart` (wave-uniform)
+__device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __restrict__ arenaA, const Slot& sb,
+                                            const uint8_t* __restrict__ arenaB, int lane, u64* table, uint32_t (&va)[kPairBatch],
+                                            uint32_t (&vb)[kPairBatch], uint32_t sparse_paths, uint32_t& part, uint32_t& spart) {
   const uint32_t na = slot_n(sa), nb = slot_n(sb);
   const uint32_t ta = slot_type(sa), tb = slot_type(sb);
-  uint32_t c;
-  if (na == 0 || nb == 0) {
-    return;
-  } else if (na == 65536u) {
-    c = nb;
+  const uint8_t* pa = arenaA + sa.off;
+  const uint8_t* pb = arenaB + sb.off;
+  if (na == 0 || nb == 0) return;
+  if (na == 65536u) {
+    spart += nb;
   } else if (nb == 65536u) {
-    c = na;
+    spart += na;
   } else if (ta == kTypeBitmap && tb == kTypeBitmap) {
     u64 wa[kWordsPerLane], wb[kWordsPerLane];
-    frag_load_bitmap(arenaA + sa.off, lane, wa);
-    frag_load_bitmap(arenaB + sb.off, lane, wb);
-    uint32_t part = 0;
+    frag_load_bitmap(pa, lane, wa);
+    frag_load_bitmap(pb, lane, wb);
 #pragma unroll
     for (int i = 0; i < kWordsPerLane; ++i) part += __popcll(wa[i] & wb[i]);
-    c = wave_reduce_add(part);
   } else if (ta == kTypeArray && tb == kTypeArray) {
     if (sparse_paths && sa.len <= kSmallArray && sb.len <= kSmallArray) {
-      uint32_t v;
-      bool al;
-      c = (uint32_t)__popcll(small_arrays_match(arenaA + sa.off, sa.len, arenaB + sb.off, sb.len, lane, v, al));
+      // all-pairs compare in registers, the shorter array broadcast value by value
+      const uint32_t a = (uint32_t)lane < sa.len ? va[0] : 0xFFFFFFFFu;
+      const uint32_t b = (uint32_t)lane < sb.len ? vb[0] : 0xFFFFFFFEu;
+      const bool a_long = sa.len >= sb.len;
+      const uint32_t lng = a_long ? a : b, sht = a_long ? b : a;
+      const uint32_t ns = a_long ? sb.len : sa.len;
+      bool m = false;
+      for (uint32_t k = 0; k < ns; ++k) m |= lng == (uint32_t)__builtin_amdgcn_readlane((int)sht, (int)k);
+      part += m ? 1u : 0u;
+    } else if (sa.len <= sb.len) {
+      part += arrays_table_probe(pa, sa.len, va, pb, sb.len, vb, lane, table);
     } else {
-      const bool a_short = sa.len <= sb.len;  // wave-uniform
-      const uint8_t* pt = a_short ? arenaA + sa.off : arenaB + sb.off;
-      const uint8_t* pp = a_short ? arenaB + sb.off : arenaA + sa.off;
-      const uint32_t lt = a_short ? sa.len : sb.len, lp = a_short ? sb.len : sa.len;
-      uint32_t vt[kPairBatch], vp[kPairBatch];
-      sparse_load(kTypeArray, pt, lt, 0, lane, vt);
-      sparse_load(kTypeArray, pp, lp, 0, lane, vp);
-      uint32_t* s32 = reinterpret_cast<uint32_t*>(lds[wv]);
-      lds_zero(lds[wv], lane);
-      wave_lds_sync();
-      sparse_xor_all(kTypeArray, pt, lt, lane, s32, vt);
-      wave_lds_sync();
-      c = wave_reduce_add(array_probe_all(pp, lp, lane, s32, vp));
+      part += arrays_table_probe(pb, sb.len, vb, pa, sa.len, va, lane, table);
     }
-  } else if ((ta == kTypeArray && tb == kTypeBitmap) || (ta == kTypeBitmap && tb == kTypeArray)) {
-    const bool a_arr = ta == kTypeArray;  // wave-uniform
-    const uint8_t* parr = a_arr ? arenaA + sa.off : arenaB + sb.off;
-    const uint8_t* pbm = a_arr ? arenaB + sb.off : arenaA + sa.off;
-    const uint32_t larr = a_arr ? sa.len : sb.len;
-    if (sparse_paths && larr <= kProbeArray) {
-      uint32_t v;
-      c = 0;
-      for (uint32_t base = 0; base < larr; base += kWave) c += (uint32_t)__popcll(array_probe_bitmap(parr, larr, base, pbm, lane, v));
-    } else {
-      u64 wb[kWordsPerLane];
-      uint32_t vp[kPairBatch];
-      frag_load_bitmap(pbm, lane, wb);
-      sparse_load(kTypeArray, parr, larr, 0, lane, vp);
-      ulonglong2* q = reinterpret_cast<ulonglong2*>(lds[wv]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        ulonglong2 x;
-        x.x = wb[2 * j];
-        x.y = wb[2 * j + 1];
-        q[j * kWave + lane] = x;  // fragment layout -> natural word order in the table
-      }
-      wave_lds_sync();
-      c = wave_reduce_add(array_probe_all(parr, larr, lane, reinterpret_cast<const uint32_t*>(lds[wv]), vp));
-    }
+  } else if (ta == kTypeArray && tb == kTypeBitmap) {
+    if (sparse_paths && sa.len <= kProbeArray) part += array_probe_global(va, sa.len, pb, lane);
+    else part += bitmap_table_probe(pb, pa, sa.len, va, lane, table);
+  } else if (ta == kTypeBitmap && tb == kTypeArray) {
+    if (sparse_paths && sb.len <= kProbeArray) part += array_probe_global(vb, sb.len, pa, lane);
+    else part += bitmap_table_probe(pa, pb, sb.len, vb, lane, table);
   } else {
+    // a run on at least one side: both operands as fragments, one clear (frag_load_pair with batch 0 in hand)
     u64 wa[kWordsPerLane], wb[kWordsPerLane];
-    frag_load_pair(sa, arenaA, sb, arenaB, lane, lds[wv], wa, wb);
-    uint32_t part = 0;
+    const bool la = ta != kTypeBitmap, lb = tb != kTypeBitmap;
+    if (!la) frag_load_bitmap(pa, lane, wa);
+    if (!lb) frag_load_bitmap(pb, lane, wb);
+    uint32_t* s32 = reinterpret_cast<uint32_t*>(table);
+    lds_zero(table, lane);
+    wave_lds_sync();
+    if (la) {
+      sparse_xor_all(ta, pa, sa.len, lane, s32, va);
+      wave_lds_sync();
+      lds_read_frag(table, lane, wa);
+      wave_lds_sync();
+    }
+    if (lb) {
+      sparse_xor_all(tb, pb, sb.len, lane, s32, vb);
+      wave_lds_sync();
+      lds_read_frag(table, lane, wb);
+      wave_lds_sync();
+      if (la) {
+#pragma unroll
+        for (int i = 0; i < kWordsPerLane; ++i) wb[i] ^= wa[i];
+      }
+    }
+    if (ta == kTypeRun) frag_parity_prefix(wa, lane);
+    if (tb == kTypeRun) frag_parity_prefix(wb, lane);
 #pragma unroll
     for (int i = 0; i < kWordsPerLane; ++i) part += __popcll(wa[i] & wb[i]);
-    c = wave_reduce_add(part);
   }
+}
+
+template <int SPW>
+__global__ void __launch_bounds__(256, 4) k_icount2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
+                                                   const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
+                                                   const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
+                                                   u64* __restrict__ out, uint32_t sparse_paths) {
+  __shared__ u64 lds[4][kWords];
+  constexpr int kWavesPerPair = kSlots / SPW;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and the compiler knows it
+  const uint64_t wid = (uint64_t)blockIdx.x * 4 + (uint64_t)wv;
+  const uint64_t pair = wid / kWavesPerPair;
+  if (pair >= n_pairs) return;
+  const uint32_t slot0 = (uint32_t)(wid % kWavesPerPair) * SPW;
+  const uint32_t ra = rowsA[pair], rb = rowsB[pair];  // both row indexes in flight together
+  const Slot* da = slotsA + (uint64_t)ra * kSlots + slot0;
+  const Slot* db = slotsB + (uint64_t)rb * kSlots + slot0;
+  Slot sa[SPW], sb[SPW];
+#pragma unroll
+  for (int k = 0; k < SPW; ++k) {
+    sa[k] = da[k];
+    sb[k] = db[k];
+  }
+  u64* table = lds[wv];
+  uint32_t part = 0, spart = 0;
+  uint32_t va[kPairBatch], vb[kPairBatch];
+  item_prefetch(sa[0], arenaA, sb[0], arenaB, lane, va, vb);
+#pragma unroll
+  for (int k = 0; k < SPW; ++k) {
+    uint32_t xa[kPairBatch], xb[kPairBatch];
+    if (k + 1 < SPW) item_prefetch(sa[k + 1], arenaA, sb[k + 1], arenaB, lane, xa, xb);
+    icount_item(sa[k], arenaA, sb[k], arenaB, lane, table, va, vb, sparse_paths, part, spart);
+    if (k + 1 < SPW) {
+#pragma unroll
+      for (int i = 0; i < kPairBatch; ++i) {
+        va[i] = xa[i];
+        vb[i] = xb[i];
+      }
+    }
+  }
+  const uint32_t c = wave_reduce_add(part) + spart;
   if (lane == 0 && c) atomicAdd(&out[pair], (u64)c);
 }
 
 // Materialising A <op> B, one wave per (pair, slot): k_setop's outputs and right-sized array paths
 // (fbk_kernels.hip.h) behind the pair loader above.
 template <int OP>
-__global__ void __launch_bounds__(256) k_setop2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
+__global__ void __launch_bounds__(256, 4) k_setop2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
                                                const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
                                                const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
                                                uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
                                                u64* __restrict__ out_counts, uint32_t direct) {
   __shared__ u64 lds[4][kWords];
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + wv;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: descriptors become scalar loads (see k_icount2)
+  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + (uint64_t)wv;
   const uint64_t pair = wslot >> 4;
   const uint32_t slot = wslot & 15;
   if (pair >= n_pairs) return;
-  const Slot sa = slotsA[(uint64_t)rowsA[pair] * kSlots + slot];
-  const Slot sb = slotsB[(uint64_t)rowsB[pair] * kSlots + slot];
+  const uint32_t ra = rowsA[pair], rb = rowsB[pair];
+  const Slot sa = slotsA[(uint64_t)ra * kSlots + slot];
+  const Slot sb = slotsB[(uint64_t)rb * kSlots + slot];
   const uint32_t na = slot_n(sa), nb = slot_n(sb);
   Slot so;
   so.off = wslot * 8192ull;

@@ -134,6 +134,7 @@ SIGNATURES = {
     "fbk_group_plan_intersection_count_total": (C.c_int32, [_vp, _vpp, _u64p]),
     "fbk_group_count_matrix": (C.c_int32, [_vp, C.POINTER(MatrixArgs), C.c_uint32, C.c_uint32, _vp]),
     "fbk_group_reduce_u64": (C.c_int32, [_vp, _vpp, C.c_uint64, _vp]),
+    "fbk_group_last_error_r": (C.c_int32, [_vp, C.c_char_p, C.c_uint64, _i32p]),
 }
 
 BSI_EQ, BSI_NEQ, BSI_LT, BSI_LTE, BSI_GT, BSI_GTE = 1, 2, 3, 4, 5, 6

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FBK_ABI_VERSION 2
+#define FBK_ABI_VERSION 3
 
 /* status codes */
 #define FBK_OK 0
@@ -263,7 +263,11 @@ int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, ui
  * The device counts bits; this equals the reference everywhere except on run containers that
  * hold a run whose last value == end-1+1 (`iv.Last == end`), where RunCountRange's
  * "subset of range" and "overlaps end" branches both fire and over-count (roaring.go:3216-3227)
- * — a case the reference's own callers (container-aligned ranges) never produce. */
+ * — a case the reference's own callers (container-aligned ranges) never produce.
+ * DEFAULT: the bit count.  Option "count_range_reference_quirk" = 1 (fbk_set_option, or
+ * FBK_COUNT_RANGE_REFERENCE_QUIRK=1 in the environment of fbk_open) makes the call reproduce
+ * RunCountRange as written, over-count included, so that a Go caller can get the reference's number on
+ * the same inputs; both modes are tested against the oracle (tests/test_gpu_parity.py). */
 int32_t fbk_count_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n, uint64_t start,
                         uint64_t end, uint64_t* out_counts);
 
@@ -619,6 +623,14 @@ int32_t fbk_group_count_matrix(fbk_group* group, const fbk_matrix_args* per_memb
  * sums, TopK counts, fold counts): device_partials[m] = `words` uint64 on member m's device (NULL =
  * zeros), produced on member m's stream. */
 int32_t fbk_group_reduce_u64(fbk_group* group, void* const* device_partials, uint64_t words, uint64_t* out_total);
+
+/* Message (and status code) of the last failing fbk_group_* call on THIS group, copied into a caller
+ * buffer: the form a cgo binding must use (see fbk_last_error_r).  Group-level failures — argument
+ * checks, "plan was not created on member m", peer / RCCL set-up, buffer growth — have no member
+ * context to be recorded on; failures inside a member's enqueue are recorded on the group AND on that
+ * member.  While a group call runs it holds every member's context lock (in member order) until the
+ * member streams are synchronised, and a call that fails half-way drains the members it had enqueued. */
+int32_t fbk_group_last_error_r(fbk_group* group, char* buf, uint64_t cap, int32_t* out_code);
 
 #ifdef __cplusplus
 }

@@ -423,3 +423,56 @@ def test_count_range_counts_bits_where_run_count_range_double_counts(gpu_ctx, or
     assert bm.count_range(15, 40) == 27  # the reference's answer for the same call
     assert gpu_ctx.count_range(b, [0], 12, 35).tolist() == [bm.count_range(12, 35)]
     b.free()
+
+
+def test_count_range_reference_quirk_mode_matches_the_reference_everywhere(gpu_ctx, oracle):
+    """Option count_range_reference_quirk = 1: fbk_count_range returns what Bitmap.CountRange returns in the
+    reference ON THE SAME INPUTS, RunCountRange's over-count (roaring.go:3216-3227) included; the default
+    mode returns the number of bits in [start, end).  Random mixed rows and ranges chosen to hit run ends."""
+    from featurebase_amd.roaring import Container
+
+    b = gpu_ctx.upload([{0: Container.run([(10, 20), (30, 40)])}])
+    gpu_ctx.set_option("count_range_reference_quirk", 1)
+    try:
+        assert gpu_ctx.count_range(b, [0], 15, 40).tolist() == [27]
+        assert gpu_ctx.count_range(b, [0], 15, 41).tolist() == [17]
+        b.free()
+        rng = D.rng_for(811)
+        rows = [D.random_row(rng, 0) for _ in range(24)]
+        batch = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+        obms = [oracle.OBitmap.from_containers(sorted(r.items())) for r in rows]
+        words = []
+        for r in rows:
+            w = np.zeros((16, 1024), dtype=np.uint64)
+            for k, c in r.items():
+                w[k & 15] = c.words()
+            words.append(w.reshape(-1))
+        idx = np.arange(len(rows))
+        ends = []
+        for r in rows:  # range ends on, one before and one past a run's last value
+            for k, c in r.items():
+                if c.typ == oracle.RUN and c.n:
+                    last = int(c.data()[int(rng.integers(0, len(c.data())))][1])
+                    ends += [((k & 15) << 16) + last + d for d in (0, 1, 2) if ((k & 15) << 16) + last + d <= 1 << 20]
+        ranges = [(int(rng.integers(0, e + 1)), e) for e in ends[:60]] + [(0, 1 << 20), (0, 0), (65536, 131072), (5, 65536 * 3 + 9)]
+        n_quirk = 0
+        for s, e in ranges:
+            want_ref = [bm.count_range(s, e) for bm in obms]
+            gpu_ctx.set_option("count_range_reference_quirk", 1)
+            assert gpu_ctx.count_range(batch, idx, s, e).tolist() == want_ref, (s, e)
+            gpu_ctx.set_option("count_range_reference_quirk", 0)
+            bits = [int(np.bitwise_count(_mask_range(w, s, e)).sum()) for w in words]
+            assert gpu_ctx.count_range(batch, idx, s, e).tolist() == bits, (s, e)
+            n_quirk += int(want_ref != bits)
+        assert n_quirk > 0, "no range hit the quirk: the test does not exercise the strict mode"
+        batch.free()
+    finally:
+        gpu_ctx.set_option("count_range_reference_quirk", 0)
+
+
+def _mask_range(w, s, e):
+    """words of a row with every bit outside [s, e) cleared"""
+    bits = np.unpackbits(w.view(np.uint8), bitorder="little").copy()
+    bits[:s] = 0
+    bits[e:] = 0
+    return np.packbits(bits, bitorder="little").view(np.uint64)
