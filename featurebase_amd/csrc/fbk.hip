@@ -97,11 +97,15 @@ struct FbkOptions {
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
   int64_t pair_spw = 2;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4): next slot's payload in flight while the current one is decoded
+  int64_t pair_persistent = 4;           // k_icount2p: blocks per CU of the persistent, software-pipelined pair count (0: one wave per pair_spw slots)
+  int64_t pair_wpb = 1;                  // wavefronts per block of k_icount2: 1 (a wave's LDS table is released when IT ends) or 4
+  int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
   int64_t pair_kernels = 2;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels (A/B runs)
 };
 
 struct fbk_ctx {
   int device = 0;
+  int n_cu = 0;  // compute units of the device (sizes persistent grids)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::mutex mu;
@@ -524,6 +528,9 @@ const OptionDesc kOptions[] = {
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 1, 2},
     {"pair_spw", &FbkOptions::pair_spw, 1, 4},
+    {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
+    {"pair_wpb", &FbkOptions::pair_wpb, 1, 4},
+    {"pair_persistent", &FbkOptions::pair_persistent, 0, 16},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
 };
 
@@ -562,6 +569,7 @@ int32_t open_on_device(int32_t device, fbk_ctx* root, fbk_ctx** out_ctx) {
   fbk_ctx* ctx = new (std::nothrow) fbk_ctx();
   if (!ctx) return fail(FBK_E_NOMEM, "host allocation failed");
   ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount;
   hipError_t e2 = hipSetDevice(device);
   if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
   if (e2 != hipSuccess) {
@@ -1142,15 +1150,30 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #undef FBK_LAUNCH_DENSE
   } else {
     HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
-    if (ctx->opt.pair_kernels >= 2) {
-#define FBK_LAUNCH_ICOUNT2(S)                                                                                                  \
-  hipLaunchKernelGGL(fbk::k_icount2<S>, dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + 3) / 4)), dim3(256), 0, ctx->stream, \
-                     p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,       \
-                     p->d_counts, uint32_t(ctx->opt.sparse_paths))
-      switch (int(ctx->opt.pair_spw)) {
-        case 1: FBK_LAUNCH_ICOUNT2(1); break;
-        case 4: FBK_LAUNCH_ICOUNT2(4); break;
-        default: FBK_LAUNCH_ICOUNT2(2); break;
+    if (ctx->opt.pair_kernels >= 2 && ctx->opt.pair_persistent) {
+      // as many blocks as the device holds at once (4 per CU: 128 registers, 34 KiB of LDS), each wave striding through the items
+      const uint64_t want = (p->n_pairs * fbk::kSlots + 3) / 4;
+      const uint64_t cap = uint64_t(ctx->n_cu > 0 ? ctx->n_cu : 256) * uint64_t(ctx->opt.pair_persistent);
+      hipLaunchKernelGGL(fbk::k_icount2p, dim3(uint32_t(std::min(want, cap))), dim3(256), 0, ctx->stream, p->a->d_slots, p->a->d_arena,
+                         p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts, uint32_t(ctx->opt.sparse_paths));
+    } else if (ctx->opt.pair_kernels >= 2) {
+#define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
+  hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
+                     p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
+                     p->d_counts, uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8))
+      const int spw = int(ctx->opt.pair_spw), wpb = int(ctx->opt.pair_wpb);
+      if (wpb == 4) {
+        switch (spw) {
+          case 1: FBK_LAUNCH_ICOUNT2(1, 4); break;
+          case 4: FBK_LAUNCH_ICOUNT2(4, 4); break;
+          default: FBK_LAUNCH_ICOUNT2(2, 4); break;
+        }
+      } else {
+        switch (spw) {
+          case 1: FBK_LAUNCH_ICOUNT2(1, 1); break;
+          case 4: FBK_LAUNCH_ICOUNT2(4, 1); break;
+          default: FBK_LAUNCH_ICOUNT2(2, 1); break;
+        }
       }
 #undef FBK_LAUNCH_ICOUNT2
     }

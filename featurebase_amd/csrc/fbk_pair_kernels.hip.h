@@ -35,84 +35,151 @@
 
 namespace fbk {
 
-constexpr int kPairBatch = 8;  // elements per lane and operand in flight (8 x 64 = 512 values / runs per batch)
+constexpr int kPairBatch = 8;  // dwords per lane and operand in flight: 8 x 64 dwords = 1024 array values / 512 runs per batch
 
-// batch `base / 512` of a sparse container, lane-consecutive: v[k] = element base + 64 k + lane
-// (array: the uint16 value; run: the {start, last} pair as one dword).  Lanes past the end hold junk.
-__device__ __forceinline__ void sparse_load(uint32_t type, const uint8_t* __restrict__ p, uint32_t len, uint32_t base, int lane,
-                                            uint32_t (&v)[kPairBatch]) {
-  if (type == kTypeArray) {
-    const uint16_t* q = reinterpret_cast<const uint16_t*>(p);
+// A sparse payload is read in DWORD units, lane-consecutively (unit i by lane i mod 64): an array dword holds two
+// values, a run dword one {start, last} interval.  The instruction count per value is what these kernels are made
+// of (rocprofv3 --pmc on config 3's row pairs, profiles/r03_pmc_pair_kernels.txt: a SIMD issues about one
+// instruction per 4 cycles whatever its kind, and the first version of this file spent ~20 on every array value —
+// index, bounds test, address, uint16 load, bit, exec-mask juggling), so a batch whose lanes are ALL valid runs
+// without any per-value predicate and only the ragged last batch tests indexes.
+__device__ __forceinline__ uint32_t sparse_units(uint32_t type, uint32_t len) { return type == kTypeArray ? (len + 1u) >> 1 : len; }
+
+// batch starting at unit `base`: v[k] = unit base + 64 k + lane (junk — zero — past the end)
+__device__ __forceinline__ void sparse_load(const uint8_t* __restrict__ p, uint32_t n_units, uint32_t base, int lane, uint32_t (&v)[kPairBatch]) {
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p) + base + (uint32_t)lane;
+  if (base + kPairBatch * kWave <= n_units) {
 #pragma unroll
-    for (int k = 0; k < kPairBatch; ++k) {
-      const uint32_t i = base + (uint32_t)k * kWave + (uint32_t)lane;
-      v[k] = i < len ? (uint32_t)q[i] : 0u;
-    }
+    for (int k = 0; k < kPairBatch; ++k) v[k] = q[k * kWave];
   } else {
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
 #pragma unroll
-    for (int k = 0; k < kPairBatch; ++k) {
-      const uint32_t i = base + (uint32_t)k * kWave + (uint32_t)lane;
-      v[k] = i < len ? q[i] : 0u;
-    }
+    for (int k = 0; k < kPairBatch; ++k) v[k] = (base + (uint32_t)k * kWave + (uint32_t)lane < n_units) ? q[k * kWave] : 0u;
   }
 }
 
-// XOR the raw bits of one batch into the table
-__device__ __forceinline__ void sparse_xor_batch(uint32_t type, uint32_t* s32, uint32_t len, uint32_t base, int lane,
+// The wave's table as a raw LDS byte offset (8 KiB aligned): the dword of bit b is base | (b[15:5] << 2) — a bit-field
+// extract and one v_lshl_or_b32 instead of shift + mask + add;
+// shift counts and bit-field offsets use the hardware's own masking of bits [4:0].
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_table_base(u64* table) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)table);
+}
+// x = the value in bits [15:0] (higher bits: anything)
+// (written in asm: the optimiser rewrites the C form of these two into shift + mask + or)
+__device__ __forceinline__ lds_u32* table_dword_lo(uint32_t base, uint32_t x) {
+  uint32_t i, a;
+  asm("v_bfe_u32 %0, %1, 5, 11" : "=v"(i) : "v"(x));
+  asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(a) : "v"(i), "s"(base));
+  return (lds_u32*)(uintptr_t)a;
+}
+// x = the value in bits [31:16]
+__device__ __forceinline__ lds_u32* table_dword_hi(uint32_t base, uint32_t x) {
+  uint32_t i, a;
+  asm("v_lshrrev_b32 %0, 21, %1" : "=v"(i) : "v"(x));
+  asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(a) : "v"(i), "s"(base));
+  return (lds_u32*)(uintptr_t)a;
+}
+__device__ __forceinline__ void toggle_lo(uint32_t base, uint32_t x) {
+  (void)__hip_atomic_fetch_xor(table_dword_lo(base, x), 1u << (x & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void toggle_hi(uint32_t base, uint32_t x) {
+  (void)__hip_atomic_fetch_xor(table_dword_hi(base, x), 1u << ((x >> 16) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// XOR the raw bits of one batch into the table (array: one bit per value; run: a toggle at start and at last + 1)
+__device__ __forceinline__ void sparse_xor_batch(uint32_t type, uint32_t tb, uint32_t len, uint32_t base, int lane,
                                                  const uint32_t (&v)[kPairBatch]) {
   if (type == kTypeArray) {
+    if ((base + kPairBatch * kWave) * 2u <= len) {  // every value of the batch exists
 #pragma unroll
-    for (int k = 0; k < kPairBatch; ++k) {
-      const uint32_t i = base + (uint32_t)k * kWave + (uint32_t)lane;
-      if (i < len) atomicXor(&s32[v[k] >> 5], 1u << (v[k] & 31u));
+      for (int k = 0; k < kPairBatch; ++k) {
+        toggle_lo(tb, v[k]);
+        toggle_hi(tb, v[k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPairBatch; ++k) {
+        const uint32_t i2 = (base + (uint32_t)k * kWave + (uint32_t)lane) * 2u;
+        if (i2 < len) toggle_lo(tb, v[k]);
+        if (i2 + 1u < len) toggle_hi(tb, v[k]);
+      }
     }
   } else {
 #pragma unroll
     for (int k = 0; k < kPairBatch; ++k) {
       const uint32_t i = base + (uint32_t)k * kWave + (uint32_t)lane;
       if (i < len) {
-        const uint32_t s = v[k] & 0xFFFFu, e = (v[k] >> 16) + 1u;
-        atomicXor(&s32[s >> 5], 1u << (s & 31u));
-        if (e < 65536u) atomicXor(&s32[e >> 5], 1u << (e & 31u));
+        const uint32_t e = (v[k] >> 16) + 1u;
+        toggle_lo(tb, v[k]);
+        if (e < 65536u) toggle_lo(tb, e);
       }
     }
   }
 }
 
 // the whole container, batch 0 already in v: the next batch is in flight while the current one is applied
-__device__ __forceinline__ void sparse_xor_all(uint32_t type, const uint8_t* __restrict__ p, uint32_t len, int lane, uint32_t* s32,
+__device__ __forceinline__ void sparse_xor_all(uint32_t type, const uint8_t* __restrict__ p, uint32_t len, int lane, uint32_t tb,
                                                uint32_t (&v)[kPairBatch]) {
+  const uint32_t n_units = sparse_units(type, len);
   for (uint32_t base = 0;;) {
     const uint32_t nb = base + kPairBatch * kWave;
     uint32_t nv[kPairBatch];
-    if (nb < len) sparse_load(type, p, len, nb, lane, nv);
-    sparse_xor_batch(type, s32, len, base, lane, v);
-    if (nb >= len) break;
+    if (nb < n_units) sparse_load(p, n_units, nb, lane, nv);
+    sparse_xor_batch(type, tb, len, base, lane, v);
+    if (nb >= n_units) break;
 #pragma unroll
     for (int k = 0; k < kPairBatch; ++k) v[k] = nv[k];
     base = nb;
   }
 }
 
-// number of this lane's array values that are set in the table (batch 0 already in v)
-__device__ __forceinline__ uint32_t array_probe_all(const uint8_t* __restrict__ p, uint32_t len, int lane, const uint32_t* s32,
-                                                    uint32_t (&v)[kPairBatch]) {
+__device__ __forceinline__ uint32_t table_bit_lo(uint32_t tb, uint32_t x) { return __builtin_amdgcn_ubfe(*table_dword_lo(tb, x), x, 1u); }
+__device__ __forceinline__ uint32_t table_bit_hi(uint32_t tb, uint32_t x) { return __builtin_amdgcn_ubfe(*table_dword_hi(tb, x), x >> 16, 1u); }
+
+// this lane's hits of one batch of array dwords against the table
+__device__ __forceinline__ uint32_t array_probe_batch(uint32_t tb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch]) {
   uint32_t hits = 0;
-  for (uint32_t base = 0;;) {
-    const uint32_t nb = base + kPairBatch * kWave;
-    uint32_t nv[kPairBatch];
-    if (nb < len) sparse_load(kTypeArray, p, len, nb, lane, nv);
+  if ((base + kPairBatch * kWave) * 2u <= len) {
+#pragma unroll
+    for (int k = 0; k < kPairBatch; ++k) hits += table_bit_lo(tb, v[k]) + table_bit_hi(tb, v[k]);
+  } else {
 #pragma unroll
     for (int k = 0; k < kPairBatch; ++k) {
-      const uint32_t i = base + (uint32_t)k * kWave + (uint32_t)lane;
-      const uint32_t w = s32[v[k] >> 5];  // (junk lanes read word 0: in bounds)
-      hits += (i < len) ? ((w >> (v[k] & 31u)) & 1u) : 0u;
+      const uint32_t i2 = (base + (uint32_t)k * kWave + (uint32_t)lane) * 2u;
+      const uint32_t b0 = table_bit_lo(tb, v[k]), b1 = table_bit_hi(tb, v[k]);  // (junk lanes read word 0: in bounds)
+      hits += (i2 < len ? b0 : 0u) + (i2 + 1u < len ? b1 : 0u);
     }
-    if (nb >= len) break;
-#pragma unroll
-    for (int k = 0; k < kPairBatch; ++k) v[k] = nv[k];
-    base = nb;
+  }
+  return hits;
+}
+
+// The probing array of an item, ALL of it in flight at once: batch 0 came with the item's prefetch, batches 1..3
+// (an array has at most 4095 values = 4 batches unless it is an oversized intermediate result) are requested by
+// probe_tail_load BEFORE the table is built, so that an array of any legal size costs one memory round trip, not
+// one per batch (a batch is probed in a tenth of the time its loads take to arrive).
+struct ProbeTail {
+  uint32_t v1[kPairBatch], v2[kPairBatch], v3[kPairBatch];
+};
+__device__ __forceinline__ void probe_tail_load(const uint8_t* __restrict__ p, uint32_t len, int lane, ProbeTail& t) {
+  const uint32_t n_units = (len + 1u) >> 1;
+  constexpr uint32_t B = kPairBatch * kWave;
+  if (n_units > B) sparse_load(p, n_units, B, lane, t.v1);
+  if (n_units > 2 * B) sparse_load(p, n_units, 2 * B, lane, t.v2);
+  if (n_units > 3 * B) sparse_load(p, n_units, 3 * B, lane, t.v3);
+}
+// number of this lane's array values that are set in the table
+__device__ __forceinline__ uint32_t array_probe_all(const uint8_t* __restrict__ p, uint32_t len, int lane, uint32_t tb,
+                                                    const uint32_t (&v0)[kPairBatch], const ProbeTail& t) {
+  const uint32_t n_units = (len + 1u) >> 1;
+  constexpr uint32_t B = kPairBatch * kWave;
+  uint32_t hits = array_probe_batch(tb, len, 0, lane, v0);
+  if (n_units > B) hits += array_probe_batch(tb, len, B, lane, t.v1);
+  if (n_units > 2 * B) hits += array_probe_batch(tb, len, 2 * B, lane, t.v2);
+  if (n_units > 3 * B) hits += array_probe_batch(tb, len, 3 * B, lane, t.v3);
+  for (uint32_t base = 4 * B; base < n_units; base += B) {  // arrays beyond 4096 values (roaring.go:5054)
+    uint32_t v[kPairBatch];
+    sparse_load(p, n_units, base, lane, v);
+    hits += array_probe_batch(tb, len, base, lane, v);
   }
   return hits;
 }
@@ -133,44 +200,271 @@ __device__ __forceinline__ void frag_parity_prefix(u64 (&w)[kWordsPerLane], int 
   }
 }
 
-// Both containers of a (pair, slot) as register fragments with at most ONE clear of the wave's table.
-__device__ __forceinline__ void frag_load_pair(const Slot& sa, const uint8_t* __restrict__ arenaA, const Slot& sb,
-                                               const uint8_t* __restrict__ arenaB, int lane, u64* scratch, u64 (&wa)[kWordsPerLane],
-                                               u64 (&wb)[kWordsPerLane]) {
-  const uint32_t ta = slot_n(sa) ? slot_type(sa) : kTypeNil, tb = slot_n(sb) ? slot_type(sb) : kTypeNil;
-  const uint8_t* pa = arenaA + sa.off;
-  const uint8_t* pb = arenaB + sb.off;
+// ---- run containers of few runs: boundary masks + a 2048-bit interior map ----------------------------------
+// The parity prefix above costs ~400 vector instructions per run container whatever it holds (16 words x a 6-step
+// 64-bit shift-xor ladder + the carries), which made the run pairs two thirds of k_icount2's instruction count on
+// config 3's rows.  A run [s, l] is instead written as what it is: a partial mask in its first and in its last
+// dword (XORed into the table: the runs of one container are disjoint, so XOR is OR — and stays separable from
+// another operand's raw bits underneath), and every dword strictly between them is FULL: those are recorded as
+// two toggles in a map with ONE BIT PER DWORD (2048 bits = 64 lanes x 32: the "mini table", 256 bytes per
+// operand), whose parity prefix is one dword per lane — 5 shift-xor steps and one ballot for the carries.  Each
+// lane then ORs 0xFFFFFFFF into the dwords of its fragment whose map bit is set.  ~100 instructions + ~30 per 64
+// runs; containers of more than kRunFillMax runs keep the toggle form, which is cheaper per run.
+constexpr uint32_t kRunFillMax = 600;
+constexpr int kMiniDwords = 64;  // per operand
+
+__device__ __forceinline__ void run_fill_batch(uint32_t tb, uint32_t mb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch]) {
+#pragma unroll
+  for (int k = 0; k < kPairBatch; ++k) {
+    const uint32_t i = base + (uint32_t)k * kWave + (uint32_t)lane;
+    if (i < len) {
+      const uint32_t s = v[k] & 0xFFFFu, l = v[k] >> 16;
+      const uint32_t ds = s >> 5, dl = l >> 5;
+      const uint32_t ms = 0xFFFFFFFFu << (s & 31u), ml = 0xFFFFFFFFu >> (~l & 31u);
+      lds_u32* first = (lds_u32*)(uintptr_t)(tb + (ds << 2));
+      if (ds == dl) {
+        (void)__hip_atomic_fetch_xor(first, ms & ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        (void)__hip_atomic_fetch_xor(first, ms, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)__hip_atomic_fetch_xor((lds_u32*)(uintptr_t)(tb + (dl << 2)), ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (dl - ds > 1u) {  // dwords ds + 1 .. dl - 1 are full
+          const uint32_t d0 = ds + 1u;
+          (void)__hip_atomic_fetch_xor((lds_u32*)(uintptr_t)(mb + ((d0 >> 5) << 2)), 1u << (d0 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_xor((lds_u32*)(uintptr_t)(mb + ((dl >> 5) << 2)), 1u << (dl & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void run_fill_all(const uint8_t* __restrict__ p, uint32_t len, int lane, uint32_t tb, uint32_t mb, uint32_t (&v)[kPairBatch]) {
+  for (uint32_t base = 0;;) {
+    const uint32_t nb = base + kPairBatch * kWave;
+    uint32_t nv[kPairBatch];
+    if (nb < len) sparse_load(p, len, nb, lane, nv);
+    run_fill_batch(tb, mb, len, base, lane, v);
+    if (nb >= len) break;
+#pragma unroll
+    for (int k = 0; k < kPairBatch; ++k) v[k] = nv[k];
+    base = nb;
+  }
+}
+
+// OR the full interior dwords recorded in the mini table at byte offset mb into a fragment of boundary masks
+__device__ __forceinline__ void frag_or_interior(u64 (&w)[kWordsPerLane], uint32_t mb, int lane) {
+  lds_u32* mine = (lds_u32*)(uintptr_t)(mb + 4u * (uint32_t)lane);
+  uint32_t x = *mine;
+  x ^= x << 1;
+  x ^= x << 2;
+  x ^= x << 4;
+  x ^= x << 8;
+  x ^= x << 16;  // inclusive parity prefix inside the dword; bit 31 = parity of the whole dword
+  const u64 odd = __ballot((x >> 31) != 0);
+  const u64 lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  if (__popcll(odd & lane_lt) & 1) x = ~x;
+  *mine = x;
+  wave_lds_sync();
+  const lds_u32* row = (const lds_u32*)(uintptr_t)(mb + 4u * ((uint32_t)lane >> 3));  // + 32 j bytes: dword 8 j + lane / 8
+  const uint32_t sh = 4u * ((uint32_t)lane & 7u);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t nib = row[8 * j] >> sh;  // bits 0..3: dwords 256 j + 4 lane + 0..3
+    const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)nib, 0, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)nib, 1, 1);
+    const uint32_t m2 = (uint32_t)__builtin_amdgcn_sbfe((int)nib, 2, 1), m3 = (uint32_t)__builtin_amdgcn_sbfe((int)nib, 3, 1);
+    w[2 * j] |= (u64)m0 | ((u64)m1 << 32);
+    w[2 * j + 1] |= (u64)m2 | ((u64)m3 << 32);
+  }
+  wave_lds_sync();
+}
+
+// Both containers of an item as register fragments, batch 0 of the sparse ones already in va / vb: bitmaps stream to
+// registers, the first sparse operand's raw bits go into the cleared table and are read back, the second's go ON
+// TOP and come back as (first ^ second) ^ first.  ONE clear of the 8 KiB table per item.  ta, tb: array / bitmap / run.
+__device__ __forceinline__ void frag_pair_decode(uint32_t ta, const uint8_t* __restrict__ pa, uint32_t lena, uint32_t tb,
+                                                 const uint8_t* __restrict__ pb, uint32_t lenb, int lane, u64* table, uint32_t* mini,
+                                                 uint32_t (&va)[kPairBatch], uint32_t (&vb)[kPairBatch], u64 (&wa)[kWordsPerLane],
+                                                 u64 (&wb)[kWordsPerLane]) {
   const bool la = ta == kTypeArray || ta == kTypeRun, lb = tb == kTypeArray || tb == kTypeRun;  // wave-uniform
-  uint32_t va[kPairBatch], vb[kPairBatch];
-  // everything that comes from global memory first
   if (ta == kTypeBitmap) frag_load_bitmap(pa, lane, wa);
   if (tb == kTypeBitmap) frag_load_bitmap(pb, lane, wb);
-  if (la) sparse_load(ta, pa, sa.len, 0, lane, va);
-  if (lb) sparse_load(tb, pb, sb.len, 0, lane, vb);
   if (ta == kTypeNil) frag_zero(wa);
   if (tb == kTypeNil) frag_zero(wb);
   if (!la && !lb) return;
-  uint32_t* s32 = reinterpret_cast<uint32_t*>(scratch);
-  lds_zero(scratch, lane);
+  const bool fa = ta == kTypeRun && lena <= kRunFillMax, fb = tb == kTypeRun && lenb <= kRunFillMax;
+  const uint32_t tbase = lds_table_base(table);
+  const uint32_t mbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)mini);
+  lds_zero(table, lane);
+  if (fa || fb) {
+    uint2 z;
+    z.x = 0;
+    z.y = 0;
+    reinterpret_cast<uint2*>(mini)[lane] = z;  // both operands' maps: 2 x 64 dwords
+  }
   wave_lds_sync();
   if (la) {
-    sparse_xor_all(ta, pa, sa.len, lane, s32, va);
+    if (fa) run_fill_all(pa, lena, lane, tbase, mbase, va);
+    else sparse_xor_all(ta, pa, lena, lane, tbase, va);
     wave_lds_sync();
-    lds_read_frag(scratch, lane, wa);  // raw bits of A: array bits / run toggles
+    lds_read_frag(table, lane, wa);  // raw bits of A: array bits / run toggles / run boundary masks
     wave_lds_sync();
   }
   if (lb) {
-    sparse_xor_all(tb, pb, sb.len, lane, s32, vb);  // on top of A's raw bits
+    if (fb) run_fill_all(pb, lenb, lane, tbase, mbase + 4u * kMiniDwords, vb);
+    else sparse_xor_all(tb, pb, lenb, lane, tbase, vb);  // on top of A's raw bits
     wave_lds_sync();
-    lds_read_frag(scratch, lane, wb);
+    lds_read_frag(table, lane, wb);
     wave_lds_sync();
     if (la) {
 #pragma unroll
       for (int i = 0; i < kWordsPerLane; ++i) wb[i] ^= wa[i];
     }
   }
-  if (ta == kTypeRun) frag_parity_prefix(wa, lane);
-  if (tb == kTypeRun) frag_parity_prefix(wb, lane);
+  if (ta == kTypeRun) {
+    if (fa) frag_or_interior(wa, mbase, lane);
+    else frag_parity_prefix(wa, lane);
+  }
+  if (tb == kTypeRun) {
+    if (fb) frag_or_interior(wb, mbase + 4u * kMiniDwords, lane);
+    else frag_parity_prefix(wb, lane);
+  }
+}
+
+// ---- the streaming form of the pair decode: the consumer sees the two containers 1 KiB at a time -----------------
+// frag_pair_decode hands back two whole fragments (64 registers).  A consumer that only folds them — the pair count —
+// does not need them whole: pair_stream keeps ONE raw fragment (the first sparse operand's, needed to take it back
+// out of what the second wrote on top; or the one bitmap operand) and calls f(a0, a1, b0, b1) for the eight pairs of
+// words of the lane's fragment as they come out of the table.  32 registers less, which is what lets the next item's
+// payload prefetch and the probing array's tail sit in registers without spilling.
+struct RunFinish {
+  uint32_t mode;   // 0: nothing to do (array / bitmap), 1: toggles -> parity prefix, 2: boundary masks + interior map
+  uint32_t carry;  // mode 1: parity of all toggles in earlier words
+  const lds_u32* row;
+  uint32_t sh;
+};
+
+__device__ __forceinline__ void run_finish_init(RunFinish& r, uint32_t type, uint32_t len, uint32_t mb, int lane) {
+  r.mode = type != kTypeRun ? 0u : (len <= kRunFillMax ? 2u : 1u);
+  r.carry = 0;
+  r.row = (const lds_u32*)(uintptr_t)(mb + 4u * ((uint32_t)lane >> 3));
+  r.sh = 4u * ((uint32_t)lane & 7u);
+  if (r.mode == 2u) {  // parity prefix of the interior map, in place (the caller synchronises before the first step)
+    lds_u32* mine = (lds_u32*)(uintptr_t)(mb + 4u * (uint32_t)lane);
+    uint32_t x = *mine;
+    x ^= x << 1;
+    x ^= x << 2;
+    x ^= x << 4;
+    x ^= x << 8;
+    x ^= x << 16;
+    const u64 odd = __ballot((x >> 31) != 0);
+    const u64 lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (__popcll(odd & lane_lt) & 1) x = ~x;
+    *mine = x;
+  }
+}
+
+template <int J>
+__device__ __forceinline__ void run_finish_step(RunFinish& r, u64& w0, u64& w1, int lane) {
+  if (r.mode == 2u) {
+    const uint32_t nib = r.row[8 * J] >> r.sh;
+    const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)nib, 0, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)nib, 1, 1);
+    const uint32_t m2 = (uint32_t)__builtin_amdgcn_sbfe((int)nib, 2, 1), m3 = (uint32_t)__builtin_amdgcn_sbfe((int)nib, 3, 1);
+    w0 |= (u64)m0 | ((u64)m1 << 32);
+    w1 |= (u64)m2 | ((u64)m3 << 32);
+  } else if (r.mode == 1u) {
+    const u64 lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t p0 = __popcll(w0) & 1u, p1 = __popcll(w1) & 1u;
+    const u64 m = __ballot((p0 ^ p1) != 0);
+    const uint32_t in = r.carry ^ (__popcll(m & lane_lt) & 1u);
+    w0 = prefix_xor64(w0) ^ (in ? ~0ull : 0ull);
+    w1 = prefix_xor64(w1) ^ ((in ^ p0) ? ~0ull : 0ull);
+    r.carry ^= __popcll(m) & 1u;
+  }
+}
+
+template <int J, class F>
+__device__ __forceinline__ void pair_stream_steps(bool la, bool lb, const u64 (&keep)[kWordsPerLane], const ulonglong2* q, RunFinish& ra, RunFinish& rb,
+                                                  int lane, F& f) {
+  if constexpr (J < 8) {
+    u64 a0, a1, b0, b1;
+    if (la && lb) {
+      const ulonglong2 x = q[J * kWave + lane];
+      a0 = keep[2 * J];
+      a1 = keep[2 * J + 1];
+      b0 = x.x ^ a0;
+      b1 = x.y ^ a1;
+    } else if (la) {
+      const ulonglong2 x = q[J * kWave + lane];
+      a0 = x.x;
+      a1 = x.y;
+      b0 = keep[2 * J];
+      b1 = keep[2 * J + 1];
+    } else {
+      const ulonglong2 x = q[J * kWave + lane];
+      a0 = keep[2 * J];
+      a1 = keep[2 * J + 1];
+      b0 = x.x;
+      b1 = x.y;
+    }
+    run_finish_step<J>(ra, a0, a1, lane);
+    run_finish_step<J>(rb, b0, b1, lane);
+    f(a0, a1, b0, b1);
+    pair_stream_steps<J + 1>(la, lb, keep, q, ra, rb, lane, f);
+  }
+}
+
+// ta, tb: array / bitmap / run, at least one of them sparse; batch 0 of the sparse ones in va / vb
+template <class F>
+__device__ __forceinline__ void pair_stream(uint32_t ta, const uint8_t* __restrict__ pa, uint32_t lena, uint32_t tb, const uint8_t* __restrict__ pb,
+                                            uint32_t lenb, int lane, u64* table, uint32_t* mini, uint32_t (&va)[kPairBatch],
+                                            uint32_t (&vb)[kPairBatch], F f) {
+  const bool la = ta != kTypeBitmap, lb = tb != kTypeBitmap;  // wave-uniform
+  u64 keep[kWordsPerLane];  // the bitmap operand, or the raw bits of A when both are sparse
+  if (!la) frag_load_bitmap(pa, lane, keep);
+  if (!lb) frag_load_bitmap(pb, lane, keep);
+  const bool fa = ta == kTypeRun && lena <= kRunFillMax, fb = tb == kTypeRun && lenb <= kRunFillMax;
+  const uint32_t tbase = lds_table_base(table);
+  const uint32_t mbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)mini);
+  lds_zero(table, lane);
+  if (fa || fb) {
+    uint2 z;
+    z.x = 0;
+    z.y = 0;
+    reinterpret_cast<uint2*>(mini)[lane] = z;
+  }
+  wave_lds_sync();
+  if (la) {
+    if (fa) run_fill_all(pa, lena, lane, tbase, mbase, va);
+    else sparse_xor_all(ta, pa, lena, lane, tbase, va);
+    wave_lds_sync();
+    if (lb) {
+      lds_read_frag(table, lane, keep);  // raw bits of A, before B goes on top
+      wave_lds_sync();
+    }
+  }
+  if (lb) {
+    if (fb) run_fill_all(pb, lenb, lane, tbase, mbase + 4u * kMiniDwords, vb);
+    else sparse_xor_all(tb, pb, lenb, lane, tbase, vb);
+    wave_lds_sync();
+  }
+  RunFinish ra, rb;
+  run_finish_init(ra, ta, lena, mbase, lane);
+  run_finish_init(rb, tb, lenb, mbase + 4u * kMiniDwords, lane);
+  wave_lds_sync();
+  pair_stream_steps<0>(la, lb, keep, reinterpret_cast<const ulonglong2*>(table), ra, rb, lane, f);
+  wave_lds_sync();
+}
+
+// The same for callers that hold only the descriptors (k_setop2): nil operands come back as zero fragments.
+__device__ __forceinline__ void frag_load_pair(const Slot& sa, const uint8_t* __restrict__ arenaA, const Slot& sb,
+                                               const uint8_t* __restrict__ arenaB, int lane, u64* table, uint32_t* mini,
+                                               u64 (&wa)[kWordsPerLane], u64 (&wb)[kWordsPerLane]) {
+  const uint32_t ta = slot_n(sa) ? slot_type(sa) : kTypeNil, tb = slot_n(sb) ? slot_type(sb) : kTypeNil;
+  const uint8_t* pa = arenaA + sa.off;
+  const uint8_t* pb = arenaB + sb.off;
+  uint32_t va[kPairBatch], vb[kPairBatch];
+  if (ta == kTypeArray || ta == kTypeRun) sparse_load(pa, sparse_units(ta, sa.len), 0, lane, va);
+  if (tb == kTypeArray || tb == kTypeRun) sparse_load(pb, sparse_units(tb, sb.len), 0, lane, vb);
+  frag_pair_decode(ta, pa, sa.len, tb, pb, sb.len, lane, table, mini, va, vb, wa, wb);
 }
 
 // ---- |A ∩ B| over row pairs, any mix of encodings (intersectionCount, roaring.go:4477-4614) -------------
@@ -190,20 +484,22 @@ __device__ __forceinline__ void item_prefetch(const Slot& sa, const uint8_t* __r
   const uint32_t na = slot_n(sa), nb = slot_n(sb);
   if (na == 0 || nb == 0 || na == 65536u || nb == 65536u) return;
   const uint32_t ta = slot_type(sa), tb = slot_type(sb);
-  if (ta == kTypeArray || ta == kTypeRun) sparse_load(ta, arenaA + sa.off, sa.len, 0, lane, va);
-  if (tb == kTypeArray || tb == kTypeRun) sparse_load(tb, arenaB + sb.off, sb.len, 0, lane, vb);
+  if (ta == kTypeArray || ta == kTypeRun) sparse_load(arenaA + sa.off, sparse_units(ta, sa.len), 0, lane, va);
+  if (tb == kTypeArray || tb == kTypeRun) sparse_load(arenaB + sb.off, sparse_units(tb, sb.len), 0, lane, vb);
 }
 
 // shorter array -> table, longer array probes it; returns this lane's hits
 __device__ __forceinline__ uint32_t arrays_table_probe(const uint8_t* __restrict__ pt, uint32_t lt, uint32_t (&vt)[kPairBatch],
                                                        const uint8_t* __restrict__ pp, uint32_t lp, uint32_t (&vp)[kPairBatch], int lane,
                                                        u64* table) {
-  uint32_t* s32 = reinterpret_cast<uint32_t*>(table);
+  ProbeTail tail;
+  probe_tail_load(pp, lp, lane, tail);
+  const uint32_t tbase = lds_table_base(table);
   lds_zero(table, lane);
   wave_lds_sync();
-  sparse_xor_all(kTypeArray, pt, lt, lane, s32, vt);
+  sparse_xor_all(kTypeArray, pt, lt, lane, tbase, vt);
   wave_lds_sync();
-  const uint32_t h = array_probe_all(pp, lp, lane, s32, vp);
+  const uint32_t h = array_probe_all(pp, lp, lane, tbase, vp, tail);
   wave_lds_sync();
   return h;
 }
@@ -213,6 +509,8 @@ __device__ __forceinline__ uint32_t bitmap_table_probe(const uint8_t* __restrict
                                                        uint32_t (&vp)[kPairBatch], int lane, u64* table) {
   u64 wb[kWordsPerLane];
   frag_load_bitmap(pbm, lane, wb);
+  ProbeTail tail;
+  probe_tail_load(parr, larr, lane, tail);
   ulonglong2* q = reinterpret_cast<ulonglong2*>(table);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -222,28 +520,39 @@ __device__ __forceinline__ uint32_t bitmap_table_probe(const uint8_t* __restrict
     q[j * kWave + lane] = x;  // fragment layout -> natural word order in the table
   }
   wave_lds_sync();
-  const uint32_t h = array_probe_all(parr, larr, lane, reinterpret_cast<const uint32_t*>(table), vp);
+  const uint32_t h = array_probe_all(parr, larr, lane, lds_table_base(table), vp, tail);
   wave_lds_sync();
   return h;
 }
 
-// values (<= 128, in v[0..1]) of an array that are set in a bitmap container in global memory
+// values (<= 128: one dword of two values per lane, in v[0]) of an array that are set in a bitmap container in
+// global memory
 __device__ __forceinline__ uint32_t array_probe_global(const uint32_t (&v)[kPairBatch], uint32_t len, const uint8_t* __restrict__ pbm, int lane) {
+  const uint32_t* bm = reinterpret_cast<const uint32_t*>(pbm);
+  const uint32_t i2 = 2u * (uint32_t)lane, lo = v[0] & 0xFFFFu, hi = v[0] >> 16;
   uint32_t h = 0;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const uint32_t i = (uint32_t)k * kWave + (uint32_t)lane;
-    if (i < len) h += (reinterpret_cast<const uint32_t*>(pbm)[v[k] >> 5] >> (v[k] & 31u)) & 1u;
-  }
+  if (i2 < len) h += (bm[lo >> 5] >> (lo & 31u)) & 1u;
+  if (i2 + 1u < len) h += (bm[hi >> 5] >> (hi & 31u)) & 1u;
   return h;
 }
 
 // one (pair, slot): adds to `part` (per lane) or `spart` (wave-uniform)
 __device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __restrict__ arenaA, const Slot& sb,
-                                            const uint8_t* __restrict__ arenaB, int lane, u64* table, uint32_t (&va)[kPairBatch],
+                                            const uint8_t* __restrict__ arenaB, int lane, u64* table, uint32_t* mini, uint32_t (&va)[kPairBatch],
                                             uint32_t (&vb)[kPairBatch], uint32_t sparse_paths, uint32_t& part, uint32_t& spart) {
+  // The lane index is laundered through an empty asm per item: otherwise the optimiser hoists every per-lane
+  // address of every path (table rows, payload pointers, masks) out of the item loop as "loop invariant",
+  // runs out of registers and spills them — one scratch reload per use, in the hot path (measured: 247 spilled
+  // registers in the two-slots-per-wave kernel).
+  asm volatile("" : "+v"(lane));
   const uint32_t na = slot_n(sa), nb = slot_n(sb);
   const uint32_t ta = slot_type(sa), tb = slot_type(sb);
+  // timing experiments (option pair_ablate, WRONG results): 2 = no item is decoded, 8 = items with a run are skipped,
+  // 16 = array x array items are skipped, 32 = bitmap x array items are skipped
+  if (sparse_paths & 0x200u) return;
+  if ((sparse_paths & 0x800u) && (ta == kTypeRun || tb == kTypeRun)) return;
+  if ((sparse_paths & 0x1000u) && ta == kTypeArray && tb == kTypeArray) return;
+  if ((sparse_paths & 0x2000u) && ((ta == kTypeArray && tb == kTypeBitmap) || (ta == kTypeBitmap && tb == kTypeArray))) return;
   const uint8_t* pa = arenaA + sa.off;
   const uint8_t* pb = arenaB + sb.off;
   if (na == 0 || nb == 0) return;
@@ -259,15 +568,19 @@ __device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __res
     for (int i = 0; i < kWordsPerLane; ++i) part += __popcll(wa[i] & wb[i]);
   } else if (ta == kTypeArray && tb == kTypeArray) {
     if (sparse_paths && sa.len <= kSmallArray && sb.len <= kSmallArray) {
-      // all-pairs compare in registers, the shorter array broadcast value by value
-      const uint32_t a = (uint32_t)lane < sa.len ? va[0] : 0xFFFFFFFFu;
-      const uint32_t b = (uint32_t)lane < sb.len ? vb[0] : 0xFFFFFFFEu;
+      // all-pairs compare in registers (two values per lane, lanes 0..31), the shorter array broadcast value by value
       const bool a_long = sa.len >= sb.len;
-      const uint32_t lng = a_long ? a : b, sht = a_long ? b : a;
-      const uint32_t ns = a_long ? sb.len : sa.len;
-      bool m = false;
-      for (uint32_t k = 0; k < ns; ++k) m |= lng == (uint32_t)__builtin_amdgcn_readlane((int)sht, (int)k);
-      part += m ? 1u : 0u;
+      const uint32_t lng = a_long ? va[0] : vb[0], sht = a_long ? vb[0] : va[0];
+      const uint32_t nl = a_long ? sa.len : sb.len, ns = a_long ? sb.len : sa.len;
+      const uint32_t lo = lng & 0xFFFFu, hi = lng >> 16;
+      bool m_lo = false, m_hi = false;
+      for (uint32_t k = 0; k < ns; ++k) {
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)sht, (int)(k >> 1));
+        const uint32_t sv = (k & 1u) ? d >> 16 : d & 0xFFFFu;
+        m_lo |= lo == sv;
+        m_hi |= hi == sv;
+      }
+      part += ((2u * (uint32_t)lane < nl && m_lo) ? 1u : 0u) + ((2u * (uint32_t)lane + 1u < nl && m_hi) ? 1u : 0u);
     } else if (sa.len <= sb.len) {
       part += arrays_table_probe(pa, sa.len, va, pb, sb.len, vb, lane, table);
     } else {
@@ -280,47 +593,44 @@ __device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __res
     if (sparse_paths && sb.len <= kProbeArray) part += array_probe_global(vb, sb.len, pa, lane);
     else part += bitmap_table_probe(pa, pb, sb.len, vb, lane, table);
   } else {
-    // a run on at least one side: both operands as fragments, one clear (frag_load_pair with batch 0 in hand)
-    u64 wa[kWordsPerLane], wb[kWordsPerLane];
-    const bool la = ta != kTypeBitmap, lb = tb != kTypeBitmap;
-    if (!la) frag_load_bitmap(pa, lane, wa);
-    if (!lb) frag_load_bitmap(pb, lane, wb);
-    uint32_t* s32 = reinterpret_cast<uint32_t*>(table);
-    lds_zero(table, lane);
-    wave_lds_sync();
-    if (la) {
-      sparse_xor_all(ta, pa, sa.len, lane, s32, va);
-      wave_lds_sync();
-      lds_read_frag(table, lane, wa);
-      wave_lds_sync();
-    }
-    if (lb) {
-      sparse_xor_all(tb, pb, sb.len, lane, s32, vb);
-      wave_lds_sync();
-      lds_read_frag(table, lane, wb);
-      wave_lds_sync();
-      if (la) {
-#pragma unroll
-        for (int i = 0; i < kWordsPerLane; ++i) wb[i] ^= wa[i];
-      }
-    }
-    if (ta == kTypeRun) frag_parity_prefix(wa, lane);
-    if (tb == kTypeRun) frag_parity_prefix(wb, lane);
-#pragma unroll
-    for (int i = 0; i < kWordsPerLane; ++i) part += __popcll(wa[i] & wb[i]);
+    // a run on at least one side: both operands 1 KiB at a time out of the table, one clear
+    uint32_t acc = 0;
+    pair_stream(ta, pa, sa.len, tb, pb, sb.len, lane, table, mini, va, vb,
+                [&acc](u64 a0, u64 a1, u64 b0, u64 b1) { acc += (uint32_t)__popcll(a0 & b0) + (uint32_t)__popcll(a1 & b1); });
+    part += acc;
   }
 }
 
-template <int SPW>
-__global__ void __launch_bounds__(256, 4) k_icount2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
-                                                   const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
-                                                   const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
-                                                   u64* __restrict__ out, uint32_t sparse_paths) {
-  __shared__ u64 lds[4][kWords];
+// items K .. SPW - 1 of a wave, the next one's batch 0 in flight while item K is worked on (a template recursion:
+// the item body is too large for the unroller, and a real loop would index the descriptor arrays dynamically)
+template <int K, int SPW>
+__device__ __forceinline__ void icount_items(const Slot (&sa)[SPW], const uint8_t* __restrict__ arenaA, const Slot (&sb)[SPW],
+                                             const uint8_t* __restrict__ arenaB, int lane, u64* table, uint32_t* mini, uint32_t (&va)[kPairBatch],
+                                             uint32_t (&vb)[kPairBatch], uint32_t sparse_paths, uint32_t& part, uint32_t& spart) {
+  if constexpr (K < SPW) {
+    uint32_t xa[kPairBatch], xb[kPairBatch];
+    if constexpr (K + 1 < SPW) item_prefetch(sa[K + 1], arenaA, sb[K + 1], arenaB, lane, xa, xb);
+    icount_item(sa[K], arenaA, sb[K], arenaB, lane, table, mini, va, vb, sparse_paths, part, spart);
+    if constexpr (K + 1 < SPW) icount_items<K + 1, SPW>(sa, arenaA, sb, arenaB, lane, table, mini, xa, xb, sparse_paths, part, spart);
+  }
+}
+
+// WPB waves per block.  A block's LDS and wave slots are released when its LAST wave ends, and an item with a run
+// lives several times as long as an array x array one: with four waves per block 84 % of the blocks of config 3's
+// row pairs held a run item and every block lived as long as its slowest wave (skipping the array x array items —
+// half of all items — shortened the kernel by 4 us out of 57).  One-wave blocks release each wave's table the
+// moment it ends.
+template <int SPW, int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
+                                                     const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
+                                                     const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
+                                                     u64* __restrict__ out, uint32_t sparse_paths) {
+  __shared__ u64 lds[WPB][kWords];
+  __shared__ uint32_t mini[WPB][2 * kMiniDwords];
   constexpr int kWavesPerPair = kSlots / SPW;
   const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and the compiler knows it
-  const uint64_t wid = (uint64_t)blockIdx.x * 4 + (uint64_t)wv;
+  const int wv = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and the compiler knows it
+  const uint64_t wid = (uint64_t)blockIdx.x * WPB + (uint64_t)wv;
   const uint64_t pair = wid / kWavesPerPair;
   if (pair >= n_pairs) return;
   const uint32_t slot0 = (uint32_t)(wid % kWavesPerPair) * SPW;
@@ -336,22 +646,82 @@ __global__ void __launch_bounds__(256, 4) k_icount2(const Slot* __restrict__ slo
   u64* table = lds[wv];
   uint32_t part = 0, spart = 0;
   uint32_t va[kPairBatch], vb[kPairBatch];
-  item_prefetch(sa[0], arenaA, sb[0], arenaB, lane, va, vb);
-#pragma unroll
-  for (int k = 0; k < SPW; ++k) {
-    uint32_t xa[kPairBatch], xb[kPairBatch];
-    if (k + 1 < SPW) item_prefetch(sa[k + 1], arenaA, sb[k + 1], arenaB, lane, xa, xb);
-    icount_item(sa[k], arenaA, sb[k], arenaB, lane, table, va, vb, sparse_paths, part, spart);
-    if (k + 1 < SPW) {
-#pragma unroll
-      for (int i = 0; i < kPairBatch; ++i) {
-        va[i] = xa[i];
-        vb[i] = xb[i];
-      }
-    }
+  if (!(sparse_paths & 0x400u)) {  // (0x400: timing experiment, descriptors only)
+    item_prefetch(sa[0], arenaA, sb[0], arenaB, lane, va, vb);
+    icount_items<0, SPW>(sa, arenaA, sb, arenaB, lane, table, mini[wv], va, vb, sparse_paths, part, spart);
+  } else {
+    spart = slot_n(sa[0]) + slot_n(sb[SPW - 1]);
   }
+  if (sparse_paths & 0x100u) return;  // (timing experiment: no output)
   const uint32_t c = wave_reduce_add(part) + spart;
   if (lane == 0 && c) atomicAdd(&out[pair], (u64)c);
+}
+
+// The PERSISTENT form (option pair_persistent, default): the grid is only as large as the device holds at once and
+// every wave strides through the (pair, slot) items as a four-stage software pipeline —
+//     item u + 3 W: its two row indexes are requested                                  (scalar loads)
+//     item u + 2 W: its two descriptors are requested, at the rows that arrived        (scalar loads)
+//     item u + W  : batch 0 of its sparse payloads is requested, at the offsets that arrived
+//     item u      : decoded and counted
+// (W = waves in the grid).  With one item per wave the three dependent round trips — row index, descriptor,
+// payload: ~4 us of HBM latency — were paid in full by every item, and with 16 waves per CU (128 registers,
+// 34 KiB of LDS per block) that wait, not instruction issue and not the LDS, set the rate: rocprofv3 --pmc showed
+// the waves parked in s_waitcnt 60 % of their life (profiles/r03_pmc_pair_kernels.txt).  Here an item's chain
+// overlaps the work of the three items before it.
+__global__ void __launch_bounds__(256, 4) k_icount2p(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
+                                                    const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
+                                                    const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
+                                                    u64* __restrict__ out, uint32_t sparse_paths) {
+  __shared__ u64 lds[4][kWords];
+  __shared__ uint32_t mini[4][2 * kMiniDwords];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint64_t n_items = n_pairs * kSlots;
+  const uint64_t stride = (uint64_t)gridDim.x * 4;
+  uint64_t u = (uint64_t)blockIdx.x * 4 + (uint64_t)wv;
+  if (u >= n_items) return;
+  const uint64_t last = n_items - 1;
+  // loads of items past the end are made at the last item (in bounds, never used)
+#define FBK_ITEM(x) ((x) < n_items ? (x) : last)
+  // prologue: fill the pipeline
+  uint64_t i0 = u, i1 = FBK_ITEM(u + stride), i2 = FBK_ITEM(u + 2 * stride);
+  uint32_t ra0 = rowsA[i0 >> 4], rb0 = rowsB[i0 >> 4];
+  uint32_t ra1 = rowsA[i1 >> 4], rb1 = rowsB[i1 >> 4];
+  uint32_t ra2 = rowsA[i2 >> 4], rb2 = rowsB[i2 >> 4];
+  Slot sa0 = slotsA[(uint64_t)ra0 * kSlots + (i0 & 15)], sb0 = slotsB[(uint64_t)rb0 * kSlots + (i0 & 15)];
+  Slot sa1 = slotsA[(uint64_t)ra1 * kSlots + (i1 & 15)], sb1 = slotsB[(uint64_t)rb1 * kSlots + (i1 & 15)];
+  uint32_t va[kPairBatch], vb[kPairBatch];
+  item_prefetch(sa0, arenaA, sb0, arenaB, lane, va, vb);
+  u64* table = lds[wv];
+  for (;;) {
+    // stage A for item u + 3 W, stage B for u + 2 W, stage C for u + W
+    const uint64_t i3 = FBK_ITEM(u + 3 * stride);
+    const uint32_t ra3 = rowsA[i3 >> 4], rb3 = rowsB[i3 >> 4];
+    const Slot sa2 = slotsA[(uint64_t)ra2 * kSlots + (i2 & 15)], sb2 = slotsB[(uint64_t)rb2 * kSlots + (i2 & 15)];
+    uint32_t xa[kPairBatch], xb[kPairBatch];
+    const bool more = u + stride < n_items;
+    if (more) item_prefetch(sa1, arenaA, sb1, arenaB, lane, xa, xb);
+    // stage D
+    uint32_t part = 0, spart = 0;
+    icount_item(sa0, arenaA, sb0, arenaB, lane, table, mini[wv], va, vb, sparse_paths, part, spart);
+    const uint32_t c = wave_reduce_add(part) + spart;
+    if (lane == 0 && c) atomicAdd(&out[u >> 4], (u64)c);
+    if (!more) break;
+    u += stride;
+    sa0 = sa1;
+    sb0 = sb1;
+    sa1 = sa2;
+    sb1 = sb2;
+    ra2 = ra3;
+    rb2 = rb3;
+    i2 = i3;
+#pragma unroll
+    for (int i = 0; i < kPairBatch; ++i) {
+      va[i] = xa[i];
+      vb[i] = xb[i];
+    }
+  }
+#undef FBK_ITEM
 }
 
 // Materialising A <op> B, one wave per (pair, slot): k_setop's outputs and right-sized array paths
@@ -363,6 +733,7 @@ __global__ void __launch_bounds__(256, 4) k_setop2(const Slot* __restrict__ slot
                                                uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
                                                u64* __restrict__ out_counts, uint32_t direct) {
   __shared__ u64 lds[4][kWords];
+  __shared__ uint32_t mini[4][2 * kMiniDwords];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: descriptors become scalar loads (see k_icount2)
   const uint64_t wslot = (uint64_t)blockIdx.x * 4 + (uint64_t)wv;
@@ -421,7 +792,7 @@ __global__ void __launch_bounds__(256, 4) k_setop2(const Slot* __restrict__ slot
     }
   }
   u64 wa[kWordsPerLane], wb[kWordsPerLane];
-  frag_load_pair(sa, arenaA, sb, arenaB, lane, lds[wv], wa, wb);
+  frag_load_pair(sa, arenaA, sb, arenaB, lane, lds[wv], mini[wv], wa, wb);
 #pragma unroll
   for (int i = 0; i < kWordsPerLane; ++i) wa[i] = apply_op<OP>(wa[i], wb[i]);
   uint32_t c = wave_reduce_add(frag_popcount(wa));
