@@ -96,8 +96,8 @@ struct FbkOptions {
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
-  int64_t pair_spw = 2;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4): next slot's payload in flight while the current one is decoded
-  int64_t pair_persistent = 4;           // k_icount2p: blocks per CU of the persistent, software-pipelined pair count (0: one wave per pair_spw slots)
+  int64_t pair_spw = 1;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4): next slot's payload in flight while the current one is decoded
+  int64_t pair_persistent = 0;           // k_icount2p: blocks per CU of the persistent, software-pipelined pair count (0: one wave per pair_spw slots)
   int64_t pair_wpb = 1;                  // wavefronts per block of k_icount2: 1 (a wave's LDS table is released when IT ends) or 4
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
   int64_t pair_kernels = 2;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels (A/B runs)
@@ -879,7 +879,7 @@ int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_r
   }
   hipError_t e = ctx_malloc(ctx, reinterpret_cast<void**>(&b->d_arena), std::max<uint64_t>(bytes, 16));
   if (e == hipSuccess) e = ctx_malloc(ctx, reinterpret_cast<void**>(&b->d_slots), std::max<uint64_t>(n_slots, 1) * sizeof(Slot));
-  if (e == hipSuccess && bytes) e = hipMemcpyAsync(b->d_arena, words, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && bytes) e = hipMemcpyAsync(b->d_arena, words, bytes, hipMemcpyDefault, ctx->stream);  // (host or device source)
   if (e == hipSuccess && n_slots) {
     e = hipMemcpyAsync(b->d_slots, b->h_slots.data(), n_slots * sizeof(Slot), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
@@ -1055,8 +1055,12 @@ void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
                        p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, p->d_counts);
+  else if (p->ctx->opt.pair_kernels >= 2 && p->ctx->opt.pair_wpb == 4)
+    hipLaunchKernelGGL((fbk::k_setop2<OP, 4>), dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
+                       p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
+                       want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
   else if (p->ctx->opt.pair_kernels >= 2)
-    hipLaunchKernelGGL(fbk::k_setop2<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
+    hipLaunchKernelGGL((fbk::k_setop2<OP, 1>), dim3(uint32_t(p->n_pairs * fbk::kSlots)), dim3(64), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
                        want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
   else
@@ -1398,6 +1402,7 @@ int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* 
 }  // extern "C"
 
 #include "fbk_query_api.inc"
+#include "fbk_prepared_api.inc"
 #include "fbk_wire_api.inc"
 #include "fbk_cache_api.inc"
 #include "fbk_group_api.inc"

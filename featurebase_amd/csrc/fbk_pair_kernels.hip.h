@@ -726,17 +726,17 @@ __global__ void __launch_bounds__(256, 4) k_icount2p(const Slot* __restrict__ sl
 
 // Materialising A <op> B, one wave per (pair, slot): k_setop's outputs and right-sized array paths
 // (fbk_kernels.hip.h) behind the pair loader above.
-template <int OP>
-__global__ void __launch_bounds__(256, 4) k_setop2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
-                                               const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
-                                               const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
-                                               uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
-                                               u64* __restrict__ out_counts, uint32_t direct) {
-  __shared__ u64 lds[4][kWords];
-  __shared__ uint32_t mini[4][2 * kMiniDwords];
+template <int OP, int WPB>
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4))) k_setop2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
+                                                    const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
+                                                    const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
+                                                    uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
+                                                    u64* __restrict__ out_counts, uint32_t direct) {
+  __shared__ u64 lds[WPB][kWords];
+  __shared__ uint32_t mini[WPB][2 * kMiniDwords];
   const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: descriptors become scalar loads (see k_icount2)
-  const uint64_t wslot = (uint64_t)blockIdx.x * 4 + (uint64_t)wv;
+  const int wv = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: descriptors become scalar loads (see k_icount2)
+  const uint64_t wslot = (uint64_t)blockIdx.x * WPB + (uint64_t)wv;
   const uint64_t pair = wslot >> 4;
   const uint32_t slot = wslot & 15;
   if (pair >= n_pairs) return;

@@ -18,6 +18,7 @@ FBK_E_INVALID, FBK_E_NODEVICE, FBK_E_HIP, FBK_E_NOMEM, FBK_E_CAPACITY, FBK_E_NOT
 TYPE_NIL, TYPE_ARRAY, TYPE_BITMAP, TYPE_RUN = 0, 1, 2, 3
 OP_AND, OP_OR, OP_XOR, OP_ANDNOT = 0, 1, 2, 3
 SETOP_KEEP_BITMAP, SETOP_OPTIMIZE = 0, 1
+QUERY_ACCUMULATE = 1
 
 
 class FbkError(RuntimeError):
@@ -126,6 +127,13 @@ SIGNATURES = {
     "fbk_bsi_range_sum_plan": (C.c_int32, [C.c_int32, C.c_uint32, C.c_int64, _vp, _vp, _vp, _vp]),
     "fbk_bsi_range_sum": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_uint32, C.c_int64, _vp, _vp, _vp, _vp]),
     "fbk_bsi_range_between": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_uint32, _vpp, _vp]),
+    "fbk_query_count_matrix": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, _vpp]),
+    "fbk_query_fold_intersection_count": (C.c_int32, [_vp, C.c_int32, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp, _vpp]),
+    "fbk_query_bsi_sum": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int64, _vp, _vp, _vpp]),
+    "fbk_query_run": (C.c_int32, [_vp, _vp, _vp, C.c_uint32]),
+    "fbk_query_result": (C.c_int32, [_vp, _vp, _vpp, _u64p]),
+    "fbk_query_read": (C.c_int32, [_vp, _vp, _vp, _vp]),
+    "fbk_query_free": (C.c_int32, [_vp, _vp]),
     "fbk_group_open": (C.c_int32, [_i32p, C.c_uint32, C.c_uint32, _vpp]),
     "fbk_group_close": (C.c_int32, [_vp]),
     "fbk_group_size": (C.c_int32, [_vp, _u32p]),

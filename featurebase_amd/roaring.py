@@ -187,6 +187,42 @@ class Plan:
             self.h = C.c_void_p(None)
 
 
+class Query:
+    """A prepared query (fbk_query_*): row lists and result buffers resident, every run launch-only."""
+
+    def __init__(self, ctx: "Context", handle: int, kind: str, shape: Tuple[int, ...]):
+        self.ctx, self.h, self.kind, self.shape = ctx, C.c_void_p(handle), kind, shape
+
+    def run(self, device_ptr: int = 0, accumulate: bool = False) -> None:
+        L.check(self.ctx.lib.fbk_query_run(self.ctx.h, self.h, C.c_void_p(device_ptr or None), L.QUERY_ACCUMULATE if accumulate else 0))
+
+    def result_ptr(self) -> Tuple[int, int]:
+        """(device pointer, bytes) of the query's own result buffer"""
+        p, n = C.c_void_p(), C.c_uint64()
+        L.check(self.ctx.lib.fbk_query_result(self.ctx.h, self.h, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def read(self, per_shard: bool = False):
+        if self.kind == "count_matrix":
+            n_shards, n_a, n_b = self.shape
+            tot = np.zeros((n_a, n_b), dtype=np.uint64)
+            ps = np.zeros((n_shards, n_a, n_b), dtype=np.uint64) if per_shard else None
+            L.check(self.ctx.lib.fbk_query_read(self.ctx.h, self.h, tot.ctypes.data, ps.ctypes.data if ps is not None else None))
+            return (tot, ps) if per_shard else tot
+        if self.kind == "fold":
+            out = np.zeros(self.shape[0], dtype=np.uint64)
+            L.check(self.ctx.lib.fbk_query_read(self.ctx.h, self.h, out.ctypes.data, None))
+            return out
+        sums, counts = np.zeros(self.shape[0], dtype=np.int64), np.zeros(self.shape[0], dtype=np.uint64)
+        L.check(self.ctx.lib.fbk_query_read(self.ctx.h, self.h, sums.ctypes.data, counts.ctypes.data))
+        return sums, counts
+
+    def free(self) -> None:
+        if self.h:
+            L.check(self.ctx.lib.fbk_query_free(self.ctx.h, self.h))
+            self.h = C.c_void_p(None)
+
+
 class Context:
     """One GPU.  Fails loudly when libfbk.so is missing or no gfx950 device is visible."""
 
@@ -510,6 +546,36 @@ class Context:
             )
         )
         return (tot, ps) if per_shard else tot
+
+    # -- prepared (launch-only) forms of the query-level calls -------------------------------
+    def prepare_count_matrix(self, a: Batch, rows_a, b: Batch, rows_b, filt: Optional[Batch] = None, rows_f=None, keep_per_shard: bool = False) -> Query:
+        ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
+        rb = np.ascontiguousarray(rows_b, dtype=np.uint32)
+        n_shards, n_a = ra.shape
+        n_b = rb.shape[1]
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        h = C.c_void_p()
+        L.check(self.lib.fbk_query_count_matrix(self.h, a.h, ra.ctypes.data, n_a, b.h, rb.ctypes.data, n_b, filt.h if filt is not None else None,
+                                                rf.ctypes.data if rf is not None else None, n_shards, 1 if keep_per_shard else 0, C.byref(h)))
+        return Query(self, h.value, "count_matrix", (n_shards, n_a, n_b))
+
+    def prepare_fold_intersection_count(self, op: int, batch: Batch, groups, filt: Optional[Batch] = None, rows_f=None) -> Query:
+        g = np.ascontiguousarray(groups, dtype=np.uint32)
+        g = g.reshape(len(groups), -1)
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        h = C.c_void_p()
+        L.check(self.lib.fbk_query_fold_intersection_count(self.h, op, batch.h, g.ctypes.data, g.shape[0], g.shape[1], filt.h if filt is not None else None,
+                                                           rf.ctypes.data if rf is not None else None, C.byref(h)))
+        return Query(self, h.value, "fold", (g.shape[0],))
+
+    def prepare_bsi_sum(self, batch: Batch, base_rows, bit_depth: int, op: int = 0, predicate: int = 0, filt: Optional[Batch] = None, rows_f=None) -> Query:
+        """op == 0: Sum over exists ∩ filt; op = BSI_*: Sum(Row(v op predicate), field = v) in one pass"""
+        base = np.ascontiguousarray(base_rows, dtype=np.uint32)
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        h = C.c_void_p()
+        L.check(self.lib.fbk_query_bsi_sum(self.h, batch.h, base.ctypes.data, base.size, bit_depth, op, C.c_int64(predicate), filt.h if filt is not None else None,
+                                           rf.ctypes.data if rf is not None else None, C.byref(h)))
+        return Query(self, h.value, "bsi", (base.size,))
 
     # -- BSI -----------------------------------------------------------------------------
     def bsi_sum(self, batch: Batch, base_rows, bit_depth: int, filt: Optional[Batch] = None, rows_f=None):

@@ -163,7 +163,9 @@ int32_t fbk_batch_upload(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t
 
 /* Dense upload: n_rows rows of 16 bitmap containers each, `words` = n_rows*16*1024
  * uint64 (row-major).  Cardinalities are recounted on the device (the analogue of
- * bitmapRepair, roaring.go:4193-4206).  Keys are assigned row*16+slot. */
+ * bitmapRepair, roaring.go:4193-4206).  Keys are assigned row*16+slot.  `words` may also be a
+ * DEVICE pointer on the context's device (rows a device-side decode produced, or a benchmark's
+ * on-device generator): the copy is then device to device. */
 int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_rows,
                                fbk_batch** out_batch);
 
@@ -339,6 +341,46 @@ int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64
 /* Borrow / take ownership of the plan's set-op output batch. */
 int32_t fbk_plan_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch);
 int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch);
+
+/* ---- prepared queries: the launch-only form of the query-level calls -------------------------
+ * fbk_plan_* above makes the PAIR operations launch-only.  A prepared query does the same for the
+ * GroupBy / TopK count matrix (fbk_count_matrix), the n-way fold with its fused count
+ * (fbk_fold_n_intersection_count / fbk_union_n_intersection_count) and BSI Sum / the one-pass
+ * Sum(Range) (fbk_bsi_sum, fbk_bsi_range_sum): the row lists are validated and uploaded ONCE, the
+ * result buffers live on the device, and every execution is memset + kernel(s) on the context's
+ * stream — no allocation, no host<->device copy, no synchronisation.  It is what one (query, node)
+ * call of mapperLocal (executor.go:6742) becomes when the same query shape runs again on resident
+ * fragments, and it leaves the partial result where the multi-GPU reduce wants it (the cell of an
+ * all-reduce).  The batches a query was prepared on must outlive it and must not be rewritten.
+ *
+ *   fbk_query_count_matrix              arguments as fbk_count_matrix; keep_per_shard != 0 keeps the
+ *                                       per-shard matrices readable (fbk_query_read's out1)
+ *   fbk_query_fold_intersection_count   arguments as fbk_fold_n_intersection_count
+ *   fbk_query_bsi_sum                   op == 0: fbk_bsi_sum; op = FBK_BSI_*: fbk_bsi_range_sum in one
+ *                                       pass (FBK_E_INVALID for the predicates only the two-pass form serves)
+ *   fbk_query_run(q, device_out, flags) enqueue one execution.  device_out == NULL: the query's own
+ *                                       result buffer; otherwise a caller-owned device buffer of the
+ *                                       result's size (count matrix: n_a * n_b uint64; fold: n_groups
+ *                                       uint64).  FBK_QUERY_ACCUMULATE adds to what the buffer holds
+ *                                       instead of overwriting it (count-valued kinds only).
+ *   fbk_query_result                    the query's own device result buffer and its size in bytes
+ *   fbk_query_read(q, out0, out1)       synchronise; copy the last run's result to the host:
+ *                                       count matrix: out0 = total [n_a * n_b] uint64, out1 = per-shard
+ *                                       [n_shards][n_a * n_b] (or NULL); fold: out0 = counts [n_groups];
+ *                                       BSI: out0 = int64 sums [n_shards], out1 = uint64 counts [n_shards]. */
+typedef struct fbk_query fbk_query;
+#define FBK_QUERY_ACCUMULATE 1u
+int32_t fbk_query_count_matrix(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a, const fbk_batch* b,
+                               const uint32_t* rows_b, uint32_t n_b, const fbk_batch* filter, const uint32_t* rows_f,
+                               uint32_t n_shards, uint32_t keep_per_shard, fbk_query** out_query);
+int32_t fbk_query_fold_intersection_count(fbk_ctx* ctx, int32_t op, const fbk_batch* batch, const uint32_t* rows, uint64_t n_groups,
+                                          uint32_t k, const fbk_batch* filter, const uint32_t* rows_f, fbk_query** out_query);
+int32_t fbk_query_bsi_sum(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards, uint32_t bit_depth,
+                          int32_t op, int64_t predicate, const fbk_batch* filter, const uint32_t* rows_f, fbk_query** out_query);
+int32_t fbk_query_run(fbk_ctx* ctx, fbk_query* query, void* device_out, uint32_t flags);
+int32_t fbk_query_result(fbk_ctx* ctx, fbk_query* query, void** out_device_ptr, uint64_t* out_bytes);
+int32_t fbk_query_read(fbk_ctx* ctx, fbk_query* query, void* out0, void* out1);
+int32_t fbk_query_free(fbk_ctx* ctx, fbk_query* query);
 
 /* ---- n-way union ---------------------------------------------------------------------
  * rows holds n_groups groups of k row ordinals (group g = rows[g*k .. g*k+k)); out row g

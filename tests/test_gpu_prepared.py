@@ -1,0 +1,148 @@
+"""Prepared queries (fbk_query_*): the launch-only forms of the count matrix, the n-way fold with its fused count
+and BSI Sum / one-pass Sum(Range).  Every result is compared with the CPU oracle (oracle/batch_oracle.c over the
+same flattened rows: groupByIterator executor.go:8880, Bitmap.Union roaring.go:1272 + IntersectionCount :711,
+fragment.sum fragment.go:724, rangeOp :937) and with the one-shot call; repeated runs, caller-owned device
+buffers and the accumulate flag included."""
+import numpy as np
+import pytest
+
+import datagen as D
+from featurebase_amd import lib as L
+from oracle import pybatch as PB
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mixed():
+    rows, groups, filt = D.config3_flat(12, 16, seed_idx=8100, workers=1)
+    return rows, groups, filt, PB.RowSet.from_flat(rows.descs(), rows.payload(), rows.n_rows), PB.RowSet.from_flat(filt.descs(), filt.payload(), filt.n_rows)
+
+
+def test_prepared_count_matrix_mixed_and_dense(gpu_ctx, mixed):
+    import torch
+
+    rows, g, filt, OA, OF = mixed
+    n = g.shape[0]
+    batch = gpu_ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
+    F = gpu_ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
+    fidx = np.arange(n)
+    for ra, rb, f in ((g[:, :8], g[:, 8:], True), (g[:, :12], g[:, 12:], False), (g, fidx.reshape(-1, 1), None)):
+        if f is None:  # TopK shape: rows x the filter row as B
+            exp = PB.topk_counts(OA, ra, OF, fidx)[:, :, None]
+            q = gpu_ctx.prepare_count_matrix(batch, ra, F, rb, keep_per_shard=True)
+        else:
+            exp = PB.count_matrix(OA, ra, OA, rb, OF if f else None, fidx if f else None)
+            q = gpu_ctx.prepare_count_matrix(batch, ra, batch, rb, F if f else None, fidx if f else None, keep_per_shard=True)
+        for _ in range(3):  # every run overwrites
+            q.run()
+        tot, ps = q.read(per_shard=True)
+        assert (ps == exp).all() and (tot == exp.sum(axis=0)).all()
+        # a caller-owned device buffer, accumulated into twice on top of a known value
+        cell = torch.full((exp.shape[1] * exp.shape[2],), 5, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        q.run(cell.data_ptr(), accumulate=True)
+        q.run(cell.data_ptr(), accumulate=True)
+        gpu_ctx.synchronize()
+        assert (cell.cpu().numpy().view(np.uint64).reshape(exp.shape[1:]) == 2 * exp.sum(axis=0) + 5).all()
+        q.run(cell.data_ptr())  # without the flag: overwritten
+        gpu_ctx.synchronize()
+        assert (cell.cpu().numpy().view(np.uint64).reshape(exp.shape[1:]) == exp.sum(axis=0)).all()
+        q.free()
+    # dense rows: the matrix-core kernel
+    wa, wb, wf = D.dense_rows(4 * 33, 0.5, 8201), D.dense_rows(4 * 40, 0.5, 8202), D.dense_rows(4, 0.5, 8203)
+    A, B, Ff = gpu_ctx.upload_dense(wa), gpu_ctx.upload_dense(wb), gpu_ctx.upload_dense(wf)
+    ra, rb = np.arange(4 * 33).reshape(4, 33), np.arange(4 * 40).reshape(4, 40)
+    exp = PB.count_matrix(PB.RowSet.from_dense(wa), ra, PB.RowSet.from_dense(wb), rb, PB.RowSet.from_dense(wf), np.arange(4))
+    q = gpu_ctx.prepare_count_matrix(A, ra, B, rb, Ff, np.arange(4))
+    q.run()
+    assert (q.read() == exp.sum(axis=0)).all()
+    assert (gpu_ctx.count_matrix(A, ra, B, rb, Ff, np.arange(4)) == exp.sum(axis=0)).all()
+    q.free()
+    for b in (A, B, Ff, batch, F):
+        b.free()
+
+
+def test_prepared_fold_intersection_count(gpu_ctx, mixed):
+    rows, g, filt, OA, OF = mixed
+    n = g.shape[0]
+    batch = gpu_ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
+    F = gpu_ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
+    fidx = np.arange(n)
+    exp, exp_u = PB.union_n_intersection_count(OA, g, OF, fidx)
+    q = gpu_ctx.prepare_fold_intersection_count(L.OP_OR, batch, g, F, fidx)
+    q.run()
+    q.run()
+    assert (q.read() == exp).all()
+    q.run(accumulate=True)
+    assert (q.read() == 2 * exp).all()
+    q.free()
+    q = gpu_ctx.prepare_fold_intersection_count(L.OP_OR, batch, g)  # no filter: |∪ rows|
+    q.run()
+    assert (q.read() == exp_u).all()
+    q.free()
+    # Intersect of the four densest rows of each shard
+    gi = g[:, :4]
+    R, _ = PB.setop(PB.OP_AND, OA, gi[:, 0], OA, gi[:, 1])
+    for k in (2, 3):
+        R, cnt = PB.setop(PB.OP_AND, R, np.arange(n), OA, gi[:, k])
+    q = gpu_ctx.prepare_fold_intersection_count(L.OP_AND, batch, gi)
+    q.run()
+    assert (q.read() == cnt).all()
+    q.free()
+    batch.free()
+    F.free()
+
+
+def test_prepared_bsi_sum_and_one_pass_range_sum(gpu_ctx):
+    n_shards, depth = 7, 20
+    rng = D.rng_for(8301)
+    w = rng.integers(0, 2**64, (n_shards, depth + 2, 16, 1024), dtype=np.uint64)
+    w[:, 0] |= rng.integers(0, 2**64, (n_shards, 16, 1024), dtype=np.uint64)
+    w[-1, 0, 11:] = 0
+    w[:, 1:] &= w[:, :1]
+    wf = rng.integers(0, 2**64, (n_shards, 16, 1024), dtype=np.uint64)
+    batch, F = gpu_ctx.upload_dense(w.reshape(-1)), gpu_ctx.upload_dense(wf)
+    OA, OF = PB.RowSet.from_dense(w.reshape(-1, 16, 1024)), PB.RowSet.from_dense(wf)
+    base, idx = np.arange(n_shards) * (depth + 2), np.arange(n_shards)
+    for filt in (False, True):
+        es, ec = PB.bsi_sum(OA, base, depth, OF if filt else None, idx if filt else None)
+        q = gpu_ctx.prepare_bsi_sum(batch, base, depth, filt=F if filt else None, rows_f=idx if filt else None)
+        q.run()
+        q.run()
+        s, c = q.read()
+        assert (s == es).all() and (c == ec).all()
+        q.free()
+    for op, pred in ((L.BSI_GT, 1234), (L.BSI_LTE, -777), (L.BSI_LT, 1 << 19), (L.BSI_GTE, -(1 << 18))):
+        R, _ = PB.bsi_range(OA, base, depth, op, pred)
+        for filt in (False, True):
+            if filt:
+                RF, _ = PB.setop(PB.OP_AND, R, idx, OF, idx)
+            es, ec = PB.bsi_sum(OA, base, depth, RF if filt else R, idx)
+            q = gpu_ctx.prepare_bsi_sum(batch, base, depth, op, pred, F if filt else None, idx if filt else None)
+            q.run()
+            s, c = q.read()
+            assert (s == es).all() and (c == ec).all(), (op, pred, filt)
+            q.free()
+    # a predicate only the two-pass form serves is refused at prepare time, with a message on the context
+    with pytest.raises(L.FbkError):
+        gpu_ctx.prepare_bsi_sum(batch, base, depth, L.BSI_EQ, 5)
+    assert "one-pass" in gpu_ctx.last_error()[1]
+    batch.free()
+    F.free()
+
+
+def test_prepared_query_argument_errors(gpu_ctx, mixed):
+    rows, g, filt, OA, OF = mixed
+    batch = gpu_ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
+    with pytest.raises(L.FbkError):
+        gpu_ctx.prepare_count_matrix(batch, g[:, :4] + 100000, batch, g[:, 4:8])  # row index out of range
+    q = gpu_ctx.prepare_count_matrix(batch, g[:, :4], batch, g[:, 4:8])
+    with pytest.raises(L.FbkError):
+        q.read()  # before the first run
+    other = gpu_ctx.fork()
+    with pytest.raises(L.FbkError):
+        L.check(other.lib.fbk_query_run(other.h, q.h, None, 0))  # prepared on another context
+    other.close()
+    q.free()
+    batch.free()
