@@ -16,7 +16,13 @@ the devices and reduce over gloo — flagged as "oversubscribed" in the output).
 reads RANK / LOCAL_RANK / WORLD_SIZE as usual.  Prints ONE JSON line on rank 0.
 
 `value` = container set-ops per second over all N GPUs (a set-op = one container pair with equal
-keys); weak scaling (1024 shards per GPU).  Also in the line: the distribution of
+keys); weak scaling (1024 shards per GPU).  For N > 1 EVERY step carries its own RCCL
+all-reduce of its partial total (one collective per query, pipelined on the device — nothing is amortised
+over several steps; the bucketed throughput mode of the earlier rounds is reported beside it as
+`throughput_mode_bucketed`), and `strong_scaling` holds BASELINE.json configs[3]: the FIXED 8192-shard
+32 x 32 IntersectionCount matrix (+ filter) split over the N ranks, one all-reduce of the 1024-cell partial
+matrix per query, the host add beside it, and the same query through the in-library group path
+(fbk_group_count_matrix, host / xGMI-peer / RCCL reduce) in `group_api`.  Also in the line: the distribution of
 the step time over repeated timed regions, bits-scanned GB/s, the roofline of the dominant kernel
 (HIP events around back-to-back launches), the materialising variant, `secondary` = BASELINE.json
 configs 3, 4 and 5 at their per-GPU sizes (N = 1), for N > 1 the per-step-collective and
@@ -41,7 +47,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 SHARDS_PER_GPU = 1024
-REDUCE_BUCKET = 16  # steps per RCCL all-reduce when N > 1 (throughput mode)
+REDUCE_BUCKET = 16  # steps per all-reduce of the bucketed throughput mode (reported beside the headline when N > 1)
+PER_QUERY_RING = 32  # result cells in rotation when every step carries its own all-reduce (N > 1 headline)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
@@ -231,11 +238,38 @@ def gpu_random_rows(torch, dev, n_rows: int, seed: int) -> np.ndarray:
     return t.cpu().numpy().view(np.uint64)
 
 
+def _cpu_batch_time(fn, min_s=0.5):
+    """seconds per call of a batch-oracle call (all shards on all host threads), repeated until min_s has elapsed"""
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_s:
+            return dt / n
+
+
+def _timed_query(torch, stream, q, iters, ctx, warm=2):
+    """A prepared query (fbk_query_*): GPU time of ONE execution — memset + kernel(s) + reduce, nothing else is
+    enqueued — between HIP events on the library's stream, and the dominant kernel alone (option time_kernels)."""
+    return _timed_call(torch, stream, q.run, iters, warm=warm, ctx=ctx)
+
+
 def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
+    """BASELINE.json configs 3, 4, 5 at their per-GPU sizes.  Timed through prepared queries (row lists and result
+    buffers resident, an execution is launch-only); with the CPU leg EVERY shard of every configuration is compared
+    with the oracle (oracle/batch_oracle.c: the restated reference calls over all shards on the host threads)."""
     from featurebase_amd import lib as L
 
+    PB = None
+    if want_cpu:
+        from oracle import pybatch as PB
     out = []
     iters = args.secondary_iters
+    timing_note = ("gpu_us / wall_us: ONE execution of the prepared query (fbk_query_run: memset + kernel(s) + reduce over shards; row lists and "
+                   "result buffers resident), HIP events on the library's stream; kernel_us: the named kernel alone (option time_kernels); "
+                   "call_us: the one-shot C-ABI call end to end (index upload, launches, result download, synchronisation)")
     # ---- config 3: mixed containers, Union-of-64 then IntersectionCount; TopK shape; GroupBy 32 x 32 ----
     if pre3 is not None:
         rows, groups, filt, gen_s = pre3
@@ -247,62 +281,66 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         fidx = np.arange(n3)
         nbytes = rows.bytes + filt.bytes
         ncont = len(rows.key) + len(filt.key)
+        q_fold = ctx.prepare_fold_intersection_count(L.OP_OR, batch, groups, F, fidx)
+        q_top = ctx.prepare_count_matrix(batch, groups, F, fidx.reshape(-1, 1), keep_per_shard=True)
+        q_gb = ctx.prepare_count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx, keep_per_shard=True)
+        for q in (q_fold, q_top, q_gb):
+            q.run()
+        got3, topn3, mat3 = q_fold.read(), q_top.read(per_shard=True)[1], q_gb.read(per_shard=True)[1]
+        assert (got3 == ctx.union_n_intersection_count(batch, groups, F, fidx)).all(), "config 3: prepared and one-shot fold disagree"
         cpu3 = None
-        got3 = ctx.union_n_intersection_count(batch, groups, F, fidx)
-        mat3 = ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx, per_shard=True)[1]
-        topn3 = ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1), per_shard=True)[1]
         if want_cpu:
-            from oracle import pybsi as PB
-            from oracle import pyoracle as O
+            OA, OF = PB.RowSet.from_flat(rows.descs(), rows.payload(), rows.n_rows), PB.RowSet.from_flat(filt.descs(), filt.payload(), filt.n_rows)
+            e_fold, _ = PB.union_n_intersection_count(OA, groups, OF, fidx)
+            assert (got3 == e_fold).all(), "config 3: GPU and oracle disagree (Union-of-64 then IntersectionCount)"
+            assert (topn3[:, :, 0] == PB.topk_counts(OA, groups, OF, fidx)).all(), "config 3 TopN: GPU and oracle disagree"
+            assert (mat3 == PB.count_matrix(OA, groups[:, :32], OA, groups[:, 32:], OF, fidx)).all(), "config 3 GroupBy: GPU and oracle disagree"
+            t_cpu = _cpu_batch_time(lambda: PB.union_n_intersection_count(OA, groups, OF, fidx))
+            t_cpu1 = _cpu_batch_time(lambda: PB.union_n_intersection_count(OA, groups[:8], OF, fidx[:8], nthreads=1)) / 8
+            t_cpu_gb = _cpu_batch_time(lambda: PB.count_matrix(OA, groups[:, :32], OA, groups[:, 32:], OF, fidx))
+            cpu3 = {"kind": "port", "cores": PB.threads(), "sample": f"all {n3} shards (64 mixed rows + filter each), oracle Bitmap.Union(63 others) + IntersectionCount, one shard per host thread",
+                    "value": n3 * 16 * 64 / t_cpu, "unit": "set-ops/s", "all_shards_s": t_cpu, "per_shard_one_thread_s": t_cpu1, "groupby_32x32_all_shards_s": t_cpu_gb}
+        common = {"shards": n3, "containers": ncont, "host_gen_s": gen_s, "upload_s": up_s, "timing": timing_note,
+                  "parity": f"every one of the {n3} shards bit-exact against the oracle" if want_cpu else "unchecked (--no-cpu-baseline)"}
 
-            d0 = rows.descs()
-            pay = rows.payload()
+        def call_us(fn, n=max(5, iters // 2)):
+            return _timed_call(torch, stream, fn, n)[0]
 
-            def ocont(d, buf):
-                p = buf[int(d["off"]):]
-                if d["type"] == 1:
-                    return O.OContainer.array(p[: 2 * int(d["len"])].view(np.uint16))
-                if d["type"] == 3:
-                    return O.OContainer.run(p[: 4 * int(d["len"])].view(np.uint16).reshape(-1, 2).tolist())
-                return O.OContainer.bitmap(p[:8192].view(np.uint64), int(d["n"]))
-
-            k = groups.shape[1]
-            bms = []
-            for r in range(k):  # shard 0's rows are rows 0..k-1
-                sel = d0[d0["row"] == r]
-                bms.append(O.OBitmap.from_containers([(int(d["key"]) & 15, ocont(d, pay)) for d in sel]))
-            fd, fp = filt.descs(), filt.payload()
-            fb = O.OBitmap.from_containers([(int(d["key"]) & 15, ocont(d, fp)) for d in fd[fd["row"] == 0]])
-            assert int(got3[0]) == bms[0].union(*bms[1:]).intersection_count(fb), "config 3: GPU and oracle disagree on shard 0"
-            e_mat = PB.groupby_counts(PB.Fragment(bms[:32]), PB.Fragment(bms[32:]), fb)
-            assert (mat3[0] == e_mat).all(), "config 3 GroupBy: GPU and oracle disagree on shard 0"
-            assert [int(x) for x in topn3[0, :, 0]] == [b.intersection_count(fb) for b in bms], "config 3 TopN: GPU and oracle disagree"
-            t_cpu = _cpu_time(lambda: bms[0].union(*bms[1:]).intersection_count(fb))
-            t_cpu_gb = _cpu_time(lambda: PB.groupby_counts(PB.Fragment(bms[:32]), PB.Fragment(bms[32:]), fb))
-            cpu3 = {"kind": "port", "cores": 1, "sample": "shard 0 (64 mixed rows + filter), oracle Bitmap.Union(63 others) + IntersectionCount, one host thread",
-                    "per_shard_s": t_cpu, "value": 16 * k / t_cpu, "unit": "set-ops/s", "groupby_32x32_per_shard_s": t_cpu_gb}
-        common = {"shards": n3, "containers": ncont, "host_gen_s": gen_s, "upload_s": up_s, "parity": "shard 0 checked against the oracle" if want_cpu else "unchecked (--no-cpu-baseline)"}
-        g, w, kq = _timed_call(torch, stream, lambda: ctx.union_n_intersection_count(batch, groups, F, fidx), iters, ctx=ctx)
+        g, w, kq = _timed_query(torch, stream, q_fold, iters, ctx)
         out.append(_entry("config3: Union-of-64 rows then IntersectionCount(filter), fused, mixed array/run/bitmap rows (rank-law density 0.001-0.5)",
-                          "k_fold_scatter<OR>", nbytes + 8 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), cpu_baseline=cpu3, **common))
-        g, w, kq = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1)), iters, ctx=ctx)
+                          "k_fold_scatter<OR>", nbytes + 8 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), cpu_baseline=cpu3,
+                          call_us=call_us(lambda: ctx.union_n_intersection_count(batch, groups, F, fidx)), **common))
+        g, w, kq = _timed_query(torch, stream, q_top, iters, ctx)
         out.append(_entry("config3 rows, TopN/TopK shape: 64 rows x 1 filter row per shard", "k_rows_vs_filter", nbytes + 8 * 64 * n3, g, w, kq,
-                          set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), **common))
-        g, w, kq = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx), max(5, iters // 2), ctx=ctx)
+                          set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), call_us=call_us(lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1))), **common))
+        g, w, kq = _timed_query(torch, stream, q_gb, max(5, iters // 2), ctx)
         out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel (default)", "k_count_matrix_fused",
                           nbytes + 8 * 1024 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
+                          call_us=call_us(lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx)),
                           hbm_note="encoded rows are the only HBM traffic (PMC fetch / algorithmic bytes in profiles/); the kernel is bound by instruction issue, not by HBM (DESIGN.md section 9)", **common))
-        ctx.set_option("matrix_fused", 0)
-        assert (ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx, per_shard=True)[1] == mat3).all(), "fused and densify paths disagree"
-        g, w, kq = _timed_call(torch, stream, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx), max(5, iters // 2), ctx=ctx)
-        ctx.set_option("matrix_fused", -1)
-        out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: densify + dense matrix-core kernel (round 1, option matrix_fused=0)",
-                          "k_densify_rows + k_count_matrix_mfma", nbytes + 8 * 1024 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
-                          hbm_note="3.7 bytes of temporary bitmap rows written and read back per byte of encoded rows", **common))
+        # row pairs of the same rows (RowSegment.IntersectionCount / Intersect on non-dense rows): rows 0..31 against rows 32..63 of every shard
+        pa, pb = groups[:, :32].reshape(-1), groups[:, 32:].reshape(-1)
+        plan = ctx.plan(batch, pa, batch, pb)
+        plan.intersection_count()
+        pc = plan.read()
+        if want_cpu:
+            assert (pc == PB.intersection_count(OA, pa, OA, pb)).all(), "config 3 row pairs: GPU and oracle disagree"
+        g, w = _timed_call(torch, stream, plan.intersection_count, iters)
+        out.append(_entry(f"config3 rows, {pa.size} row pairs (rows 0..31 x rows 32..63 of every shard): IntersectionCount, launch-only plan", "k_icount2", rows.bytes, g, w,
+                          set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), **common))
+        g, w = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND), iters)
+        out.append(_entry(f"config3 rows, {pa.size} row pairs: Intersect materialised (8 KiB cells), launch-only plan", "k_setop2<AND>", rows.bytes + pa.size * 16 * 8192, g, w,
+                          set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), **common))
+        plan.free()
         g, w = _timed_call(torch, stream, lambda: ctx.union_n(batch, groups, L.SETOP_OPTIMIZE)[0].free(), max(5, iters // 2))
-        out.append(_entry("config3 rows, Union-of-64 materialised + optimize() re-encode", "k_fold_scatter<OR> + k_encode_*", nbytes, g, w, **common))
+        out.append(_entry("config3 rows, Union-of-64 materialised + optimize() re-encode (one-shot call)", "k_fold_scatter<OR> + k_encode_*", nbytes, g, w, **common))
+        for q in (q_fold, q_top, q_gb):
+            q.free()
         batch.free()
         F.free()
+        if want_cpu:
+            OA.free()
+            OF.free()
     # ---- config 4 (per-GPU slice of the 8192-shard configuration): 32 x 32 count matrix + filter, dense ----
     n4, n_a, n_b = args.shards4, 32, 32
     if n4:
@@ -311,27 +349,31 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         gen_s = time.perf_counter() - t0
         A, B, F = ctx.upload_dense(wa), ctx.upload_dense(wb), ctx.upload_dense(wf)
         ra, rb, rf = np.arange(n4 * n_a).reshape(n4, n_a), np.arange(n4 * n_b).reshape(n4, n_b), np.arange(n4)
-        tot = ctx.count_matrix(A, ra, B, rb, F, rf)
+        q4 = ctx.prepare_count_matrix(A, ra, B, rb, F, rf, keep_per_shard=True)
+        q4.run()
+        tot, ps4 = q4.read(per_shard=True)
         exp = int(sum(np.bitwise_count(wa[s * n_a + 3] & wb[s * n_b + 5] & wf[s]).sum() for s in range(n4)))
         assert int(tot[3, 5]) == exp, "config 4: GPU and numpy disagree"
         cpu4 = None
         if want_cpu:
-            from oracle import pybsi as PB
-            from oracle import pyoracle as O
-
-            mk = lambda w: O.OBitmap.from_containers([(sl, O.OContainer.bitmap(np.asarray(w).reshape(16, 1024)[sl])) for sl in range(16)])  # noqa: E731
-            fa, fb, ff = PB.Fragment([mk(wa[i]) for i in range(n_a)]), PB.Fragment([mk(wb[j]) for j in range(n_b)]), mk(wf[0])
-            ps0 = ctx.count_matrix(A, ra[:1], B, rb[:1], F, rf[:1])
-            assert (ps0 == PB.groupby_counts(fa, fb, ff)).all(), "config 4: GPU and oracle disagree on shard 0"
-            t_cpu = _cpu_time(lambda: PB.groupby_counts(fa, fb, ff))
-            cpu4 = {"kind": "port", "cores": 1, "sample": "shard 0 (32 x 32 dense rows + filter), oracle groupByIterator counts, one host thread",
-                    "per_shard_s": t_cpu, "value": 16 * n_a * n_b / t_cpu, "unit": "set-ops/s"}
+            OA, OB, OF = PB.RowSet.from_dense(wa), PB.RowSet.from_dense(wb), PB.RowSet.from_dense(wf)
+            t0 = time.perf_counter()
+            e4 = PB.count_matrix(OA, ra, OB, rb, OF, rf)
+            t_cpu = time.perf_counter() - t0
+            assert (ps4 == e4).all() and (tot == e4.sum(axis=0)).all(), "config 4: GPU and oracle disagree"
+            t_cpu1 = _cpu_batch_time(lambda: PB.count_matrix(OA, ra[:2], OB, rb[:2], OF, rf[:2], nthreads=1)) / 2
+            cpu4 = {"kind": "port", "cores": PB.threads(), "sample": f"all {n4} shards (32 x 32 dense rows + filter), oracle groupByIterator counts, one shard per host thread",
+                    "value": n4 * 16 * n_a * n_b / t_cpu, "unit": "set-ops/s", "all_shards_s": t_cpu, "per_shard_one_thread_s": t_cpu1}
+            for o in (OA, OB, OF):
+                o.free()
         nbytes = n4 * (n_a + n_b + 1) * 16 * 8192
-        g, w, kq = _timed_call(torch, stream, lambda: ctx.count_matrix(A, ra, B, rb, F, rf), max(5, iters // 2), ctx=ctx)
+        g, w, kq = _timed_query(torch, stream, q4, max(5, iters // 2), ctx)
         out.append(_entry(f"config4 slice: {n4} shards x (32 x 32 rows + filter), dense bitmaps, IntersectionCount matrix", "k_count_matrix_mfma",
                           nbytes + 8 * n_a * n_b * n4, g, w, kq, shards=n4, host_gen_s=gen_s, set_ops_per_s=n4 * 16 * n_a * n_b / (g["median"] * 1e-6),
-                          pair_bits_scanned_GBps=n4 * n_a * n_b * 2 * 16 * 8192 / (g["median"] * 1e-6) / 1e9, cpu_baseline=cpu4,
-                          parity=f"cell (3,5) vs numpy over all shards" + ("; shard 0 vs the oracle" if want_cpu else "")))
+                          pair_bits_scanned_GBps=n4 * n_a * n_b * 2 * 16 * 8192 / (g["median"] * 1e-6) / 1e9, cpu_baseline=cpu4, timing=timing_note,
+                          call_us=_timed_call(torch, stream, lambda: ctx.count_matrix(A, ra, B, rb, F, rf), 5)[0],
+                          parity=f"every one of the {n4} per-shard matrices bit-exact against the oracle" if want_cpu else "cell (3,5) vs numpy over all shards"))
+        q4.free()
         for b in (A, B, F):
             b.free()
         del wa, wb, wf
@@ -341,39 +383,110 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         w = gpu_random_rows(torch, dev, n5 * (depth + 2), 51).reshape(n5, depth + 2, 16, 1024)
         w[:, 0] = np.uint64(0xFFFFFFFFFFFFFFFF)  # exists: every column has a value
         w[-1, 0, 6:] = 0  # last shard partial (100M columns = 95 full shards + 385 280 columns)
+        w[-1, 0, 5, 900:] = 0
+        w[:, 1:] &= w[:, :1]  # planes only where a value exists
         batch = ctx.upload_dense(w.reshape(-1))
         base = np.arange(n5, dtype=np.uint32) * (depth + 2)
+        idx5 = np.arange(n5)
         kk = 1 << 62
         plane_bytes = n5 * 16 * 8192
         rng_out, rng_cnt = ctx.bsi_range(batch, base, L.BSI_GT, depth, kk)
-        sums, cnts = ctx.bsi_sum(batch, base, depth, rng_out, np.arange(n5))
+        q_sum = ctx.prepare_bsi_sum(batch, base, depth, filt=rng_out, rows_f=idx5)
+        q_fused = ctx.prepare_bsi_sum(batch, base, depth, L.BSI_GT, kk)
+        q_sum.run()
+        q_fused.run()
+        sums, cnts = q_sum.read()
+        fsum, fcnt = q_fused.read()
+        assert (fsum == sums).all() and (fcnt == cnts).all(), "config 5 fused Range+Sum: differs from Range then Sum"
         cpu5 = None
         if want_cpu:
-            from oracle import pybsi as PB
-            from oracle import pyoracle as O
-
-            fr = PB.Fragment([O.OBitmap.from_containers([(sl, O.OContainer.bitmap(w[0, r, sl])) for sl in range(16)]) for r in range(depth + 2)])
-            e_rng = PB.bsi_range(fr, PB.GT, depth, kk)
-            assert int(rng_cnt[0]) == e_rng.count(), "config 5 Range: GPU and oracle disagree on shard 0"
-            e_sum, e_cnt = PB.bsi_sum(fr, e_rng, True)
-            assert (int(sums[0]), int(cnts[0])) == (int(e_sum), int(e_cnt)), "config 5 Sum: GPU and oracle disagree on shard 0"
-            t_sum = _cpu_time(lambda: PB.bsi_sum(fr, None, False))
-            t_rng = _cpu_time(lambda: PB.bsi_range(fr, PB.GT, depth, kk))
-            cpu5 = {"kind": "port", "cores": 1, "sample": "shard 0 (66 dense rows), oracle fragment.rangeOp(GT) / fragment.sum, one host thread",
-                    "range_per_shard_s": t_rng, "sum_per_shard_s": t_sum}
+            OA = PB.RowSet.from_dense(w.reshape(-1, 16, 1024))
+            e_rng, e_cnt = PB.bsi_range(OA, base, depth, PB.GT, kk)
+            assert (rng_cnt == e_cnt).all(), "config 5 Range: GPU and oracle disagree"
+            d5, p5, nr5 = rng_out.download_flat()
+            assert (PB.RowSet.from_flat(d5, p5, nr5).words() == e_rng.words()).all(), "config 5 Range: bit content differs from the oracle"
+            e_sum, e_c = PB.bsi_sum(OA, base, depth, e_rng, idx5)
+            assert (sums == e_sum).all() and (cnts == e_c).all(), "config 5 Sum: GPU and oracle disagree"
+            t_rng = _cpu_batch_time(lambda: PB.bsi_range(OA, base, depth, PB.GT, kk)[0].free())
+            t_sum = _cpu_batch_time(lambda: PB.bsi_sum(OA, base, depth, e_rng, idx5))
+            cpu5 = {"kind": "port", "cores": PB.threads(), "sample": f"all {n5} shards (66 dense rows each), oracle fragment.rangeOp(GT) / fragment.sum, one shard per host thread",
+                    "range_all_shards_s": t_rng, "sum_all_shards_s": t_sum}
+            e_rng.free()
+            OA.free()
+        par5 = f"every one of the {n5} shards bit-exact against the oracle" if want_cpu else "unchecked"
         g, wl, kq = _timed_call(torch, stream, lambda: ctx.bsi_range(batch, base, L.BSI_GT, depth, kk)[0].free(), iters, ctx=ctx)
-        out.append(_entry(f"config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense", "k_bsi_range_slot", plane_bytes * (depth + 3), g, wl, kq, shards=n5,
-                          cpu_baseline=cpu5, parity="shard 0 vs the oracle" if want_cpu else "unchecked"))
-        g, wl, kq = _timed_call(torch, stream, lambda: ctx.bsi_sum(batch, base, depth, rng_out, np.arange(n5)), iters, ctx=ctx)
-        out.append(_entry("config5: BSI Sum(filter = the Range result)", "k_bsi_sum_slot", plane_bytes * (depth + 3), g, wl, kq, shards=n5))
-        # the same query in ONE pass over the planes (SURVEY §8d "fused"): must give the two-pass totals
-        fsum, fcnt = ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, kk)
-        assert (fsum == sums).all() and (fcnt == cnts).all(), "config 5 fused Range+Sum: differs from Range then Sum"
-        g, wl, kq = _timed_call(torch, stream, lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, kk), iters, ctx=ctx)
+        out.append(_entry(f"config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense (one-shot call: the result row is a new batch)", "k_bsi_range_slot",
+                          plane_bytes * (depth + 3), g, wl, kq, shards=n5, cpu_baseline=cpu5, parity=par5))
+        g, wl, kq = _timed_query(torch, stream, q_sum, iters, ctx)
+        out.append(_entry("config5: BSI Sum(filter = the Range result)", "k_bsi_sum_slot", plane_bytes * (depth + 3), g, wl, kq, shards=n5, parity=par5, timing=timing_note,
+                          call_us=_timed_call(torch, stream, lambda: ctx.bsi_sum(batch, base, depth, rng_out, idx5), 5)[0]))
+        g, wl, kq = _timed_query(torch, stream, q_fused, iters, ctx)
         out.append(_entry("config5 fused: Sum(Range(> 2^62)) of the same field, one pass over the planes", "k_bsi_range_sum_half", plane_bytes * (depth + 2), g, wl, kq, shards=n5,
-                          parity="equal to the Range-then-Sum totals of the two entries above, every shard"))
+                          timing=timing_note, call_us=_timed_call(torch, stream, lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, kk), 5)[0],
+                          parity="equal to the Range-then-Sum totals of the entry above (oracle-checked), every shard"))
+        q_sum.free()
+        q_fused.free()
         rng_out.free()
         batch.free()
+    return out
+
+
+def config4_strong(torch, dist, fdist, dev, ctx, stream, rank, world, args, cpu_group, want_cpu):
+    """BASELINE.json configs[3]: the FIXED problem of 8192 shards x (32 x 32 rows + filter row), split over the
+    ranks (shard s on rank s mod N: executor.go:6449-6533), GroupBy-style IntersectionCount matrix per shard
+    (groupByIterator, executor.go:8880-8934), the 1024-cell partial matrices of the ranks summed by ONE all-reduce
+    per query (mergeGroupCounts across nodes, executor.go:3728-3762).  Rows are generated on the device (70 GB at
+    N = 1).  Returns this rank's dict; times are this rank's clock (the caller takes the max over ranks)."""
+    total, n_a, n_b = args.shards4_total, 32, 32
+    mine = fdist.shards_for_rank(total, rank, world)
+    ns = len(mine)
+    t0 = time.perf_counter()
+
+    def gen(n_rows, seed):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        return torch.randint(-(2**63), 2**63 - 1, (n_rows, 16, 1024), dtype=torch.int64, device=dev, generator=g)
+
+    ta, tb, tf = gen(ns * n_a, 4100 + 3 * rank), gen(ns * n_b, 4101 + 3 * rank), gen(ns, 4102 + 3 * rank)
+    torch.cuda.synchronize()
+    A, B, F = ctx.upload_dense_device(ta.data_ptr(), ns * n_a), ctx.upload_dense_device(tb.data_ptr(), ns * n_b), ctx.upload_dense_device(tf.data_ptr(), ns)
+    # a sample of this rank's shards for the oracle, before the generator's tensors are released
+    n_chk = min(16, ns)
+    sample = [t[: n_chk * k].cpu().numpy().view(np.uint64) for t, k in ((ta, n_a), (tb, n_b), (tf, 1))]
+    del ta, tb, tf
+    torch.cuda.empty_cache()
+    resident_s = time.perf_counter() - t0
+    ra, rb, rf = np.arange(ns * n_a).reshape(ns, n_a), np.arange(ns * n_b).reshape(ns, n_b), np.arange(ns)
+    q = ctx.prepare_count_matrix(A, ra, B, rb, F, rf, keep_per_shard=True)
+    q.run()
+    local, ps = q.read(per_shard=True)
+    parity = "unchecked (--no-cpu-baseline)"
+    if want_cpu:
+        from oracle import pybatch as PB
+
+        OA, OB, OF = (PB.RowSet.from_dense(x) for x in sample)
+        e = PB.count_matrix(OA, ra[:n_chk], OB, rb[:n_chk], OF, rf[:n_chk])
+        assert (ps[:n_chk] == e).all(), "config 4 strong: GPU and oracle disagree"
+        parity = f"the first {n_chk} shards of every rank bit-exact against the oracle; all shards: tests/test_gpu_fullsize.py at 1024 shards"
+    assert (ps.sum(axis=0) == local).all()
+    expected = torch.from_numpy(local.view(np.int64).reshape(-1).copy()).to(dev)
+    if world > 1:
+        dist.all_reduce(expected)
+    expected = expected.cpu().numpy().view(np.uint64)
+    # the kernel alone (HIP events by the library around the launch) and one execution of the prepared query
+    g_us, w_us, k_us = _timed_query(torch, stream, q, 5, ctx)
+
+    def run_local(cell):
+        q.run(cell.data_ptr())
+
+    res = fdist.strong_scaling_queries(run_local, n_a * n_b, args.queries4, dev, expected=expected, sync=torch.cuda.synchronize, depth=4, cpu_group=cpu_group)
+    nbytes = ns * (n_a + n_b + 1) * 16 * 8192
+    out = {"shards_total": total, "shards_this_rank": ns, "rows": f"{n_a} x {n_b} + filter row per shard, dense bitmaps (generated on the device)", "resident_bytes_this_rank": nbytes,
+           "make_resident_s": resident_s, "kernel_us": k_us, "query_gpu_us": g_us, "kernel_GBps_this_rank": nbytes / (k_us["median"] * 1e-6) / 1e9,
+           "kernel_frac_of_8TBps": nbytes / (k_us["median"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, "parity": parity, **res}
+    q.free()
+    for b in (A, B, F):
+        b.free()
     return out
 
 
@@ -424,6 +537,8 @@ def main():
     ap.add_argument("--shards4", type=int, default=1024)
     ap.add_argument("--shards5", type=int, default=96)
     ap.add_argument("--secondary-iters", type=int, default=20)
+    ap.add_argument("--shards4-total", type=int, default=8192, help="BASELINE configs[3], strong scaling: this many shards in total, split over the ranks (0 = skip)")
+    ap.add_argument("--queries4", type=int, default=10, help="timed queries per reduce mode of the strong-scaling section")
     ap.add_argument("--cold-sets", type=int, default=4, help="distinct resident data sets cycled for the L3-cold roofline (1 = skip)")
     args = ap.parse_args()
 
@@ -494,12 +609,27 @@ def main():
     # steps and, for N > 1, all-reduced over RCCL/xGMI once per REDUCE_BUCKET steps, asynchronously.
     red = fdist.BucketedCountReducer(REDUCE_BUCKET, dev)
 
-    def step():
+    def step_bucketed():
         # per-shard |a ∩ b| and the per-node reduce in ONE launch: every workgroup of k_icount_dense
         # adds its count to the step's (zeroed) slot.  Measured alternatives: a second launch
         # (k_sum_u64) +2.3 us, "last workgroup sums the per-shard counts" +3.1 us per step.
         plan.intersection_count_accumulate(red.slot_ptr())
         red.advance()  # N > 1: RCCL sum of the partial counts over xGMI once the bucket is full
+
+    # N > 1, the headline: EVERY step's partial total is all-reduced on its own (one collective per query, asynchronous on
+    # the communicator's stream, PER_QUERY_RING cells rotating so that the next steps' kernels never touch a cell a
+    # collective still reads).  The ring is cleared once per revolution.
+    pq = fdist.PerQueryReducer(1, PER_QUERY_RING, dev)
+
+    def step_per_query():
+        if pq.k % PER_QUERY_RING == 0:
+            pq.flush()
+            pq.buf.zero_()
+        plan.intersection_count_accumulate(pq.cell().data_ptr())
+        pq.reduce()
+
+    step = step_per_query if n_gpus > 1 else step_bucketed
+    flush = (lambda: pq.flush()) if n_gpus > 1 else (lambda: red.flush())
 
     def barrier():
         if n_gpus > 1:
@@ -512,7 +642,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(k):
             step()
-        reduced = red.flush()  # the tail bucket + every outstanding collective: inside the timed region
+        reduced = flush()  # every outstanding collective (N = 1: nothing to wait for): inside the timed region
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -522,7 +652,7 @@ def main():
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             step()
-        red.flush()
+        flush()
         dt, reduced = timed_region(args.steps)  # THE timed region: exactly --steps steps
 
         # parity spot check of the timed result (numpy popcount of this rank's shards)
@@ -534,7 +664,7 @@ def main():
         if n_gpus > 1:
             dist.all_reduce(ge)
         global_expected = int(ge.item())
-        vals = torch.cat([b for b in reduced]).cpu().numpy()
+        vals = torch.cat([b.reshape(-1) for b in reduced]).cpu().numpy()
         vals = vals[vals != 0]
         assert vals.size > 0 and (vals == global_expected).all(), "reduced totals differ from the sum of the per-shard counts"
 
@@ -552,6 +682,18 @@ def main():
         # (b) the same with the total read back by the host after every step (per-query latency);
         # (c) "copy the partials to the host and add": D2H of each rank's partial + a gloo all-reduce
         if n_gpus > 1:
+            # the bucketed throughput mode of the earlier rounds (REDUCE_BUCKET steps per collective): NOT what a query sees
+            saved = (step, flush)
+            step, flush = step_bucketed, (lambda: red.flush())
+            for _ in range(args.warmup):
+                step()
+            flush()
+            bdt, _b = timed_region(args.steps)
+            step, flush = saved
+            tb = torch.tensor([bdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            extra["throughput_mode_bucketed"] = {"ms_per_step": float(tb.item()) / args.steps * 1e3, "set_ops_per_s": n_gpus * n * 16 * args.steps / float(tb.item()),
+                                                 "steps_per_collective": REDUCE_BUCKET, "note": "one all-reduce per 16 steps, asynchronous: a throughput mode no single query sees; the headline reduces every step on its own"}
             lat_steps = min(args.steps, 200)
 
             def step_collective():
@@ -597,7 +739,7 @@ def main():
                 "collective_per_step_set_ops_per_s": n_gpus * n * 16 / (pipelined * 1e-3),
                 "collective_per_step_host_readback_latency_ms": dist_of(lat),
                 "host_add_latency_ms": host_lat,
-                "note": f"value/ms_per_step reduce {REDUCE_BUCKET} steps per collective (throughput mode); these are the per-query costs: one all-reduce per step",
+                "note": "the headline already carries one all-reduce per step (pipelined over a ring of cells); here the same with ONE cell (each step waits for the previous collective) and with the total read back by the host after every step",
             }
 
         # ---- roofline of the dominant kernel: HIP events around back-to-back launches
@@ -667,6 +809,37 @@ def main():
         torch.cuda.synchronize()
         assert int(total.item()) == local_expected
 
+        strong = None
+        if args.shards4_total:
+            try:
+                cpu_group = dist.new_group(backend="gloo") if n_gpus > 1 else None
+                mine4 = config4_strong(torch, dist if n_gpus > 1 else None, fdist, dev, ctx, stream, rank, n_gpus, args, cpu_group, not args.no_cpu_baseline)
+                # max over ranks of every time; the reduced matrix was checked against the sum of the ranks' own results in every mode
+                keys = [("pipelined_s_per_query", None), ("latency_s", "median"), ("host_add_latency_s", "median")]
+                tv = torch.tensor([mine4[k] if sub is None else mine4[k][sub] for k, sub in keys] + [mine4["kernel_us"]["median"]], dtype=torch.float64, device=dev)
+                if n_gpus > 1:
+                    dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+                tv = tv.tolist()
+                total_ops = args.shards4_total * 16 * 32 * 32
+                strong = {
+                    "workload": f"configs[3]: {args.shards4_total} shards x (32 x 32 rows + filter), dense, IntersectionCount matrix; shard s on rank s mod N; one all-reduce of the 1024-cell partial matrix per query",
+                    "scaling": "strong",
+                    "n_gpus": n_gpus,
+                    "backend": (("rccl" if backend == "nccl" else backend) if n_gpus > 1 else None),
+                    "ms_per_query_pipelined": tv[0] * 1e3,
+                    "set_ops_per_s": total_ops / tv[0],
+                    "ms_per_query_latency_host_readback": tv[1] * 1e3,
+                    "ms_per_query_host_add": tv[2] * 1e3,
+                    "kernel_us_max_over_ranks": tv[3],
+                    "rank0": mine4,
+                }
+            except Exception as e:  # noqa: BLE001 — the headline is measured already
+                import traceback
+
+                strong = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc().splitlines()[-6:]}
+                if n_gpus > 1:
+                    raise  # a rank that left the section early would leave the others in a collective
+
         secondary = None
         if n_gpus == 1 and not args.no_secondary:
             t_s0 = time.perf_counter()
@@ -691,15 +864,16 @@ def main():
         devs = ",".join(str(r if backend == "nccl" else r % n_dev) for r in range(n_gpus))
         try:
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK")}
-            p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "group_bench.py"), "--devices", devs, "--shards", str(n), "--steps", str(min(args.steps, 200))],
-                               capture_output=True, text=True, timeout=180, env=env)
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "group_bench.py"), "--devices", devs, "--shards", str(n), "--steps", str(min(args.steps, 200)),
+                                "--matrix", "32", "--matrix-total-shards", str(args.shards4_total)],
+                               capture_output=True, text=True, timeout=300, env=env)
             line = [x for x in p.stdout.splitlines() if x.startswith("{")]
             group_api = json.loads(line[-1]) if line else {"error": (p.stderr or "no output")[-400:]}
         except subprocess.TimeoutExpired as e:  # a reduce mode hung (the script prints a line per finished mode: keep those)
             so = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
             line = [x for x in so.splitlines() if x.startswith("{")]
             group_api = json.loads(line[-1]) if line else {}
-            group_api["error"] = "scripts/group_bench.py did not finish within 180 s (killed); modes listed are the ones that completed"
+            group_api["error"] = "scripts/group_bench.py did not finish within 300 s (killed); modes listed are the ones that completed"
         except Exception as e:  # noqa: BLE001
             group_api = {"error": str(e)}
     elif n_gpus == 1:
@@ -731,7 +905,8 @@ def main():
                 "shards_per_gpu": n,
                 "containers_per_gpu": 2 * n * 16,
                 "op": "Count(Intersect(Row,Row)) as IntersectionCount + per-node sum"
-                + (f" + {'RCCL' if backend == 'nccl' else backend} all-reduce of the partial totals ({REDUCE_BUCKET} steps per collective, async)" if n_gpus > 1 else ""),
+                + (f" + one {'RCCL' if backend == 'nccl' else backend} all-reduce of the partial total PER STEP (asynchronous, {PER_QUERY_RING} result cells in rotation)" if n_gpus > 1 else ""),
+                "collectives_per_step": 1 if n_gpus > 1 else 0,
                 "parallelism": f"shards/{n_gpus}gpu",
                 "backend": (("rccl" if backend == "nccl" else backend) if n_gpus > 1 else None),
                 "ranks": n_gpus,
@@ -767,6 +942,8 @@ def main():
         out.update(extra)
         if secondary is not None:
             out["secondary"] = secondary
+        if strong is not None:
+            out["strong_scaling"] = strong
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             try:

@@ -96,9 +96,9 @@ struct FbkOptions {
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
-  int64_t pair_spw = 1;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4): next slot's payload in flight while the current one is decoded
+  int64_t pair_spw = 0;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4; 0 = by the rows' payload size): next slot's payload in flight while the current one is decoded
   int64_t pair_persistent = 0;           // k_icount2p: blocks per CU of the persistent, software-pipelined pair count (0: one wave per pair_spw slots)
-  int64_t pair_wpb = 1;                  // wavefronts per block of k_icount2: 1 (a wave's LDS table is released when IT ends) or 4
+  int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
   int64_t pair_kernels = 2;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels (A/B runs)
 };
@@ -527,9 +527,9 @@ const OptionDesc kOptions[] = {
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 1, 2},
-    {"pair_spw", &FbkOptions::pair_spw, 1, 4},
+    {"pair_spw", &FbkOptions::pair_spw, 0, 4},
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
-    {"pair_wpb", &FbkOptions::pair_wpb, 1, 4},
+    {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
     {"pair_persistent", &FbkOptions::pair_persistent, 0, 16},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
 };
@@ -1049,13 +1049,19 @@ namespace {
 
 int32_t optimize_cells(fbk_ctx* ctx, fbk_batch* o, const uint32_t* d_runs);  // fbk_query_api.inc
 
+// average encoded payload per container below 256 bytes (arrays of at most ~100 values, a few runs)
+bool pair_rows_are_tiny(const fbk_batch* a, const fbk_batch* b) {
+  const uint64_t slots = (uint64_t(a->n_rows) + b->n_rows) * fbk::kSlots;
+  return slots && (a->arena_bytes + b->arena_bytes) < 256 * slots;
+}
+
 template <int OP>
 void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
   const uint32_t blocks = uint32_t(p->n_pairs * fbk::kSlots / 4);
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
                        p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, p->d_counts);
-  else if (p->ctx->opt.pair_kernels >= 2 && p->ctx->opt.pair_wpb == 4)
+  else if (p->ctx->opt.pair_kernels >= 2 && (p->ctx->opt.pair_wpb == 4 || (p->ctx->opt.pair_wpb == 0 && pair_rows_are_tiny(p->a, p->b))))
     hipLaunchKernelGGL((fbk::k_setop2<OP, 4>), dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
                        want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
@@ -1165,7 +1171,10 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
                      p->d_counts, uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8))
-      const int spw = int(ctx->opt.pair_spw), wpb = int(ctx->opt.pair_wpb);
+      // rows of tiny containers (a few values each): the launch of one block per item is what such a kernel costs, so four
+      // waves per block and four slots per wave; everything else: one wave per block and item (see k_icount2)
+      const bool tiny = pair_rows_are_tiny(p->a, p->b);
+      const int spw = ctx->opt.pair_spw ? int(ctx->opt.pair_spw) : (tiny ? 4 : 1), wpb = ctx->opt.pair_wpb ? int(ctx->opt.pair_wpb) : (tiny ? 4 : 1);
       if (wpb == 4) {
         switch (spw) {
           case 1: FBK_LAUNCH_ICOUNT2(1, 4); break;

@@ -120,3 +120,132 @@ class BucketedCountReducer:
         self._free(0)
         self._free(1)
         return self.buf
+
+
+class PerQueryReducer:
+    """One collective per query, pipelined on the device: what a single query pays for its exchange step.
+
+    A query's partial result (1 count, or the n_a x n_b cells of a GroupBy matrix: mergeGroupCounts,
+    executor.go:3728-3762) is written by the rank's kernels into a CELL of `width` int64 on the device and
+    all-reduced on its own — no bucketing over queries.  `depth` cells rotate so that the kernels of query
+    k + 1 never write the buffer the collective of query k is still reading: `cell()` hands out the next one
+    after (stream-)waiting for the collective that last used it, `reduce()` starts the asynchronous
+    all-reduce of the cell just written.  With no process group (N = 1) nothing is exchanged."""
+
+    def __init__(self, width: int, depth: int, device=None):
+        import torch
+
+        self.width, self.depth = int(width), int(depth)
+        self.buf = torch.zeros((self.depth, self.width), dtype=torch.int64, device=device)
+        self.work = [None] * self.depth
+        self.k = 0
+        self.collectives = 0
+
+    def cell(self):
+        i = self.k % self.depth
+        if self.work[i] is not None:
+            self.work[i].wait()
+            self.work[i] = None
+        return self.buf[i]
+
+    def reduce(self):
+        import torch.distributed as dist
+
+        i = self.k % self.depth
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.work[i] = dist.all_reduce(self.buf[i], op=dist.ReduceOp.SUM, async_op=True)
+            self.collectives += 1
+        self.k += 1
+        return i
+
+    def flush(self):
+        for i in range(self.depth):
+            if self.work[i] is not None:
+                self.work[i].wait()
+                self.work[i] = None
+        return self.buf
+
+
+def host_add(partial, pinned, cpu_group=None):
+    """"Copy the partials to the host and add": the alternative to the device collective.
+    `partial` is this rank's device (or CPU) tensor, `pinned` a host tensor of the same shape; returns `pinned`
+    holding the sum over ranks (gloo all-reduce on the host)."""
+    import torch
+    import torch.distributed as dist
+
+    pinned.copy_(partial, non_blocking=True)
+    if partial.is_cuda:
+        torch.cuda.synchronize()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(pinned, op=dist.ReduceOp.SUM, group=cpu_group)
+    return pinned
+
+
+def strong_scaling_queries(run_local, width: int, n_queries: int, device, expected=None, sync=None, depth: int = 8, cpu_group=None, warmup: int = 2):
+    """The multi-GPU query loop of bench.py's strong-scaling section, independent of what computes the partials:
+    `run_local(cell)` enqueues this rank's partial result (width int64) into `cell`.  Measures, over n_queries
+    queries each: (a) one device all-reduce per query, pipelined (throughput of independent queries, no query
+    amortises another's collective); (b) the same with the result read back by the host after every query (the
+    latency one query sees); (c) host add.  `expected` (numpy uint64 [width], the sum over all ranks) is checked
+    in every mode.  Returns a dict of seconds per query (this rank's clock; the caller takes the max over ranks)."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    sync = sync or (lambda: None)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def barrier():
+        if multi:
+            dist.barrier()
+
+    def check(t, what):
+        if expected is not None:
+            got = t.detach().cpu().numpy().view(np.uint64).reshape(-1)
+            assert (got == np.asarray(expected, dtype=np.uint64).reshape(-1)).all(), f"{what}: reduced result differs from the expected total"
+
+    red = PerQueryReducer(width, depth, device)
+    for _ in range(warmup):
+        run_local(red.cell())
+        red.reduce()
+    red.flush()
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n_queries):
+        run_local(red.cell())
+        red.reduce()
+    bufs = red.flush()
+    sync()
+    barrier()
+    pipelined = (time.perf_counter() - t0) / n_queries
+    for i in range(min(depth, n_queries)):
+        check(bufs[i], "collective per query")
+    lat = []
+    for _ in range(n_queries):
+        t1 = time.perf_counter()
+        c = red.cell()
+        run_local(c)
+        i = red.reduce()
+        red.flush()
+        sync()
+        host = bufs[i].cpu()
+        lat.append(time.perf_counter() - t1)
+    check(host, "collective per query, read back")
+    pinned = torch.zeros(width, dtype=torch.int64)
+    if device is not None and torch.device(device).type == "cuda":
+        pinned = pinned.pin_memory()
+    cell = torch.zeros(width, dtype=torch.int64, device=device)
+    hl = []
+    for _ in range(n_queries):
+        t1 = time.perf_counter()
+        run_local(cell)
+        sync()
+        host_add(cell, pinned, cpu_group)
+        hl.append(time.perf_counter() - t1)
+    check(pinned, "host add")
+    lat.sort()
+    hl.sort()
+    return {"pipelined_s_per_query": pipelined, "latency_s": {"median": lat[len(lat) // 2], "p10": lat[len(lat) // 10], "p90": lat[(len(lat) * 9) // 10]},
+            "host_add_latency_s": {"median": hl[len(hl) // 2], "p10": hl[len(hl) // 10], "p90": hl[(len(hl) * 9) // 10]}, "collectives": red.collectives, "queries": n_queries}

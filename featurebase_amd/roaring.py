@@ -328,6 +328,13 @@ class Context:
         L.check(self.lib.fbk_batch_upload_rbf(self.h, file_bytes, len(file_bytes), root_pgno, C.byref(h), ids.ctypes.data, cap, C.byref(n)))
         return Batch(self, h.value), ids[: n.value].copy()
 
+    def upload_dense_device(self, device_ptr: int, n_rows: int) -> Batch:
+        """n_rows dense rows (16 x 1024 uint64 each) that already sit in this device's memory at device_ptr
+        (fbk_batch_upload_dense accepts a device source: the copy is device to device)."""
+        h = C.c_void_p()
+        L.check(self.lib.fbk_batch_upload_dense(self.h, C.c_void_p(device_ptr), n_rows, C.byref(h)))
+        return Batch(self, h.value)
+
     def upload_dense(self, words: np.ndarray) -> Batch:
         w = np.ascontiguousarray(words, dtype=np.uint64)
         assert w.size % (SLOTS * BITMAP_WORDS) == 0

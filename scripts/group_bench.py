@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--matrix", type=int, default=0, help="also time a GroupBy count matrix of this many rows per side (dense rows)")
     ap.add_argument("--matrix-shards", type=int, default=32, help="shards per member for --matrix")
+    ap.add_argument("--matrix-total-shards", type=int, default=0, help="--matrix over this many shards in TOTAL, split over the members (strong scaling: BASELINE configs[3] with 8192), rows generated on the devices")
     args = ap.parse_args()
     devices = [int(x) for x in args.devices.split(",")]
     G = len(devices)
@@ -107,17 +108,45 @@ def main():
     for b in batches:
         b.free()
     if args.matrix:
+        import torch
+
         n_a = n_b = args.matrix
-        ns = args.matrix_shards
+        strong = args.matrix_total_shards > 0
         per_member, keep, exp = [], [], np.zeros((n_a, n_b), dtype=np.uint64)
+        shards_of = [len(range(m, args.matrix_total_shards, G)) if strong else args.matrix_shards for m in range(G)]
         for m, ctx in enumerate(grp.members):
-            wa, wb, wf = D.dense_rows(ns * n_a, 0.5, 7100 + 3 * m), D.dense_rows(ns * n_b, 0.5, 7101 + 3 * m), D.dense_rows(ns, 0.5, 7102 + 3 * m)
-            A, B, F = ctx.upload_dense(wa), ctx.upload_dense(wb), ctx.upload_dense(wf)
+            ns = shards_of[m]
+            if ns == 0:
+                per_member.append(None)
+                continue
+            if strong:  # rows generated on the member's device (8192 shards x 65 rows = 70 GB in total)
+                dev = torch.device("cuda", devices[m])
+
+                def gen(n_rows, seed):
+                    g = torch.Generator(device=dev)
+                    g.manual_seed(seed)
+                    return torch.randint(-(2**63), 2**63 - 1, (n_rows, 16, 1024), dtype=torch.int64, device=dev, generator=g)
+
+                ta, tb, tf = gen(ns * n_a, 7100 + 3 * m), gen(ns * n_b, 7101 + 3 * m), gen(ns, 7102 + 3 * m)
+                torch.cuda.synchronize(dev)
+                A, B, F = ctx.upload_dense_device(ta.data_ptr(), ns * n_a), ctx.upload_dense_device(tb.data_ptr(), ns * n_b), ctx.upload_dense_device(tf.data_ptr(), ns)
+                chk = min(ns, 8)  # spot check of one cell on the member's first shards (all shards: the library's own tests)
+                wa, wb, wf = (t[: chk * k].cpu().numpy().view(np.uint64) for t, k in ((ta, n_a), (tb, n_b), (tf, 1)))
+                del ta, tb, tf
+                torch.cuda.empty_cache()
+            else:
+                wa, wb, wf = D.dense_rows(ns * n_a, 0.5, 7100 + 3 * m), D.dense_rows(ns * n_b, 0.5, 7101 + 3 * m), D.dense_rows(ns, 0.5, 7102 + 3 * m)
+                A, B, F = ctx.upload_dense(wa), ctx.upload_dense(wb), ctx.upload_dense(wf)
+                chk = ns
             keep += [A, B, F]
             per_member.append(dict(a=A, rows_a=np.arange(ns * n_a).reshape(ns, n_a), b=B, rows_b=np.arange(ns * n_b).reshape(ns, n_b), filt=F, rows_f=np.arange(ns)))
-            for s in range(ns):  # spot check of one cell per member
-                exp[1, 2] += np.bitwise_count(wa[s * n_a + 1] & wb[s * n_b + 2] & wf[s]).sum()
-        mm = {}
+            if strong:  # the member's first shards as a query of their own, against numpy
+                sub = ctx.count_matrix(A, np.arange(chk * n_a).reshape(chk, n_a), B, np.arange(chk * n_b).reshape(chk, n_b), F, np.arange(chk))
+                assert int(sub[1, 2]) == int(sum(np.bitwise_count(wa[s * n_a + 1] & wb[s * n_b + 2] & wf[s]).sum() for s in range(chk))), ("member", m)
+            else:
+                for s in range(ns):
+                    exp[1, 2] += np.bitwise_count(wa[s * n_a + 1] & wb[s * n_b + 2] & wf[s]).sum()
+        mm, ref = {}, None
         for name, mode in modes:
             try:
                 grp.set_reduce(mode)
@@ -126,14 +155,23 @@ def main():
                 continue
             for _ in range(3):
                 tot = grp.count_matrix(per_member, n_a, n_b)
-            assert int(tot[1, 2]) == int(exp[1, 2]), (name, int(tot[1, 2]), int(exp[1, 2]))
-            t0 = time.perf_counter()
-            it = max(5, args.steps // 10)
+            if not strong:
+                assert int(tot[1, 2]) == int(exp[1, 2]), (name, int(tot[1, 2]), int(exp[1, 2]))
+            if ref is None:
+                ref = tot  # every reduce mode must deliver the same matrix
+            assert (tot == ref).all(), name
+            it = max(5, args.steps // 20)
+            lat = []
             for _ in range(it):
+                t1 = time.perf_counter()
                 grp.count_matrix(per_member, n_a, n_b)
-            dt = (time.perf_counter() - t0) / it
-            mm[name] = {"ms_per_call": dt * 1e3, "container_pairs_per_s": G * ns * 16 * n_a * n_b / dt}
-        out["count_matrix"] = {"rows_per_side": args.matrix, "shards_per_member": ns, "modes": mm}
+                lat.append(time.perf_counter() - t1)
+            lat.sort()
+            dt = sum(lat) / it
+            mm[name] = {"ms_per_call": dt * 1e3, "ms_per_call_median": lat[len(lat) // 2] * 1e3, "container_pairs_per_s": sum(shards_of) * 16 * n_a * n_b / dt}
+            out["count_matrix"] = {"rows_per_side": args.matrix, "shards_per_member": shards_of, "scaling": "strong" if strong else "weak",
+                                   "op": "fbk_group_count_matrix: GroupBy IntersectionCount matrix over every member's shards, reduced matrix on the host after every call", "modes": mm}
+            print(json.dumps(out), flush=True)
         for b in keep:
             b.free()
     grp.close()

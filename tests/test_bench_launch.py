@@ -28,3 +28,31 @@ def test_world_size_mismatch_is_refused():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=4" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpus_2_line_schema_on_the_gpu_box():
+    """`bench.py --gpus 2` end to end on whatever the box has (one GPU: the two ranks share it and reduce over gloo —
+    the complete N > 1 code path, flagged "oversubscribed"): the line must carry the per-query-collective headline,
+    the bucketed throughput mode beside it, BASELINE configs[3] strong-scaled (`strong_scaling`) and the in-library
+    group path (`group_api`), every reduced result having been checked inside the run."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3", "--shards", "128", "--repeats", "2", "--cold-sets", "1",
+           "--shards4-total", "48", "--queries4", "3"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=850)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stderr[-2000:])
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["ranks"] == 2 and r["steps"] == 20 and r["scaling"] == "weak" and r["unit"] == "set-ops/s"
+    assert r["config"]["backend"] in ("rccl", "gloo") and r["config"]["collectives_per_step"] == 1
+    assert r["throughput_mode_bucketed"]["steps_per_collective"] == 16 and r["per_query"]["collective_per_step_pipelined_ms_per_step"] > 0
+    s = r["strong_scaling"]
+    assert "error" not in s, s
+    assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["backend"] == r["config"]["backend"] and s["rank0"]["shards_total"] == 48 and s["rank0"]["shards_this_rank"] == 24
+    assert s["ms_per_query_pipelined"] > 0 and s["ms_per_query_host_add"] > 0 and s["rank0"]["collectives"] == 2 + 3 + 3
+    g = r["group_api"]
+    assert g["members"] == 2 and "host" in g["modes"] and g["count_matrix"]["scaling"] == "strong" and sum(g["count_matrix"]["shards_per_member"]) == 48
+    assert r["roofline"]["frac"] > 0 and "cpu_baseline" not in r  # (the CPU leg runs at N = 1 only)

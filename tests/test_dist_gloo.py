@@ -167,3 +167,86 @@ def test_bucketed_reducer_without_a_process_group():
     vals = torch.cat(bufs).tolist()
     # the last two buckets hold steps 4..7 and 8..9 (+ two cleared slots)
     assert sorted(v for v in vals if v) == seen[4:]
+
+
+def _strong_worker(rank: int, world: int, port: int, n_shards: int, q):
+    """bench.py's strong-scaling section (config 4: GroupBy matrix over a FIXED number of shards split over the
+    ranks) with the oracle standing in for the GPU: the same featurebase_amd.dist.strong_scaling_queries loop —
+    per-query collectives through the PerQueryReducer ring, the host-readback latency mode and host add."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import datagen as D
+    from featurebase_amd import dist as fd
+    from oracle import pybatch as PB
+
+    fd.init("gloo")
+    n_a = n_b = 4
+    mine = fd.shards_for_rank(n_shards, rank, world)
+
+    def shard_rows(s):
+        return D.dense_rows(n_a + n_b + 1, 0.5, 4400 + s)  # rows 0..3 field A, 4..7 field B, 8 the filter
+
+    def matrix_of(shards):
+        w = np.concatenate([shard_rows(s) for s in shards]) if shards else np.zeros((0, 16, 1024), dtype=np.uint64)
+        if not shards:
+            return np.zeros((n_a, n_b), dtype=np.uint64)
+        rs = PB.RowSet.from_dense(w)
+        base = np.arange(len(shards))[:, None] * (n_a + n_b + 1)
+        return PB.count_matrix(rs, base + np.arange(n_a), rs, base + n_a + np.arange(n_b), rs, (base + n_a + n_b).reshape(-1), nthreads=1).sum(axis=0)
+
+    partial = torch.from_numpy(matrix_of(mine).view(np.int64).reshape(-1).copy())
+    expected = matrix_of(list(range(n_shards))).reshape(-1)
+    calls = [0]
+
+    def run_local(cell):
+        cell.copy_(partial)  # the kernels' job on the GPU box: this rank's partial matrix into the cell
+        calls[0] += 1
+
+    res = fd.strong_scaling_queries(run_local, n_a * n_b, 11, None, expected=expected, depth=4)
+    q.put((rank, mine, res, calls[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_strong_scaling_query_loop_two_ranks():
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as O
+
+    O.build()
+    n_shards, world = 9, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, n_shards, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = [q.get(timeout=240) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)  # (every mode checked its reduced matrix against the all-shard oracle result)
+    seen = []
+    for rank, mine, res, calls in results:
+        seen += mine
+        assert res["queries"] == 11 and res["collectives"] == 2 + 11 + 11  # warm-up + pipelined + read-back: one collective per query, never bucketed
+        assert calls == 2 + 3 * 11
+        assert set(res) >= {"pipelined_s_per_query", "latency_s", "host_add_latency_s"} and res["latency_s"]["median"] > 0
+    assert sorted(seen) == list(range(n_shards))
+
+
+def test_per_query_reducer_without_a_process_group():
+    import torch
+
+    from featurebase_amd.dist import PerQueryReducer
+
+    red = PerQueryReducer(3, 2, torch.device("cpu"))
+    for k in range(5):
+        c = red.cell()
+        c.copy_(torch.tensor([k, k + 1, k + 2]))
+        assert red.reduce() == k % 2
+    bufs = red.flush()
+    assert red.collectives == 0 and bufs.tolist() == [[4, 5, 6], [3, 4, 5]]
