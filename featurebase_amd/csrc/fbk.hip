@@ -100,7 +100,7 @@ struct FbkOptions {
   int64_t pair_persistent = 0;           // k_icount2p: blocks per CU of the persistent, software-pipelined pair count (0: one wave per pair_spw slots)
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
-  int64_t pair_kernels = 2;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels (A/B runs)
+  int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
 
 struct fbk_ctx {
@@ -526,7 +526,7 @@ const OptionDesc kOptions[] = {
     {"bsi_half_waves", &FbkOptions::bsi_half_waves, 0, 1},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
-    {"pair_kernels", &FbkOptions::pair_kernels, 1, 2},
+    {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
     {"pair_spw", &FbkOptions::pair_spw, 0, 4},
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
@@ -1049,10 +1049,19 @@ namespace {
 
 int32_t optimize_cells(fbk_ctx* ctx, fbk_batch* o, const uint32_t* d_runs);  // fbk_query_api.inc
 
-// average encoded payload per container below 256 bytes (arrays of at most ~100 values, a few runs)
-bool pair_rows_are_tiny(const fbk_batch* a, const fbk_batch* b) {
+// Average encoded payload per container of the two batches below `limit` bytes.  Rows of tiny containers (arrays of a
+// few values, a handful of runs) are served better by the round-2 kernels: four waves per block and the all-pairs /
+// probe shortcuts — there the launch of a block per item is what a kernel costs, not decode work or latency
+// (BenchmarkCtOps matrix, profiles/ctops_r03.txt: Ary16 x Ary16 10.5 us with k_icount, 18 us with k_icount2).
+bool pair_rows_below(const fbk_batch* a, const fbk_batch* b, uint64_t limit) {
   const uint64_t slots = (uint64_t(a->n_rows) + b->n_rows) * fbk::kSlots;
-  return slots && (a->arena_bytes + b->arena_bytes) < 256 * slots;
+  return slots && (a->arena_bytes + b->arena_bytes) < limit * slots;
+}
+// which generation of the pair kernels a launch uses: option pair_kernels pins it (1 / 2), 0 decides by the rows
+bool use_pair_kernels2(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* b, int op /* -1: count */) {
+  if (ctx->opt.pair_kernels) return ctx->opt.pair_kernels >= 2;
+  // XOR: k_setop2<XOR> needs 128 registers and spills; it wins on rows of KiB-sized containers only
+  return !pair_rows_below(a, b, op == FBK_OP_XOR ? 1536 : 256);
 }
 
 template <int OP>
@@ -1061,11 +1070,11 @@ void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
                        p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, p->d_counts);
-  else if (p->ctx->opt.pair_kernels >= 2 && (p->ctx->opt.pair_wpb == 4 || (p->ctx->opt.pair_wpb == 0 && pair_rows_are_tiny(p->a, p->b))))
+  else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT) && p->ctx->opt.pair_wpb == 4)
     hipLaunchKernelGGL((fbk::k_setop2<OP, 4>), dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
                        want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
-  else if (p->ctx->opt.pair_kernels >= 2)
+  else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT))
     hipLaunchKernelGGL((fbk::k_setop2<OP, 1>), dim3(uint32_t(p->n_pairs * fbk::kSlots)), dim3(64), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
                        want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
@@ -1160,21 +1169,19 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #undef FBK_LAUNCH_DENSE
   } else {
     HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
-    if (ctx->opt.pair_kernels >= 2 && ctx->opt.pair_persistent) {
+    const bool pk2 = use_pair_kernels2(ctx, p->a, p->b, -1);
+    if (pk2 && ctx->opt.pair_persistent) {
       // as many blocks as the device holds at once (4 per CU: 128 registers, 34 KiB of LDS), each wave striding through the items
       const uint64_t want = (p->n_pairs * fbk::kSlots + 3) / 4;
       const uint64_t cap = uint64_t(ctx->n_cu > 0 ? ctx->n_cu : 256) * uint64_t(ctx->opt.pair_persistent);
       hipLaunchKernelGGL(fbk::k_icount2p, dim3(uint32_t(std::min(want, cap))), dim3(256), 0, ctx->stream, p->a->d_slots, p->a->d_arena,
                          p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts, uint32_t(ctx->opt.sparse_paths));
-    } else if (ctx->opt.pair_kernels >= 2) {
+    } else if (pk2) {
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
                      p->d_counts, uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8))
-      // rows of tiny containers (a few values each): the launch of one block per item is what such a kernel costs, so four
-      // waves per block and four slots per wave; everything else: one wave per block and item (see k_icount2)
-      const bool tiny = pair_rows_are_tiny(p->a, p->b);
-      const int spw = ctx->opt.pair_spw ? int(ctx->opt.pair_spw) : (tiny ? 4 : 1), wpb = ctx->opt.pair_wpb ? int(ctx->opt.pair_wpb) : (tiny ? 4 : 1);
+      const int spw = ctx->opt.pair_spw ? int(ctx->opt.pair_spw) : 1, wpb = ctx->opt.pair_wpb ? int(ctx->opt.pair_wpb) : 1;
       if (wpb == 4) {
         switch (spw) {
           case 1: FBK_LAUNCH_ICOUNT2(1, 4); break;

@@ -11,6 +11,7 @@ case $s in
 pytest) (timeout ${PYTEST_TIMEOUT:-900} python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} 2>&1 | tail -25) > $O/pytest.log ;;
 pytest_full) (timeout 600 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q --durations=10 2>&1 | tail -40) > $O/pytest_full.log ;;
 pairs) timeout 300 python scripts/bench_pairs.py --out $O/pairs.json ${PAIRS_ARGS:-} > $O/pairs.txt 2> $O/pairs.err ;;
+ctops_small) timeout 400 python scripts/bench_ctops.py --rows 1024 --iters 20 --out $O/ctops_small.json --only Empty,Ary1,Ary16,Ary256,Ary512,BM4096,RunFull,Run16,Run256 2>&1 | grep -v amdgpu.ids | tail -40 > $O/ctops_small.txt ;;
 ctops) timeout 600 python scripts/bench_ctops.py --rows 1024 --iters 20 --out $O/ctops.json 2>&1 | grep -v amdgpu.ids | tail -80 > $O/ctops.txt ;;
 bench) timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err ;;
 bench2) timeout 400 python bench.py --gpus 2 --steps 100 > $O/bench_n2.json 2> $O/bench_n2.err ;;
@@ -21,4 +22,4 @@ pmc_pairs) KF=${KF:-icount}; bash scripts/fused_pmc.sh $TAG/pmc_v1 64 pair_kerne
 esac
 done
 ls -R $O | head -40
-for f in $O/pytest.log $O/pytest_full.log $O/pairs.txt; do [ -f $f ] && tail -60 $f; done
+for f in $O/pytest.log $O/pytest_full.log $O/bench_n1.err $O/bench_n2.err; do [ -f $f ] && tail -60 $f; done
