@@ -178,3 +178,72 @@ def write_db(bitmaps: Dict[str, List[Tuple[int, int, int, np.ndarray]]], leaf_ce
         pos += 6 + len(nb)
     pages[1] = bytes(rr)
     return b"".join(pages)
+
+
+# ---- the write-side POLICY of the reference's cursor: which cell a container becomes -------------------------------
+# (restated so that RLE cells, BitmapPtr cells and merged cells of this oracle's images are what the reference itself
+# would have written for the same roaring containers; pinned by the expectations of rbf/cursor_test.go:290-440,
+# 601-640 in tests/test_oracle_rbf.py)
+def convert_to_leaf(key: int, c):
+    """ConvertToLeafArgs (rbf/cursor.go:1299-1341): oracle container -> (key, fbk type, n, payload) or None when
+    empty.  Arrays of more than ArrayMaxSize values and run containers of more than RLEMaxSize runs become bitmaps
+    (:1309-1315, :1327-1334); bitmaps are stored as BitmapPtr cells by putLeafCell (:421-477)."""
+    from . import pyoracle as O
+
+    if c is None or not c.p or c.n == 0:
+        return None
+    if c.typ == O.ARRAY:
+        if c.n > ARRAY_MAX:
+            return (key, 2, c.n, c.words())
+        return (key, 1, c.n, np.asarray(c.data(), dtype=np.uint16))
+    if c.typ == O.RUN:
+        if c.length > RLE_MAX:
+            return (key, 2, c.n, c.words())
+        return (key, 3, c.n, np.asarray(c.data(), dtype=np.uint16).reshape(-1, 2))
+    return (key, 2, c.n, c.words())
+
+
+def leaf_to_container(leaf):
+    """toContainer / merge's reconstruction (rbf/cursorx.go:230-266, cursor.go:1352-1366)"""
+    from . import pyoracle as O
+
+    _, t, n, payload = leaf
+    if t == 1:
+        return O.OContainer.array(payload)
+    if t == 3:
+        return O.OContainer.run([tuple(x) for x in np.asarray(payload).reshape(-1, 2).tolist()])
+    return O.OContainer.bitmap(np.asarray(payload, dtype=np.uint64), n)
+
+
+class CursorModel:
+    """The leaf cells of one RBF bitmap as Cursor.AddRoaring leaves them (rbf/cursor.go:1376-1408): a container
+    under a new key is converted and inserted; under an existing key it is merged — roaring.Union (union +
+    optimize(), roaring.go:7610-7615) of the incoming container and the stored one, rewritten only when the union has
+    more bits than the incoming container (`res.N() != data.N()`, :1367 — the reference compares with the INCOMING
+    container, so merging a subset of what is stored reports "changed" and rewrites the cell)."""
+
+    def __init__(self):
+        self.cells = {}
+
+    def add_roaring(self, items) -> bool:
+        """items: [(key, oracle container)] in key order -> changed"""
+        from . import pyoracle as O
+
+        changed = False
+        for key, cont in items:
+            leaf = convert_to_leaf(key, cont)
+            if leaf is None:  # leaf.BitN == 0: skipped (:1381-1383)
+                continue
+            if key not in self.cells:
+                self.cells[key] = leaf
+                changed = True
+                continue
+            stored = leaf_to_container(self.cells[key])
+            res = O.optimize(O.union(cont, stored))
+            if res.n != cont.n:
+                self.cells[key] = convert_to_leaf(key, res)
+                changed = True
+        return changed
+
+    def containers(self):
+        return [self.cells[k] for k in sorted(self.cells)]
