@@ -118,10 +118,15 @@ def test_cursor_add_roaring_table_and_cell_types(oracle):
     cells = {k: (t, n) for k, t, n, _ in model.containers()}
     rmax = META["RLEMaxSize"]
     # key 0: array {1,2,3,4} merged with bitmap {75}: roaring.Union optimize()s {1-4, 75} (2 runs <= 5 / 2) into a RUN
-    # container -> RLE cell; key 1: run [1, 20000]; key 3: {4, 8, 12, 75}: 4 runs > 4 / 2 -> array; key 10: 0..4080 ∪ the
-    # 2041 runs -> bitmap
+    # container -> RLE cell; key 1: run [1, 20000]; key 3: {4, 8, 12, 75}: 4 runs > 4 / 2 -> array
     assert cells[0] == (3, 5) and cells[1] == (3, 20000) and cells[3] == (1, 4) and 11 not in cells
-    assert cells[10][0] == 2 and cells[10][1] == len(set(range(META["ArrayMaxSize"] + 2)) | {v for i in range(rmax + 2) for v in (3 * i, 3 * i + 1)})
+    # key 10: "too Big Array" alone is a bitmap page (4081 values > ArrayMaxSize); merged with "too Big RLE" the union is one
+    # long run [0, 4081] plus 680 short ones: optimize() makes it a run container of 681 runs <= RLEMaxSize -> an RLE cell
+    want10 = set(range(META["ArrayMaxSize"] + 2)) | {v for i in range(rmax + 2) for v in (3 * i, 3 * i + 1)}
+    assert cells[10] == (3, len(want10)) and len([c for c in model.containers() if c[0] == 10][0][3]) == len(D.runs_of_vals(np.array(sorted(want10))))
+    only_big = pyrbf.CursorModel()
+    only_big.add_roaring([(10, _add_roaring_cases(oracle)[8][2])])
+    assert only_big.containers()[0][1] == 2  # BitmapPtr
     # written as an RBF image and read back: same cells, RLE / BitmapPtr cell types on the page
     f = pyrbf.write_db({"x": model.containers()})
     back = pyrbf.read_bitmap(f, pyrbf.find_root(f, "x"))
@@ -214,5 +219,13 @@ def test_cursor_policy_image_through_upload_rbf(gpu_ctx, oracle):
     assert sorted(got) == sorted(want)
     for k, c in got.items():
         assert c.n == want[k].n and (c.words() == want[k].words()).all(), k
-    assert got[0].typ == 3 and got[1].typ == 3 and got[3].typ == 1 and got[10].typ == 2  # RLE, RLE, array, bitmap page
+    assert got[0].typ == 3 and got[1].typ == 3 and got[3].typ == 1 and got[10].typ == 3  # RLE, RLE, array, RLE
+    # and a BitmapPtr cell: the oversized array on its own
+    only_big = pyrbf.CursorModel()
+    only_big.add_roaring([(10, _add_roaring_cases(oracle)[8][2])])
+    f2 = pyrbf.write_db({"x": only_big.containers()})
+    b2, _ = gpu_ctx.upload_rbf(f2, gpu_ctx.rbf_find_root(f2, "x"))
+    c10 = b2.download()[0][10]
+    assert c10.typ == 2 and c10.n == META["ArrayMaxSize"] + 2 and (c10.words() == D.words_of(np.arange(META["ArrayMaxSize"] + 2))).all()
+    b2.free()
     batch.free()
