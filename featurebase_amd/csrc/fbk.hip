@@ -163,6 +163,7 @@ struct fbk_batch {
   // batch, dropped whenever the containers are rewritten (plan outputs, optimize)
   mutable uint4* d_win = nullptr;
   mutable std::mutex win_mu;
+  std::mutex slots_mu;  // refresh_slots: h_slots / slots_stale
 };
 
 namespace {
@@ -333,11 +334,18 @@ struct D2H {
   }
 };
 
+// The host copy of a batch's descriptors, refreshed after the device rewrote them (plan outputs, optimize).  Any
+// context of the device may read a batch (fbk_ctx_fork): the refresh is serialised per BATCH (two forks reading a
+// stale plan output would otherwise race on the host vector) and runs on the CALLING context's stream, whose lock
+// the caller holds — never on the owner's stream behind the owner's back.  The owner's stream is drained first when
+// the caller is another context, so that the rewrite that made the copy stale has landed.
 int32_t refresh_slots(fbk_batch* b) {
+  std::lock_guard<std::mutex> g(b->slots_mu);
   if (!b->slots_stale) return FBK_OK;
-  HIP_TRY(hipMemcpyAsync(b->h_slots.data(), b->d_slots, b->h_slots.size() * sizeof(Slot),
-                         hipMemcpyDeviceToHost, b->ctx->stream));
-  HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+  fbk_ctx* c = g_scope_ctx && g_scope_ctx->device == b->ctx->device ? g_scope_ctx : b->ctx;
+  if (c != b->ctx) HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+  HIP_TRY(hipMemcpyAsync(b->h_slots.data(), b->d_slots, b->h_slots.size() * sizeof(Slot), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   b->slots_stale = false;
   return FBK_OK;
 }
@@ -361,14 +369,19 @@ int32_t window_index(fbk_ctx* ctx, const fbk_batch* b, const uint4** out) {
   if (!b->d_win) {
     const uint64_t n_slots = uint64_t(b->n_rows) * fbk::kSlots;
     uint4* w = nullptr;
-    HIP_TRY(ctx_malloc(b->ctx, reinterpret_cast<void**>(&w), std::max<uint64_t>(n_slots, 1) * sizeof(uint4)));
+    // from the CALLING context's pool: a pooled block is only safe to reuse on the stream that freed it (reuse is
+    // ordered by the stream), and the kernel below runs on the caller's stream — a block the owner had freed with
+    // work still pending on ITS stream would be overwritten under that work.  The finished index then belongs to
+    // the batch's owner, which frees it with the batch.
+    HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&w), std::max<uint64_t>(n_slots, 1) * sizeof(uint4)));
     if (n_slots) hipLaunchKernelGGL(fbk::k_window_index, dim3(uint32_t((n_slots + 3) / 4)), dim3(256), 0, ctx->stream, b->d_slots, b->d_arena, n_slots, w);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
-      (void)ctx_free(b->ctx, w);
+      (void)ctx_free(ctx, w);
       return fail(FBK_E_HIP, std::string("window index: ") + hipGetErrorString(e));
     }
+    pool_rehome(ctx, b->ctx, w);
     b->d_win = w;
   }
   *out = b->d_win;
