@@ -1062,19 +1062,29 @@ namespace {
 
 int32_t optimize_cells(fbk_ctx* ctx, fbk_batch* o, const uint32_t* d_runs);  // fbk_query_api.inc
 
-// Average encoded payload per container of the two batches below `limit` bytes.  Rows of tiny containers (arrays of a
-// few values, a handful of runs) are served better by the round-2 kernels: four waves per block and the all-pairs /
-// probe shortcuts — there the launch of a block per item is what a kernel costs, not decode work or latency
-// (BenchmarkCtOps matrix, profiles/ctops_r03.txt: Ary16 x Ary16 10.5 us with k_icount, 18 us with k_icount2).
-bool pair_rows_below(const fbk_batch* a, const fbk_batch* b, uint64_t limit) {
-  const uint64_t slots = (uint64_t(a->n_rows) + b->n_rows) * fbk::kSlots;
-  return slots && (a->arena_bytes + b->arena_bytes) < limit * slots;
+// Average encoded payload per container of a batch, in bytes.
+uint64_t batch_avg_payload(const fbk_batch* b) {
+  const uint64_t slots = uint64_t(b->n_rows) * fbk::kSlots;
+  return slots ? b->arena_bytes / slots : 0;
 }
-// which generation of the pair kernels a launch uses: option pair_kernels pins it (1 / 2), 0 decides by the rows
+// Which generation of the pair kernels a launch uses (option pair_kernels pins it: 1 / 2; 0 decides by the rows).
+// Rows of tiny containers on BOTH sides (arrays of a few values, a handful of runs) are served better by the round-2
+// kernels: there the launch of a block per item is what a kernel costs, not decode work or latency (BenchmarkCtOps
+// matrix, profiles/ctops_r03.txt: Ary16 x Ary16 10.5 us with k_icount, 18 us with k_icount2).  XOR: k_setop2<XOR> needs
+// 128 registers and spills; it wins on rows whose containers are KiB-sized on both sides only.
 bool use_pair_kernels2(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* b, int op /* -1: count */) {
   if (ctx->opt.pair_kernels) return ctx->opt.pair_kernels >= 2;
-  // XOR: k_setop2<XOR> needs 128 registers and spills; it wins on rows of KiB-sized containers only
-  return !pair_rows_below(a, b, op == FBK_OP_XOR ? 1536 : 256);
+  const uint64_t lo = std::min(batch_avg_payload(a), batch_avg_payload(b)), both = (a->arena_bytes + b->arena_bytes);
+  const uint64_t slots = (uint64_t(a->n_rows) + b->n_rows) * fbk::kSlots;
+  if (op == FBK_OP_XOR) return lo >= 1536;
+  return slots && both >= 256 * slots;
+}
+// Waves per block of the round-3 pair kernels (option pair_wpb pins it).  One-wave blocks release a wave's LDS table the
+// moment IT ends, which is what heterogeneous items (runs next to arrays) need; when one side's containers are tiny the
+// items are all alike and short, and four waves per block quarter the number of blocks to launch.
+int pair_wpb_for(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* b) {
+  if (ctx->opt.pair_wpb) return int(ctx->opt.pair_wpb);
+  return std::min(batch_avg_payload(a), batch_avg_payload(b)) < 256 ? 4 : 1;
 }
 
 template <int OP>
@@ -1083,7 +1093,7 @@ void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
                        p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, p->d_counts);
-  else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT) && p->ctx->opt.pair_wpb == 4)
+  else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT) && pair_wpb_for(p->ctx, p->a, p->b) == 4)
     hipLaunchKernelGGL((fbk::k_setop2<OP, 4>), dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
                        want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
@@ -1194,7 +1204,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
                      p->d_counts, uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8))
-      const int spw = ctx->opt.pair_spw ? int(ctx->opt.pair_spw) : 1, wpb = ctx->opt.pair_wpb ? int(ctx->opt.pair_wpb) : 1;
+      const int spw = ctx->opt.pair_spw ? int(ctx->opt.pair_spw) : 1, wpb = pair_wpb_for(ctx, p->a, p->b);
       if (wpb == 4) {
         switch (spw) {
           case 1: FBK_LAUNCH_ICOUNT2(1, 4); break;
