@@ -93,12 +93,14 @@ struct FbkOptions {
   int64_t bsi_range_blocks = 0;          // 1: one 256-thread block per (shard, slot) for Range (round-1 kernel, A/B runs); 0: one wavefront
   int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)
   int64_t bsi_half_waves = 1;            // dense BSI batches: the one-pass Range + Sum runs half a container per wavefront; 0: one wavefront per container (A/B runs)
+  int64_t bsi_between_parts = 4;         // one-pass Sum(Between) on dense batches: parts of a container per wavefront (4: a quarter; 2: half, the round-2 form)
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
   int64_t pair_spw = 0;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4; 0 = by the rows' payload size): next slot's payload in flight while the current one is decoded
   int64_t pair_persistent = 0;           // k_icount2p: blocks per CU of the persistent, software-pipelined pair count (0: one wave per pair_spw slots)
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
+  int64_t pair_resolve = 1;              // k_icount2 reads the plan's resolved item records and stores one count per wave (0: row index -> descriptor per wave, atomics; A/B runs)
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
@@ -164,6 +166,7 @@ struct fbk_batch {
   mutable uint4* d_win = nullptr;
   mutable std::mutex win_mu;
   std::mutex slots_mu;  // refresh_slots: h_slots / slots_stale
+  uint64_t version = 0;  // bumped whenever the device descriptors are rewritten (a plan's resolved item records follow it)
 };
 
 namespace {
@@ -355,6 +358,7 @@ int32_t refresh_slots(fbk_batch* b) {
 // index behind the rewrite in stream order, or already synchronised.)
 void slots_rewritten(fbk_batch* b) {
   b->slots_stale = true;
+  ++b->version;
   std::lock_guard<std::mutex> g(b->win_mu);
   if (b->d_win) {
     (void)ctx_free(b->ctx, b->d_win);
@@ -537,11 +541,13 @@ const OptionDesc kOptions[] = {
     {"bsi_range_blocks", &FbkOptions::bsi_range_blocks, 0, 1},
     {"bsi_range_sum_two_pass", &FbkOptions::bsi_range_sum_two_pass, 0, 1},
     {"bsi_half_waves", &FbkOptions::bsi_half_waves, 0, 1},
+    {"bsi_between_parts", &FbkOptions::bsi_between_parts, 2, 4},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
     {"pair_spw", &FbkOptions::pair_spw, 0, 4},
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
+    {"pair_resolve", &FbkOptions::pair_resolve, 0, 1},
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
     {"pair_persistent", &FbkOptions::pair_persistent, 0, 16},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
@@ -1056,6 +1062,11 @@ struct fbk_plan {
   fbk_batch* out = nullptr;    // lazily created by the first set-op enqueue
   uint32_t* d_runs = nullptr;  // per output slot run count (optimize pass)
   std::vector<uint32_t> h_rows_a, h_rows_b;
+  // k_icount2: the (pair, slot) item records resolved once per plan (re-resolved when a batch's descriptors were
+  // rewritten since) and one count per wave, summed per pair by k_sum_wave_counts
+  Slot* d_items = nullptr;
+  uint32_t* d_wave_counts = nullptr;
+  uint64_t items_va = ~0ull, items_vb = ~0ull;
 };
 
 namespace {
@@ -1123,6 +1134,8 @@ void free_plan_storage(fbk_plan* p) {
   if (p->d_total) (void)ctx_free(p->ctx, p->d_total);
   if (p->d_done) (void)ctx_free(p->ctx, p->d_done);
   if (p->d_runs) (void)ctx_free(p->ctx, p->d_runs);
+  if (p->d_items) (void)ctx_free(p->ctx, p->d_items);
+  if (p->d_wave_counts) (void)ctx_free(p->ctx, p->d_wave_counts);
   free_batch_storage(p->out);
   delete p;
 }
@@ -1191,8 +1204,22 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
     }
 #undef FBK_LAUNCH_DENSE
   } else {
-    HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     const bool pk2 = use_pair_kernels2(ctx, p->a, p->b, -1);
+    const bool resolved = pk2 && !ctx->opt.pair_persistent && ctx->opt.pair_resolve;
+    if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
+    if (resolved) {
+      const uint64_t n_items = p->n_pairs * fbk::kSlots;
+      if (!p->d_items) {
+        HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_items), n_items * 2 * sizeof(Slot)));
+        HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_wave_counts), n_items * sizeof(uint32_t)));
+      }
+      if (p->items_va != p->a->version || p->items_vb != p->b->version) {
+        hipLaunchKernelGGL(fbk::k_resolve_items, dim3(uint32_t((n_items + 255) / 256)), dim3(256), 0, ctx->stream, p->a->d_slots, p->d_rows_a, p->b->d_slots,
+                           p->d_rows_b, p->n_pairs, p->d_items);
+        p->items_va = p->a->version;
+        p->items_vb = p->b->version;
+      }
+    }
     if (pk2 && ctx->opt.pair_persistent) {
       // as many blocks as the device holds at once (4 per CU: 128 registers, 34 KiB of LDS), each wave striding through the items
       const uint64_t want = (p->n_pairs * fbk::kSlots + 3) / 4;
@@ -1203,7 +1230,8 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
-                     p->d_counts, uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8))
+                     p->d_counts, uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8), resolved ? p->d_items : (const Slot*)nullptr,  \
+                     resolved ? p->d_wave_counts : (uint32_t*)nullptr)
       const int spw = ctx->opt.pair_spw ? int(ctx->opt.pair_spw) : 1, wpb = pair_wpb_for(ctx, p->a, p->b);
       if (wpb == 4) {
         switch (spw) {
@@ -1219,6 +1247,9 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
         }
       }
 #undef FBK_LAUNCH_ICOUNT2
+      if (resolved)
+        hipLaunchKernelGGL(fbk::k_sum_wave_counts, dim3(uint32_t((p->n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, p->d_wave_counts,
+                           uint32_t(fbk::kSlots / spw), p->n_pairs, p->d_counts);
     }
     else
       hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,

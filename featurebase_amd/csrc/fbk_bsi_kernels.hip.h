@@ -863,7 +863,7 @@ __device__ __forceinline__ void between_sum_plane(uint32_t a0, uint32_t a1, uint
 template <int NW, typename LoadPlane, typename LoadRow>
 __device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int lane, LoadRow&& load_row, LoadPlane&& load_plane, bool has_filter,
                                                  u64* __restrict__ out4, uint64_t shard) {
-  constexpr int kAhead = NW == kHalfWords ? 4 : 2;
+  constexpr int kAhead = NW <= kHalfWords ? 4 : 2;
   const uint32_t depth = plan.depth;
   u64 X0[NW], X1[NW], M0[NW], M1[NW], T[kAhead][NW];
   load_row(0u, X0);  // exists
@@ -940,27 +940,65 @@ __device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int
   }
 }
 
-__global__ void __launch_bounds__(64) k_bsi_between_sum_half(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ base, uint32_t n_shards,
+// NW words per lane = NW * 512 bytes of every plane per wavefront: 8 = half a container (round 2: four 8-word fragments
+// + four planes in flight = 223 registers, two wavefronts per SIMD, and the two-lane plane step bound by the vector
+// ALU at that occupancy: 205-215 us for 830 MB), 4 = a QUARTER (round 3: ~110 registers, four wavefronts per SIMD,
+// 6144 wavefronts for 96 shards; sums and counts are reductions, the parts just add into the same totals).
+template <int NW>
+__device__ __forceinline__ void part_load(const uint8_t* __restrict__ p, int lane, u64 (&w)[NW]) {
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+#pragma unroll
+  for (int j = 0; j < NW / 2; ++j) {
+    const ulonglong2 v = ld_stream(&q[j * kWave + lane]);
+    w[2 * j] = v.x;
+    w[2 * j + 1] = v.y;
+  }
+}
+
+// part `part` of any container (the filter row may come from anywhere): bitmaps directly, the rest through the full decode
+template <int NW>
+__device__ __forceinline__ void part_load_any(const Slot& s, const uint8_t* __restrict__ arena, int lane, uint32_t part, u64* lds, u64 (&w)[NW]) {
+  if (slot_n(s) == 0) {
+#pragma unroll
+    for (int q = 0; q < NW; ++q) w[q] = 0;
+  } else if (slot_type(s) == kTypeBitmap) {
+    part_load<NW>(arena + s.off + part * (NW * 512u), lane, w);
+  } else {
+    u64 full[kWordsPerLane];
+    frag_load(s, arena, lane, lds, full);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      u64 v = full[q];
+#pragma unroll
+      for (int pp = 1; pp < kWordsPerLane / NW; ++pp) v = part == (uint32_t)pp ? full[pp * NW + q] : v;
+      w[q] = v;
+    }
+  }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64) k_bsi_between_sum_part(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ base, uint32_t n_shards,
                                                             const BetweenSumPlan* __restrict__ planp, const Slot* __restrict__ fslots,
                                                             const uint8_t* __restrict__ farena, const uint32_t* __restrict__ frows, u64* __restrict__ out4) {
   __shared__ u64 lds[kWords];
+  constexpr uint32_t kParts = kWordsPerLane / NW;
   const int lane = threadIdx.x;
-  const uint32_t h = blockIdx.x & 1u;
-  const uint64_t cell = blockIdx.x >> 1;
+  const uint32_t part = blockIdx.x % kParts;
+  const uint64_t cell = blockIdx.x / kParts;
   const uint64_t shard = cell >> 4;
   const uint32_t slot = cell & 15;
   if (shard >= n_shards) return;
-  const uint8_t* const row0 = arena + ((uint64_t)base[shard] * kSlots + slot) * 8192ull + h * 4096u;
+  const uint8_t* const row0 = arena + ((uint64_t)base[shard] * kSlots + slot) * 8192ull + part * (NW * 512u);
   constexpr uint64_t kRow = (uint64_t)kSlots * 8192ull;
   Slot sf;
   sf.off = 0, sf.len = 0, sf.tn = 0;
   if (fslots) sf = fslots[(uint64_t)frows[shard] * kSlots + slot];
-  auto load_row = [&](uint32_t r, u64 (&w)[kHalfWords]) {
-    if (r == ~0u) half_load_any(sf, farena, lane, h, lds, w);
-    else half_load(row0 + kRow * r, lane, w);
+  auto load_row = [&](uint32_t r, u64 (&w)[NW]) {
+    if (r == ~0u) part_load_any<NW>(sf, farena, lane, part, lds, w);
+    else part_load<NW>(row0 + kRow * r, lane, w);
   };
-  auto load_plane = [&](uint32_t i, u64 (&w)[kHalfWords]) { half_load(row0 + kRow * (2u + i), lane, w); };
-  between_sum_body<kHalfWords>(*planp, lane, load_row, load_plane, fslots != nullptr, out4, shard);
+  auto load_plane = [&](uint32_t i, u64 (&w)[NW]) { part_load<NW>(row0 + kRow * (2u + i), lane, w); };
+  between_sum_body<NW>(*planp, lane, load_row, load_plane, fslots != nullptr, out4, shard);
 }
 
 // ---- BSI Min / Max ------------------------------------------------------------------------------

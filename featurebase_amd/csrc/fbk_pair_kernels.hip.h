@@ -624,7 +624,8 @@ template <int SPW, int WPB>
 __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
                                                      const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
                                                      const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
-                                                     u64* __restrict__ out, uint32_t sparse_paths) {
+                                                     u64* __restrict__ out, uint32_t sparse_paths, const Slot* __restrict__ items,
+                                                     uint32_t* __restrict__ wave_out) {
   __shared__ u64 lds[WPB][kWords];
   __shared__ uint32_t mini[WPB][2 * kMiniDwords];
   constexpr int kWavesPerPair = kSlots / SPW;
@@ -634,14 +635,25 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
   const uint64_t pair = wid / kWavesPerPair;
   if (pair >= n_pairs) return;
   const uint32_t slot0 = (uint32_t)(wid % kWavesPerPair) * SPW;
-  const uint32_t ra = rowsA[pair], rb = rowsB[pair];  // both row indexes in flight together
-  const Slot* da = slotsA + (uint64_t)ra * kSlots + slot0;
-  const Slot* db = slotsB + (uint64_t)rb * kSlots + slot0;
   Slot sa[SPW], sb[SPW];
+  if (items) {
+    // the plan's resolved item records (k_resolve_items): {A's descriptor, B's descriptor} per (pair, slot), in item
+    // order — ONE scalar round trip instead of row index -> descriptor, and neighbouring waves share its lines
+    const Slot* it = items + (pair * kSlots + slot0) * 2;
 #pragma unroll
-  for (int k = 0; k < SPW; ++k) {
-    sa[k] = da[k];
-    sb[k] = db[k];
+    for (int k = 0; k < SPW; ++k) {
+      sa[k] = it[2 * k];
+      sb[k] = it[2 * k + 1];
+    }
+  } else {
+    const uint32_t ra = rowsA[pair], rb = rowsB[pair];  // both row indexes in flight together
+    const Slot* da = slotsA + (uint64_t)ra * kSlots + slot0;
+    const Slot* db = slotsB + (uint64_t)rb * kSlots + slot0;
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) {
+      sa[k] = da[k];
+      sb[k] = db[k];
+    }
   }
   u64* table = lds[wv];
   uint32_t part = 0, spart = 0;
@@ -654,7 +666,34 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
   }
   if (sparse_paths & 0x100u) return;  // (timing experiment: no output)
   const uint32_t c = wave_reduce_add(part) + spart;
-  if (lane == 0 && c) atomicAdd(&out[pair], (u64)c);
+  if (wave_out) {
+    // one plain store per wave; k_sum_wave_counts adds a pair's waves up.  (The uint64 atomics of the 16 waves of a
+    // pair onto out[pair] — from up to 8 XCDs, so executed at the memory side — and the memset they need in front cost
+    // ~8 us of a 46 us launch.)
+    if (lane == 0) wave_out[wid] = c;
+  } else if (lane == 0 && c) {
+    atomicAdd(&out[pair], (u64)c);
+  }
+}
+
+// out[pair] = the sum of the pair's waves' counts (per = 16 / SPW of them, consecutive)
+__global__ void __launch_bounds__(256) k_sum_wave_counts(const uint32_t* __restrict__ wave_counts, uint32_t per, uint64_t n_pairs, u64* __restrict__ out) {
+  const uint64_t pair = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pair >= n_pairs) return;
+  const uint32_t* w = wave_counts + pair * per;
+  u64 acc = 0;
+  for (uint32_t i = 0; i < per; ++i) acc += w[i];
+  out[pair] = acc;
+}
+
+// item records of a plan: items[2 i] = A's descriptor, items[2 i + 1] = B's, i = pair * 16 + slot
+__global__ void __launch_bounds__(256) k_resolve_items(const Slot* __restrict__ slotsA, const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
+                                                      const uint32_t* __restrict__ rowsB, uint64_t n_pairs, Slot* __restrict__ items) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pairs * kSlots) return;
+  const uint64_t pair = i >> 4, slot = i & 15;
+  items[2 * i] = slotsA[(uint64_t)rowsA[pair] * kSlots + slot];
+  items[2 * i + 1] = slotsB[(uint64_t)rowsB[pair] * kSlots + slot];
 }
 
 // The PERSISTENT form (option pair_persistent, default): the grid is only as large as the device holds at once and

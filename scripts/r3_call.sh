@@ -18,6 +18,7 @@ bench2) timeout 400 python bench.py --gpus 2 --steps 100 > $O/bench_n2.json 2> $
 misc) (cd /tmp; export TMPDIR=/tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/misc -o misc -- python $R/scripts/profile_misc.py 64 > $O/misc.json 2> /dev/null) ;;
 benchprof) (cd /tmp; export TMPDIR=/tmp; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --repeats 5 --no-cpu-baseline > $O/bench_prof.json 2> /dev/null) ;;
 pmc_pairs) KF=${KF:-icount}; bash scripts/fused_pmc.sh $TAG/pmc_v1 64 pair_kernels=1 pairs_pmc.py $KF > $O/pmc_pairs_v1.txt 2>&1; bash scripts/fused_pmc.sh $TAG/pmc_v2 64 pair_kernels=2,pair_spw=2 pairs_pmc.py $KF > $O/pmc_pairs_v2.txt 2>&1 ;;
+bsi) (FBK_BSI_BETWEEN_PARTS=2 timeout 200 python scripts/bsi_bench.py 2>&1 | grep -v amdgpu.ids > $O/bsi_bench_parts2.txt; FBK_BSI_BETWEEN_PARTS=4 timeout 200 python scripts/bsi_bench.py 2>&1 | grep -v amdgpu.ids > $O/bsi_bench_parts4.txt) ;;
 *) echo "unknown step $s" ;;
 esac
 done
