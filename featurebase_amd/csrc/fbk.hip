@@ -1088,7 +1088,12 @@ bool use_pair_kernels2(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* 
   const uint64_t lo = std::min(batch_avg_payload(a), batch_avg_payload(b)), both = (a->arena_bytes + b->arena_bytes);
   const uint64_t slots = (uint64_t(a->n_rows) + b->n_rows) * fbk::kSlots;
   if (op == FBK_OP_XOR) return lo >= 1536;
-  return slots && both >= 256 * slots;
+  if (!slots || both < 256 * slots) return false;
+  // one side tiny: when the other one is all bitmaps (or there is nothing on one side at all) the items are probes of a
+  // few dwords in global memory in either generation, and the round-2 kernel's four-wave blocks launch faster
+  // (Ary1 x BM512 7.4 us vs 9.3); against big arrays / run lists the table + probe form wins (Ary4096 x Ary1 48 -> 27 us)
+  if (lo < 256 && (a->arena_bytes == 0 || b->arena_bytes == 0 || (batch_avg_payload(a) < 256 ? b->dense : a->dense))) return false;
+  return true;
 }
 // Waves per block of the round-3 pair kernels (option pair_wpb pins it).  One-wave blocks release a wave's LDS table the
 // moment IT ends, which is what heterogeneous items (runs next to arrays) need; when one side's containers are tiny the
@@ -1205,7 +1210,8 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #undef FBK_LAUNCH_DENSE
   } else {
     const bool pk2 = use_pair_kernels2(ctx, p->a, p->b, -1);
-    const bool resolved = pk2 && !ctx->opt.pair_persistent && ctx->opt.pair_resolve;
+    // (resolved item records + a count per wave pay for their second launch only where the items are heavy: one-wave blocks)
+    const bool resolved = pk2 && !ctx->opt.pair_persistent && ctx->opt.pair_resolve && pair_wpb_for(ctx, p->a, p->b) == 1;
     if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     if (resolved) {
       const uint64_t n_items = p->n_pairs * fbk::kSlots;
