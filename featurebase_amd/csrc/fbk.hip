@@ -1087,7 +1087,15 @@ bool use_pair_kernels2(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* 
   if (ctx->opt.pair_kernels) return ctx->opt.pair_kernels >= 2;
   const uint64_t lo = std::min(batch_avg_payload(a), batch_avg_payload(b)), both = (a->arena_bytes + b->arena_bytes);
   const uint64_t slots = (uint64_t(a->n_rows) + b->n_rows) * fbk::kSlots;
-  if (op == FBK_OP_XOR) return lo >= 1536;
+  if (op >= 0) {
+    // materialising operations (8 KiB written per pair whatever the operands): k_setop2 wins where at least one side
+    // holds KiB-sized SPARSE containers — arrays from ~1000 values, long run lists — whose decode and load latency it
+    // was built around (Ary4096 x Ary1 XOR 73 -> 53 us; config 3's rows 89 -> 69 us); with small arrays on one side and
+    // small arrays or bitmaps on the other the round-2 kernel's cheaper per-item path is 10-25 % ahead
+    // (BenchmarkCtOps matrix, profiles/ctops_r03.txt)
+    const uint64_t big_sparse = std::max(a->dense ? 0 : batch_avg_payload(a), b->dense ? 0 : batch_avg_payload(b));
+    return big_sparse >= 1536;
+  }
   if (!slots || both < 256 * slots) return false;
   // one side tiny: when the other one is all bitmaps (or there is nothing on one side at all) the items are probes of a
   // few dwords in global memory in either generation, and the round-2 kernel's four-wave blocks launch faster
