@@ -98,7 +98,6 @@ struct FbkOptions {
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
   int64_t pair_spw = 0;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4; 0 = by the rows' payload size): next slot's payload in flight while the current one is decoded
-  int64_t pair_persistent = 0;           // k_icount2p: blocks per CU of the persistent, software-pipelined pair count (0: one wave per pair_spw slots)
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
   int64_t pair_resolve = 1;              // k_icount2 reads the plan's resolved item records and stores one count per wave (0: row index -> descriptor per wave, atomics; A/B runs)
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
@@ -549,7 +548,6 @@ const OptionDesc kOptions[] = {
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
     {"pair_resolve", &FbkOptions::pair_resolve, 0, 1},
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
-    {"pair_persistent", &FbkOptions::pair_persistent, 0, 16},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
 };
 
@@ -1219,7 +1217,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
   } else {
     const bool pk2 = use_pair_kernels2(ctx, p->a, p->b, -1);
     // (resolved item records + a count per wave pay for their second launch only where the items are heavy: one-wave blocks)
-    const bool resolved = pk2 && !ctx->opt.pair_persistent && ctx->opt.pair_resolve && pair_wpb_for(ctx, p->a, p->b) == 1;
+    const bool resolved = pk2 && ctx->opt.pair_resolve && pair_wpb_for(ctx, p->a, p->b) == 1;
     if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     if (resolved) {
       const uint64_t n_items = p->n_pairs * fbk::kSlots;
@@ -1234,13 +1232,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
         p->items_vb = p->b->version;
       }
     }
-    if (pk2 && ctx->opt.pair_persistent) {
-      // as many blocks as the device holds at once (4 per CU: 128 registers, 34 KiB of LDS), each wave striding through the items
-      const uint64_t want = (p->n_pairs * fbk::kSlots + 3) / 4;
-      const uint64_t cap = uint64_t(ctx->n_cu > 0 ? ctx->n_cu : 256) * uint64_t(ctx->opt.pair_persistent);
-      hipLaunchKernelGGL(fbk::k_icount2p, dim3(uint32_t(std::min(want, cap))), dim3(256), 0, ctx->stream, p->a->d_slots, p->a->d_arena,
-                         p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts, uint32_t(ctx->opt.sparse_paths));
-    } else if (pk2) {
+    if (pk2) {
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \

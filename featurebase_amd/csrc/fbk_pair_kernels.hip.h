@@ -696,72 +696,10 @@ __global__ void __launch_bounds__(256) k_resolve_items(const Slot* __restrict__ 
   items[2 * i + 1] = slotsB[(uint64_t)rowsB[pair] * kSlots + slot];
 }
 
-// The PERSISTENT form (option pair_persistent, default): the grid is only as large as the device holds at once and
-// every wave strides through the (pair, slot) items as a four-stage software pipeline —
-//     item u + 3 W: its two row indexes are requested                                  (scalar loads)
-//     item u + 2 W: its two descriptors are requested, at the rows that arrived        (scalar loads)
-//     item u + W  : batch 0 of its sparse payloads is requested, at the offsets that arrived
-//     item u      : decoded and counted
-// (W = waves in the grid).  With one item per wave the three dependent round trips — row index, descriptor,
-// payload: ~4 us of HBM latency — were paid in full by every item, and with 16 waves per CU (128 registers,
-// 34 KiB of LDS per block) that wait, not instruction issue and not the LDS, set the rate: rocprofv3 --pmc showed
-// the waves parked in s_waitcnt 60 % of their life (profiles/r03_pmc_pair_kernels.txt).  Here an item's chain
-// overlaps the work of the three items before it.
-__global__ void __launch_bounds__(256, 4) k_icount2p(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
-                                                    const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
-                                                    const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
-                                                    u64* __restrict__ out, uint32_t sparse_paths) {
-  __shared__ u64 lds[4][kWords];
-  __shared__ uint32_t mini[4][2 * kMiniDwords];
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint64_t n_items = n_pairs * kSlots;
-  const uint64_t stride = (uint64_t)gridDim.x * 4;
-  uint64_t u = (uint64_t)blockIdx.x * 4 + (uint64_t)wv;
-  if (u >= n_items) return;
-  const uint64_t last = n_items - 1;
-  // loads of items past the end are made at the last item (in bounds, never used)
-#define FBK_ITEM(x) ((x) < n_items ? (x) : last)
-  // prologue: fill the pipeline
-  uint64_t i0 = u, i1 = FBK_ITEM(u + stride), i2 = FBK_ITEM(u + 2 * stride);
-  uint32_t ra0 = rowsA[i0 >> 4], rb0 = rowsB[i0 >> 4];
-  uint32_t ra1 = rowsA[i1 >> 4], rb1 = rowsB[i1 >> 4];
-  uint32_t ra2 = rowsA[i2 >> 4], rb2 = rowsB[i2 >> 4];
-  Slot sa0 = slotsA[(uint64_t)ra0 * kSlots + (i0 & 15)], sb0 = slotsB[(uint64_t)rb0 * kSlots + (i0 & 15)];
-  Slot sa1 = slotsA[(uint64_t)ra1 * kSlots + (i1 & 15)], sb1 = slotsB[(uint64_t)rb1 * kSlots + (i1 & 15)];
-  uint32_t va[kPairBatch], vb[kPairBatch];
-  item_prefetch(sa0, arenaA, sb0, arenaB, lane, va, vb);
-  u64* table = lds[wv];
-  for (;;) {
-    // stage A for item u + 3 W, stage B for u + 2 W, stage C for u + W
-    const uint64_t i3 = FBK_ITEM(u + 3 * stride);
-    const uint32_t ra3 = rowsA[i3 >> 4], rb3 = rowsB[i3 >> 4];
-    const Slot sa2 = slotsA[(uint64_t)ra2 * kSlots + (i2 & 15)], sb2 = slotsB[(uint64_t)rb2 * kSlots + (i2 & 15)];
-    uint32_t xa[kPairBatch], xb[kPairBatch];
-    const bool more = u + stride < n_items;
-    if (more) item_prefetch(sa1, arenaA, sb1, arenaB, lane, xa, xb);
-    // stage D
-    uint32_t part = 0, spart = 0;
-    icount_item(sa0, arenaA, sb0, arenaB, lane, table, mini[wv], va, vb, sparse_paths, part, spart);
-    const uint32_t c = wave_reduce_add(part) + spart;
-    if (lane == 0 && c) atomicAdd(&out[u >> 4], (u64)c);
-    if (!more) break;
-    u += stride;
-    sa0 = sa1;
-    sb0 = sb1;
-    sa1 = sa2;
-    sb1 = sb2;
-    ra2 = ra3;
-    rb2 = rb3;
-    i2 = i3;
-#pragma unroll
-    for (int i = 0; i < kPairBatch; ++i) {
-      va[i] = xa[i];
-      vb[i] = xb[i];
-    }
-  }
-#undef FBK_ITEM
-}
+// (A PERSISTENT form — a grid as large as the device holds, every wave striding through the items as a four-stage
+// software pipeline: row indexes of item u + 3 W, descriptors of u + 2 W, payload batch 0 of u + W in flight while item u is
+// decoded — was built and measured this round: 64 us against 46 for the 2048 config-3 pairs (128 registers, static striding
+// over items of very different cost).  Removed; the one-wave blocks above give the hardware's dispatcher that job.)
 
 // Materialising A <op> B, one wave per (pair, slot): k_setop's outputs and right-sized array paths
 // (fbk_kernels.hip.h) behind the pair loader above.

@@ -64,8 +64,17 @@ def as_int(w):
     return int.from_bytes(w.tobytes(), "little")
 
 
+@pytest.mark.parametrize("gen", [1, 2])
 @pytest.mark.parametrize("it", range(ITERS))
-def test_fuzz_pairwise_and_folds(gpu_ctx, oracle, it):
+def test_fuzz_pairwise_and_folds(gpu_ctx, oracle, it, gen):
+    gpu_ctx.set_option("pair_kernels", gen)  # both generations of the pair kernels see every case
+    try:
+        _fuzz_pairwise_and_folds(gpu_ctx, oracle, it)
+    finally:
+        gpu_ctx.set_option("pair_kernels", 0)
+
+
+def _fuzz_pairwise_and_folds(gpu_ctx, oracle, it):
     O = oracle
     rng = D.rng_for(7000, it)
     X, WX = make_batch(gpu_ctx, rng, int(rng.integers(1, 50)))
