@@ -1079,8 +1079,7 @@ uint64_t batch_avg_payload(const fbk_batch* b) {
 // Which generation of the pair kernels a launch uses (option pair_kernels pins it: 1 / 2; 0 decides by the rows).
 // Rows of tiny containers on BOTH sides (arrays of a few values, a handful of runs) are served better by the round-2
 // kernels: there the launch of a block per item is what a kernel costs, not decode work or latency (BenchmarkCtOps
-// matrix, profiles/ctops_r03.txt: Ary16 x Ary16 10.5 us with k_icount, 18 us with k_icount2).  XOR: k_setop2<XOR> needs
-// 128 registers and spills; it wins on rows whose containers are KiB-sized on both sides only.
+// matrix, profiles/ctops_r03.txt: Ary16 x Ary16 10.5 us with k_icount, 18 us with k_icount2).
 bool use_pair_kernels2(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* b, int op /* -1: count */) {
   if (ctx->opt.pair_kernels) return ctx->opt.pair_kernels >= 2;
   const uint64_t lo = std::min(batch_avg_payload(a), batch_avg_payload(b)), both = (a->arena_bytes + b->arena_bytes);

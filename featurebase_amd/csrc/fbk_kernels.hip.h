@@ -732,7 +732,13 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
   frag_load(sa, arenaA, lane, lds[wv], wa);
   frag_load(sb, arenaB, lane, lds[wv], wb);
 #pragma unroll
-  for (int i = 0; i < kWordsPerLane; ++i) wa[i] = apply_op<OP>(wa[i], wb[i]);
+  for (int i = 0; i < kWordsPerLane; ++i) {
+    wa[i] = apply_op<OP>(wa[i], wb[i]);
+    // XOR only: without this barrier the optimiser re-derives a ^ b inside the population / run counts and the array peeling
+    // below instead of keeping the result, and the kernel needs 146 registers instead of 83 (3 waves per SIMD: Ary4096 x
+    // Ary1 73 us where Union takes 59)
+    if (OP == 2) asm volatile("" : "+v"(wa[i]));
+  }
   uint32_t c = wave_reduce_add(frag_popcount(wa));
   uint32_t r = 0;
   if (outRuns) r = wave_reduce_add(frag_count_runs(wa, lane));

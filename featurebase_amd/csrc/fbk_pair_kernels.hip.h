@@ -772,10 +772,8 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
   frag_load_pair(sa, arenaA, sb, arenaB, lane, lds[wv], mini[wv], wa, wb);
 #pragma unroll
   for (int i = 0; i < kWordsPerLane; ++i) {
-    // (XOR: the operand is made opaque first — the optimiser otherwise fuses this XOR with the one that takes the first
-    // operand's raw bits back out of the second's read-back and keeps both raw fragments alive: 141 registers)
-    if (OP == 2) asm volatile("" : "+v"(wb[i]));
     wa[i] = apply_op<OP>(wa[i], wb[i]);
+    if (OP == 2) asm volatile("" : "+v"(wa[i]));  // (as in k_setop: keeps the XOR's result instead of re-deriving it; 141 -> ~100 registers)
   }
   uint32_t c = wave_reduce_add(frag_popcount(wa));
   uint32_t r = 0;
