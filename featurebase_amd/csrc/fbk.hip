@@ -100,6 +100,7 @@ struct FbkOptions {
   int64_t pair_spw = 0;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4; 0 = by the rows' payload size): next slot's payload in flight while the current one is decoded
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
   int64_t pair_resolve = 1;              // k_icount2 reads the plan's resolved item records and stores one count per wave (0: row index -> descriptor per wave, atomics; A/B runs)
+  int64_t pair_stamp = 0;                // timing experiment on k_icount2: waves report shader cycles of a phase instead of counts (WRONG results)
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
@@ -546,6 +547,7 @@ const OptionDesc kOptions[] = {
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
     {"pair_spw", &FbkOptions::pair_spw, 0, 4},
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
+    {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
     {"pair_resolve", &FbkOptions::pair_resolve, 0, 1},
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
@@ -1235,7 +1237,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
-                     p->d_counts, uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8), resolved ? p->d_items : (const Slot*)nullptr,  \
+                     p->d_counts, uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16), resolved ? p->d_items : (const Slot*)nullptr,  \
                      resolved ? p->d_wave_counts : (uint32_t*)nullptr)
       const int spw = ctx->opt.pair_spw ? int(ctx->opt.pair_spw) : 1, wpb = pair_wpb_for(ctx, p->a, p->b);
       if (wpb == 4) {

@@ -628,6 +628,7 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
                                                      uint32_t* __restrict__ wave_out) {
   __shared__ u64 lds[WPB][kWords];
   __shared__ uint32_t mini[WPB][2 * kMiniDwords];
+  const u64 t0 = (sparse_paths >> 16) ? __builtin_readcyclecounter() : 0;
   constexpr int kWavesPerPair = kSlots / SPW;
   const int lane = threadIdx.x & 63;
   const int wv = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and the compiler knows it
@@ -658,9 +659,35 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
   u64* table = lds[wv];
   uint32_t part = 0, spart = 0;
   uint32_t va[kPairBatch], vb[kPairBatch];
+  // option pair_stamp (timing experiment, WRONG results): the wave reports shader cycles instead of its count —
+  // 1: launch -> descriptors in registers, 2: -> batch 0 of both operands landed, 3: -> decoded, 4: the whole wave
+  const uint32_t stamp = (sparse_paths >> 16) & 7u;
+  u64 t_mark = 0, t_prev = 0;
+  if (stamp) {
+    t_prev = t0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    t_mark = __builtin_readcyclecounter();
+    if (stamp == 1) spart = (uint32_t)(t_mark - t_prev);
+    if (stamp != 4) t_prev = t_mark;
+  }
   if (!(sparse_paths & 0x400u)) {  // (0x400: timing experiment, descriptors only)
     item_prefetch(sa[0], arenaA, sb[0], arenaB, lane, va, vb);
+    if (stamp) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      t_mark = __builtin_readcyclecounter();
+      if (stamp == 2) spart = (uint32_t)(t_mark - t_prev);
+      if (stamp != 4) t_prev = t_mark;
+    }
     icount_items<0, SPW>(sa, arenaA, sb, arenaB, lane, table, mini[wv], va, vb, sparse_paths, part, spart);
+    if (stamp >= 3) {
+      const uint32_t keep = wave_reduce_add(part);  // (the decode has to finish before the stamp)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      t_mark = __builtin_readcyclecounter();
+      spart = (uint32_t)(t_mark - t_prev) + (keep & 0u);
+      part = 0;
+    } else if (stamp) {
+      part = 0;
+    }
   } else {
     spart = slot_n(sa[0]) + slot_n(sb[SPW - 1]);
   }
