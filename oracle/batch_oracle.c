@@ -227,6 +227,22 @@ void orc_batch_intersection_count(const orc_rowset* A, const uint32_t* ra, const
   parallel_for(n_pairs, threads, icount_item, &j);
 }
 
+/* the same, `passes` times over, on ONE pool of threads (bench.py's CPU leg: thread start-up must not be what is timed);
+ * item i is pair i mod n_pairs, so every pass walks every shard once and consecutive items stream through distinct rows */
+typedef struct {
+  pair_job j;
+  uint64_t n_pairs;
+} repeat_job;
+static void icount_repeat_item(uint64_t i, void* a) {
+  repeat_job* r = (repeat_job*)a;
+  icount_item(i % r->n_pairs, &r->j);
+}
+void orc_batch_intersection_count_repeat(const orc_rowset* A, const uint32_t* ra, const orc_rowset* B, const uint32_t* rb, uint64_t n_pairs,
+                                         uint64_t* out, int32_t threads, uint64_t passes) {
+  repeat_job r = {{A, B, ra, rb, out, 0, NULL}, n_pairs};
+  parallel_for(n_pairs * passes, threads, icount_repeat_item, &r);
+}
+
 static void setop_item(uint64_t i, void* a) {
   pair_job* j = (pair_job*)a;
   const orc_bitmap* x = j->A->rows[j->ra[i]];

@@ -43,6 +43,7 @@ def _lib() -> C.CDLL:
             "orc_rowset_words": (None, [vp, vp, i32]),
             "orc_rowset_counts": (None, [vp, vp, u64, vp]),
             "orc_batch_intersection_count": (None, [vp, vp, vp, vp, u64, vp, i32]),
+            "orc_batch_intersection_count_repeat": (None, [vp, vp, vp, vp, u64, vp, i32, u64]),
             "orc_batch_setop": (vp, [i32, vp, vp, vp, vp, u64, vp, i32]),
             "orc_batch_union_n_icount": (None, [vp, vp, u64, u32, vp, vp, vp, vp, i32]),
             "orc_batch_union_n": (vp, [vp, vp, u64, u32, vp, i32]),
@@ -115,6 +116,14 @@ def intersection_count(A: RowSet, ra, B: RowSet, rb, nthreads: int = 0) -> np.nd
     ra, rb = _u32(ra), _u32(rb)
     out = np.zeros(ra.size, dtype=np.uint64)
     _lib().orc_batch_intersection_count(A.h, ra.ctypes.data, B.h, rb.ctypes.data, ra.size, out.ctypes.data, nthreads or threads())
+    return out
+
+
+def intersection_count_repeat(A: RowSet, ra, B: RowSet, rb, passes: int, nthreads: int = 0) -> np.ndarray:
+    """`passes` passes over the pairs on one pool of threads (for timing: thread start-up amortised)"""
+    ra, rb = _u32(ra), _u32(rb)
+    out = np.zeros(ra.size, dtype=np.uint64)
+    _lib().orc_batch_intersection_count_repeat(A.h, ra.ctypes.data, B.h, rb.ctypes.data, ra.size, out.ctypes.data, nthreads or threads(), passes)
     return out
 
 
