@@ -88,9 +88,6 @@ struct FbkOptions {
   int64_t last_kernel_ns = 0;            //    ... read its duration back here (fbk_get_option) after the call
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
-  int64_t bsi_minmax_blocks = 0;         // 1: one block per shard for Min / Max (round-1 kernel, A/B runs); 0: one wavefront per (shard, slot)
-  int64_t bsi_sum_blocks = 0;            // 1: one 256-thread block per (shard, slot) for Sum (round-1 kernel, A/B runs); 0: one wavefront
-  int64_t bsi_range_blocks = 0;          // 1: one 256-thread block per (shard, slot) for Range (round-1 kernel, A/B runs); 0: one wavefront
   int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)
   int64_t bsi_half_waves = 1;            // dense BSI batches: the one-pass Range + Sum runs half a container per wavefront; 0: one wavefront per container (A/B runs)
   int64_t bsi_between_parts = 4;         // one-pass Sum(Between) on dense batches: parts of a container per wavefront (4: a quarter; 2: half, the round-2 form)
@@ -536,9 +533,6 @@ const OptionDesc kOptions[] = {
     {"time_kernels", &FbkOptions::time_kernels, 0, 1},
     {"last_kernel_ns", &FbkOptions::last_kernel_ns, 0, INT64_MAX},
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
-    {"bsi_minmax_blocks", &FbkOptions::bsi_minmax_blocks, 0, 1},
-    {"bsi_sum_blocks", &FbkOptions::bsi_sum_blocks, 0, 1},
-    {"bsi_range_blocks", &FbkOptions::bsi_range_blocks, 0, 1},
     {"bsi_range_sum_two_pass", &FbkOptions::bsi_range_sum_two_pass, 0, 1},
     {"bsi_half_waves", &FbkOptions::bsi_half_waves, 0, 1},
     {"bsi_between_parts", &FbkOptions::bsi_between_parts, 2, 4},

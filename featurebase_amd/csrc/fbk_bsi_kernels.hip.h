@@ -120,98 +120,12 @@ __device__ __forceinline__ Slot bsi_desc(const Slot* __restrict__ slots, uint64_
 
 // ---- BSI Sum ---------------------------------------------------------------------------------
 // positive = filter ∩ exists \ sign, negative = filter ∩ exists ∩ sign stay in registers while
-// the bit planes stream past once, U planes in flight:
+// the bit planes stream past once:
 //   psum += |positive ∩ plane_i| << i ; nsum += |negative ∩ plane_i| << i   (uint64 wrap-around,
 // roaring/filter.go:1157-1160).  Rows of the BSI fragment of shard s are base[s] + {0: exists,
 // 1: sign, 2+i: bit i} (fragment.go:62-65).  out3[shard] = {psum, nsum, count}.
-__global__ void __launch_bounds__(256) k_bsi_sum(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
-                                                const uint32_t* __restrict__ base, uint32_t n_shards,
-                                                uint32_t bit_depth, const Slot* __restrict__ fslots,
-                                                const uint8_t* __restrict__ farena, const uint32_t* __restrict__ frows,
-                                                u64* __restrict__ out3) {
-  __shared__ u64 scratch[kWords];
-  __shared__ u64 part[4];
-  const int t = threadIdx.x;
-  const uint64_t shard = blockIdx.x >> 4;
-  const uint32_t slot = blockIdx.x & 15;
-  if (shard >= n_shards) return;
-  const uint64_t r0 = base[shard];
-  const Slot se = slots[(r0 + 0) * kSlots + slot];
-  if (slot_n(se) == 0) return;  // no existence bits: positive stays nil (filter.go:1135)
-  u64 pos[kBW], neg[kBW], w[kBW];
-  if (fslots) {
-    const Slot sf = fslots[(uint64_t)frows[shard] * kSlots + slot];
-    if (slot_n(sf) == 0) return;  // ConsiderKey rejects: no filter container here (filter.go:1112)
-    bfrag_load(se, arena, t, scratch, pos);
-    bfrag_load(sf, farena, t, scratch, w);
-#pragma unroll
-    for (int q = 0; q < kBW; ++q) pos[q] &= w[q];
-  } else {
-    bfrag_load(se, arena, t, scratch, pos);
-  }
-  const u64 cnt = bfrag_popcount(pos);
-  const Slot ss = slots[(r0 + 1) * kSlots + slot];
-  bfrag_load(ss, arena, t, scratch, w);  // nil sign row => zeros
-#pragma unroll
-  for (int q = 0; q < kBW; ++q) {
-    neg[q] = pos[q] & w[q];
-    pos[q] &= ~w[q];
-  }
-  constexpr int U = 8;
-  u64 psum = 0, nsum = 0;
-  for (uint32_t i0 = 0; i0 < bit_depth; i0 += U) {
-    Slot sd[U];
-    bool fast = true;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      sd[u].off = 0;
-      sd[u].len = 0;
-      sd[u].tn = 0;
-      if (i0 + u < bit_depth) sd[u] = slots[(r0 + 2 + i0 + u) * kSlots + slot];
-      fast = fast && bfrag_is_fast(sd[u]);
-    }
-    if (fast) {  // block-uniform
-      u64 T[U][kBW];
-#pragma unroll
-      for (int u = 0; u < U; ++u) bfrag_load_fast(sd[u], arena, t, T[u]);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        uint32_t pc = 0, nc = 0;
-#pragma unroll
-        for (int q = 0; q < kBW; ++q) {
-          pc += __popcll(pos[q] & T[u][q]);
-          nc += __popcll(neg[q] & T[u][q]);
-        }
-        const uint32_t sh = (i0 + u) & 63u;  // planes past bit_depth are zero, any shift will do
-        psum += (u64)pc << sh;
-        nsum += (u64)nc << sh;
-      }
-    } else {  // some plane of this group is an array / run container: one plane at a time
-#pragma unroll 1
-      for (uint32_t i = i0; i < min(i0 + U, bit_depth); ++i) {
-        bfrag_load(slots[(r0 + 2 + i) * kSlots + slot], arena, t, scratch, w);
-        uint32_t pc = 0, nc = 0;
-#pragma unroll
-        for (int q = 0; q < kBW; ++q) {
-          pc += __popcll(pos[q] & w[q]);
-          nc += __popcll(neg[q] & w[q]);
-        }
-        psum += (u64)pc << i;
-        nsum += (u64)nc << i;
-      }
-    }
-  }
-  psum = block_reduce_add_u64(psum, part);
-  nsum = block_reduce_add_u64(nsum, part);
-  const u64 count = block_reduce_add_u64(cnt, part);
-  if (t == 0) {
-    if (psum) atomicAdd(&out3[shard * 3 + 0], psum);
-    if (nsum) atomicAdd(&out3[shard * 3 + 1], nsum);
-    if (count) atomicAdd(&out3[shard * 3 + 2], count);
-  }
-}
-
-// The same sum with one WAVEFRONT per (shard, slot) (round 2; k_bsi_sum above stays behind option bsi_sum_blocks=1):
+// One WAVEFRONT per (shard, slot) (the round-1 form, a 256-thread block per (shard, slot) that loaded 8 planes and waited
+// for all of them, was removed in round 3: 141 us against 130):
 // the planes of a slot do not depend on each other, so a wavefront keeps positive / negative (16 words per lane each)
 // in registers and streams the planes with kAhead of them in flight — 1536 independent streams for 100 M columns,
 // no LDS staging for bitmap planes, no barrier, and ONE wave reduction at the very end: a lane adds its own
@@ -384,89 +298,10 @@ __device__ __forceinline__ void bsi_apply2(uint32_t op, u64 (&X)[NW], u64 (&M)[N
   }
 }
 
-__global__ void __launch_bounds__(256) k_bsi_range(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
-                                                  const uint32_t* __restrict__ base, uint32_t n_shards,
-                                                  const uint32_t* __restrict__ prog, uint32_t prog_len,
-                                                  uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
-                                                  uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts) {
-  __shared__ u64 scratch[kWords];
-  __shared__ u64 part[4];
-  __shared__ uint8_t tops[512];
-  const int t = threadIdx.x;
-  const uint64_t cell = blockIdx.x;
-  const uint64_t shard = cell >> 4;
-  const uint32_t slot = cell & 15;
-  if (shard >= n_shards) return;
-  const uint64_t r0 = base[shard];
-  u64 X[kBW], M[kBW], S[kBW];
-  bfrag_zero(X);
-  bfrag_zero(M);
-  bfrag_zero(S);
-  constexpr int U = 4;
-  for (uint32_t pc0 = 0; pc0 < prog_len; pc0 += U) {
-    Slot sd[U];
-    uint32_t ops[U];
-    bool fast = true;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      ops[u] = kNop;
-      sd[u].off = 0;
-      sd[u].len = 0;
-      sd[u].tn = 0;
-      if (pc0 + u < prog_len) {
-        const uint32_t ins = prog[pc0 + u];
-        ops[u] = ins >> 24;
-        if (ops[u] <= kMorXAn) sd[u] = slots[(r0 + (ins & 0xFFFFFFu)) * kSlots + slot];
-      }
-      fast = fast && bfrag_is_fast(sd[u]);
-    }
-    if (fast) {  // block-uniform: the U loads go out together, the updates follow in program order
-      u64 T[U][kBW];
-#pragma unroll
-      for (int u = 0; u < U; ++u) bfrag_load_fast(sd[u], arena, t, T[u]);
-#pragma unroll
-      for (int u = 0; u < U; ++u) bsi_apply<kBW>(ops[u], X, M, S, T[u]);
-    } else {  // an array / run container among them: one instruction at a time
-#pragma unroll 1
-      for (uint32_t pc = pc0; pc < min(pc0 + U, prog_len); ++pc) {
-        const uint32_t ins = prog[pc];
-        const uint32_t op = ins >> 24;
-        u64 T1[kBW];
-        bfrag_zero(T1);
-        if (op <= kMorXAn) bfrag_load(slots[(r0 + (ins & 0xFFFFFFu)) * kSlots + slot], arena, t, scratch, T1);
-        bsi_apply<kBW>(op, X, M, S, T1);
-      }
-    }
-  }
-  const uint32_t c = (uint32_t)block_reduce_add_u64(bfrag_popcount(X), part);
-  Slot so;
-  so.off = cell * 8192ull;
-  so.len = kWords;
-  so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
-  if (c) bfrag_store_bitmap(arenaO + so.off, t, X);
-  uint32_t rr = 0;
-  if (outRuns) {
-    // bitmapCountRuns (roaring.go:3372-3380): a run starts at every 1-bit whose predecessor
-    // is 0; the predecessor of a chunk's first bit is the top bit of the previous chunk
-    tops[t] = (uint8_t)(X[1] >> 63);
-    tops[256 + t] = (uint8_t)(X[3] >> 63);
-    __syncthreads();
-    const u64 l0 = t ? tops[t - 1] : 0, l1 = tops[255 + t];
-    uint32_t r = __popcll(X[0] & ~((X[0] << 1) | l0)) + __popcll(X[1] & ~((X[1] << 1) | (X[0] >> 63))) +
-                 __popcll(X[2] & ~((X[2] << 1) | l1)) + __popcll(X[3] & ~((X[3] << 1) | (X[2] >> 63)));
-    rr = (uint32_t)block_reduce_add_u64(r, part);
-  }
-  if (t == 0) {
-    outSlots[cell] = so;
-    if (outRuns) outRuns[cell] = rr;
-    if (c && out_counts) atomicAdd(&out_counts[shard], (u64)c);
-  }
-}
-
-// The same interpreter with one WAVEFRONT per (shard, slot) (round 2; the block form above stays behind option
-// bsi_range_blocks=1): X / M / S are 16 words per lane, the planes of the next kAhead instructions are in flight while
-// the current one is applied (a load never depends on X / M / S; k_bsi_range issues U loads, waits for all of them,
-// applies, and only then reads the next U descriptors — the chip idles through every descriptor round trip).
+// The plane-program interpreter, one WAVEFRONT per (shard, slot): X / M / S are 16 words per lane, the planes of the next
+// kAhead instructions are in flight while the current one is applied (a load never depends on X / M / S).  (The round-1
+// form — a 256-thread block per (shard, slot) that issued U loads, waited for all of them, applied, and only then read
+// the next U descriptors — was removed in round 3: 142 us against 131.)
 __global__ void __launch_bounds__(64) k_bsi_range_slot(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
                                                       const uint32_t* __restrict__ base, uint32_t n_shards,
                                                       const uint32_t* __restrict__ prog, uint32_t prog_len, uint32_t n_rows_frag,
@@ -1002,119 +837,15 @@ __global__ void __launch_bounds__(64) k_bsi_between_sum_part(const uint8_t* __re
 }
 
 // ---- BSI Min / Max ------------------------------------------------------------------------------
-// fragment.min / fragment.max / minUnsigned / maxUnsigned (fragment.go:754-853).  The scan
-// over the bit planes is sequential and every step needs the cardinality of a whole ROW
-// (16 containers), so one 1024-thread block owns one shard: wavefront w holds slot w of the
-// candidate set in registers, the per-plane row count is a 16-entry LDS reduction and one
-// barrier per plane.  out2[shard] = {value (int64 bits), count}.
-//   mode 0 = min, 1 = max.
-__global__ void __launch_bounds__(1024) k_bsi_minmax(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
-                                                    const uint32_t* __restrict__ base, uint32_t n_shards,
-                                                    uint32_t bit_depth, uint32_t mode, const Slot* __restrict__ fslots,
-                                                    const uint8_t* __restrict__ farena, const uint32_t* __restrict__ frows,
-                                                    u64* __restrict__ out2) {
-  __shared__ u64 lds[kSlots][kWords];  // per-wave decode scratch (128 KiB)
-  __shared__ uint32_t s_cnt[2][kSlots];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;  // = slot
-  const uint64_t shard = blockIdx.x;
-  if (shard >= n_shards) return;  // block-uniform
-  const uint64_t r0 = base[shard];
-  auto row_total = [&](uint32_t c, int buf) -> uint32_t {  // block-wide row cardinality
-    if (lane == 0) s_cnt[buf][wv] = c;
-    __syncthreads();
-    uint32_t tot = 0;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) tot += s_cnt[buf][i];
-    return tot;
-  };
-  u64 F[kWordsPerLane], T[kWordsPerLane];
-  // consider = exists ∩ filter
-  {
-    const Slot se = slots[(r0 + 0) * kSlots + wv];
-    if (slot_n(se) == 0) frag_zero(F);
-    else frag_load(se, arena, lane, lds[wv], F);
-    if (fslots) {
-      const Slot sf = fslots[(uint64_t)frows[shard] * kSlots + wv];
-      if (slot_n(sf) == 0) frag_zero(T);
-      else frag_load(sf, farena, lane, lds[wv], T);
-#pragma unroll
-      for (int q = 0; q < kWordsPerLane; ++q) F[q] &= T[q];
-    }
-  }
-  uint32_t cur = row_total(wave_reduce_add(frag_popcount(F)), 0);
-  if (cur == 0) {  // no columns to consider: (0, 0)   (fragment.go:764-766, 815-817)
-    if (threadIdx.x == 0) {
-      out2[shard * 2] = 0;
-      out2[shard * 2 + 1] = 0;
-    }
-    return;
-  }
-  // choose the unsigned scan and the sign of the result
-  bool scan_max, negate;
-  {
-    const Slot ss = slots[(r0 + 1) * kSlots + wv];
-    if (slot_n(ss) == 0) frag_zero(T);
-    else frag_load(ss, arena, lane, lds[wv], T);
-    u64 G[kWordsPerLane];
-    if (mode == 0) {  // min: negatives present => -(maxUnsigned over them)
-#pragma unroll
-      for (int q = 0; q < kWordsPerLane; ++q) G[q] = F[q] & T[q];
-    } else {  // max: positives present => maxUnsigned over them, else -(minUnsigned(consider))
-#pragma unroll
-      for (int q = 0; q < kWordsPerLane; ++q) G[q] = F[q] & ~T[q];
-    }
-    const uint32_t g = row_total(wave_reduce_add(frag_popcount(G)), 1);
-    if (g != 0) {
-      scan_max = true;
-      negate = (mode == 0);
-      cur = g;
-#pragma unroll
-      for (int q = 0; q < kWordsPerLane; ++q) F[q] = G[q];
-    } else {
-      scan_max = false;
-      negate = (mode == 1);
-    }
-  }
-  u64 val = 0;
-  int buf = 0;
-  for (int i = (int)bit_depth - 1; i >= 0; --i) {
-    const Slot sp = slots[(r0 + 2 + (uint64_t)i) * kSlots + wv];
-    if (slot_n(sp) == 0) frag_zero(T);
-    else frag_load(sp, arena, lane, lds[wv], T);
-    // maxUnsigned: row = plane ∩ filter (fragment.go:838); minUnsigned: row = filter \ plane (:788)
-    if (scan_max) {
-#pragma unroll
-      for (int q = 0; q < kWordsPerLane; ++q) T[q] = F[q] & T[q];
-    } else {
-#pragma unroll
-      for (int q = 0; q < kWordsPerLane; ++q) T[q] = F[q] & ~T[q];
-    }
-    const uint32_t c = row_total(wave_reduce_add(frag_popcount(T)), buf);
-    buf ^= 1;
-    if (c > 0) {
-#pragma unroll
-      for (int q = 0; q < kWordsPerLane; ++q) F[q] = T[q];
-      cur = c;
-      if (scan_max) val += 1ull << i;
-    } else if (!scan_max) {
-      val += 1ull << i;
-    }
-  }
-  if (threadIdx.x == 0) {
-    out2[shard * 2] = negate ? (0ull - val) : val;
-    out2[shard * 2 + 1] = cur;  // |final candidate set| (count of the last non-empty row / filter)
-  }
-}
-
-// The same scan per (shard, SLOT): min / max over a shard = min / max over its 16 slots' own minima /
-// maxima (the count of the winning value adds up over the slots that reach it), so the 16 slots
-// need not be scanned in lock step.  k_bsi_minmax above runs 96 blocks for 100 M columns — 96 of
-// 256 CUs, each limited to its own ~33 GB/s share of HBM: 256 us for 830 MB (3.2 TB/s,
-// profiles/r02_misc_kernel_stats.csv).  Here one wavefront owns one (shard, slot): 1536 independent
-// scans fill the chip, the next plane's loads are in flight while the current plane is counted
-// (they do not depend on the decision), and there is no barrier at all.  out2[(shard * 16 + slot)]
-// = {magnitude, count | scan flag}; the host folds the 16 pairs of a shard (fbk_query_api.inc bsi_minmax).
+// fragment.min / fragment.max / minUnsigned / maxUnsigned (fragment.go:754-853): a scan over the bit planes, MSB -> LSB,
+// that keeps the candidate set and at every plane needs the cardinality of candidates ∩ plane (max) or candidates \ plane
+// (min).  Done per (shard, SLOT): min / max over a shard = min / max over its 16 slots' own minima / maxima (the count of
+// the winning value adds up over the slots that reach it), so the 16 slots need not be scanned in lock step: one wavefront
+// owns one (shard, slot) — 1536 independent scans for 100 M columns fill the chip, the next plane's loads are in flight
+// while the current plane is counted (they do not depend on the decision), and there is no barrier at all.  (The round-1
+// form, one 1024-thread block per shard with a barrier per plane, ran 96 blocks on 256 CUs: 256 us against 121; removed in
+// round 3.)  mode 0 = min, 1 = max.  out2[(shard * 16 + slot)] = {magnitude, count | scan flag}; the host folds the 16
+// pairs of a shard (fbk_query_api.inc bsi_minmax).
 __global__ void __launch_bounds__(64) k_bsi_minmax_slot(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
                                                        const uint32_t* __restrict__ base, uint32_t n_shards, uint32_t bit_depth,
                                                        uint32_t mode, const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,

@@ -47,29 +47,10 @@ def line(what, nbytes, fn):
     print(f"{what:58s} {med:8.1f} us (min {lo:6.1f})  {nbytes / med / 1e6:6.2f} TB/s = {nbytes / med / 1e6 / 8:.2f}")
 
 
-ref = None
-for blocks in (1, 0):
-    ctx.set_option("bsi_sum_blocks", blocks)
-    got = ctx.bsi_sum(batch, base, depth, filt, fidx)
-    got_nf = ctx.bsi_sum(batch, base, depth)
-    if ref is None:
-        ref = (got, got_nf)
-    else:
-        assert all((a == b).all() for a, b in zip(ref[0], got)) and all((a == b).all() for a, b in zip(ref[1], got_nf)), "Sum: the two kernels disagree"
-    name = "k_bsi_sum (block per (shard, slot))" if blocks else "k_bsi_sum_slot (wavefront per (shard, slot))"
-    line(f"Sum(filter)  {name}", plane_bytes * (depth + 3), lambda: ctx.bsi_sum(batch, base, depth, filt, fidx))
-    line(f"Sum()        {name}", plane_bytes * (depth + 2), lambda: ctx.bsi_sum(batch, base, depth))
-ctx.set_option("bsi_sum_blocks", 0)
+line("Sum(filter)  k_bsi_sum_slot (wavefront per (shard, slot))", plane_bytes * (depth + 3), lambda: ctx.bsi_sum(batch, base, depth, filt, fidx))
+line("Sum()        k_bsi_sum_slot (wavefront per (shard, slot))", plane_bytes * (depth + 2), lambda: ctx.bsi_sum(batch, base, depth))
 for op, pred, what in ((L.BSI_GT, 1 << 62, "Range(> 2^62)"), (L.BSI_LT, -5, "Range(< -5)"), (L.BSI_EQ, 12345, "Range(== 12345)")):
-    outs = []
-    for blocks in (1, 0):
-        ctx.set_option("bsi_range_blocks", blocks)
-        o, c = ctx.bsi_range(batch, base, op, depth, pred, L.SETOP_OPTIMIZE)
-        outs.append((o.to_roaring(), c.tolist()))
-        o.free()
-        line(f"{what:16s} {'k_bsi_range (block)' if blocks else 'k_bsi_range_slot (wavefront)'}", plane_bytes * (depth + 3), lambda: ctx.bsi_range(batch, base, op, depth, pred)[0].free())
-    assert outs[0] == outs[1], "Range: the two kernels disagree"
-ctx.set_option("bsi_range_blocks", 0)
+    line(f"{what:16s} k_bsi_range_slot (wavefront)", plane_bytes * (depth + 3), lambda: ctx.bsi_range(batch, base, op, depth, pred)[0].free())
 for two_pass in (1, 0):
     ctx.set_option("bsi_range_sum_two_pass", two_pass)
     r = ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, 1 << 62)
@@ -94,8 +75,6 @@ for (lo, hi), ref_x, what in (((-(1 << 61), 1 << 62), ref_b, "both signs"), ((1 
     assert (ref_x[0] == r[0]).all() and (ref_x[1] == r[1]).all(), "Between+Sum: one pass and two passes disagree"
     line(f"Sum(Between) one pass, {what:22s} k_bsi_between_sum_half", plane_bytes * (depth + 2), lambda: ctx.bsi_range_between_sum(batch, base, depth, lo, hi))
 line("Between (row output)                     k_bsi_range_slot", plane_bytes * (depth + 2), lambda: ctx.bsi_range_between(batch, base, depth, 1 << 60, 1 << 62)[0].free())
-for blocks in (1, 0):
-    ctx.set_option("bsi_minmax_blocks", blocks)
-    line(f"Min          {'k_bsi_minmax (block per shard)' if blocks else 'k_bsi_minmax_slot (wavefront per (shard, slot))'}", plane_bytes * (depth + 2), lambda: ctx.bsi_min(batch, base, depth))
-    line(f"Max(filter)  {'k_bsi_minmax (block per shard)' if blocks else 'k_bsi_minmax_slot (wavefront per (shard, slot))'}", plane_bytes * (depth + 3), lambda: ctx.bsi_max(batch, base, depth, filt, fidx))
-ctx.set_option("bsi_minmax_blocks", 0)
+line("Min          k_bsi_minmax_slot (wavefront per (shard, slot))", plane_bytes * (depth + 2), lambda: ctx.bsi_min(batch, base, depth))
+line("Max(filter)  k_bsi_minmax_slot (wavefront per (shard, slot))", plane_bytes * (depth + 3), lambda: ctx.bsi_max(batch, base, depth, filt, fidx))
+

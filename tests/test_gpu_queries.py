@@ -248,14 +248,13 @@ def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B, bsi_kernel_form):
     batch.free()
 
 
-@pytest.fixture(params=[0, 1], ids=["wavefront-kernels", "block-kernels"])
+@pytest.fixture(params=[4, 2], ids=["quarter-container-waves", "half-container-waves"])
 def bsi_kernel_form(request, gpu_ctx):
-    """Sum / Range / Between run as one wavefront per (shard, slot) (default) or as round 1's block per (shard, slot)."""
-    for name in ("bsi_sum_blocks", "bsi_range_blocks"):
-        gpu_ctx.set_option(name, request.param)
+    """The one-pass Sum(Between) on dense batches runs a quarter (default) or half a container per wavefront (the round-2
+    form); the other BSI kernels have one form since round 3 (the round-1 block kernels are gone)."""
+    gpu_ctx.set_option("bsi_between_parts", request.param)
     yield request.param
-    for name in ("bsi_sum_blocks", "bsi_range_blocks"):
-        gpu_ctx.set_option(name, 0)
+    gpu_ctx.set_option("bsi_between_parts", 4)
 
 
 def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle, bsi_kernel_form):
@@ -436,17 +435,15 @@ def test_bsi_minmax_random_multi_shard_vs_oracle(gpu_ctx, B):
         batch, base = upload_bsi(gpu_ctx, frags)
         F = gpu_ctx.upload([fbk_row_of_bitmap(f) for f in filts])
         try:
-            for blocks in (0, 1):  # one wavefront per (shard, slot) + host fold (default) / one block per shard (round-1 kernel)
-                gpu_ctx.set_option("bsi_minmax_blocks", blocks)
-                for fn, ofn in ((gpu_ctx.bsi_min, B.bsi_min), (gpu_ctx.bsi_max, B.bsi_max)):
-                    v, c = fn(batch, base, depth)
-                    for s, fr in enumerate(frags):
-                        assert (int(v[s]), int(c[s])) == ofn(fr, None, depth), (depth, s, blocks)
-                    v, c = fn(batch, base, depth, F, np.arange(len(frags)))
-                    for s, fr in enumerate(frags):
-                        assert (int(v[s]), int(c[s])) == ofn(fr, filts[s], depth), (depth, s, "filtered", blocks)
+            for fn, ofn in ((gpu_ctx.bsi_min, B.bsi_min), (gpu_ctx.bsi_max, B.bsi_max)):  # one wavefront per (shard, slot) + host fold
+                v, c = fn(batch, base, depth)
+                for s, fr in enumerate(frags):
+                    assert (int(v[s]), int(c[s])) == ofn(fr, None, depth), (depth, s)
+                v, c = fn(batch, base, depth, F, np.arange(len(frags)))
+                for s, fr in enumerate(frags):
+                    assert (int(v[s]), int(c[s])) == ofn(fr, filts[s], depth), (depth, s, "filtered")
         finally:
-            gpu_ctx.set_option("bsi_minmax_blocks", 0)
+            pass
         batch.free()
         F.free()
 
