@@ -407,6 +407,61 @@ __device__ __forceinline__ void range_sum_plane(uint32_t act, u64 (&X)[kWordsPer
   }
 }
 
+// ---- planes in flight, counted by hand -------------------------------------------------------------------------
+// The one-pass kernels keep kAhead planes in flight per wavefront and refill a register set as soon as its plane has been
+// applied.  Written with ordinary loads, the compiler's s_waitcnt insertion has to merge "loaded in the prologue" with
+// "refilled in the previous iteration" at the loop header (and, with the refill behind a condition, at every step): the
+// ISA then waits for vmcnt(0) before a step — the plane requested a moment ago must land before the oldest one may be
+// used, ONE plane in flight whatever kAhead says (round 3: found in the listing of every BSI streaming kernel).  Here the
+// loads are `asm volatile` (invisible to that pass) and the kernel states the count itself: a plane's NW / 2 loads have
+// landed when at most `PENDING` younger loads are outstanding.  Nothing else in the loop may touch vmcnt (plan values come
+// through scalar loads and the masks of plane_codes); scripts/isa_stats.py --vmem lists a kernel's vector-memory
+// instructions to check that.
+typedef uint32_t bsi_u4 __attribute__((ext_vector_type(4)));
+
+template <int NW>
+__device__ __forceinline__ void plane_request(const uint8_t* __restrict__ p, int lane, bsi_u4 (&w)[NW / 2]) {
+#pragma unroll
+  for (int j = 0; j < NW / 2; ++j) {
+    const uint8_t* a = p + (uint32_t)(j * kWave + lane) * 16u;
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(w[j]) : "v"(a));
+  }
+}
+template <int NW, int PENDING>
+__device__ __forceinline__ void plane_landed(bsi_u4 (&w)[NW / 2]) {
+  static_assert(NW == 4 || NW == 8, "a plane is two or four 16-byte loads per lane");
+  if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(PENDING));
+  else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(PENDING));
+}
+template <int NW>
+__device__ __forceinline__ void plane_words(const bsi_u4 (&w)[NW / 2], u64 (&t)[NW]) {
+#pragma unroll
+  for (int j = 0; j < NW / 2; ++j) {
+    t[2 * j] = ((u64)w[j][1] << 32) | w[j][0];
+    t[2 * j + 1] = ((u64)w[j][3] << 32) | w[j][2];
+  }
+}
+
+// The per-plane codes of a plan (one byte per plane, values 0..7) as three 64-bit masks in SCALAR registers: bit i of
+// mask k = bit k of codes[i].  Read ONCE, by one vector load + three ballots, before any plane is requested.  Reading
+// `codes[i]` inside the plane loop compiles to a global_load_ubyte (the scalar unit has no byte loads) followed by
+// s_waitcnt vmcnt(0) — which also waits for EVERY plane in flight: the planes loaded ahead were serialised behind each
+// step (found in the ISA in round 3; the one-pass kernels ran 129 / 199 us with it).
+struct PlaneCodes {
+  u64 b0, b1, b2;
+};
+__device__ __forceinline__ PlaneCodes plane_codes(const uint8_t* __restrict__ codes, int lane) {
+  const uint32_t c = codes[lane];
+  PlaneCodes m;
+  m.b0 = __ballot((c & 1u) != 0);
+  m.b1 = __ballot((c & 2u) != 0);
+  m.b2 = __ballot((c & 4u) != 0);
+  return m;
+}
+__device__ __forceinline__ uint32_t plane_code(const PlaneCodes& m, uint32_t i) {  // i: wave-uniform
+  return (uint32_t)((m.b0 >> i) & 1ull) | ((uint32_t)((m.b1 >> i) & 1ull) << 1) | ((uint32_t)((m.b2 >> i) & 1ull) << 2);
+}
+
 struct RangeSumPlan {
   u64 vhi[64];
   uint8_t action[64];  // 0: sums only; 1: X &= T; 2: X &= ~T; 3: D = X & T & ~M; 4: D = X & ~T & ~M  (D: newly matched)
@@ -430,6 +485,7 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_slot(const Slot* __restric
   const uint64_t r0 = base[shard];
   const RangeSumPlan& plan = *planp;  // (uniform: scalar loads)
   const uint32_t depth = plan.depth;
+  const PlaneCodes codes = plane_codes(plan.action, lane);
   bsi_stage_descs(slots, r0, slot, depth + 2, lane, tab);
   if (slot_n(tab[0]) == 0) return;
   constexpr int kAhead = OTHER ? 2 : 3;
@@ -470,7 +526,7 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_slot(const Slot* __restric
       const uint32_t j = j0 + (uint32_t)u;
       if (j < depth) {  // (wave-uniform)
         const uint32_t i = depth - 1 - j;
-        const uint32_t act = plan.action[i];
+        const uint32_t act = plane_code(codes, i);
         uint32_t a = 0, o = 0, d = 0;
         range_sum_plane<OTHER>(act, X, M, O, T[u], a, o, d);
         sum_m += ((u64)a << i) + (u64)d * plan.vhi[i];
@@ -546,15 +602,17 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __rest
   if (shard >= n_shards) return;
   const RangeSumPlan& plan = *planp;
   const uint32_t depth = plan.depth;
+  const PlaneCodes codes = plane_codes(plan.action, lane);
   const uint8_t* const row0 = arena + ((uint64_t)base[shard] * kSlots + slot) * 8192ull + h * 4096u;
   constexpr uint64_t kRow = (uint64_t)kSlots * 8192ull;
   constexpr int kAhead = 4;
-  u64 X[kHalfWords], M[kHalfWords], O[OTHER ? kHalfWords : 1], T[kAhead][kHalfWords];
+  u64 X[kHalfWords], M[kHalfWords], O[OTHER ? kHalfWords : 1], R[kHalfWords];
+  bsi_u4 T[kAhead][kHalfWords / 2];  // planes in flight (see plane_request)
   half_load(row0, lane, X);
   if (fslots) {
-    half_load_any(fslots[(uint64_t)frows[shard] * kSlots + slot], farena, lane, h, lds, T[0]);
+    half_load_any(fslots[(uint64_t)frows[shard] * kSlots + slot], farena, lane, h, lds, R);
 #pragma unroll
-    for (int q = 0; q < kHalfWords; ++q) X[q] &= T[0][q];
+    for (int q = 0; q < kHalfWords; ++q) X[q] &= R[q];
   }
   {
     uint32_t any = 0;
@@ -562,12 +620,12 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __rest
     for (int q = 0; q < kHalfWords; ++q) any |= (uint32_t)(X[q] != 0);
     if (__ballot(any != 0) == 0) return;  // nothing to consider in this half
   }
-  half_load(row0 + kRow, lane, T[0]);
+  half_load(row0 + kRow, lane, R);
   {
     const u64 sp = plan.scan_positive ? ~0ull : 0ull;
 #pragma unroll
     for (int q = 0; q < kHalfWords; ++q) {
-      const u64 e = X[q], sg = T[0][q];
+      const u64 e = X[q], sg = R[q];
       X[q] = e & (sg ^ sp);
       if (OTHER) O[q] = e & ~(sg ^ sp);
       M[q] = 0;
@@ -577,33 +635,50 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __rest
   uint32_t cnt_m = 0;
 #pragma unroll
   for (int u = 0; u < kAhead; ++u)
-    if ((uint32_t)u < depth) half_load(row0 + kRow * (2u + depth - 1 - (uint32_t)u), lane, T[u]);
-  for (uint32_t j0 = 0; j0 < depth; j0 += kAhead) {
+    if ((uint32_t)u < depth) plane_request<kHalfWords>(row0 + kRow * (2u + depth - 1 - (uint32_t)u), lane, T[u]);
+  auto step = [&](uint32_t j, const bsi_u4 (&w)[kHalfWords / 2]) {
+    const uint32_t i = depth - 1 - j;
+    const uint32_t act = plane_code(codes, i);
+    const u64 inv = (act == 2u || act == 4u) ? ~0ull : 0ull;
+    const u64 keep_x = (act == 1u || act == 2u) ? 0ull : ~0ull;
+    const u64 match = act >= 3u ? ~0ull : 0ull;
+    u64 tw[kHalfWords];
+    plane_words<kHalfWords>(w, tw);
+    uint32_t a = 0, o = 0, d = 0;
+#pragma unroll
+    for (int q = 0; q < kHalfWords; ++q) {
+      const u64 t = tw[q];
+      a += __popcll(M[q] & t);
+      if (OTHER) o += __popcll(O[OTHER ? q : 0] & t);
+      const u64 tx = t ^ inv;
+      const u64 nw = X[q] & tx & ~M[q] & match;
+      d += __popcll(nw);
+      M[q] |= nw;
+      X[q] &= tx | keep_x;
+    }
+    sum_m += ((u64)a << i) + (u64)d * plan.vhi[i];
+    sum_o += (u64)o << i;
+    cnt_m += d;
+  };
+  // full groups: every step refills its register set, so exactly kAhead - 1 younger planes are in flight at each use
+  uint32_t j0 = 0;
+  for (; j0 + 2u * kAhead <= depth; j0 += kAhead) {
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      plane_landed<kHalfWords, (kAhead - 1) * (kHalfWords / 2)>(T[u]);
+      step(j0 + (uint32_t)u, T[u]);
+      plane_request<kHalfWords>(row0 + kRow * (2u + depth - 1 - (j0 + (uint32_t)u + kAhead)), lane, T[u]);
+    }
+  }
+  // the last planes: at most 2 kAhead - 1 steps, refills only while planes remain
+  for (; j0 < depth; j0 += kAhead) {
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) {
       const uint32_t j = j0 + (uint32_t)u;
-      if (j < depth) {
-        const uint32_t i = depth - 1 - j;
-        const uint32_t act = plan.action[i];
-        const u64 inv = (act == 2u || act == 4u) ? ~0ull : 0ull;
-        const u64 keep_x = (act == 1u || act == 2u) ? 0ull : ~0ull;
-        const u64 match = act >= 3u ? ~0ull : 0ull;
-        uint32_t a = 0, o = 0, d = 0;
-#pragma unroll
-        for (int q = 0; q < kHalfWords; ++q) {
-          const u64 t = T[u][q];
-          a += __popcll(M[q] & t);
-          if (OTHER) o += __popcll(O[OTHER ? q : 0] & t);
-          const u64 tx = t ^ inv;
-          const u64 nw = X[q] & tx & ~M[q] & match;
-          d += __popcll(nw);
-          M[q] |= nw;
-          X[q] &= tx | keep_x;
-        }
-        sum_m += ((u64)a << i) + (u64)d * plan.vhi[i];
-        sum_o += (u64)o << i;
-        cnt_m += d;
-        if (j + kAhead < depth) half_load(row0 + kRow * (2u + depth - 1 - (j + kAhead)), lane, T[u]);
+      if (j < depth) {  // (wave-uniform)
+        plane_landed<kHalfWords, 0>(T[u]);
+        step(j, T[u]);
+        if (j + kAhead < depth) plane_request<kHalfWords>(row0 + kRow * (2u + depth - 1 - (j + kAhead)), lane, T[u]);
       }
     }
   }
@@ -700,12 +775,14 @@ __device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int
                                                  u64* __restrict__ out4, uint64_t shard) {
   constexpr int kAhead = NW <= kHalfWords ? 4 : 2;
   const uint32_t depth = plan.depth;
-  u64 X0[NW], X1[NW], M0[NW], M1[NW], T[kAhead][NW];
+  const PlaneCodes codes0 = plane_codes(plan.action[0], lane), codes1 = plane_codes(plan.action[1], lane), codes_sp = plane_codes(plan.split, lane);
+  u64 X0[NW], X1[NW], M0[NW], M1[NW], R[NW];
+  bsi_u4 T[kAhead][NW / 2];
   load_row(0u, X0);  // exists
   if (has_filter) {
-    load_row(~0u, T[0]);
+    load_row(~0u, R);
 #pragma unroll
-    for (int q = 0; q < NW; ++q) X0[q] &= T[0][q];
+    for (int q = 0; q < NW; ++q) X0[q] &= R[q];
   }
   {
     uint32_t any = 0;
@@ -713,13 +790,13 @@ __device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int
     for (int q = 0; q < NW; ++q) any |= (uint32_t)(X0[q] != 0);
     if (__ballot(any != 0) == 0) return;  // nothing to consider here
   }
-  load_row(1u, T[0]);  // sign
+  load_row(1u, R);  // sign
   {
     const u64 p0 = plan.class_pos[0] ? ~0ull : 0ull, p1 = plan.class_pos[1] ? ~0ull : 0ull;
     const u64 ib = plan.init_b ? ~0ull : 0ull, w0 = plan.whole[0] ? ~0ull : 0ull, w1 = plan.whole[1] ? ~0ull : 0ull;
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
-      const u64 e = X0[q], sg = T[0][q];
+      const u64 e = X0[q], sg = R[q];
       const u64 c0 = e & (sg ^ p0), c1 = e & (sg ^ p1) & ib;
       X0[q] = c0 & ~w0;
       M0[q] = c0 & w0;
@@ -737,18 +814,35 @@ __device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int
 #pragma unroll
   for (int u = 0; u < kAhead; ++u)
     if ((uint32_t)u < depth) load_plane(depth - 1 - (uint32_t)u, T[u]);
-  for (uint32_t j0 = 0; j0 < depth; j0 += kAhead) {
+  auto step = [&](uint32_t j, const bsi_u4 (&w)[NW / 2]) {
+    const uint32_t i = depth - 1 - j;
+    u64 t[NW];
+    plane_words<NW>(w, t);
+    uint32_t low[2] = {0, 0}, d[2] = {0, 0};
+    between_sum_plane<NW>(plane_code(codes0, i), plane_code(codes1, i), (uint32_t)((codes_sp.b0 >> i) & 1ull), X0, X1, M0, M1, t, low, d);
+    sum[0] += ((u64)low[0] << i) + (u64)d[0] * plan.vhi[0][i];
+    sum[1] += ((u64)low[1] << i) + (u64)d[1] * plan.vhi[1][i];
+    cnt[0] += d[0];
+    cnt[1] += d[1];
+  };
+  // full groups: every step refills its register set, so exactly kAhead - 1 younger planes are in flight at each use
+  uint32_t j0 = 0;
+  for (; j0 + 2u * kAhead <= depth; j0 += kAhead) {
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      plane_landed<NW, (kAhead - 1) * (NW / 2)>(T[u]);
+      step(j0 + (uint32_t)u, T[u]);
+      load_plane(depth - 1 - (j0 + (uint32_t)u + kAhead), T[u]);
+    }
+  }
+  // the last planes: at most 2 kAhead - 1 steps, refills only while planes remain
+  for (; j0 < depth; j0 += kAhead) {
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) {
       const uint32_t j = j0 + (uint32_t)u;
       if (j < depth) {  // (wave-uniform)
-        const uint32_t i = depth - 1 - j;
-        uint32_t low[2] = {0, 0}, d[2] = {0, 0};
-        between_sum_plane<NW>(plan.action[0][i], plan.action[1][i], plan.split[i], X0, X1, M0, M1, T[u], low, d);
-        sum[0] += ((u64)low[0] << i) + (u64)d[0] * plan.vhi[0][i];
-        sum[1] += ((u64)low[1] << i) + (u64)d[1] * plan.vhi[1][i];
-        cnt[0] += d[0];
-        cnt[1] += d[1];
+        plane_landed<NW, 0>(T[u]);
+        step(j, T[u]);
         if (j + kAhead < depth) load_plane(depth - 1 - (j + kAhead), T[u]);
       }
     }
@@ -832,7 +926,7 @@ __global__ void __launch_bounds__(64) k_bsi_between_sum_part(const uint8_t* __re
     if (r == ~0u) part_load_any<NW>(sf, farena, lane, part, lds, w);
     else part_load<NW>(row0 + kRow * r, lane, w);
   };
-  auto load_plane = [&](uint32_t i, u64 (&w)[NW]) { part_load<NW>(row0 + kRow * (2u + i), lane, w); };
+  auto load_plane = [&](uint32_t i, bsi_u4 (&w)[NW / 2]) { plane_request<NW>(row0 + kRow * (2u + i), lane, w); };
   between_sum_body<NW>(*planp, lane, load_row, load_plane, fslots != nullptr, out4, shard);
 }
 
