@@ -416,7 +416,9 @@ __device__ __forceinline__ void range_sum_plane(uint32_t act, u64 (&X)[kWordsPer
 // loads are `asm volatile` (invisible to that pass) and the kernel states the count itself: a plane's NW / 2 loads have
 // landed when at most `PENDING` younger loads are outstanding.  Nothing else in the loop may touch vmcnt (plan values come
 // through scalar loads and the masks of plane_codes); scripts/isa_stats.py --vmem lists a kernel's vector-memory
-// instructions to check that.
+// instructions to check that.  A register set with a load in flight must not be COPIED either: the main loops below keep
+// each set in fixed registers (checked in the listing); where the compiler is free to merge code paths — the last planes —
+// everything is drained first (planes_drain) and the few planes never requested are read with ordinary loads.
 typedef uint32_t bsi_u4 __attribute__((ext_vector_type(4)));
 
 template <int NW>
@@ -432,6 +434,15 @@ __device__ __forceinline__ void plane_landed(bsi_u4 (&w)[NW / 2]) {
   static_assert(NW == 4 || NW == 8, "a plane is two or four 16-byte loads per lane");
   if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(PENDING));
   else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(PENDING));
+}
+// everything requested so far has landed; afterwards the register sets hold ordinary values (the compiler may copy them)
+template <int NW, int K>
+__device__ __forceinline__ void planes_drain(bsi_u4 (&T)[K][NW / 2]) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < K; ++u)
+#pragma unroll
+    for (int j = 0; j < NW / 2; ++j) asm volatile("" : "+v"(T[u][j]));
 }
 template <int NW>
 __device__ __forceinline__ void plane_words(const bsi_u4 (&w)[NW / 2], u64 (&t)[NW]) {
@@ -607,7 +618,7 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __rest
   constexpr uint64_t kRow = (uint64_t)kSlots * 8192ull;
   constexpr int kAhead = 4;
   u64 X[kHalfWords], M[kHalfWords], O[OTHER ? kHalfWords : 1], R[kHalfWords];
-  bsi_u4 T[kAhead][kHalfWords / 2];  // planes in flight (see plane_request)
+  bsi_u4 T[kAhead][kHalfWords / 2] = {};  // planes in flight (see plane_request)
   half_load(row0, lane, X);
   if (fslots) {
     half_load_any(fslots[(uint64_t)frows[shard] * kSlots + slot], farena, lane, h, lds, R);
@@ -636,14 +647,12 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __rest
 #pragma unroll
   for (int u = 0; u < kAhead; ++u)
     if ((uint32_t)u < depth) plane_request<kHalfWords>(row0 + kRow * (2u + depth - 1 - (uint32_t)u), lane, T[u]);
-  auto step = [&](uint32_t j, const bsi_u4 (&w)[kHalfWords / 2]) {
+  auto step_words = [&](uint32_t j, const u64 (&tw)[kHalfWords]) {
     const uint32_t i = depth - 1 - j;
     const uint32_t act = plane_code(codes, i);
     const u64 inv = (act == 2u || act == 4u) ? ~0ull : 0ull;
     const u64 keep_x = (act == 1u || act == 2u) ? 0ull : ~0ull;
     const u64 match = act >= 3u ? ~0ull : 0ull;
-    u64 tw[kHalfWords];
-    plane_words<kHalfWords>(w, tw);
     uint32_t a = 0, o = 0, d = 0;
 #pragma unroll
     for (int q = 0; q < kHalfWords; ++q) {
@@ -660,6 +669,11 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __rest
     sum_o += (u64)o << i;
     cnt_m += d;
   };
+  auto step = [&](uint32_t j, const bsi_u4 (&w)[kHalfWords / 2]) {
+    u64 tw[kHalfWords];
+    plane_words<kHalfWords>(w, tw);
+    step_words(j, tw);
+  };
   // full groups: every step refills its register set, so exactly kAhead - 1 younger planes are in flight at each use
   uint32_t j0 = 0;
   for (; j0 + 2u * kAhead <= depth; j0 += kAhead) {
@@ -670,17 +684,15 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __rest
       plane_request<kHalfWords>(row0 + kRow * (2u + depth - 1 - (j0 + (uint32_t)u + kAhead)), lane, T[u]);
     }
   }
-  // the last planes: at most 2 kAhead - 1 steps, refills only while planes remain
-  for (; j0 < depth; j0 += kAhead) {
+  // the last planes: what is in the register sets (planes j0 .. j0 + kAhead - 1 as far as they exist), then the at
+  // most kAhead - 1 planes that were never requested
+  planes_drain<kHalfWords, kAhead>(T);
 #pragma unroll
-    for (int u = 0; u < kAhead; ++u) {
-      const uint32_t j = j0 + (uint32_t)u;
-      if (j < depth) {  // (wave-uniform)
-        plane_landed<kHalfWords, 0>(T[u]);
-        step(j, T[u]);
-        if (j + kAhead < depth) plane_request<kHalfWords>(row0 + kRow * (2u + depth - 1 - (j + kAhead)), lane, T[u]);
-      }
-    }
+  for (int u = 0; u < kAhead; ++u)
+    if (j0 + (uint32_t)u < depth) step(j0 + (uint32_t)u, T[u]);
+  for (uint32_t j = j0 + kAhead; j < depth; ++j) {
+    half_load(row0 + kRow * (2u + depth - 1 - j), lane, R);
+    step_words(j, R);
   }
   uint32_t cnt_o = 0;
   if (OTHER) {
@@ -777,7 +789,7 @@ __device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int
   const uint32_t depth = plan.depth;
   const PlaneCodes codes0 = plane_codes(plan.action[0], lane), codes1 = plane_codes(plan.action[1], lane), codes_sp = plane_codes(plan.split, lane);
   u64 X0[NW], X1[NW], M0[NW], M1[NW], R[NW];
-  bsi_u4 T[kAhead][NW / 2];
+  bsi_u4 T[kAhead][NW / 2] = {};
   load_row(0u, X0);  // exists
   if (has_filter) {
     load_row(~0u, R);
@@ -814,16 +826,19 @@ __device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int
 #pragma unroll
   for (int u = 0; u < kAhead; ++u)
     if ((uint32_t)u < depth) load_plane(depth - 1 - (uint32_t)u, T[u]);
-  auto step = [&](uint32_t j, const bsi_u4 (&w)[NW / 2]) {
+  auto step_words = [&](uint32_t j, const u64 (&t)[NW]) {
     const uint32_t i = depth - 1 - j;
-    u64 t[NW];
-    plane_words<NW>(w, t);
     uint32_t low[2] = {0, 0}, d[2] = {0, 0};
     between_sum_plane<NW>(plane_code(codes0, i), plane_code(codes1, i), (uint32_t)((codes_sp.b0 >> i) & 1ull), X0, X1, M0, M1, t, low, d);
     sum[0] += ((u64)low[0] << i) + (u64)d[0] * plan.vhi[0][i];
     sum[1] += ((u64)low[1] << i) + (u64)d[1] * plan.vhi[1][i];
     cnt[0] += d[0];
     cnt[1] += d[1];
+  };
+  auto step = [&](uint32_t j, const bsi_u4 (&w)[NW / 2]) {
+    u64 t[NW];
+    plane_words<NW>(w, t);
+    step_words(j, t);
   };
   // full groups: every step refills its register set, so exactly kAhead - 1 younger planes are in flight at each use
   uint32_t j0 = 0;
@@ -835,17 +850,15 @@ __device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int
       load_plane(depth - 1 - (j0 + (uint32_t)u + kAhead), T[u]);
     }
   }
-  // the last planes: at most 2 kAhead - 1 steps, refills only while planes remain
-  for (; j0 < depth; j0 += kAhead) {
+  // the last planes: what is in the register sets (planes j0 .. j0 + kAhead - 1 as far as they exist), then the at
+  // most kAhead - 1 planes that were never requested
+  planes_drain<NW, kAhead>(T);
 #pragma unroll
-    for (int u = 0; u < kAhead; ++u) {
-      const uint32_t j = j0 + (uint32_t)u;
-      if (j < depth) {  // (wave-uniform)
-        plane_landed<NW, 0>(T[u]);
-        step(j, T[u]);
-        if (j + kAhead < depth) load_plane(depth - 1 - (j + kAhead), T[u]);
-      }
-    }
+  for (int u = 0; u < kAhead; ++u)
+    if (j0 + (uint32_t)u < depth) step(j0 + (uint32_t)u, T[u]);
+  for (uint32_t j = j0 + kAhead; j < depth; ++j) {
+    load_row(2u + (depth - 1 - j), R);
+    step_words(j, R);
   }
   {  // what is left in a lane equals its bound
     uint32_t r0 = 0, r1 = 0;
