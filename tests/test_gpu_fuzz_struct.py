@@ -332,7 +332,7 @@ def test_fuzz_bsi(gpu_ctx, oracle, it):
             assert all((got[k & 15].words() == c.words()).all() for k, c in e.items() if c.n)
         out.free()
     finally:
-        gpu_ctx.set_option("bsi_between_parts", 4)
+        gpu_ctx.set_option("bsi_between_parts", 2)
         gpu_ctx.set_option("bsi_half_waves", 1)
         batch.free()
         F.free()

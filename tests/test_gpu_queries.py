@@ -248,13 +248,12 @@ def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B, bsi_kernel_form):
     batch.free()
 
 
-@pytest.fixture(params=[4, 2], ids=["quarter-container-waves", "half-container-waves"])
+@pytest.fixture(params=[2, 4], ids=["half-container-waves", "quarter-container-waves"])
 def bsi_kernel_form(request, gpu_ctx):
-    """The one-pass Sum(Between) on dense batches runs a quarter (default) or half a container per wavefront (the round-2
-    form); the other BSI kernels have one form since round 3 (the round-1 block kernels are gone)."""
+    """The one-pass Sum(Between) on dense batches runs half (default) or a quarter of a container per wavefront; the other BSI kernels have one form since round 3 (the round-1 block kernels are gone)."""
     gpu_ctx.set_option("bsi_between_parts", request.param)
     yield request.param
-    gpu_ctx.set_option("bsi_between_parts", 4)
+    gpu_ctx.set_option("bsi_between_parts", 2)
 
 
 def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle, bsi_kernel_form):
