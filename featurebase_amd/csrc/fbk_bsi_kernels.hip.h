@@ -600,7 +600,7 @@ __device__ __forceinline__ void half_load_any(const Slot& s, const uint8_t* __re
   }
 }
 
-template <bool OTHER>
+template <bool OTHER, int AHEAD = 4>
 __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ base, uint32_t n_shards,
                                                           const RangeSumPlan* __restrict__ planp, const Slot* __restrict__ fslots,
                                                           const uint8_t* __restrict__ farena, const uint32_t* __restrict__ frows, u64* __restrict__ out4) {
@@ -616,7 +616,7 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __rest
   const PlaneCodes codes = plane_codes(plan.action, lane);
   const uint8_t* const row0 = arena + ((uint64_t)base[shard] * kSlots + slot) * 8192ull + h * 4096u;
   constexpr uint64_t kRow = (uint64_t)kSlots * 8192ull;
-  constexpr int kAhead = 4;
+  constexpr int kAhead = AHEAD;  // planes in flight per wavefront (option bsi_planes_ahead)
   u64 X[kHalfWords], M[kHalfWords], O[OTHER ? kHalfWords : 1], R[kHalfWords];
   bsi_u4 T[kAhead][kHalfWords / 2] = {};  // planes in flight (see plane_request)
   half_load(row0, lane, X);
@@ -782,10 +782,10 @@ __device__ __forceinline__ void between_sum_plane(uint32_t a0, uint32_t a1, uint
   between_lane_any<NW>(a1, X1, M1, T, low[1], d[1]);
 }
 
-template <int NW, typename LoadPlane, typename LoadRow>
+template <int NW, int AHEAD, typename LoadPlane, typename LoadRow>
 __device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int lane, LoadRow&& load_row, LoadPlane&& load_plane, bool has_filter,
                                                  u64* __restrict__ out4, uint64_t shard) {
-  constexpr int kAhead = NW <= kHalfWords ? 4 : 2;
+  constexpr int kAhead = AHEAD;  // planes in flight per wavefront (option bsi_planes_ahead)
   const uint32_t depth = plan.depth;
   const PlaneCodes codes0 = plane_codes(plan.action[0], lane), codes1 = plane_codes(plan.action[1], lane), codes_sp = plane_codes(plan.split, lane);
   u64 X0[NW], X1[NW], M0[NW], M1[NW], R[NW];
@@ -918,7 +918,7 @@ __device__ __forceinline__ void part_load_any(const Slot& s, const uint8_t* __re
   }
 }
 
-template <int NW>
+template <int NW, int AHEAD = 4>
 __global__ void __launch_bounds__(64) k_bsi_between_sum_part(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ base, uint32_t n_shards,
                                                             const BetweenSumPlan* __restrict__ planp, const Slot* __restrict__ fslots,
                                                             const uint8_t* __restrict__ farena, const uint32_t* __restrict__ frows, u64* __restrict__ out4) {
@@ -940,7 +940,7 @@ __global__ void __launch_bounds__(64) k_bsi_between_sum_part(const uint8_t* __re
     else part_load<NW>(row0 + kRow * r, lane, w);
   };
   auto load_plane = [&](uint32_t i, bsi_u4 (&w)[NW / 2]) { plane_request<NW>(row0 + kRow * (2u + i), lane, w); };
-  between_sum_body<NW>(*planp, lane, load_row, load_plane, fslots != nullptr, out4, shard);
+  between_sum_body<NW, AHEAD>(*planp, lane, load_row, load_plane, fslots != nullptr, out4, shard);
 }
 
 // ---- BSI Min / Max ------------------------------------------------------------------------------
