@@ -90,8 +90,7 @@ struct FbkOptions {
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
   int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)
   int64_t bsi_half_waves = 1;            // dense BSI batches: the one-pass Range + Sum runs half a container per wavefront; 0: one wavefront per container (A/B runs)
-  int64_t bsi_planes_ahead = 4;          // one-pass BSI kernels on dense batches: planes in flight per wavefront (2 .. 4)
-  int64_t bsi_between_parts = 2;         // one-pass Sum(Between) on dense batches: parts of a container per wavefront (2: half — the faster form once the planes in flight were counted by hand; 4: a quarter)
+  int64_t bsi_planes_ahead = 3;          // one-pass BSI kernels on dense batches: planes in flight per wavefront (3 or 4)
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
@@ -536,8 +535,7 @@ const OptionDesc kOptions[] = {
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
     {"bsi_range_sum_two_pass", &FbkOptions::bsi_range_sum_two_pass, 0, 1},
     {"bsi_half_waves", &FbkOptions::bsi_half_waves, 0, 1},
-    {"bsi_between_parts", &FbkOptions::bsi_between_parts, 2, 4},
-    {"bsi_planes_ahead", &FbkOptions::bsi_planes_ahead, 2, 4},
+    {"bsi_planes_ahead", &FbkOptions::bsi_planes_ahead, 3, 4},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},

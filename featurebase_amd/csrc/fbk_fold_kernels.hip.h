@@ -314,13 +314,18 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
       while (Q.i < cnt) {
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
+          // Every slot of a lap waits and reloads whether or not the sequence still has a chunk for it (an exhausted
+          // producer reads the arena's first 16 bytes, see load_chunk): the number of loads behind a slot then does not
+          // depend on the path, which is what the constant in the wait assumes — and what scripts/check_inflight.py, which
+          // follows the control flow and not the values, can verify.  (With the whole slot behind "if (Q.i < cnt)" it has to
+          // assume a slot running after an earlier one was skipped, one load short; at most NCH - 1 idle slots per wave.)
+          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(C[q]) : "n"(NCH - 1));
           if (Q.i < cnt) {
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(C[q]) : "n"(NCH - 1));
             const uint32_t d[4] = {C[q][0], C[q][1], C[q][2], C[q][3]};
             scatter_chunk<OP>(d, Q.tn >> 24, Q.len, Q.j, lane, acc32);
             advance(Q);
-            load_chunk(C[q]);
           }
+          load_chunk(C[q]);
         }
       }
       // loads still in flight target registers the compiler is about to reuse

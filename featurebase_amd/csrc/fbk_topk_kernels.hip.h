@@ -236,8 +236,9 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
     while (Q.i < cnt) {
 #pragma unroll
       for (int q = 0; q < NCH; ++q) {
+        // (every slot of a lap waits and reloads, only the counting is conditional: see k_fold_scatter)
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(C[q]) : "n"(NCH - 1));
         if (Q.i < cnt) {
-          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(C[q]) : "n"(NCH - 1));
           const uint32_t d[4] = {C[q][0], C[q][1], C[q][2], C[q][3]};
           c += count_chunk(d, Q.tn >> 24, Q.len, Q.j);
           const uint32_t row = Q.i;
@@ -250,8 +251,8 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
             if (lane == 0 && tot) atomicAdd(&out_shard[(uint64_t)shard * nA + base + row], (u64)tot);
             c = 0;
           }
-          load_chunk(C[q]);
         }
+        load_chunk(C[q]);
       }
     }
     // loads still in flight target registers the compiler is about to reuse

@@ -286,8 +286,7 @@ def test_fuzz_bsi(gpu_ctx, oracle, it):
         batch, base = gpu_ctx.upload(rows), np.array(base, dtype=np.uint32)
     F = gpu_ctx.upload([{k & 15: D.to_fbk(c) for k, c in f.items() if c.n} for f in filts])
     rf = np.arange(n_sh)
-    gpu_ctx.set_option("bsi_between_parts", int(rng.choice([2, 4])))
-    gpu_ctx.set_option("bsi_planes_ahead", int(rng.choice([2, 3, 4])))
+    gpu_ctx.set_option("bsi_planes_ahead", int(rng.choice([3, 4])))
     gpu_ctx.set_option("bsi_half_waves", int(rng.integers(0, 2)))
     try:
         for use_f in (False, True):
@@ -333,8 +332,7 @@ def test_fuzz_bsi(gpu_ctx, oracle, it):
             assert all((got[k & 15].words() == c.words()).all() for k, c in e.items() if c.n)
         out.free()
     finally:
-        gpu_ctx.set_option("bsi_between_parts", 2)
-        gpu_ctx.set_option("bsi_planes_ahead", 4)
+        gpu_ctx.set_option("bsi_planes_ahead", 3)
         gpu_ctx.set_option("bsi_half_waves", 1)
         batch.free()
         F.free()

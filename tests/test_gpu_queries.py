@@ -248,16 +248,14 @@ def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B, bsi_kernel_form):
     batch.free()
 
 
-@pytest.fixture(params=[(2, 4), (4, 4), (2, 2), (4, 3), (2, 3)], ids=["half-container-waves", "quarter-container-waves", "half-2-planes-ahead", "quarter-3-planes-ahead", "half-3-planes-ahead"])
+@pytest.fixture(params=[3, 4], ids=["3-planes-ahead", "4-planes-ahead"])
 def bsi_kernel_form(request, gpu_ctx):
-    """The one-pass Sum(Between) on dense batches runs half (default) or a quarter of a container per wavefront, the one-pass
-    kernels keep 2 .. 4 planes in flight (counted by hand: every depth is its own instantiation); the other BSI kernels
-    have one form since round 3 (the round-1 block kernels are gone)."""
-    gpu_ctx.set_option("bsi_between_parts", request.param[0])
-    gpu_ctx.set_option("bsi_planes_ahead", request.param[1])
+    """The one-pass kernels on dense batches keep 3 (default) or 4 planes in flight, counted by hand: every depth is its
+    own instantiation (scripts/check_inflight.py verifies the binary of each).  The other BSI kernels have one form since
+    round 3 (the round-1 block kernels and the quarter-container Sum(Between) are gone)."""
+    gpu_ctx.set_option("bsi_planes_ahead", request.param)
     yield request.param
-    gpu_ctx.set_option("bsi_between_parts", 2)
-    gpu_ctx.set_option("bsi_planes_ahead", 4)
+    gpu_ctx.set_option("bsi_planes_ahead", 3)
 
 
 def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle, bsi_kernel_form):

@@ -1,0 +1,74 @@
+"""The shipped device code must never touch a vector register whose load is still in flight.
+
+Several kernels issue their streaming loads as `asm volatile` and count the outstanding ones by hand (the one-pass
+BSI kernels, the chunk rings of k_fold_scatter / k_rows_vs_filter): the compiler does not know those registers are
+not ready, so a copy it places between the load and the hand-written wait would move stale data.  On the GPU that shows
+as a parity failure (it did, twice, in round 3); here it is a build-time failure: scripts/check_inflight.py takes the
+gfx950 code object out of libfbk.so — the very file the GPU box loads —, disassembles it and runs a data-flow analysis
+of the outstanding vector-memory operations over every kernel (compiler-managed ones included).  No GPU needed."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+LIB = os.path.join(ROOT, "featurebase_amd", "csrc", "libfbk.so")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    import check_inflight as C
+
+    if not os.path.exists(os.path.join(C.LLVM, "llvm-objdump")):
+        pytest.skip("no llvm-objdump in this image")
+    if not os.path.exists(LIB):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return C, C.parse(C.disassemble(LIB))
+
+
+@pytest.mark.timeout(600)
+def test_no_kernel_touches_a_register_in_flight(kernels):
+    C, funcs = kernels
+    bad = []
+    for name, insns in funcs.items():
+        bad += C.check_kernel(name, insns)
+    assert not bad, "\n".join(bad[:20])
+
+
+def test_the_hand_counted_kernels_are_in_the_binary(kernels):
+    """(the check above must not pass because the kernels it is there for were renamed away)"""
+    _, funcs = kernels
+    names = "\n".join(funcs)
+    for k in ("k_bsi_range_sum_halfILb0ELi3", "k_bsi_range_sum_halfILb1ELi4", "k_bsi_between_sum_partILi8ELi3", "k_bsi_between_sum_partILi8ELi4", "k_fold_scatterILi1", "k_rows_vs_filter"):
+        assert k in names, k
+    # and they do contain hand-written waits with loads in flight behind them
+    for k in ("k_bsi_range_sum_halfILb0ELi3", "k_fold_scatterILi1ELb0"):
+        insns = next(v for n, v in funcs.items() if k in n)
+        assert any(i.kind == "wait" and i.vm_wait not in (None, 0) for i in insns), k
+
+
+def test_the_checker_finds_a_planted_copy():
+    """A copy of a register between its load and the wait is reported; the same code with the copy behind the wait is clean."""
+    import check_inflight as C
+
+    def kernel(copy_first):
+        lines = ["0000000000001000 <planted>:"]
+        body = ["global_load_dwordx4 v[4:7], v[0:1], off", "global_load_dwordx4 v[8:11], v[0:1], off offset:16"]
+        body += ["v_mov_b32_e32 v12, v4", "s_waitcnt vmcnt(1)"] if copy_first else ["s_waitcnt vmcnt(1)", "v_mov_b32_e32 v12, v4"]
+        body += ["s_waitcnt vmcnt(0)", "v_add_u32_e32 v13, v8, v12", "s_endpgm"]
+        for k, b in enumerate(body):
+            op, _, ops = b.partition(" ")
+            lines.append(f"\t{op} {ops}    // {0x1000 + 4 * k:012X}: 00000000")
+        return C.parse("\n".join(lines))["planted"]
+
+    assert C.check_kernel("planted", kernel(False)) == []
+    bad = C.check_kernel("planted", kernel(True))
+    assert len(bad) == 1 and "v_mov_b32_e32 v12, v4" in bad[0]
+    # one load too few behind the register for the count in the wait
+    short = kernel(False)
+    short[2].vm_wait = 2
+    assert C.check_kernel("planted", short)
