@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t fx_win_dyn(const uint4& w, uint32_t k) {
 __device__ __forceinline__ uint32_t fx_wave_incl_scan(uint32_t v) { return wave_incl_scan(v); }
 __device__ __forceinline__ uint32_t fx_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-template <bool HAS_F, bool PROF = false>
+template <bool HAS_F, bool PROF = false, int PF = 0>
 __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
     const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA, const uint4* __restrict__ winA, const uint32_t* __restrict__ rowsA, uint32_t nA,
     const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB, const uint4* __restrict__ winB, const uint32_t* __restrict__ rowsB, uint32_t nBtot,
@@ -415,6 +415,46 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
     i0 = win_of(T, row, q);                                                            // first run whose last value is >= lo
     i1 = q + 1 < (uint32_t)kFxStages ? min(win_of(T, row, q + 1) + 1u, len) : len;       // one past the last run that can start below hi
   };
+  // PF = 0, the round-2 form: every load walks its own chain through the work lists, behind its own condition (sixteen LDS
+  // round trips one after the other, but the fewest vector instructions: kept because the kernel is issue-bound, see below)
+  auto prefetch_chains = [&](uint32_t it, Pre& P) {
+    const uint32_t si = it / kFxStages, q = it % kFxStages;
+    const FxTab& T = tabs[si & 1u];
+    P.item_base = T.ibase[q];  // (<= kFxItemCap)
+    P.n_items = min(T.icnt[q], (uint32_t)kFxItemCap - P.item_base);  // (fits by construction; the clamp keeps a corrupt window index inside the pool)
+    const uint32_t nbm = T.nbm, nrun = T.nrun;
+#pragma unroll
+    for (int k = 0; k < kFxPref; ++k) {
+      P.a_nv[k] = 0;
+      if (!(ablate & 2u)) fetch_item(T, first_group + gq + (uint32_t)kFxGroups * k, P.n_items, P.item_base, P.a_w[k], P.a_nv[k], P.a_off[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kFxBmPref; ++k) {
+      P.b_off[k] = ~0u;
+      const uint32_t e = pw + (uint32_t)kFxProducers * k;
+      if (e < nbm && !(ablate & 8u)) {
+        const uint32_t row = T.bml[e];
+        uint32_t len;
+        const uint8_t* p = row_ptr(T, row, len);
+        P.b_w[k] = fx_ld_global16(p + (q * (uint32_t)kFxSB + lane16));
+        P.b_off[k] = row * (uint32_t)kFxStride;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kFxRunPref; ++k) {
+      const uint32_t e = (uint32_t)(kFxProducers - 1) - pw + (uint32_t)kFxProducers * k;
+      P.r_i0[k] = P.r_i1[k] = 0;
+      if (e < nrun && !(ablate & 4u)) {
+        const uint32_t row = T.runl[e];
+        uint32_t len;
+        const uint8_t* p = row_ptr(T, row, len);
+        run_range(T, row, q, len, P.r_i0[k], P.r_i1[k]);
+        const uint32_t idx = P.r_i0[k] + (uint32_t)lane;
+        P.r_iv[k][0] = idx < len ? fx_ld_global4(p + 4u * idx) : 0u;
+        P.r_row[k] = row;
+      }
+    }
+  };
   // loads of stage `it` (slot si, eighth q): array items, bitmap KiBs, the first runs of the run rows.
   // Every address hangs off a chain through the work lists in LDS (list head -> list entry -> row table [-> window
   // index] -> global load).  Written item by item behind its own condition (round 2) that was SIXTEEN LDS round trips
@@ -422,7 +462,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
   // producer wave at once (cycle stamps, profiles/r02_fused_v5_cycle_stamps.txt; the waits are in the listing).  Here
   // the chain is walked level by level for all six loads together: indexes are clamped so that every LDS read is a
   // valid address whether or not the entry exists, nothing branches until the global loads, and a level is ONE round trip.
-  auto prefetch = [&](uint32_t it, Pre& P) {
+  auto prefetch_levels = [&](uint32_t it, Pre& P) {
     const uint32_t si = it / kFxStages, q = it % kFxStages;
     const FxTab& T = tabs[si & 1u];
     // ---- level 0: the list heads ----
@@ -526,8 +566,8 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
     uint32_t base = i0;
     if (have_first) {
       toggle(i0 + (uint32_t)lane, first_iv);
-      toggle(i0 + 64u + (uint32_t)lane, second_iv);  // (idx < i1 decides: the lanes past the end hold 0)
-      base += 128u;
+      if (PF) toggle(i0 + 64u + (uint32_t)lane, second_iv);  // (idx < i1 decides: the lanes past the end hold 0)
+      base += PF ? 128u : 64u;
     }
     if (base < i1) {  // more than 128 runs inside one eighth of the container (or a row beyond the prefetched two)
       uint32_t len;
@@ -557,7 +597,10 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
 #pragma unroll
     for (int k = 0; k < kFxBmPref; ++k) asm volatile("" : "+v"(P.b_w[k]));
 #pragma unroll
-    for (int k = 0; k < kFxRunPref; ++k) asm volatile("" : "+v"(P.r_iv[k][0]), "+v"(P.r_iv[k][1]));
+    for (int k = 0; k < kFxRunPref; ++k) {
+      asm volatile("" : "+v"(P.r_iv[k][0]));
+      if (PF) asm volatile("" : "+v"(P.r_iv[k][1]));
+    }
   };
   Desc next_d = {};
   Build bld = {};
@@ -577,7 +620,10 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
       if (cur.b_off[k] != ~0u) *reinterpret_cast<mm_u4*>(ring8 + (bufoff + lane16) + cur.b_off[k]) = cur.b_w[k];
     stamp(it, 1);
     // ---- 2. the next stage's loads go out ----
-    if (it + 1 < n_stage) prefetch(it + 1, nxt);
+    if (it + 1 < n_stage) {
+      if constexpr (PF == 0) prefetch_chains(it + 1, nxt);
+      else prefetch_levels(it + 1, nxt);
+    }
     //      a wave's third and later bitmap rows (more than 24 bitmap rows among the 65) are loaded in place,
     //      all of them before the first is stored
     if (cur.b_off[kFxBmPref - 1] != ~0u && !(ablate & 8u)) {
@@ -675,7 +721,10 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
   __syncthreads();
   if (n_stage && pw < 8u) build_items(tabs[0], pw, bld);
   __syncthreads();  // the work lists and the clean ring are visible
-  if (n_stage) prefetch(0, P0);
+  if (n_stage) {
+    if constexpr (PF == 0) prefetch_chains(0, P0);
+    else prefetch_levels(0, P0);
+  }
   for (uint32_t it = 0; it <= n_stage; it += 2) {  // (n_stage is a multiple of 8)
     if (it < n_stage) stage(it, P0, P1);
     __syncthreads();
