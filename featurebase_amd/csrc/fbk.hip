@@ -86,7 +86,6 @@ struct FbkOptions {
   int64_t matrix_fp4 = -1;               // dense count matrix on the FP4 matrix instruction: 1 always, 0 never, -1 when it has several tiles
   int64_t time_kernels = 0;              // 1: HIP events around the dominant kernel of a query-level call (count matrix, fold, BSI range / sum)
   int64_t last_kernel_ns = 0;            //    ... read its duration back here (fbk_get_option) after the call
-  int64_t matrix_fused_prefetch = 0;     // fused count matrix, stage prefetch: 0 = one chain per load (round 2), 1 = level by level + 128 runs ahead (round 3 experiment: fewer LDS round trips, more vector instructions)
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
   int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)
@@ -530,7 +529,6 @@ const OptionDesc kOptions[] = {
     {"matrix_densify", &FbkOptions::matrix_densify, -1, 1},
     {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
     {"matrix_fp4", &FbkOptions::matrix_fp4, -1, 1},
-    {"matrix_fused_prefetch", &FbkOptions::matrix_fused_prefetch, 0, 1},
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
     {"time_kernels", &FbkOptions::time_kernels, 0, 1},
     {"last_kernel_ns", &FbkOptions::last_kernel_ns, 0, INT64_MAX},

@@ -30,6 +30,10 @@
 //   * array bits are OR-ed in with LDS atomics, so any group may write any row; the CONSUMERS zero
 //     the piece of every row they have just read (the buffer is clean when the producers get it
 //     back), which removes the ordering "zero before scatter" between producer waves;
+//   * (round 3, tried and dropped: walking the six address chains of a stage's prefetch level by level — 5 LDS round
+//     trips instead of 16 — with clamped, branch-free indexes, and loading 128 runs ahead instead of 64.  418 us against
+//     397: the clamps and selects are vector instructions, and issue slots, not LDS latency, are what this kernel is short
+//     of.  profiles/r03_fused_prefetch_ab.txt)
 //   * every global load is issued a WHOLE stage ahead (two register sets alternate: items, bitmap KiBs
 //     and run windows of stage t + 1 go out at the start of stage t), so a stage never waits for HBM;
 //   * bitmap rows: the q-th KiB of the container, global -> registers (a stage ahead) -> LDS;
@@ -92,7 +96,7 @@ __device__ __forceinline__ uint32_t fx_win_dyn(const uint4& w, uint32_t k) {
 __device__ __forceinline__ uint32_t fx_wave_incl_scan(uint32_t v) { return wave_incl_scan(v); }
 __device__ __forceinline__ uint32_t fx_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-template <bool HAS_F, bool PROF = false, int PF = 0>
+template <bool HAS_F, bool PROF = false>
 __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
     const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA, const uint4* __restrict__ winA, const uint32_t* __restrict__ rowsA, uint32_t nA,
     const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB, const uint4* __restrict__ winB, const uint32_t* __restrict__ rowsB, uint32_t nBtot,
@@ -344,7 +348,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
     uint32_t n_items, item_base;  // the stage's item list
     mm_u4 b_w[kFxBmPref];      // bitmap rows: this lane's 16 bytes of the stage's KiB
     uint32_t b_off[kFxBmPref];  //   byte offset of the row; ~0u: none
-    uint32_t r_iv[kFxRunPref][2];  // run rows: runs (i0 + lane) and (i0 + 64 + lane) of the stage — 128 runs is the most one eighth of a <= 1024-run container holds: no run row of the stage is read in place
+    uint32_t r_iv[kFxRunPref];  // run rows: run (i0 + lane) of the stage
     uint32_t r_i0[kFxRunPref], r_i1[kFxRunPref];  //   the runs [i0, i1) can intersect the stage (i0 == i1: nothing to do)
     uint32_t r_row[kFxRunPref];
   };
@@ -355,7 +359,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
 #pragma unroll
     for (int k = 0; k < kFxBmPref; ++k) P.b_w[k] = mm_u4{0, 0, 0, 0}, P.b_off[k] = ~0u;
 #pragma unroll
-    for (int k = 0; k < kFxRunPref; ++k) P.r_iv[k][0] = P.r_iv[k][1] = 0, P.r_i0[k] = 0, P.r_i1[k] = 0, P.r_row[k] = 0;
+    for (int k = 0; k < kFxRunPref; ++k) P.r_iv[k] = 0, P.r_i0[k] = 0, P.r_i1[k] = 0, P.r_row[k] = 0;
     P.n_items = P.item_base = 0;
   };
   clear_pre(P0);
@@ -415,9 +419,8 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
     i0 = win_of(T, row, q);                                                            // first run whose last value is >= lo
     i1 = q + 1 < (uint32_t)kFxStages ? min(win_of(T, row, q + 1) + 1u, len) : len;       // one past the last run that can start below hi
   };
-  // PF = 0, the round-2 form: every load walks its own chain through the work lists, behind its own condition (sixteen LDS
-  // round trips one after the other, but the fewest vector instructions: kept because the kernel is issue-bound, see below)
-  auto prefetch_chains = [&](uint32_t it, Pre& P) {
+  // loads of stage `it` (slot si, eighth q): array items, bitmap KiBs, the first runs of the run rows
+  auto prefetch = [&](uint32_t it, Pre& P) {
     const uint32_t si = it / kFxStages, q = it % kFxStages;
     const FxTab& T = tabs[si & 1u];
     P.item_base = T.ibase[q];  // (<= kFxItemCap)
@@ -450,100 +453,8 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
         const uint8_t* p = row_ptr(T, row, len);
         run_range(T, row, q, len, P.r_i0[k], P.r_i1[k]);
         const uint32_t idx = P.r_i0[k] + (uint32_t)lane;
-        P.r_iv[k][0] = idx < len ? fx_ld_global4(p + 4u * idx) : 0u;
+        P.r_iv[k] = idx < len ? fx_ld_global4(p + 4u * idx) : 0u;
         P.r_row[k] = row;
-      }
-    }
-  };
-  // loads of stage `it` (slot si, eighth q): array items, bitmap KiBs, the first runs of the run rows.
-  // Every address hangs off a chain through the work lists in LDS (list head -> list entry -> row table [-> window
-  // index] -> global load).  Written item by item behind its own condition (round 2) that was SIXTEEN LDS round trips
-  // one after the other — ds_read, s_waitcnt lgkmcnt(0), ds_read, ... — about 2 100 of a stage's 8 000 cycles on every
-  // producer wave at once (cycle stamps, profiles/r02_fused_v5_cycle_stamps.txt; the waits are in the listing).  Here
-  // the chain is walked level by level for all six loads together: indexes are clamped so that every LDS read is a
-  // valid address whether or not the entry exists, nothing branches until the global loads, and a level is ONE round trip.
-  auto prefetch_levels = [&](uint32_t it, Pre& P) {
-    const uint32_t si = it / kFxStages, q = it % kFxStages;
-    const FxTab& T = tabs[si & 1u];
-    // ---- level 0: the list heads ----
-    const uint32_t ib = T.ibase[q], n_raw = T.icnt[q], nbm = T.nbm, nrun = T.nrun;
-    P.item_base = ib;  // (<= kFxItemCap)
-    P.n_items = min(n_raw, (uint32_t)kFxItemCap - ib);  // (fits by construction; the clamp keeps a corrupt window index inside the pool)
-    // ---- level 1: the list entries ----
-    uint32_t a_it[kFxPref], b_row[kFxBmPref], r_row[kFxRunPref];
-    bool a_ok[kFxPref], b_ok[kFxBmPref], r_ok[kFxRunPref];
-#pragma unroll
-    for (int k = 0; k < kFxPref; ++k) {
-      const uint32_t idx = first_group + gq + (uint32_t)kFxGroups * k;
-      a_ok[k] = idx < P.n_items && !(ablate & 2u);
-      a_it[k] = T.pool[min(ib + idx, (uint32_t)kFxItemCap - 1u)];
-    }
-#pragma unroll
-    for (int k = 0; k < kFxBmPref; ++k) {
-      const uint32_t e = pw + (uint32_t)kFxProducers * k;
-      b_ok[k] = e < nbm && !(ablate & 8u);
-      b_row[k] = T.bml[min(e, 71u)];
-    }
-#pragma unroll
-    for (int k = 0; k < kFxRunPref; ++k) {
-      const uint32_t e = (uint32_t)(kFxProducers - 1) - pw + (uint32_t)kFxProducers * k;
-      r_ok[k] = e < nrun && !(ablate & 4u);
-      r_row[k] = T.runl[min(e, 71u)];
-    }
-    // ---- level 2: the row table (an entry that does not exist reads row 64 or whatever the slot holds: discarded) ----
-    uint2 a_p[kFxPref], b_p[kFxBmPref];
-    uint4 r_t[kFxRunPref];
-    uint32_t r_w0[kFxRunPref], r_w1[kFxRunPref];
-#pragma unroll
-    for (int k = 0; k < kFxPref; ++k) {
-      const uint32_t row = min(a_it[k] & 127u, (uint32_t)kFxNR - 1u);
-      a_p[k] = *reinterpret_cast<const uint2*>(&T.row[row][0]);
-      P.a_off[k] = row * (uint32_t)kFxStride;
-    }
-#pragma unroll
-    for (int k = 0; k < kFxBmPref; ++k) {
-      b_row[k] = min(b_row[k], (uint32_t)kFxNR - 1u);
-      b_p[k] = *reinterpret_cast<const uint2*>(&T.row[b_row[k]][0]);
-    }
-#pragma unroll
-    for (int k = 0; k < kFxRunPref; ++k) {
-      r_row[k] = min(r_row[k], (uint32_t)kFxNR - 1u);
-      r_t[k] = T.row[r_row[k]][0];
-      r_w0[k] = win_of(T, r_row[k], q);
-      r_w1[k] = win_of(T, r_row[k], min(q + 1u, (uint32_t)kFxStages - 1u));
-    }
-    // ---- level 3: the global loads ----
-#pragma unroll
-    for (int k = 0; k < kFxPref; ++k) {
-      const int mine = a_ok[k] ? (int)__builtin_amdgcn_ubfe(a_it[k], 19u, 7u) + 1 - (int)gl8 : 0;  // values of the item from this lane's first on
-      P.a_nv[k] = 0;
-      if (mine > 0) {
-        P.a_nv[k] = (uint32_t)min(mine, 8);
-        const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)a_p[k].y << 32) | a_p[k].x);
-        P.a_w[k] = fx_ld_global16_u(p + (((a_it[k] >> 6) & 0x1FFEu) + gl16));  // 2 * (first value of the item + 8 * lane)
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < kFxBmPref; ++k) {
-      P.b_off[k] = ~0u;
-      if (b_ok[k]) {
-        const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)b_p[k].y << 32) | b_p[k].x);
-        P.b_w[k] = fx_ld_global16(p + (q * (uint32_t)kFxSB + lane16));
-        P.b_off[k] = b_row[k] * (uint32_t)kFxStride;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < kFxRunPref; ++k) {
-      P.r_i0[k] = P.r_i1[k] = 0;
-      if (r_ok[k]) {
-        const uint32_t len = r_t[k].z;
-        const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)r_t[k].y << 32) | r_t[k].x);
-        P.r_i0[k] = r_w0[k];                                                                   // first run whose last value is >= lo
-        P.r_i1[k] = q + 1 < (uint32_t)kFxStages ? min(r_w1[k] + 1u, len) : len;                  // one past the last run that can start below hi
-        const uint32_t idx = P.r_i0[k] + (uint32_t)lane;
-        P.r_iv[k][0] = idx < len ? fx_ld_global4(p + 4u * idx) : 0u;
-        P.r_iv[k][1] = idx + 64u < P.r_i1[k] ? fx_ld_global4(p + 4u * (idx + 64u)) : 0u;
-        P.r_row[k] = r_row[k];
       }
     }
   };
@@ -551,7 +462,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
   // [i0, i1) (the first 64 of them were loaded a stage ahead); (2) the parity prefix over the row's 1 KiB.  The two
   // steps are issued apart — toggles of all the wave's run rows, then the array items, then the prefixes — so that
   // the LDS round trip between a row's atomics and the read-back of its words is covered by other work.
-  auto run_toggles = [&](const FxTab& T, uint32_t row, uint32_t q, uint32_t bufoff, uint32_t i0, uint32_t i1, bool have_first, uint32_t first_iv, uint32_t second_iv) {
+  auto run_toggles = [&](const FxTab& T, uint32_t row, uint32_t q, uint32_t bufoff, uint32_t i0, uint32_t i1, bool have_first, uint32_t first_iv) {
     const uint32_t lo = q * (uint32_t)(kFxSB * 8), hi = lo + (uint32_t)(kFxSB * 8);
     const uint32_t rowaddr = bufoff + row * (uint32_t)kFxStride;
     auto toggle = [&](uint32_t idx, uint32_t iv) {
@@ -566,10 +477,9 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
     uint32_t base = i0;
     if (have_first) {
       toggle(i0 + (uint32_t)lane, first_iv);
-      if (PF) toggle(i0 + 64u + (uint32_t)lane, second_iv);  // (idx < i1 decides: the lanes past the end hold 0)
-      base += PF ? 128u : 64u;
+      base += 64u;
     }
-    if (base < i1) {  // more than 128 runs inside one eighth of the container (or a row beyond the prefetched two)
+    if (base < i1) {  // more than 64 runs inside one eighth of the container (or a row beyond the prefetched two)
       uint32_t len;
       const uint8_t* p = row_ptr(T, row, len);
       for (; base < i1; base += 64u) {
@@ -597,10 +507,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
 #pragma unroll
     for (int k = 0; k < kFxBmPref; ++k) asm volatile("" : "+v"(P.b_w[k]));
 #pragma unroll
-    for (int k = 0; k < kFxRunPref; ++k) {
-      asm volatile("" : "+v"(P.r_iv[k][0]));
-      if (PF) asm volatile("" : "+v"(P.r_iv[k][1]));
-    }
+    for (int k = 0; k < kFxRunPref; ++k) asm volatile("" : "+v"(P.r_iv[k]));
   };
   Desc next_d = {};
   Build bld = {};
@@ -620,10 +527,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
       if (cur.b_off[k] != ~0u) *reinterpret_cast<mm_u4*>(ring8 + (bufoff + lane16) + cur.b_off[k]) = cur.b_w[k];
     stamp(it, 1);
     // ---- 2. the next stage's loads go out ----
-    if (it + 1 < n_stage) {
-      if constexpr (PF == 0) prefetch_chains(it + 1, nxt);
-      else prefetch_levels(it + 1, nxt);
-    }
+    if (it + 1 < n_stage) prefetch(it + 1, nxt);
     //      a wave's third and later bitmap rows (more than 24 bitmap rows among the 65) are loaded in place,
     //      all of them before the first is stored
     if (cur.b_off[kFxBmPref - 1] != ~0u && !(ablate & 8u)) {
@@ -651,7 +555,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
     // ---- 3a. run rows, step 1 (each run row is owned by one wave, so its parity prefix follows this wave's own toggles) ----
 #pragma unroll
     for (int k = 0; k < kFxRunPref; ++k)
-      if (cur.r_i0[k] < cur.r_i1[k]) run_toggles(T, cur.r_row[k], q, bufoff, cur.r_i0[k], cur.r_i1[k], true, cur.r_iv[k][0], cur.r_iv[k][1]);
+      if (cur.r_i0[k] < cur.r_i1[k]) run_toggles(T, cur.r_row[k], q, bufoff, cur.r_i0[k], cur.r_i1[k], true, cur.r_iv[k]);
     // ---- 3. array items: the prefetched ones, then (long lists only) the rest ----
 #pragma unroll
     for (int k = 0; k < kFxPref; ++k) scatter8(cur.a_w[k], cur.a_nv[k], bufoff + cur.a_off[k]);
@@ -693,7 +597,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
         (void)row_ptr(T, row, len);
         run_range(T, row, q, len, i0, i1);
         if (i0 < i1) {
-          run_toggles(T, row, q, bufoff, i0, i1, false, 0u, 0u);
+          run_toggles(T, row, q, bufoff, i0, i1, false, 0u);
           wave_lds_sync();
           run_prefix(row, bufoff);
         }
@@ -721,10 +625,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
   __syncthreads();
   if (n_stage && pw < 8u) build_items(tabs[0], pw, bld);
   __syncthreads();  // the work lists and the clean ring are visible
-  if (n_stage) {
-    if constexpr (PF == 0) prefetch_chains(0, P0);
-    else prefetch_levels(0, P0);
-  }
+  if (n_stage) prefetch(0, P0);
   for (uint32_t it = 0; it <= n_stage; it += 2) {  // (n_stage is a multiple of 8)
     if (it < n_stage) stage(it, P0, P1);
     __syncthreads();

@@ -55,24 +55,6 @@ got = gb()
 ok2 = bool((got == ref).all())
 print(f"fused                      {t(gb):8.1f} us  parity {ok2}  ({nbytes / t(gb) / 1e6:.2f} TB/s)")
 
-def kernel_us(fn, iters=15):
-    ctx.set_option("time_kernels", 1)
-    ts = []
-    for _ in range(iters):
-        fn()
-        ts.append(ctx.get_option("last_kernel_ns") / 1e3)
-    ctx.set_option("time_kernels", 0)
-    ts.sort()
-    return ts[len(ts) // 2], ts[0]
-
-
-for rep in range(2):  # A/B of the stage prefetch, interleaved twice (kernel time by the library's own HIP events)
-    for pf, what in ((0, "one chain per load (round 2)"), (1, "level by level, 128 runs ahead")):
-        ctx.set_option("matrix_fused_prefetch", pf)
-        assert (gb() == ref).all(), ("prefetch variant", pf)
-        med, lo = kernel_us(gb)
-        print(f"fused, prefetch {pf} {what:32s} kernel {med:7.1f} us (min {lo:6.1f})")
-ctx.set_option("matrix_fused_prefetch", 0)
 if not ok2:
     bad = np.argwhere(got != ref)
     print("mismatches:", len(bad), bad[:10].tolist(), got[got != ref][:10].tolist(), ref[got != ref][:10].tolist())
