@@ -90,7 +90,6 @@ struct FbkOptions {
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
   int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)
   int64_t bsi_half_waves = 1;            // dense BSI batches: the one-pass Range + Sum runs half a container per wavefront; 0: one wavefront per container (A/B runs)
-  int64_t bsi_sum_dense = 1;             // Sum on a dense batch: k_bsi_sum_half (half a container per wavefront, counted loads); 0: k_bsi_sum_slot as for any batch (A/B runs, cross-check in the tests)
   int64_t bsi_planes_ahead = 3;          // one-pass BSI kernels on dense batches: planes in flight per wavefront (3 or 4)
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
@@ -536,7 +535,6 @@ const OptionDesc kOptions[] = {
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
     {"bsi_range_sum_two_pass", &FbkOptions::bsi_range_sum_two_pass, 0, 1},
     {"bsi_half_waves", &FbkOptions::bsi_half_waves, 0, 1},
-    {"bsi_sum_dense", &FbkOptions::bsi_sum_dense, 0, 1},
     {"bsi_planes_ahead", &FbkOptions::bsi_planes_ahead, 3, 4},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},

@@ -711,91 +711,6 @@ __global__ void __launch_bounds__(64) k_bsi_range_sum_half(const uint8_t* __rest
   }
 }
 
-// Sum on a DENSE batch (round 3): half a container per wavefront like k_bsi_range_sum_half, the planes in flight counted by
-// hand — k_bsi_sum_slot reads its planes through the descriptor-driven frag_load (any encoding) and runs on the compiler's
-// waits, which keep one plane in flight (§4 of DESIGN.md).  Same totals as k_bsi_sum_slot: out3[shard] += {Σ positive
-// magnitudes, Σ negative magnitudes, considered columns} — sums and counts are reductions, the halves just add up.
-template <int AHEAD>
-__global__ void __launch_bounds__(64) k_bsi_sum_half(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ base, uint32_t n_shards, uint32_t depth,
-                                                    const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena, const uint32_t* __restrict__ frows,
-                                                    u64* __restrict__ out3) {
-  __shared__ u64 lds[kWords];
-  const int lane = threadIdx.x;
-  const uint32_t h = blockIdx.x & 1u;
-  const uint64_t cell = blockIdx.x >> 1;
-  const uint64_t shard = cell >> 4;
-  const uint32_t slot = cell & 15;
-  if (shard >= n_shards) return;
-  const uint8_t* const row0 = arena + ((uint64_t)base[shard] * kSlots + slot) * 8192ull + h * 4096u;
-  constexpr uint64_t kRow = (uint64_t)kSlots * 8192ull;
-  constexpr int kAhead = AHEAD;
-  u64 pos[kHalfWords], neg[kHalfWords], R[kHalfWords];
-  bsi_u4 T[kAhead][kHalfWords / 2] = {};  // planes in flight (see plane_request)
-  half_load(row0, lane, pos);  // exists
-  if (fslots) {
-    half_load_any(fslots[(uint64_t)frows[shard] * kSlots + slot], farena, lane, h, lds, R);
-#pragma unroll
-    for (int q = 0; q < kHalfWords; ++q) pos[q] &= R[q];
-  }
-  uint32_t cnt = 0;
-#pragma unroll
-  for (int q = 0; q < kHalfWords; ++q) cnt += __popcll(pos[q]);
-  cnt = wave_reduce_add(cnt);
-  if (cnt == 0) return;  // (wave-uniform) nothing considered in this half: every term below is zero
-  half_load(row0 + kRow, lane, R);  // sign
-#pragma unroll
-  for (int q = 0; q < kHalfWords; ++q) {
-    neg[q] = pos[q] & R[q];
-    pos[q] &= ~R[q];
-  }
-  u64 psum = 0, nsum = 0;
-  // planes least significant first, as k_bsi_sum_slot reads them (the order does not matter to a sum)
-#pragma unroll
-  for (int u = 0; u < kAhead; ++u)
-    if ((uint32_t)u < depth) plane_request<kHalfWords>(row0 + kRow * (2u + (uint32_t)u), lane, T[u]);
-  auto step_words = [&](uint32_t i, const u64 (&tw)[kHalfWords]) {
-    uint32_t pc = 0, nc = 0;
-#pragma unroll
-    for (int q = 0; q < kHalfWords; ++q) {
-      pc += __popcll(pos[q] & tw[q]);
-      nc += __popcll(neg[q] & tw[q]);
-    }
-    psum += (u64)pc << i;
-    nsum += (u64)nc << i;
-  };
-  auto step = [&](uint32_t i, const bsi_u4 (&w)[kHalfWords / 2]) {
-    u64 tw[kHalfWords];
-    plane_words<kHalfWords>(w, tw);
-    step_words(i, tw);
-  };
-  // full groups: every step refills its register set, so exactly kAhead - 1 younger planes are in flight at each use
-  uint32_t i0 = 0;
-  for (; i0 + 2u * kAhead <= depth; i0 += kAhead) {
-#pragma unroll
-    for (int u = 0; u < kAhead; ++u) {
-      plane_landed<kHalfWords, (kAhead - 1) * (kHalfWords / 2)>(T[u]);
-      step(i0 + (uint32_t)u, T[u]);
-      plane_request<kHalfWords>(row0 + kRow * (2u + i0 + (uint32_t)u + kAhead), lane, T[u]);
-    }
-  }
-  // the last planes: what is in the register sets, then the at most kAhead - 1 planes that were never requested
-  planes_drain<kHalfWords, kAhead>(T);
-#pragma unroll
-  for (int u = 0; u < kAhead; ++u)
-    if (i0 + (uint32_t)u < depth) step(i0 + (uint32_t)u, T[u]);
-  for (uint32_t i = i0 + kAhead; i < depth; ++i) {
-    half_load(row0 + kRow * (2u + i), lane, R);
-    step_words(i, R);
-  }
-  psum = wave_reduce_add_u64(psum);
-  nsum = wave_reduce_add_u64(nsum);
-  if (lane == 0) {
-    if (psum) atomicAdd(&out3[shard * 3 + 0], psum);
-    if (nsum) atomicAdd(&out3[shard * 3 + 1], nsum);
-    atomicAdd(&out3[shard * 3 + 2], (u64)cnt);
-  }
-}
-
 // ---- Sum over lo <= v <= hi of the same field, one pass ---------------------------------------------------------
 // Two scan lanes, each with its own remaining set X and matched set M.  lo < 0 <= hi: lane 0 = the positive columns with
 // magnitude <= hi, lane 1 = the negative ones with magnitude <= |lo| (two "less or equal" scans from the top plane).

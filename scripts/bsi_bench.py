@@ -47,16 +47,8 @@ def line(what, nbytes, fn):
     print(f"{what:58s} {med:8.1f} us (min {lo:6.1f})  {nbytes / med / 1e6:6.2f} TB/s = {nbytes / med / 1e6 / 8:.2f}")
 
 
-ref_sum = None
-for dense, name in ((0, "k_bsi_sum_slot (wavefront per (shard, slot), any encoding)"), (1, "k_bsi_sum_half (dense batch, counted loads)")):
-    ctx.set_option("bsi_sum_dense", dense)
-    got = (ctx.bsi_sum(batch, base, depth, filt, fidx), ctx.bsi_sum(batch, base, depth))
-    if ref_sum is None:
-        ref_sum = got
-    assert all((a == b).all() for x, y in zip(ref_sum, got) for a, b in zip(x, y)), "Sum: the two kernels disagree"
-    line(f"Sum(filter)  {name}", plane_bytes * (depth + 3), lambda: ctx.bsi_sum(batch, base, depth, filt, fidx))
-    line(f"Sum()        {name}", plane_bytes * (depth + 2), lambda: ctx.bsi_sum(batch, base, depth))
-ctx.set_option("bsi_sum_dense", 1)
+line("Sum(filter)  k_bsi_sum_slot (wavefront per (shard, slot))", plane_bytes * (depth + 3), lambda: ctx.bsi_sum(batch, base, depth, filt, fidx))
+line("Sum()        k_bsi_sum_slot (wavefront per (shard, slot))", plane_bytes * (depth + 2), lambda: ctx.bsi_sum(batch, base, depth))
 for op, pred, what in ((L.BSI_GT, 1 << 62, "Range(> 2^62)"), (L.BSI_LT, -5, "Range(< -5)"), (L.BSI_EQ, 12345, "Range(== 12345)")):
     line(f"{what:16s} k_bsi_range_slot (wavefront)", plane_bytes * (depth + 3), lambda: ctx.bsi_range(batch, base, op, depth, pred)[0].free())
 for two_pass in (1, 0):

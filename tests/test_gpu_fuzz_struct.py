@@ -287,7 +287,6 @@ def test_fuzz_bsi(gpu_ctx, oracle, it):
     F = gpu_ctx.upload([{k & 15: D.to_fbk(c) for k, c in f.items() if c.n} for f in filts])
     rf = np.arange(n_sh)
     gpu_ctx.set_option("bsi_planes_ahead", int(rng.choice([3, 4])))
-    gpu_ctx.set_option("bsi_sum_dense", int(rng.integers(0, 2)))
     gpu_ctx.set_option("bsi_half_waves", int(rng.integers(0, 2)))
     try:
         for use_f in (False, True):
@@ -334,7 +333,6 @@ def test_fuzz_bsi(gpu_ctx, oracle, it):
         out.free()
     finally:
         gpu_ctx.set_option("bsi_planes_ahead", 3)
-        gpu_ctx.set_option("bsi_sum_dense", 1)
         gpu_ctx.set_option("bsi_half_waves", 1)
         batch.free()
         F.free()

@@ -248,17 +248,14 @@ def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B, bsi_kernel_form):
     batch.free()
 
 
-@pytest.fixture(params=[(3, 1), (4, 1), (3, 0)], ids=["3-planes-ahead", "4-planes-ahead", "sum-by-slot-kernel"])
+@pytest.fixture(params=[3, 4], ids=["3-planes-ahead", "4-planes-ahead"])
 def bsi_kernel_form(request, gpu_ctx):
-    """The kernels for dense batches (one-pass Sum(Range) / Sum(Between), Sum) keep 3 (default) or 4 planes in flight, counted
-    by hand: every depth is its own instantiation (scripts/check_inflight.py verifies the binary of each); Sum on a dense
-    batch is also run through the any-encoding kernel k_bsi_sum_slot.  The round-1 block kernels and the quarter-container
-    Sum(Between) are gone."""
-    gpu_ctx.set_option("bsi_planes_ahead", request.param[0])
-    gpu_ctx.set_option("bsi_sum_dense", request.param[1])
+    """The one-pass kernels on dense batches keep 3 (default) or 4 planes in flight, counted by hand: every depth is its
+    own instantiation (scripts/check_inflight.py verifies the binary of each).  The other BSI kernels have one form since
+    round 3 (the round-1 block kernels and the quarter-container Sum(Between) are gone)."""
+    gpu_ctx.set_option("bsi_planes_ahead", request.param)
     yield request.param
     gpu_ctx.set_option("bsi_planes_ahead", 3)
-    gpu_ctx.set_option("bsi_sum_dense", 1)
 
 
 def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle, bsi_kernel_form):
