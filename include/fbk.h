@@ -500,7 +500,9 @@ int32_t fbk_topk(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint3
  *   otherwise:  cnt >= min_threshold and count >= min_threshold                              (:1357, :1394)
  * Every row is counted exactly: the rank cache's early exits (:1404-1422) only skip rows that could
  * not qualify, its truncation to the first N cached rows is an approximation this path does not
- * need.  Totals are summed over the shards (Pairs.Add, cache.go:463), ordered count descending /
+ * need — so fbk_topn can return a row that the reference's cache (cache.go, rankCache: at most
+ * CacheSize rows, refreshed lazily) had dropped or not yet ranked; on inputs whose rows all fit the
+ * cache the two agree (tests/golden/topn_vectors.json).  Totals are summed over the shards (Pairs.Add, cache.go:463), ordered count descending /
  * row index ascending, at most n results (n = 0: all).  fbk_topk is fbk_topn with both thresholds 0. */
 int32_t fbk_topn(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a, const fbk_batch* filter,
                  const uint32_t* rows_f, uint32_t n_shards, uint32_t n, uint64_t min_threshold, uint64_t tanimoto_threshold,
