@@ -351,7 +351,9 @@ int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_bat
  * stream — no allocation, no host<->device copy, no synchronisation.  It is what one (query, node)
  * call of mapperLocal (executor.go:6742) becomes when the same query shape runs again on resident
  * fragments, and it leaves the partial result where the multi-GPU reduce wants it (the cell of an
- * all-reduce).  The batches a query was prepared on must outlive it and must not be rewritten.
+ * all-reduce).  The batches a query was prepared on must outlive it and must not be rewritten; calls on
+ * one query are serialised by its context's mutex (run and read from different threads are safe, the
+ * read returns the result of whichever run was enqueued last).
  *
  *   fbk_query_count_matrix              arguments as fbk_count_matrix; keep_per_shard != 0 keeps the
  *                                       per-shard matrices readable (fbk_query_read's out1)
