@@ -882,10 +882,12 @@ __device__ __forceinline__ void between_sum_body(const BetweenSumPlan& plan, int
   }
 }
 
-// NW words per lane = NW * 512 bytes of every plane per wavefront: 8 = half a container (round 2: four 8-word fragments
-// + four planes in flight = 223 registers, two wavefronts per SIMD, and the two-lane plane step bound by the vector
-// ALU at that occupancy: 205-215 us for 830 MB), 4 = a QUARTER (round 3: ~110 registers, four wavefronts per SIMD,
-// 6144 wavefronts for 96 shards; sums and counts are reductions, the parts just add into the same totals).
+// NW words per lane = NW * 512 bytes of every plane per wavefront.  The library instantiates 8 = half a container (four
+// 8-word fragments + AHEAD planes in flight: ~205-220 registers, two wavefronts per SIMD; sums and counts are reductions,
+// the two halves just add into the same totals).  Round 2 measured 205-215 us for 830 MB and called the step "vector-ALU
+// bound"; the listing showed s_waitcnt vmcnt(0) in front of every step (see plane_request): with the planes really in flight
+// it is 135-141 us.  NW = 4 (a quarter: ~120 registers, 6144 wavefronts) was tried in round 3 — 199 us before, 143-145 us
+// after the same fix, and two of its instantiations failed scripts/check_inflight.py: not instantiated any more.
 template <int NW>
 __device__ __forceinline__ void part_load(const uint8_t* __restrict__ p, int lane, u64 (&w)[NW]) {
   const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
