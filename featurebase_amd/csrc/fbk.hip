@@ -86,6 +86,10 @@ struct FbkOptions {
   int64_t matrix_fp4 = -1;               // dense count matrix on the FP4 matrix instruction: 1 always, 0 never, -1 when it has several tiles
   int64_t time_kernels = 0;              // 1: HIP events around the dominant kernel of a query-level call (count matrix, fold, BSI range / sum)
   int64_t last_kernel_ns = 0;            //    ... read its duration back here (fbk_get_option) after the call
+  int64_t matrix_shadow = 1;             // count matrix over encoded rows: dense shadows of the heavy containers, built per batch on first use (heavy_shadow); 0: decode every container in every query
+  int64_t matrix_shadow_array = 2048;    //   arrays longer than this are heavy (run containers always are)
+  int64_t matrix_shadow_max_mb = 65536;  //   no shadow for a batch that would need more than this
+  int64_t matrix_shadow_apref = 1;       //   array items per group loaded a stage ahead when rows are shadowed (1 or 2; filtered queries)
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
   int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)
@@ -162,6 +166,14 @@ struct fbk_batch {
   // batch, dropped whenever the containers are rewritten (plan outputs, optimize)
   mutable uint4* d_win = nullptr;
   mutable std::mutex win_mu;
+  // dense shadows of the heavy containers (run containers, long arrays), built on the first count matrix over mixed rows
+  // (heavy_shadow): a copy of the descriptor table in which those containers are bitmaps in a shadow arena.  The matrix-core
+  // kernel with in-kernel decode then streams them like any bitmap row instead of decoding them in every query.  Under win_mu,
+  // dropped with the window index.  shadow_state: 0 not looked at, 1 built, 2 nothing heavy / over the memory cap
+  mutable uint8_t* d_shadow_arena = nullptr;
+  mutable Slot* d_shadow_slots = nullptr;
+  mutable uint64_t shadow_bytes = 0;
+  mutable int shadow_state = 0;
   std::mutex slots_mu;  // refresh_slots: h_slots / slots_stale
   uint64_t version = 0;  // bumped whenever the device descriptors are rewritten (a plan's resolved item records follow it)
 };
@@ -361,6 +373,12 @@ void slots_rewritten(fbk_batch* b) {
     (void)ctx_free(b->ctx, b->d_win);
     b->d_win = nullptr;
   }
+  if (b->d_shadow_arena) (void)ctx_free(b->ctx, b->d_shadow_arena);
+  if (b->d_shadow_slots) (void)ctx_free(b->ctx, b->d_shadow_slots);
+  b->d_shadow_arena = nullptr;
+  b->d_shadow_slots = nullptr;
+  b->shadow_bytes = 0;
+  b->shadow_state = 0;
 }
 
 // The window index of `b`, built on first use (one pass over its arrays and run lists) on the
@@ -386,6 +404,79 @@ int32_t window_index(fbk_ctx* ctx, const fbk_batch* b, const uint4** out) {
     b->d_win = w;
   }
   *out = b->d_win;
+  return FBK_OK;
+}
+
+// The descriptor table the in-kernel-decode count matrix should read for `b`: the batch's own, or — option matrix_shadow — a copy
+// in which every HEAVY container (a run container, an array of more than matrix_shadow_array values) is a bitmap in a shadow
+// arena built here on first use.  k_count_matrix_fused is bound by vector instruction issue, and what it issues them for is
+// decoding exactly those containers again in every query (397 us for 581 MB of config 3's rows); as bitmap
+// rows they cost one 16-byte load per lane and stage.  The trade is the review's option (a): more bytes per query (8 KiB per
+// heavy container instead of its payload) and resident memory for the shadows (capped: matrix_shadow_max_mb), paid once per
+// batch like the window index and amortised over every query on a cached fragment.  Shadow descriptors address the shadow arena
+// relative to the batch's arena (the kernels form arena + off in 64-bit arithmetic).
+int32_t heavy_shadow(fbk_ctx* ctx, const fbk_batch* b, const Slot** out_slots, bool* out_shadowed) {
+  *out_slots = b->d_slots;
+  *out_shadowed = false;
+  if (!ctx->opt.matrix_shadow) return FBK_OK;
+  if (int32_t rc = refresh_slots(const_cast<fbk_batch*>(b))) return rc;
+  std::lock_guard<std::mutex> g(b->win_mu);
+  if (b->shadow_state == 0) {
+    const uint64_t n_slots = uint64_t(b->n_rows) * fbk::kSlots;
+    const uint32_t thr = uint32_t(ctx->opt.matrix_shadow_array);
+    std::vector<uint32_t> list;
+    for (uint64_t i = 0; i < n_slots; ++i) {
+      const Slot& s = b->h_slots[i];
+      const uint32_t n = s.tn & 0xFFFFFFu, t = s.tn >> 24;
+      if (n != 0 && (t == fbk::kTypeRun || (t == fbk::kTypeArray && s.len > thr))) list.push_back(uint32_t(i));
+    }
+    b->shadow_state = 2;
+    const uint64_t bytes = uint64_t(list.size()) * 8192ull;
+    if (!list.empty() && bytes <= uint64_t(ctx->opt.matrix_shadow_max_mb) << 20) {
+      std::vector<Slot> hs(b->h_slots);
+      uint8_t* arena = nullptr;
+      Slot* dslots = nullptr;
+      DevBuf dlist;
+      hipError_t e = ctx_malloc(ctx, reinterpret_cast<void**>(&arena), bytes);
+      if (e == hipSuccess) e = ctx_malloc(ctx, reinterpret_cast<void**>(&dslots), n_slots * sizeof(Slot));
+      if (e == hipSuccess) e = dlist.alloc(ctx, list.size() * 4);
+      if (e == hipSuccess) {
+        const uint64_t rel = uint64_t(reinterpret_cast<uintptr_t>(arena)) - uint64_t(reinterpret_cast<uintptr_t>(b->d_arena));
+        for (size_t k = 0; k < list.size(); ++k) {
+          Slot& s = hs[list[k]];
+          s.off = rel + uint64_t(k) * 8192ull;
+          s.len = fbk::kWords;
+          s.tn = fbk::make_tn(fbk::kTypeBitmap, s.tn & 0xFFFFFFu);
+        }
+        e = hipMemcpyAsync(dlist.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dslots, hs.data(), n_slots * sizeof(Slot), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+          hipLaunchKernelGGL(fbk::k_shadow_build, dim3(uint32_t((list.size() + 3) / 4)), dim3(256), 0, ctx->stream, b->d_slots, b->d_arena,
+                             dlist.as<uint32_t>(), uint64_t(list.size()), arena);
+          e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (the host vectors above are read by the copies)
+      }
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (arena) (void)ctx_free(ctx, arena);
+        if (dslots) (void)ctx_free(ctx, dslots);
+        if (e != hipErrorOutOfMemory) return fail(FBK_E_HIP, std::string("heavy-row shadow: ") + hipGetErrorString(e));
+        // out of memory: the query runs on the encoded rows
+      } else {
+        pool_rehome(ctx, b->ctx, arena);
+        pool_rehome(ctx, b->ctx, dslots);
+        b->d_shadow_arena = arena;
+        b->d_shadow_slots = dslots;
+        b->shadow_bytes = bytes + n_slots * sizeof(Slot);
+        b->shadow_state = 1;
+      }
+    }
+  }
+  if (b->shadow_state == 1) {
+    *out_slots = b->d_shadow_slots;
+    *out_shadowed = true;
+  }
   return FBK_OK;
 }
 
@@ -529,6 +620,10 @@ const OptionDesc kOptions[] = {
     {"matrix_densify", &FbkOptions::matrix_densify, -1, 1},
     {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
     {"matrix_fp4", &FbkOptions::matrix_fp4, -1, 1},
+    {"matrix_shadow", &FbkOptions::matrix_shadow, 0, 1},
+    {"matrix_shadow_array", &FbkOptions::matrix_shadow_array, 0, 65536},
+    {"matrix_shadow_max_mb", &FbkOptions::matrix_shadow_max_mb, 0, 1 << 20},
+    {"matrix_shadow_apref", &FbkOptions::matrix_shadow_apref, 1, 2},
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
     {"time_kernels", &FbkOptions::time_kernels, 0, 1},
     {"last_kernel_ns", &FbkOptions::last_kernel_ns, 0, INT64_MAX},
@@ -697,6 +792,8 @@ int32_t fbk_batch_free(fbk_ctx* ctx, fbk_batch* b) {
   if (b->d_arena) (void)ctx_free(b->ctx, b->d_arena);
   if (b->d_slots) (void)ctx_free(b->ctx, b->d_slots);
   if (b->d_win) (void)ctx_free(b->ctx, b->d_win);
+  if (b->d_shadow_arena) (void)ctx_free(b->ctx, b->d_shadow_arena);
+  if (b->d_shadow_slots) (void)ctx_free(b->ctx, b->d_shadow_slots);
   delete b;
   return FBK_OK;
 }
@@ -1129,6 +1226,8 @@ void free_batch_storage(fbk_batch* b) {
   if (b->d_arena) (void)ctx_free(b->ctx, b->d_arena);
   if (b->d_slots) (void)ctx_free(b->ctx, b->d_slots);
   if (b->d_win) (void)ctx_free(b->ctx, b->d_win);
+  if (b->d_shadow_arena) (void)ctx_free(b->ctx, b->d_shadow_arena);
+  if (b->d_shadow_slots) (void)ctx_free(b->ctx, b->d_shadow_slots);
   delete b;
 }
 

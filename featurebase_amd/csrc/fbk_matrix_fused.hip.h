@@ -54,8 +54,10 @@ constexpr int kFxConsumers = 4;
 constexpr int kFxProducers = 12;
 constexpr int kFxWaves = kFxConsumers + kFxProducers;
 constexpr int kFxGroups = kFxProducers * 4;  // 16-lane groups
-constexpr int kFxPref = 2;                   // array items per group and stage that are loaded a stage ahead (96 per stage; longer lists load in place)
-constexpr int kFxBmPref = 2;                 // bitmap rows per wave whose KiB is loaded a stage ahead (a wave owns at most 6)
+// (template parameters of the kernel: APREF = array items per 16-lane group and stage that are loaded a stage ahead — 48 groups:
+// 96 per stage with 2, longer lists load in place; BPREF = bitmap rows per wave whose KiB is loaded a stage ahead — 12 waves: 24
+// rows with 2.  Encoded rows as uploaded: 2 / 2.  Rows whose heavy containers have a dense shadow (fbk.hip heavy_shadow): mostly
+// bitmap rows and short arrays, 1 / 3.)
 constexpr int kFxRunPref = 2;                // run rows per wave whose first 64 runs are loaded a stage ahead
 constexpr int kFxItemArrayMax = 4096;        // arrays up to this length go through the item lists (ArrayMaxSize, roaring.go:46)
 constexpr int kFxItemCap = 2624;             // >= 65 rows x (4096 / 128 + 8) items per container slot
@@ -96,7 +98,7 @@ __device__ __forceinline__ uint32_t fx_win_dyn(const uint4& w, uint32_t k) {
 __device__ __forceinline__ uint32_t fx_wave_incl_scan(uint32_t v) { return wave_incl_scan(v); }
 __device__ __forceinline__ uint32_t fx_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-template <bool HAS_F, bool PROF = false>
+template <bool HAS_F, bool PROF = false, int APREF = 2, int BPREF = 2>
 __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
     const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA, const uint4* __restrict__ winA, const uint32_t* __restrict__ rowsA, uint32_t nA,
     const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB, const uint4* __restrict__ winB, const uint32_t* __restrict__ rowsB, uint32_t nBtot,
@@ -108,6 +110,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
   // producers k = 0 stage start, 1 this stage's loads settled and bitmap rows stored, 2 next stage's loads issued,
   // 3 array items done, 4 run rows (and list building) done, 5 past the barrier; consumers k = 0 start,
   // 1 arithmetic done, 5 past the barrier
+  constexpr int kFxPref = APREF, kFxBmPref = BPREF;
   const bool traced = PROF && blockIdx.x == (gridDim.x / 2 | 1u);
   auto stamp = [&](uint32_t st, int k) {
     if (PROF && traced && (threadIdx.x & 63) == 0 && st < 24u) prof[((threadIdx.x >> 6) * 24u + st) * 8u + k] = (u64)__builtin_readcyclecounter();

@@ -292,4 +292,20 @@ __global__ void __launch_bounds__(256) k_densify_rows(DensifyArgs args) {
   frag_store_bitmap(S.out + wslot * 8192ull, lane, w);
 }
 
+// Dense shadows of a batch's heavy containers (fbk.hip heavy_shadow): one wavefront per listed container decodes it into an
+// 8 KiB bitmap.  list[k] = index of the container's descriptor; shadow k goes to out + k * 8192.
+__global__ void __launch_bounds__(256) k_shadow_build(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena, const uint32_t* __restrict__ list,
+                                                     uint64_t n_list, uint8_t* __restrict__ out) {
+  __shared__ u64 lds[4][kWords];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
+  if (k >= n_list) return;
+  const Slot s = slots[list[k]];
+  u64 w[kWordsPerLane];
+  if (slot_n(s) == 0) frag_zero(w);
+  else frag_load(s, arena, lane, lds[wv], w);
+  frag_store_bitmap(out + k * 8192ull, lane, w);
+}
+
 }  // namespace fbk

@@ -55,6 +55,33 @@ got = gb()
 ok2 = bool((got == ref).all())
 print(f"fused                      {t(gb):8.1f} us  parity {ok2}  ({nbytes / t(gb) / 1e6:.2f} TB/s)")
 
+
+
+def kernel_us(fn, iters=12):
+    ctx.set_option("time_kernels", 1)
+    ts = []
+    for _ in range(iters):
+        fn()
+        ts.append(ctx.get_option("last_kernel_ns") / 1e3)
+    ctx.set_option("time_kernels", 0)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+# heavy-row shadows (option matrix_shadow): every variant on its own upload of the rows (a shadow is built once per batch)
+for shadow, thr, apref in ((0, 0, 1), (1, 4096, 1), (1, 2048, 1), (1, 2048, 2), (1, 1024, 1), (1, 1024, 2), (1, 512, 1), (0, 0, 1)):
+    ctx.set_option("matrix_shadow", shadow)
+    ctx.set_option("matrix_shadow_array", thr)
+    ctx.set_option("matrix_shadow_apref", apref)
+    bt = ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
+    fn = lambda: ctx.count_matrix(bt, groups[:, :32], bt, groups[:, 32:], F, fidx)  # noqa: E731
+    ok = bool((fn() == ref).all())
+    med, lo = kernel_us(fn)
+    print(f"fused, shadows {'arrays > %4d + runs, %d item(s) ahead' % (thr, apref) if shadow else 'off                                 '}  kernel {med:7.1f} us (min {lo:6.1f})  parity {ok}")
+    bt.free()
+ctx.set_option("matrix_shadow", 1)
+ctx.set_option("matrix_shadow_array", 2048)
+ctx.set_option("matrix_shadow_apref", 1)
 if not ok2:
     bad = np.argwhere(got != ref)
     print("mismatches:", len(bad), bad[:10].tolist(), got[got != ref][:10].tolist(), ref[got != ref][:10].tolist())

@@ -655,8 +655,22 @@ def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
     batch.free()
 
 
+@pytest.fixture(params=[(1, 2048, 1), (1, 64, 2), (0, 2048, 1)], ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows"])
+def shadow_mode(request, gpu_ctx):
+    """Count matrix over encoded rows: run containers and long arrays as dense shadows built per batch on first use (default),
+    the same with nearly every array shadowed (and two array items per group loaded ahead), and every container decoded in
+    every query (the round-2 behaviour)."""
+    gpu_ctx.set_option("matrix_shadow", request.param[0])
+    gpu_ctx.set_option("matrix_shadow_array", request.param[1])
+    gpu_ctx.set_option("matrix_shadow_apref", request.param[2])
+    yield request.param
+    gpu_ctx.set_option("matrix_shadow", 1)
+    gpu_ctx.set_option("matrix_shadow_array", 2048)
+    gpu_ctx.set_option("matrix_shadow_apref", 1)
+
+
 @pytest.mark.parametrize("a_dense,b_dense,f_mode", [(False, False, "mixed"), (True, False, "none"), (False, True, "dense"), (False, False, "none")])
-def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle, B, a_dense, b_dense, f_mode):
+def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle, B, a_dense, b_dense, f_mode, shadow_mode):
     """nA x nB >= 100 with array / run containers among the rows: fbk_count_matrix densifies the
     referenced rows into temporary bitmap rows and runs the dense matrix kernel; every mix of
     dense and encoded operands, checked against the oracle's groupByIterator counts — and against
@@ -724,7 +738,7 @@ def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle
 
 
 @pytest.mark.parametrize("f_kind", ["cluster", "run", "bitmap", "none"])
-def test_count_matrix_fused_window_edges(gpu_ctx, oracle, B, f_kind):
+def test_count_matrix_fused_window_edges(gpu_ctx, oracle, B, f_kind, shadow_mode):
     """The in-kernel decode works through a container in eight windows of 8192 values, from work lists
     built out of the batch's window index: arrays clustered inside ONE window (up to 32 items of one
     row in one stage, more than a thousand items per stage: the list loop past the prefetched items),
@@ -804,7 +818,7 @@ def test_count_matrix_fused_window_edges(gpu_ctx, oracle, B, f_kind):
             b.free()
 
 
-def test_count_matrix_window_index_follows_rewritten_batches(gpu_ctx, oracle, B):
+def test_count_matrix_window_index_follows_rewritten_batches(gpu_ctx, oracle, B, shadow_mode):
     """The in-kernel decode reads a per-batch window index that is built on first use.  A plan's output batch
     is rewritten by every run of the plan (8 KiB cells, a different set of them nil each time): used as the
     GroupBy filter after each run, the index is dropped with the rewrite and rebuilt on the next use."""
