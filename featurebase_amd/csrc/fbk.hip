@@ -89,7 +89,7 @@ struct FbkOptions {
   int64_t matrix_shadow = 1;             // count matrix over encoded rows: dense shadows of the heavy containers, built per batch on first use (heavy_shadow); 0: decode every container in every query
   int64_t matrix_shadow_array = 2048;    //   arrays longer than this are heavy (run containers always are)
   int64_t matrix_shadow_max_mb = 65536;  //   no shadow for a batch that would need more than this
-  int64_t matrix_shadow_apref = 1;       //   array items per group loaded a stage ahead when rows are shadowed (1 or 2; filtered queries)
+  int64_t matrix_shadow_apref = 2;       //   array items per group loaded a stage ahead when rows are shadowed (1 or 2; filtered queries: 323 vs 349 us, profiles/r03_fused_shadow_ab.txt)
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
   int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)

@@ -81,7 +81,7 @@ for shadow, thr, apref in ((0, 0, 1), (1, 4096, 1), (1, 2048, 1), (1, 2048, 2), 
     bt.free()
 ctx.set_option("matrix_shadow", 1)
 ctx.set_option("matrix_shadow_array", 2048)
-ctx.set_option("matrix_shadow_apref", 1)
+ctx.set_option("matrix_shadow_apref", 2)
 if not ok2:
     bad = np.argwhere(got != ref)
     print("mismatches:", len(bad), bad[:10].tolist(), got[got != ref][:10].tolist(), ref[got != ref][:10].tolist())

@@ -655,10 +655,10 @@ def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
     batch.free()
 
 
-@pytest.fixture(params=[(1, 2048, 1), (1, 64, 2), (0, 2048, 1)], ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows"])
+@pytest.fixture(params=[(1, 2048, 2), (1, 64, 1), (0, 2048, 2)], ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows"])
 def shadow_mode(request, gpu_ctx):
     """Count matrix over encoded rows: run containers and long arrays as dense shadows built per batch on first use (default),
-    the same with nearly every array shadowed (and two array items per group loaded ahead), and every container decoded in
+    the same with nearly every array shadowed (and one array item per group loaded ahead), and every container decoded in
     every query (the round-2 behaviour)."""
     gpu_ctx.set_option("matrix_shadow", request.param[0])
     gpu_ctx.set_option("matrix_shadow_array", request.param[1])
@@ -666,7 +666,7 @@ def shadow_mode(request, gpu_ctx):
     yield request.param
     gpu_ctx.set_option("matrix_shadow", 1)
     gpu_ctx.set_option("matrix_shadow_array", 2048)
-    gpu_ctx.set_option("matrix_shadow_apref", 1)
+    gpu_ctx.set_option("matrix_shadow_apref", 2)
 
 
 @pytest.mark.parametrize("a_dense,b_dense,f_mode", [(False, False, "mixed"), (True, False, "none"), (False, True, "dense"), (False, False, "none")])
