@@ -341,10 +341,18 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         out.append(_entry("config3 rows, TopN/TopK shape: 64 rows x 1 filter row per shard", "k_rows_vs_filter", nbytes + 8 * 64 * n3, g, w, kq,
                           set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), call_us=call_us(lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1))), **common))
         g, w, kq = _timed_query(torch, stream, q_gb, max(5, iters // 2), ctx)
-        out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel (default)", "k_count_matrix_fused",
+        # heavy containers (run containers, arrays of more than 2048 values) are read through dense shadows the library builds per
+        # batch on the first count matrix (option matrix_shadow, fbk.hip heavy_shadow): what that costs in memory and traffic
+        dd = rows.descs()
+        heavy = int((((dd["type"] == 3) & (dd["n"] != 0)) | ((dd["type"] == 1) & (dd["len"] > 2048))).sum())
+        heavy_payload = int((dd["len"][(dd["type"] == 3) & (dd["n"] != 0)].astype(np.int64) * 4).sum() + (dd["len"][(dd["type"] == 1) & (dd["len"] > 2048)].astype(np.int64) * 2).sum())
+        out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel, heavy containers through dense shadows (default)", "k_count_matrix_fused",
                           nbytes + 8 * 1024 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
                           call_us=call_us(lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx)),
-                          hbm_note="encoded rows are the only HBM traffic (PMC fetch / algorithmic bytes in profiles/); the kernel is bound by instruction issue, not by HBM (DESIGN.md section 9)", **common))
+                          heavy_row_shadows={"containers": heavy, "resident_bytes": heavy * 8192 + 16 * 16 * rows.n_rows, "built": "once per batch, on the first count matrix that reads it",
+                                             "bytes_read_per_query": nbytes - heavy_payload + heavy * 8192,
+                                             "note": "frac / kernel_frac are quoted on the ENCODED bytes (the algorithmic bytes of the query); the kernel itself reads bytes_read_per_query"},
+                          hbm_note="the kernel is bound by vector instruction issue, not by HBM: reading the run containers and long arrays as 8 KiB bitmaps instead of decoding them in every query trades bytes for issue slots (DESIGN.md section 9; option matrix_shadow=0: 397 us)", **common))
         # row pairs of the same rows (RowSegment.IntersectionCount / Intersect on non-dense rows): rows 0..31 against rows 32..63 of every shard
         pa, pb = groups[:, :32].reshape(-1), groups[:, 32:].reshape(-1)
         plan = ctx.plan(batch, pa, batch, pb)
