@@ -134,7 +134,10 @@ int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
 /* Tuning / test knobs (A/B measurements, forcing code paths in tests).  The environment variables
  * FBK_<NAME> are read ONCE, by fbk_open; afterwards only these calls change an option.  Names:
  * dense_spb, fold_register, matrix_valu, matrix_spb, matrix_pass_kb, matrix_densify, matrix_fused,
- * matrix_fp4, bsi_range_sum_two_pass, bsi_half_waves, bsi_planes_ahead, topk_device_sort, sparse_paths,
+ * matrix_fp4, matrix_shadow (1: the count matrix over encoded rows reads run containers and arrays of more
+ * than matrix_shadow_array values through dense shadows built per batch on first use — up to
+ * matrix_shadow_max_mb of device memory per batch; 0: every container is decoded in every query),
+ * bsi_range_sum_two_pass, bsi_half_waves, bsi_planes_ahead, topk_device_sort, sparse_paths,
  * setop_direct_encode, pair_kernels, pair_spw, pair_wpb, pair_resolve, count_range_reference_quirk.
  * Measurement: time_kernels = 1 makes the query-level calls (count matrix, n-way fold, BSI range /
  * sum / min / max) record HIP events on the context's stream right before and after their dominant kernel;
