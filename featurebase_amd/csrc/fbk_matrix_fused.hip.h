@@ -280,11 +280,11 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
   auto build_rows = [&](FxTab& T, const Desc& x) {
     const uint32_t type = slot_n(x.d) ? slot_type(x.d) : 0u;
     const uint32_t typeF = (HAS_F && slot_n(x.df)) ? slot_type(x.df) : 0u;  // wave-uniform
-    const uintptr_t pa = (uintptr_t)(my_base + x.d.off);
+    const uintptr_t pa = (uintptr_t)my_base + x.d.off;  // (integer arithmetic: a shadow descriptor's offset reaches into another allocation, fbk.hip heavy_shadow)
     T.row[lane][0] = uint4{(uint32_t)pa, (uint32_t)(pa >> 32), x.d.len, type};
     T.row[lane][1] = x.w;
     if (HAS_F && lane == 0) {
-      const uintptr_t pf = (uintptr_t)(arenaF + x.df.off);
+      const uintptr_t pf = (uintptr_t)arenaF + x.df.off;
       T.row[64][0] = uint4{(uint32_t)pf, (uint32_t)(pf >> 32), x.df.len, typeF};
       T.row[64][1] = x.wf;
     }
