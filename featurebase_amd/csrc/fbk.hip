@@ -425,7 +425,7 @@ int32_t heavy_shadow(fbk_ctx* ctx, const fbk_batch* b, const Slot** out_slots, b
     const uint64_t n_slots = uint64_t(b->n_rows) * fbk::kSlots;
     const uint32_t thr = uint32_t(ctx->opt.matrix_shadow_array);
     std::vector<uint32_t> list;
-    for (uint64_t i = 0; i < n_slots; ++i) {
+    for (uint64_t i = 0; i < n_slots && i < b->h_slots.size(); ++i) {
       const Slot& s = b->h_slots[i];
       const uint32_t n = s.tn & 0xFFFFFFu, t = s.tn >> 24;
       if (n != 0 && (t == fbk::kTypeRun || (t == fbk::kTypeArray && s.len > thr))) list.push_back(uint32_t(i));
