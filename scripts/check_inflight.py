@@ -18,6 +18,7 @@ silently.  This script makes that a BUILD-TIME failure instead of a wrong answer
     registers: the younger one wins).  FLAT operations return out of order: after one, only vmcnt(0) retires.
 
     python scripts/check_inflight.py [--lib path/to/libfbk.so] [kernel name regex ...]
+    python scripts/check_inflight.py --lint-serialised [regex ...]     # performance lint: loops whose waits are all vmcnt(0)
 
 Without a regex every kernel of the library is checked (compiler-managed loads must pass as well: the check is a
 model of the hardware rule, not of the source).  Exit status 1 and one line per violation if anything is found.
@@ -210,14 +211,47 @@ def check_kernel(name, insns):
     return list(bad.values())
 
 
+def serialised_loops(name, insns):
+    """A performance lint, not a correctness check: loops (a backward branch and the address range it closes) that issue
+    vector loads into registers and in which EVERY s_waitcnt on vmcnt waits for 0 — whatever the source meant to keep in
+    flight across iterations, each pass drains it.  That is how the compiler's wait insertion ends where it cannot count
+    (conditional loads, a merge of "loaded before the loop" with "reloaded in the last pass"); whether it costs anything
+    depends on how much arithmetic the loop has to hide (the one-pass BSI kernels: 199 -> 137 us; k_bsi_sum_slot: nothing).
+    Returns (loop start, loop end, loads, waits) tuples."""
+    index = {ins.addr: i for i, ins in enumerate(insns)}
+    out = []
+    for i, ins in enumerate(insns):
+        if ins.kind in ("branch", "cbranch") and ins.target is not None and ins.target in index and ins.target <= ins.addr:
+            body = insns[index[ins.target] : i + 1]
+            loads = [b for b in body if b.kind == "load" and b.dest]
+            waits = [b for b in body if b.kind == "wait" and b.vm_wait is not None]
+            if len(loads) >= 2 and waits and all(w.vm_wait == 0 for w in waits):
+                out.append((ins.target, ins.addr, len(loads), len(waits)))
+    # innermost first, drop loops that contain an already reported one
+    out.sort(key=lambda t: t[1] - t[0])
+    kept = []
+    for t in out:
+        if not any(k[0] >= t[0] and k[1] <= t[1] for k in kept):
+            kept.append(t)
+    return kept
+
+
 def main(argv):
     lib = os.path.join(ROOT, "featurebase_amd", "csrc", "libfbk.so")
     if "--lib" in argv:
         k = argv.index("--lib")
         lib = argv[k + 1]
         argv = argv[:k] + argv[k + 2:]
+    lint = "--lint-serialised" in argv
+    argv = [a for a in argv if a != "--lint-serialised"]
     pats = [re.compile(p) for p in argv] or [re.compile(".")]
     funcs = parse(disassemble(lib))
+    if lint:
+        for name, insns in funcs.items():
+            if any(p.search(name) for p in pats) and "fbk" in name:
+                for a, b, nl, nw in serialised_loops(name, insns):
+                    print(f"{name[:90]}  loop +{a:#x}..+{b:#x}: {nl} vector loads, {nw} waits, all vmcnt(0)")
+        return 0
     n, out = 0, []
     for name, insns in funcs.items():
         if not any(p.search(name) for p in pats) or not insns:
