@@ -72,3 +72,35 @@ def test_the_checker_finds_a_planted_copy():
     short = kernel(False)
     short[2].vm_wait = 2
     assert C.check_kernel("planted", short)
+
+
+def test_the_checker_follows_a_software_pipeline_around_its_loop():
+    """Two register sets refilled in turn with one load each: waiting for vmcnt(1) before a set is used is right (one
+    younger load in flight), vmcnt(2) is one load short — found through the back-edge, not in the first pass."""
+    import check_inflight as C
+
+    def kernel(n):
+        body = [
+            "global_load_dwordx4 v[4:7], v[0:1], off",      # set 0
+            "global_load_dwordx4 v[8:11], v[0:1], off",     # set 1
+            f"s_waitcnt vmcnt({n})",                         # <- loop header (0x1008)
+            "v_add_u32_e32 v12, v4, v12",
+            "global_load_dwordx4 v[4:7], v[0:1], off",
+            f"s_waitcnt vmcnt({n})",
+            "v_add_u32_e32 v12, v8, v12",
+            "global_load_dwordx4 v[8:11], v[0:1], off",
+            "s_cbranch_scc1 65528",                          # back to the header
+            "s_waitcnt vmcnt(0)",
+            "s_endpgm",
+        ]
+        lines = ["0000000000001000 <pipe>:"]
+        for k, b in enumerate(body):
+            op, _, ops = b.partition(" ")
+            tail = "  <pipe+0x8>" if op.startswith("s_cbranch") else ""
+            lines.append(f"\t{op} {ops}    // {0x1000 + 4 * k:012X}: 00000000{tail}")
+        return C.parse("\n".join(lines))["pipe"]
+
+    assert C.check_kernel("pipe", kernel(1)) == []
+    bad = C.check_kernel("pipe", kernel(2))
+    assert bad and all("may be outstanding" in b for b in bad)
+    assert C.serialised_loops("pipe", kernel(1)) == [] and C.serialised_loops("pipe", kernel(0)) != []
