@@ -485,11 +485,6 @@ def config4_strong(torch, dist, fdist, dev, ctx, stream, rank, world, args, cpu_
     ta, tb, tf = gen(ns * n_a, 4100 + 3 * rank), gen(ns * n_b, 4101 + 3 * rank), gen(ns, 4102 + 3 * rank)
     torch.cuda.synchronize()
     A, B, F = ctx.upload_dense_device(ta.data_ptr(), ns * n_a), ctx.upload_dense_device(tb.data_ptr(), ns * n_b), ctx.upload_dense_device(tf.data_ptr(), ns)
-    # a sample of this rank's shards for the oracle, before the generator's tensors are released
-    n_chk = min(16, ns)
-    sample = [t[: n_chk * k].cpu().numpy().view(np.uint64) for t, k in ((ta, n_a), (tb, n_b), (tf, 1))]
-    del ta, tb, tf
-    torch.cuda.empty_cache()
     resident_s = time.perf_counter() - t0
     ra, rb, rf = np.arange(ns * n_a).reshape(ns, n_a), np.arange(ns * n_b).reshape(ns, n_b), np.arange(ns)
     q = ctx.prepare_count_matrix(A, ra, B, rb, F, rf, keep_per_shard=True)
@@ -497,12 +492,23 @@ def config4_strong(torch, dist, fdist, dev, ctx, stream, rank, world, args, cpu_
     local, ps = q.read(per_shard=True)
     parity = "unchecked (--no-cpu-baseline)"
     if want_cpu:
+        # EVERY shard of this rank against the oracle, a chunk of shards at a time (the rank's rows are up to 70 GB: they
+        # stay on the device, the generator's tensors are copied to the host chunk by chunk for the checker)
         from oracle import pybatch as PB
 
-        OA, OB, OF = (PB.RowSet.from_dense(x) for x in sample)
-        e = PB.count_matrix(OA, ra[:n_chk], OB, rb[:n_chk], OF, rf[:n_chk])
-        assert (ps[:n_chk] == e).all(), "config 4 strong: GPU and oracle disagree"
-        parity = f"the first {n_chk} shards of every rank bit-exact against the oracle; all shards: tests/test_gpu_fullsize.py at 1024 shards"
+        t_chk = time.perf_counter()
+        chunk = 256
+        for c0 in range(0, ns, chunk):
+            c1 = min(ns, c0 + chunk)
+            OA, OB, OF = (PB.RowSet.from_dense(t[c0 * k: c1 * k].cpu().numpy().view(np.uint64)) for t, k in ((ta, n_a), (tb, n_b), (tf, 1)))
+            m = c1 - c0
+            e = PB.count_matrix(OA, np.arange(m * n_a).reshape(m, n_a), OB, np.arange(m * n_b).reshape(m, n_b), OF, np.arange(m))
+            assert (ps[c0:c1] == e).all(), f"config 4 strong: GPU and oracle disagree in shards {c0}..{c1 - 1} of rank {rank}"
+            for o in (OA, OB, OF):
+                o.free()
+        parity = f"every one of this rank's {ns} shards bit-exact against the oracle ({time.perf_counter() - t_chk:.1f} s, {PB.threads()} host threads)"
+    del ta, tb, tf
+    torch.cuda.empty_cache()
     assert (ps.sum(axis=0) == local).all()
     expected = torch.from_numpy(local.view(np.int64).reshape(-1).copy()).to(dev)
     if world > 1:
@@ -916,6 +922,24 @@ def main():
             group_api = group_in_process(None, wa, wb, local_expected, 50)
         except Exception as e:  # noqa: BLE001
             group_api = {"error": str(e)}
+    # ---- the CPU path beside it, at EVERY N (north_star: "alongside the reference Go CPU path timed on the same box's
+    # host cores"): rank 0 times it on its own 1024 shards — the N = 1 workload — while the other ranks SLEEP in a gloo
+    # barrier (sockets; an RCCL barrier would have every waiting rank spin on a host core the baseline is using)
+    cb = None
+    if not args.no_cpu_baseline:
+        wait_group = None
+        if n_gpus > 1:
+            try:
+                wait_group = dist.new_group(backend="gloo")
+            except Exception:  # noqa: BLE001 — no gloo: the ranks wait in the RCCL barrier below instead
+                wait_group = None
+        if rank == 0:
+            cb = cpu_baseline(wa, wb)
+            assert cb.pop("total_count") == local_expected, "oracle and GPU disagree"
+            if n_gpus > 1:
+                cb["sample"] += f"; timed on rank 0 (its {n} shards = the N = 1 workload) after the timed GPU regions, the other {n_gpus - 1} ranks asleep in a host barrier"
+        if wait_group is not None:
+            dist.barrier(group=wait_group)
     if n_gpus > 1:
         dist.barrier()
 
@@ -986,9 +1010,7 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc passes of an earlier run of this command, not measured in this run)"
             except Exception:
                 pass
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(wa, wb)
-            assert cb.pop("total_count") == local_expected, "oracle and GPU disagree"
+        if cb is not None:
             out["cpu_baseline"] = cb
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -88,9 +88,11 @@ struct FbkOptions {
   int64_t last_kernel_ns = 0;            //    ... read its duration back here (fbk_get_option) after the call
   int64_t matrix_shadow = 1;             // count matrix over encoded rows: dense shadows of the heavy containers, built per batch on first use (heavy_shadow); 0: decode every container in every query
   int64_t matrix_shadow_array = 2048;    //   arrays longer than this are heavy (run containers always are)
-  int64_t matrix_shadow_max_mb = 65536;  //   no shadow for a batch that would need more than this
+  int64_t matrix_shadow_max_mb = 16384;  //   no shadow for a batch that would need more than this (nor more than twice its arena, nor a quarter of the free device memory)
   int64_t matrix_shadow_apref = 2;       //   array items per group loaded a stage ahead when rows are shadowed (1 or 2; filtered queries: 323 vs 349 us, profiles/r03_fused_shadow_ab.txt)
+#ifdef FBK_EXPERIMENTS  // (scripts/ build their own variant with -DFBK_EXPERIMENTS into build_variants/; the product library has neither the options nor the device branches)
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
+#endif
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
   int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)
   int64_t bsi_half_waves = 1;            // dense BSI batches: the one-pass Range + Sum runs half a container per wavefront; 0: one wavefront per container (A/B runs)
@@ -98,11 +100,13 @@ struct FbkOptions {
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
-  int64_t pair_spw = 0;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4; 0 = by the rows' payload size): next slot's payload in flight while the current one is decoded
+  int64_t pair_spw = 0;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4; 0 and 3 are read as 1 and 2): next slot's payload in flight while the current one is decoded
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
   int64_t pair_resolve = 1;              // k_icount2 reads the plan's resolved item records and stores one count per wave (0: row index -> descriptor per wave, atomics; A/B runs)
+#ifdef FBK_EXPERIMENTS
   int64_t pair_stamp = 0;                // timing experiment on k_icount2: waves report shader cycles of a phase instead of counts (WRONG results)
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
+#endif
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
 
@@ -280,9 +284,21 @@ void cache_release_all(fbk_ctx* ctx);  // fbk_cache_api.inc needs fbk_batch: def
 struct DevBuf {
   fbk_ctx* c = nullptr;
   void* p = nullptr;
+  uint64_t cap = 0;  // bytes asked for by the last alloc / ensure
   hipError_t alloc(fbk_ctx* ctx, uint64_t bytes) {
     c = ctx;
-    return ctx_malloc(ctx, &p, bytes);
+    const hipError_t e = ctx_malloc(ctx, &p, bytes);
+    cap = e == hipSuccess ? bytes : 0;
+    return e;
+  }
+  // a buffer kept between calls (a prepared query's): at least `bytes`, reallocated when a later call needs more.
+  // The old block goes back to the pool; everything on a context is ordered by its one stream, so work still
+  // queued on it finishes before the block's next user starts.
+  hipError_t ensure(fbk_ctx* ctx, uint64_t bytes) {
+    if (p && cap >= bytes) return hipSuccess;
+    if (p) ctx_free(c, p);
+    p = nullptr;
+    return alloc(ctx, bytes);
   }
   ~DevBuf() {
     if (p) ctx_free(c, p);
@@ -432,7 +448,15 @@ int32_t heavy_shadow(fbk_ctx* ctx, const fbk_batch* b, const Slot** out_slots, b
     }
     b->shadow_state = 2;
     const uint64_t bytes = uint64_t(list.size()) * 8192ull;
-    if (!list.empty() && bytes <= uint64_t(ctx->opt.matrix_shadow_max_mb) << 20) {
+    // no shadow beyond the option's cap, beyond twice the batch's own arena, or beyond a quarter of what the device has
+    // free right now (the shadows live outside the fragment cache's accounting until its next get / release: they must
+    // never be what makes a later upload fail).  The threshold and this decision are the FIRST caller's: the shadow is
+    // built once per batch content.
+    uint64_t limit = std::min<uint64_t>(uint64_t(ctx->opt.matrix_shadow_max_mb) << 20, 2 * std::max<uint64_t>(b->arena_bytes, 1 << 20));
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) limit = std::min<uint64_t>(limit, (uint64_t(mem_free) + ctx->pool_cached_bytes) / 4);
+    else (void)hipGetLastError();
+    if (!list.empty() && bytes <= limit) {
       std::vector<Slot> hs(b->h_slots);
       uint8_t* arena = nullptr;
       Slot* dslots = nullptr;
@@ -624,7 +648,9 @@ const OptionDesc kOptions[] = {
     {"matrix_shadow_array", &FbkOptions::matrix_shadow_array, 0, 65536},
     {"matrix_shadow_max_mb", &FbkOptions::matrix_shadow_max_mb, 0, 1 << 20},
     {"matrix_shadow_apref", &FbkOptions::matrix_shadow_apref, 1, 2},
+#ifdef FBK_EXPERIMENTS
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
+#endif
     {"time_kernels", &FbkOptions::time_kernels, 0, 1},
     {"last_kernel_ns", &FbkOptions::last_kernel_ns, 0, INT64_MAX},
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
@@ -635,8 +661,10 @@ const OptionDesc kOptions[] = {
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
     {"pair_spw", &FbkOptions::pair_spw, 0, 4},
+#ifdef FBK_EXPERIMENTS
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
+#endif
     {"pair_resolve", &FbkOptions::pair_resolve, 0, 1},
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
@@ -1315,9 +1343,18 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
     if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     if (resolved) {
       const uint64_t n_items = p->n_pairs * fbk::kSlots;
-      if (!p->d_items) {
-        HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_items), n_items * 2 * sizeof(Slot)));
-        HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_wave_counts), n_items * sizeof(uint32_t)));
+      if (!p->d_items || !p->d_wave_counts) {
+        // both buffers or neither: a plan that got only the first (out of memory on the second) must not take the resolved path next time
+        Slot* di = nullptr;
+        uint32_t* dw = nullptr;
+        HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&di), n_items * 2 * sizeof(Slot)));
+        if (hipError_t e = ctx_malloc(ctx, reinterpret_cast<void**>(&dw), n_items * sizeof(uint32_t)); e != hipSuccess) {
+          ctx_free(ctx, di);
+          HIP_TRY(e);
+        }
+        p->d_items = di;
+        p->d_wave_counts = dw;
+        p->items_va = p->items_vb = ~0ull;
       }
       if (p->items_va != p->a->version || p->items_vb != p->b->version) {
         hipLaunchKernelGGL(fbk::k_resolve_items, dim3(uint32_t((n_items + 255) / 256)), dim3(256), 0, ctx->stream, p->a->d_slots, p->d_rows_a, p->b->d_slots,
@@ -1330,9 +1367,15 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
-                     p->d_counts, uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16), resolved ? p->d_items : (const Slot*)nullptr,  \
+                     p->d_counts, pair_flags, resolved ? p->d_items : (const Slot*)nullptr,  \
                      resolved ? p->d_wave_counts : (uint32_t*)nullptr)
-      const int spw = ctx->opt.pair_spw ? int(ctx->opt.pair_spw) : 1, wpb = pair_wpb_for(ctx, p->a, p->b);
+      // slots per wave: 1 (also the meaning of 0), 2 or 4 — normalised ONCE, the launch and k_sum_wave_counts below must agree
+      const int spw = ctx->opt.pair_spw == 4 ? 4 : ctx->opt.pair_spw >= 2 ? 2 : 1, wpb = pair_wpb_for(ctx, p->a, p->b);
+#ifdef FBK_EXPERIMENTS
+      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16);
+#else
+      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths);
+#endif
       if (wpb == 4) {
         switch (spw) {
           case 1: FBK_LAUNCH_ICOUNT2(1, 4); break;

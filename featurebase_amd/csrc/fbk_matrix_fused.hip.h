@@ -111,6 +111,9 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fused(
   // 3 array items done, 4 run rows (and list building) done, 5 past the barrier; consumers k = 0 start,
   // 1 arithmetic done, 5 past the barrier
   constexpr int kFxPref = APREF, kFxBmPref = BPREF;
+#ifndef FBK_EXPERIMENTS
+  ablate = 0;  // experiment builds only (the option does not exist in the product library): the branches on it fold away
+#endif
   const bool traced = PROF && blockIdx.x == (gridDim.x / 2 | 1u);
   auto stamp = [&](uint32_t st, int k) {
     if (PROF && traced && (threadIdx.x & 63) == 0 && st < 24u) prof[((threadIdx.x >> 6) * 24u + st) * 8u + k] = (u64)__builtin_readcyclecounter();

@@ -628,6 +628,9 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
                                                      uint32_t* __restrict__ wave_out) {
   __shared__ u64 lds[WPB][kWords];
   __shared__ uint32_t mini[WPB][2 * kMiniDwords];
+#ifndef FBK_EXPERIMENTS
+  sparse_paths &= 0xFFu;  // the ablation / cycle-stamp bits exist in experiment builds only: every branch on them below folds away
+#endif
   const u64 t0 = (sparse_paths >> 16) ? __builtin_readcyclecounter() : 0;
   constexpr int kWavesPerPair = kSlots / SPW;
   const int lane = threadIdx.x & 63;

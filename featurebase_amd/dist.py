@@ -130,11 +130,21 @@ class PerQueryReducer:
     all-reduced on its own — no bucketing over queries.  `depth` cells rotate so that the kernels of query
     k + 1 never write the buffer the collective of query k is still reading: `cell()` hands out the next one
     after (stream-)waiting for the collective that last used it, `reduce()` starts the asynchronous
-    all-reduce of the cell just written.  With no process group (N = 1) nothing is exchanged."""
+    all-reduce of the cell just written.  With no process group (N = 1) nothing is exchanged.
 
-    def __init__(self, width: int, depth: int, device=None):
+    STREAM RULE.  The collective is ordered against torch's CURRENT stream only.  The kernels that write the cell
+    run on the fbk context's stream, so either (a) the context runs on torch's current stream
+    (`ctx.set_stream(torch.cuda.current_stream().cuda_stream)` inside `with torch.cuda.stream(...)`, what bench.py
+    does), or (b) pass the producer's stream as `producer_stream` (a torch.cuda.Stream / ExternalStream wrapping
+    the context's stream): `reduce()` then records an event on it and makes the current stream wait for that event
+    before the all-reduce is enqueued.  With neither, the collective may read a cell before it is written."""
+
+    def __init__(self, width: int, depth: int, device=None, producer_stream=None):
         import torch
 
+        if int(width) < 1 or int(depth) < 1:
+            raise ValueError("PerQueryReducer: width and depth must be >= 1")
+        self.producer_stream = producer_stream
         self.width, self.depth = int(width), int(depth)
         self.buf = torch.zeros((self.depth, self.width), dtype=torch.int64, device=device)
         self.work = [None] * self.depth
@@ -153,6 +163,12 @@ class PerQueryReducer:
 
         i = self.k % self.depth
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if self.producer_stream is not None and self.buf.is_cuda:
+                import torch
+
+                ev = torch.cuda.Event()
+                ev.record(self.producer_stream)
+                torch.cuda.current_stream(self.buf.device).wait_event(ev)
             self.work[i] = dist.all_reduce(self.buf[i], op=dist.ReduceOp.SUM, async_op=True)
             self.collectives += 1
         self.k += 1
@@ -193,6 +209,8 @@ def strong_scaling_queries(run_local, width: int, n_queries: int, device, expect
     import torch
     import torch.distributed as dist
 
+    if n_queries < 1:
+        raise ValueError("strong_scaling_queries: n_queries must be >= 1")
     sync = sync or (lambda: None)
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 

@@ -30,6 +30,11 @@ def main():
     ap.add_argument("--only-count", action="store_true")
     ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
+    if "pair_ablate" in args.variants or "pair_stamp" in args.variants or any("ablate" in o or "stamp" in o for o in args.opt):
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import _experiments
+
+        _experiments.use()  # those options exist in the -DFBK_EXPERIMENTS build only
     rows, groups, filt = D.config3_flat(args.shards, mp="fork")
     import torch
 

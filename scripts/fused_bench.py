@@ -10,6 +10,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import _experiments  # noqa: E402
+
+_experiments.use()  # the -DFBK_EXPERIMENTS build: the ablation / cycle-stamp options do not exist in the product library
 import numpy as np  # noqa: E402
 
 import datagen as D  # noqa: E402

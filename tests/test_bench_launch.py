@@ -55,4 +55,7 @@ def test_gpus_2_line_schema_on_the_gpu_box():
     assert s["ms_per_query_pipelined"] > 0 and s["ms_per_query_host_add"] > 0 and s["rank0"]["collectives"] == 2 + 3 + 3
     g = r["group_api"]
     assert g["members"] == 2 and "host" in g["modes"] and g["count_matrix"]["scaling"] == "strong" and sum(g["count_matrix"]["shards_per_member"]) == 48
-    assert r["roofline"]["frac"] > 0 and "cpu_baseline" not in r  # (the CPU leg runs at N = 1 only)
+    # the CPU leg is part of EVERY line (same keys as at N = 1): rank 0 times it while the other ranks sleep
+    cb = r["cpu_baseline"]
+    assert r["roofline"]["frac"] > 0 and cb["kind"] == "port" and cb["unit"] == "set-ops/s" and cb["value"] > 0 and cb["cores"] >= 1
+    assert "rank 0" in cb["sample"] and cb["single_thread_set_ops_per_s"] > 0
