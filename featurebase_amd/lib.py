@@ -56,6 +56,18 @@ class MatrixArgs(C.Structure):
     ]
 
 
+class BsiArgs(C.Structure):
+    """Mirror of fbk_bsi_args (include/fbk.h): one group member's arguments of a BSI Sum."""
+
+    _fields_ = [("batch", C.c_void_p), ("base_rows", C.c_void_p), ("filter", C.c_void_p), ("rows_f", C.c_void_p), ("n_shards", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class TopnArgs(C.Structure):
+    """Mirror of fbk_topn_args (include/fbk.h): one group member's arguments of a TopN."""
+
+    _fields_ = [("a", C.c_void_p), ("rows_a", C.c_void_p), ("filter", C.c_void_p), ("rows_f", C.c_void_p), ("n_shards", C.c_uint32), ("pad", C.c_uint32)]
+
+
 REDUCE_HOST, REDUCE_PEER, REDUCE_RCCL = 0, 1, 2
 
 _vp, _u32p, _u64p, _i32p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
@@ -142,6 +154,8 @@ SIGNATURES = {
     "fbk_group_plan_intersection_count_total": (C.c_int32, [_vp, _vpp, _u64p]),
     "fbk_group_count_matrix": (C.c_int32, [_vp, C.POINTER(MatrixArgs), C.c_uint32, C.c_uint32, _vp]),
     "fbk_group_reduce_u64": (C.c_int32, [_vp, _vpp, C.c_uint64, _vp]),
+    "fbk_group_bsi_sum": (C.c_int32, [_vp, C.POINTER(BsiArgs), C.c_uint32, C.POINTER(C.c_int64), _u64p]),
+    "fbk_group_topn": (C.c_int32, [_vp, C.POINTER(TopnArgs), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint32, _u32p]),
     "fbk_group_last_error_r": (C.c_int32, [_vp, C.c_char_p, C.c_uint64, _i32p]),
 }
 

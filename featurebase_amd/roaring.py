@@ -746,6 +746,46 @@ class Group:
         L.check(self.lib.fbk_group_count_matrix(self.h, args, n_a, n_b, tot.ctypes.data))
         return tot
 
+    def bsi_sum(self, per_member: Sequence[Optional[dict]], bit_depth: int) -> Tuple[int, int]:
+        """per_member[m]: None or dict(batch=Batch, base_rows=[n_shards], filt=Batch|None, rows_f=[n_shards]).
+        Returns (sum, count) over every shard of every member (fbk_group_bsi_sum)."""
+        args = (L.BsiArgs * len(self.members))()
+        keep = []
+        for m, pm in enumerate(per_member):
+            if pm is None:
+                continue
+            base = np.ascontiguousarray(pm["base_rows"], dtype=np.uint32)
+            rf = np.ascontiguousarray(pm["rows_f"], dtype=np.uint32) if pm.get("filt") is not None else None
+            keep += [base, rf]
+            args[m].batch, args[m].base_rows = pm["batch"].h, base.ctypes.data
+            args[m].filter = pm["filt"].h if pm.get("filt") is not None else None
+            args[m].rows_f = rf.ctypes.data if rf is not None else None
+            args[m].n_shards = base.size
+        s, c = C.c_int64(), C.c_uint64()
+        L.check(self.lib.fbk_group_bsi_sum(self.h, args, bit_depth, C.byref(s), C.byref(c)))
+        return int(s.value), int(c.value)
+
+    def topn(self, per_member: Sequence[Optional[dict]], n_a: int, n: int = 0, min_threshold: int = 0, tanimoto_threshold: int = 0):
+        """per_member[m]: None or dict(a=Batch, rows_a=[n_shards, n_a], filt=Batch|None, rows_f=[n_shards]).
+        Returns (row indexes, counts) of the two-pass TopN over all members (fbk_group_topn)."""
+        args = (L.TopnArgs * len(self.members))()
+        keep = []
+        for m, pm in enumerate(per_member):
+            if pm is None:
+                continue
+            ra = np.ascontiguousarray(pm["rows_a"], dtype=np.uint32)
+            assert ra.ndim == 2 and ra.shape[1] == n_a
+            rf = np.ascontiguousarray(pm["rows_f"], dtype=np.uint32) if pm.get("filt") is not None else None
+            keep += [ra, rf]
+            args[m].a, args[m].rows_a = pm["a"].h, ra.ctypes.data
+            args[m].filter = pm["filt"].h if pm.get("filt") is not None else None
+            args[m].rows_f = rf.ctypes.data if rf is not None else None
+            args[m].n_shards = ra.shape[0]
+        cap = n_a
+        idx, cnt, got = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint64), C.c_uint32()
+        L.check(self.lib.fbk_group_topn(self.h, args, n_a, n, min_threshold, tanimoto_threshold, idx.ctypes.data, cnt.ctypes.data, cap, C.byref(got)))
+        return idx[: got.value].copy(), cnt[: got.value].copy()
+
     def reduce_u64(self, device_ptrs: Sequence[int], words: int) -> np.ndarray:
         arr = (C.c_void_p * len(self.members))(*[(p or None) for p in device_ptrs])
         out = np.zeros(words, dtype=np.uint64)

@@ -668,6 +668,41 @@ typedef struct fbk_matrix_args {
 int32_t fbk_group_count_matrix(fbk_group* group, const fbk_matrix_args* per_member, uint32_t n_a, uint32_t n_b,
                                uint64_t* out_total);
 
+/* Sum(field = v) over the shards of all members (executeSumCountShard, executor.go:2155, reduced by ValCount.Add
+ * :8438): per_member[m] are member m's arguments of fbk_bsi_sum (n_shards == 0: none of its shards), each member
+ * folds its shards on its device into {psum, nsum, count} and the three words are reduced over the members.
+ * *out_sum = int64(psum) - int64(nsum) with uint64 wrap-around (roaring/filter.go:1103-1108) = the sum of
+ * fbk_bsi_sum's out_sums over every shard of every member; *out_count likewise.  The caller adds count * Base. */
+typedef struct fbk_bsi_args {
+  const fbk_batch* batch;
+  const uint32_t* base_rows; /* [n_shards] */
+  const fbk_batch* filter;   /* may be NULL */
+  const uint32_t* rows_f;    /* [n_shards] */
+  uint32_t n_shards;
+  uint32_t pad;
+} fbk_bsi_args;
+int32_t fbk_group_bsi_sum(fbk_group* group, const fbk_bsi_args* per_member, uint32_t bit_depth, int64_t* out_sum,
+                          uint64_t* out_count);
+
+/* TopN over the shards of all members, in the reference's two passes (executeTopN, executor.go:2779-2827):
+ * (1) every member counts its shards as fbk_topn does and orders its own totals — its first n rows are its
+ * candidates (what a node returns to the coordinator, executeTopNShards :2829-2864); (2) the sorted union of the
+ * candidate row ids goes back to every member ("ids", :2814-2818), whose totals of exactly those rows are reduced
+ * over the members (Pairs.Add) in ONE collective of |candidates| words; the result is ordered count descending /
+ * row index ascending and trimmed to n (:2823-2825).  As in the reference, a row outside every member's local
+ * top n is not returned; n = 0 makes every row a candidate (exact).  per_member[m] are member m's arguments of
+ * fbk_topn; outputs as fbk_topn. */
+typedef struct fbk_topn_args {
+  const fbk_batch* a;
+  const uint32_t* rows_a;  /* [n_shards][n_a] */
+  const fbk_batch* filter; /* may be NULL */
+  const uint32_t* rows_f;  /* [n_shards] */
+  uint32_t n_shards;
+  uint32_t pad;
+} fbk_topn_args;
+int32_t fbk_group_topn(fbk_group* group, const fbk_topn_args* per_member, uint32_t n_a, uint32_t n, uint64_t min_threshold,
+                       uint64_t tanimoto_threshold, uint32_t* out_index, uint64_t* out_count, uint32_t cap, uint32_t* out_n);
+
 /* The reduce alone, for count-valued partials the caller produced with the member contexts (BSI
  * sums, TopK counts, fold counts): device_partials[m] = `words` uint64 on member m's device (NULL =
  * zeros), produced on member m's stream. */

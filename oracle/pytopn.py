@@ -144,3 +144,29 @@ def top_exact(shards: Sequence[Dict[int, Iterable[int]]], ids: Sequence[int], n:
                 tot[r] += count
     out = sorted([(r, c) for r, c in tot.items() if c], key=lambda p: (-p[1], p[0]))
     return out[:n] if n else out
+
+
+def top_two_pass(node_shards: Sequence[Sequence[Dict[int, Iterable[int]]]], ids: Sequence[int], n: int = 0,
+                 node_srcs: Optional[Sequence[Optional[Sequence[Iterable[int]]]]] = None, min_threshold: int = 0,
+                 tanimoto_threshold: int = 0) -> List[Tuple[int, int]]:
+    """executeTopN (executor.go:2779-2827) over several nodes, with the exact per-shard counting of top_exact in place of
+    the rank cache: node_shards[m] = the shards node m owns (node_srcs[m] their filter rows).
+      pass 1 (:2795): every node's answer is its own merged, sorted list (executeTopNShards :2829-2864) — here its first
+              n rows by (count descending, id ascending); a node without shards answers nothing;
+      ids    (:2814-2816): the keys of all answers, sorted;
+      pass 2 (:2818): every node's totals of exactly those ids (fragment.top does not truncate when ids are given,
+              fragment.go:1324-1327), added up over the nodes (Pairs.Add, cache.go:463), sorted, trimmed to n (:2823)."""
+    per_node = []
+    for m, shards in enumerate(node_shards):
+        if not shards:
+            per_node.append({})
+            continue
+        srcs = node_srcs[m] if node_srcs is not None else None
+        per_node.append(dict(top_exact(shards, ids, 0, srcs, min_threshold, tanimoto_threshold)))
+    cand = set()
+    for tot in per_node:
+        first = sorted(tot.items(), key=lambda p: (-p[1], p[0]))
+        cand.update(r for r, _ in (first[:n] if n else first))
+    merged = {r: sum(tot.get(r, 0) for tot in per_node) for r in sorted(cand)}
+    out = sorted([(r, c) for r, c in merged.items() if c], key=lambda p: (-p[1], p[0]))
+    return out[:n] if n else out

@@ -1,7 +1,7 @@
-# one gpurun call of round 3: STEPS is a space-separated list of step names (default: all)
+# one gpurun call of round 4: STEPS is a space-separated list of step names (default: all)
 set -x
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r3a}
+TAG=${TAG:-r4a}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -20,7 +20,7 @@ benchprof) (cd /tmp; export TMPDIR=/tmp; timeout 500 rocprofv3 --kernel-trace --
 pmc_pairs) KF=${KF:-icount}; bash scripts/fused_pmc.sh $TAG/pmc_v1 64 pair_kernels=1 pairs_pmc.py $KF > $O/pmc_pairs_v1.txt 2>&1; bash scripts/fused_pmc.sh $TAG/pmc_v2 64 pair_kernels=2,pair_spw=2 pairs_pmc.py $KF > $O/pmc_pairs_v2.txt 2>&1 ;;
 bsi_ahead) (for a in 3 4; do FBK_BSI_PLANES_AHEAD=$a timeout 200 python scripts/bsi_bench.py 2>&1 | grep -i "one pass\|half_waves\|Sum()" > $O/bsi_ahead$a.txt; done) ;;
 bsi) (timeout 200 python scripts/bsi_bench.py 2>&1 | grep -v amdgpu.ids > $O/bsi_bench.txt) ;;
-pmc_hbm) (cd /tmp; export TMPDIR=/tmp; BA="--steps 20 --warmup 2 --repeats 2 --no-cpu-baseline --cold-sets 1 --shards4 128 --shards4-total 0"; timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o b -- python $R/bench.py $BA > /dev/null 2>&1; timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o b -- python $R/bench.py $BA > /dev/null 2>&1; python3 $R/scripts/pmc_hbm_summary.py $O "bench.py $BA (round 3)" > $O/pmc_hbm_bytes.txt 2>&1) ;;
+pmc_hbm) (cd /tmp; export TMPDIR=/tmp; BA="--steps 20 --warmup 2 --repeats 2 --no-cpu-baseline --cold-sets 1 --shards4 128 --shards4-total 0"; timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o b -- python $R/bench.py $BA > /dev/null 2>&1; timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o b -- python $R/bench.py $BA > /dev/null 2>&1; python3 $R/scripts/pmc_hbm_summary.py $O "bench.py $BA (round 4)" > $O/pmc_hbm_bytes.txt 2>&1) ;;
 pmc_scatter) bash scripts/fused_pmc.sh $TAG/pmc_scatter 256 0 scatter_pmc.py ${KF:-k_} > $O/pmc_scatter.txt 2>&1 ;;
 fused) timeout 400 python scripts/fused_bench.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_bench.txt ;;
 fusedprof) timeout 300 python scripts/fused_prof.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_prof.txt ;;

@@ -171,3 +171,102 @@ def test_upload_does_not_trust_the_callers_cardinality(gpu_ctx):
     assert b.count([0, 1]).tolist() == [65536 + 20, int(np.bitwise_count(half).sum()) + 5]
     assert gpu_ctx.intersection_count(b, [0], b, [1]).tolist() == [int(np.bitwise_count(half).sum()) + 5]
     b.free()
+
+
+def test_group_bsi_sum_matches_the_sum_of_the_shards(gpu_ctx, oracle):
+    """fbk_group_bsi_sum: {psum, nsum, count} folded per member on its device and reduced over the members
+    (executeSumCountShard executor.go:2155, ValCount.Add :8438) == the oracle's fragment.sum added up over every shard."""
+    from oracle import pybsi as B
+    from test_gpu_queries import fbk_row_of_bitmap, upload_bsi
+
+    B._lib()
+    rng = D.rng_for(2240)
+    depth, n_shards, G = 64, 7, 3
+    frags, filts = [], []
+    for s in range(n_shards):
+        ncol = [30000, 2000, 150, 1 << 15, 5, 9000, 1][s]
+        cols = rng.choice(1 << 20, size=ncol, replace=False)
+        mag = rng.integers(0, 1 << 62, size=ncol) + rng.integers(0, 1000, size=ncol)
+        sign = np.where(rng.random(ncol) < 0.4, -1, 1)
+        frags.append(B.bsi_fragment_from_values({int(c): int(m) * int(g) for c, m, g in zip(cols, mag, sign)}, depth))
+        filts.append(B.row_from_columns([int(c) for c in cols[:: 2 + (s % 3)]] + [5, 70000]))
+    mask = (1 << 64) - 1
+
+    def wrap(v):  # int64 wrap-around of the reference's uint64 sums
+        v &= mask
+        return v - (1 << 64) if v >> 63 else v
+
+    grp = Group([0] * G)
+    keep = []
+    for use_f in (False, True):
+        per, e_sum, e_cnt = [], 0, 0
+        for m, c in enumerate(grp.members):
+            mine = list(range(m, n_shards, G))
+            batch, base = upload_bsi(c, [frags[s] for s in mine])
+            f = c.upload([fbk_row_of_bitmap(filts[s]) for s in mine]) if use_f else None
+            keep += [batch] + ([f] if f is not None else [])
+            per.append(dict(batch=batch, base_rows=base, filt=f, rows_f=np.arange(len(mine)) if use_f else None))
+        for s in range(n_shards):
+            es, ec = B.bsi_sum(frags[s], filts[s] if use_f else None, use_f)
+            e_sum, e_cnt = e_sum + es, e_cnt + ec
+        for mode in (L.REDUCE_HOST, L.REDUCE_PEER):
+            grp.set_reduce(mode)
+            assert grp.bsi_sum(per, depth) == (wrap(e_sum), e_cnt), (use_f, mode)
+        # a member without a shard of this query
+        es1 = sum(B.bsi_sum(frags[s], filts[s] if use_f else None, use_f)[0] for s in range(n_shards) if s % G != 1)
+        ec1 = sum(B.bsi_sum(frags[s], filts[s] if use_f else None, use_f)[1] for s in range(n_shards) if s % G != 1)
+        assert grp.bsi_sum([per[0], None, per[2]], depth) == (wrap(es1), ec1)
+    with pytest.raises(L.FbkError):
+        grp.bsi_sum(per, 65)
+    for b in keep:
+        b.free()
+    grp.close()
+
+
+def test_group_topn_two_passes(gpu_ctx):
+    """fbk_group_topn against the two-pass restatement of executeTopN (oracle/pytopn.top_two_pass): candidates = every
+    member's own first n rows, their totals reduced over the members; n = 0 is the exact TopN of all shards."""
+    from oracle import pytopn as T
+    from test_gpu_topn import row_of_columns
+
+    rng = np.random.default_rng(2241)
+    n_shards, n_a, G = 7, 48, 3
+    shards, srcs = [], []
+    for s in range(n_shards):
+        rows = {}
+        for r in range(n_a):
+            k = int(rng.integers(0, 4))
+            # member-dependent skew: the rows a member ranks first differ between the members
+            m = [0, int(rng.integers(1, 30)), int(rng.integers(100, 3000)), int(rng.integers(5000, 30000))][k] * (1 + ((r + s) % G == 0))
+            rows[r] = sorted(set(rng.integers(0, 1 << 17, m).tolist()))
+        shards.append(rows)
+        srcs.append(sorted(set(rng.integers(0, 1 << 17, 20000).tolist())))
+    grp = Group([0] * G)
+    per, keep, node_shards, node_srcs = [], [], [], []
+    for m, c in enumerate(grp.members):
+        mine = list(range(m, n_shards, G))
+        a = c.upload([row_of_columns(shards[s][r]) for s in mine for r in range(n_a)])
+        f = c.upload([row_of_columns(srcs[s]) for s in mine])
+        keep += [a, f]
+        per.append(dict(a=a, rows_a=np.arange(len(mine) * n_a).reshape(len(mine), n_a), filt=f, rows_f=np.arange(len(mine))))
+        node_shards.append([shards[s] for s in mine])
+        node_srcs.append([srcs[s] for s in mine])
+    nofilt = [dict(p, filt=None, rows_f=None) for p in per]
+    for mode in (L.REDUCE_HOST, L.REDUCE_PEER):
+        grp.set_reduce(mode)
+        for use_src in (True, False):
+            for mt, tt, n in [(0, 0, 0), (0, 0, 3), (0, 0, 1), (5, 0, 6), (300, 0, 0), (0, 20, 4), (0, 60, 0)]:
+                if tt and not use_src:
+                    continue
+                exp = T.top_two_pass(node_shards, list(range(n_a)), n, node_srcs if use_src else None, mt, tt)
+                idx, cnt = grp.topn(per if use_src else nofilt, n_a, n, mt, tt)
+                assert list(zip(idx.tolist(), [int(x) for x in cnt])) == exp, (mode, use_src, mt, tt, n)
+                if n == 0:  # every row a candidate: the exact TopN over all shards
+                    assert exp == T.top_exact(shards, list(range(n_a)), 0, srcs if use_src else None, mt, tt)
+    # a member that owns no shard of the query
+    exp = T.top_two_pass([node_shards[0], [], node_shards[2]], list(range(n_a)), 5, [node_srcs[0], None, node_srcs[2]])
+    idx, cnt = grp.topn([per[0], None, per[2]], n_a, 5)
+    assert list(zip(idx.tolist(), [int(x) for x in cnt])) == exp
+    for b in keep:
+        b.free()
+    grp.close()

@@ -48,3 +48,20 @@ def test_exact_specification_agrees_with_the_restatement():
         b = T.top_exact([rows], sorted(rows), 0, [src] if src is not None else None, mt, tt)
         assert sorted(a) == sorted(b), (trial, rows, src, mt, tt)
         assert [p[1] for p in a] == [p[1] for p in b]  # both are in descending count order
+
+
+def test_two_pass_topn_restatement():
+    """oracle/pytopn.top_two_pass (executeTopN, executor.go:2779-2827): with one node or n = 0 it is top_exact; with several
+    nodes a row that is in no node's own first n is lost — the reference's known approximation, reproduced on purpose."""
+    from oracle import pytopn as T
+
+    # node 0 ranks row 0 first, node 1 ranks row 1 first; row 2 is second on both and has the largest total
+    n0 = [{0: range(10), 1: range(1), 2: range(9)}]
+    n1 = [{0: range(1), 1: range(10), 2: range(9)}]
+    ids = [0, 1, 2]
+    assert T.top_exact(n0 + n1, ids, 1) == [(2, 18)]
+    assert T.top_two_pass([n0, n1], ids, 1) == [(0, 11)]  # candidates {0, 1}: totals 11, 11 -> id ascending
+    assert T.top_two_pass([n0, n1], ids, 2) == [(2, 18), (0, 11)]
+    assert T.top_two_pass([n0, n1], ids, 0) == T.top_exact(n0 + n1, ids, 0)
+    assert T.top_two_pass([n0 + n1], ids, 1) == T.top_exact(n0 + n1, ids, 1)
+    assert T.top_two_pass([n0, []], ids, 2) == T.top_exact(n0, ids, 2)
