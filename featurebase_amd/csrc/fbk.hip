@@ -78,6 +78,7 @@ inline uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
 struct FbkOptions {
   int64_t dense_spb = 16;                // slots per block of k_icount_dense: 1|2|4|8|16
   int64_t fold_register = 0;             // 1: register-accumulating fold kernel for every op (A/B runs)
+  int64_t fold_encode = 1;               // n-way Union / Xor / Difference + optimize(): 1 encode in the fold kernel's epilogue, 0 the separate re-encode pass (cross-check)
   int64_t matrix_valu = 0;               // 1: vector-ALU count-matrix kernel instead of the matrix cores (A/B runs)
   int64_t matrix_spb = 0;                // slots per block of the dense count matrix; 0 = chosen per launch
   int64_t matrix_pass_kb = 1 << 20;      // per-shard matrices are produced in passes of at most this many KiB
@@ -638,6 +639,7 @@ struct OptionDesc {
 const OptionDesc kOptions[] = {
     {"dense_spb", &FbkOptions::dense_spb, 1, 16},
     {"fold_register", &FbkOptions::fold_register, 0, 1},
+    {"fold_encode", &FbkOptions::fold_encode, 0, 1},
     {"matrix_valu", &FbkOptions::matrix_valu, 0, 1},
     {"matrix_spb", &FbkOptions::matrix_spb, 0, 16},
     {"matrix_pass_kb", &FbkOptions::matrix_pass_kb, 1, int64_t(1) << 40},

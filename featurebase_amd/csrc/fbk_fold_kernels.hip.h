@@ -149,7 +149,13 @@ __device__ __forceinline__ void scatter_big(const uint8_t* __restrict__ p, uint3
   }
 }
 
-template <int OP, bool WRITE>
+// WRITE: 0 counts only; 1 the result as an 8 KiB bitmap cell (+ its run count for a later optimize pass);
+// 2 Container.optimize() in the epilogue (roaring.go:3412-3461): the block knows N and the run count of its
+// result, picks the encoding by optimize()'s rule, stages arrays / run lists in the (now free) LDS accumulator
+// and writes exactly the encoded bytes into the head of the cell — no second pass over the cells, no scan, no
+// compaction, no host round trip (the separate re-encode pass cost 150 of the 270 us of a materialised
+// Union-of-64 + optimize() on 256 shards).  Cells stay at their 8 KiB stride in the output arena.
+template <int OP, int WRITE>
 __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
                                                      const uint32_t* __restrict__ rows, uint64_t n_groups, uint32_t k,
                                                      const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,
@@ -161,6 +167,7 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
   __shared__ u64 aux[kWords];  // decode scratch for the filter row and for r0 of a difference
   __shared__ uint32_t s_short;
   __shared__ uint32_t s_cnt[3][4];
+  __shared__ uint32_t s_scan[2][4];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
     cf = __popcll(w[0] & pf[0]) + __popcll(w[1] & pf[1]) + __popcll(w[2] & pf[2]) + __popcll(w[3] & pf[3]);
   }
   uint32_t rr = 0;
-  if (WRITE && outRuns) {
+  if (WRITE == 2 || (WRITE && outRuns)) {
     // bitmapCountRuns (roaring.go:3372-3380): predecessor of a chunk's first bit is the top
     // bit of the previous chunk — publish the result and read the neighbour's last word
     __syncthreads();
@@ -414,7 +421,90 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
   __syncthreads();
   const uint32_t tot_u = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
   const uint32_t tot_f = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
-  if (WRITE) {
+  if (WRITE == 2) {
+    const uint32_t tot_r = s_cnt[2][0] + s_cnt[2][1] + s_cnt[2][2] + s_cnt[2][3];
+    // optimize() (roaring.go:3412-3461): nil when empty; runs when runs <= 2048 and runs <= N / 2; an array when N < 4096; else the bitmap
+    const uint32_t enc = tot_u == 0 ? kTypeNil : (tot_r <= 2048u && tot_r <= tot_u / 2u) ? kTypeRun : tot_u < 4096u ? kTypeArray : kTypeBitmap;
+    Slot so;
+    so.off = enc == kTypeNil ? 0ull : cell * 8192ull;
+    so.len = 0;
+    so.tn = make_tn(enc, tot_u);
+    uint8_t* dst = arenaO + cell * 8192ull;
+    if (enc == kTypeBitmap) {
+      ulonglong2* q = reinterpret_cast<ulonglong2*>(dst);
+      ulonglong2 v0, v1;
+      v0.x = w[0];
+      v0.y = w[1];
+      v1.x = w[2];
+      v1.y = w[3];
+      st_stream(&q[t], v0);
+      st_stream(&q[256 + t], v1);
+      so.len = kWords;
+    } else if (enc != kTypeNil) {
+      // the encoded payload is staged in the accumulator (8 KiB: 4095 values or 2048 intervals fit; every thread read its
+      // part of it before the barriers of the count reduction) in value order: the first halves of all threads (words
+      // 2t, 2t+1), then the second halves (words 512+2t, 513+2t).  Counts travel as two 16-bit fields of one scan.
+      uint16_t* st16 = reinterpret_cast<uint16_t*>(acc);
+      const uint32_t v0 = 128u * (uint32_t)t, v1 = 32768u + 128u * (uint32_t)t;  // value of bit 0 of w[0] / w[2]
+      u64 a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];  // array: the values themselves; runs: the run starts
+      u64 e0 = 0, e1 = 0, e2 = 0, e3 = 0;              // runs: the run ends
+      if (enc == kTypeRun) {
+        // (aux holds the published result: the neighbours' boundary bits)
+        const u64 l0 = t ? (aux[2 * t - 1] >> 63) : 0ull, l1 = aux[512 + 2 * t - 1] >> 63;
+        const u64 n0 = aux[2 * t + 2] & 1ull, n1 = t < 255 ? (aux[512 + 2 * t + 2] & 1ull) : 0ull;
+        a0 = w[0] & ~((w[0] << 1) | l0);
+        a1 = w[1] & ~((w[1] << 1) | (w[0] >> 63));
+        a2 = w[2] & ~((w[2] << 1) | l1);
+        a3 = w[3] & ~((w[3] << 1) | (w[2] >> 63));
+        e0 = w[0] & ~((w[0] >> 1) | ((w[1] & 1ull) << 63));
+        e1 = w[1] & ~((w[1] >> 1) | (n0 << 63));
+        e2 = w[2] & ~((w[2] >> 1) | ((w[3] & 1ull) << 63));
+        e3 = w[3] & ~((w[3] >> 1) | (n1 << 63));
+      }
+      const uint32_t ca = (uint32_t)(__popcll(a0) + __popcll(a1)) | ((uint32_t)(__popcll(a2) + __popcll(a3)) << 16);
+      const uint32_t ce = (uint32_t)(__popcll(e0) + __popcll(e1)) | ((uint32_t)(__popcll(e2) + __popcll(e3)) << 16);
+      const uint32_t ia = wave_incl_scan(ca), ie = wave_incl_scan(ce);
+      if (lane == 63) {
+        s_scan[0][wv] = ia;
+        s_scan[1][wv] = ie;
+      }
+      __syncthreads();
+      uint32_t wa = 0, we = 0, ta = 0, te = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < wv) wa += s_scan[0][k], we += s_scan[1][k];
+        ta += s_scan[0][k], te += s_scan[1][k];
+      }
+      const uint32_t xa = wa + ia - ca, xe = we + ie - ce;  // exclusive, per field
+      uint32_t pa0 = xa & 0xFFFFu, pa1 = (ta & 0xFFFFu) + (xa >> 16);
+      uint32_t pe0 = xe & 0xFFFFu, pe1 = (te & 0xFFFFu) + (xe >> 16);
+      const uint32_t stride = enc == kTypeRun ? 2u : 1u;  // intervals: start at 2k, last at 2k + 1
+      auto emit = [&](u64 bits, uint32_t base, uint32_t& at, uint32_t odd) {
+        while (bits) {
+          st16[stride * (at++) + odd] = (uint16_t)(base + (uint32_t)__builtin_ctzll(bits));
+          bits &= bits - 1;
+        }
+      };
+      emit(a0, v0, pa0, 0u);
+      emit(a1, v0 + 64u, pa0, 0u);
+      emit(a2, v1, pa1, 0u);
+      emit(a3, v1 + 64u, pa1, 0u);
+      if (enc == kTypeRun) {
+        emit(e0, v0, pe0, 1u);
+        emit(e1, v0 + 64u, pe0, 1u);
+        emit(e2, v1, pe1, 1u);
+        emit(e3, v1 + 64u, pe1, 1u);
+      }
+      __syncthreads();
+      so.len = enc == kTypeRun ? tot_r : tot_u;
+      const uint32_t chunks = ((enc == kTypeRun ? 4u * tot_r : 2u * tot_u) + 15u) >> 4;  // <= 512
+      const ulonglong2* src = reinterpret_cast<const ulonglong2*>(acc);
+      ulonglong2* q = reinterpret_cast<ulonglong2*>(dst);
+      if ((uint32_t)t < chunks) st_stream(&q[t], src[t]);
+      if (256u + (uint32_t)t < chunks) st_stream(&q[256 + t], src[256 + t]);
+    }
+    if (t == 0) outSlots[cell] = so;
+  } else if (WRITE) {
     Slot so;
     so.off = cell * 8192ull;
     so.len = kWords;

@@ -142,6 +142,10 @@ SIGNATURES = {
     "fbk_query_count_matrix": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, _vpp]),
     "fbk_query_fold_intersection_count": (C.c_int32, [_vp, C.c_int32, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp, _vpp]),
     "fbk_query_bsi_sum": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int64, _vp, _vp, _vpp]),
+    "fbk_query_bsi_range": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_uint32, C.c_int64, _vpp]),
+    "fbk_query_fold": (C.c_int32, [_vp, C.c_int32, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vpp]),
+    "fbk_query_topn": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _vpp]),
+    "fbk_query_output": (C.c_int32, [_vp, _vp, _vpp]),
     "fbk_query_run": (C.c_int32, [_vp, _vp, _vp, C.c_uint32]),
     "fbk_query_result": (C.c_int32, [_vp, _vp, _vpp, _u64p]),
     "fbk_query_read": (C.c_int32, [_vp, _vp, _vp, _vp]),

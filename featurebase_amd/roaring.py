@@ -209,13 +209,27 @@ class Query:
             ps = np.zeros((n_shards, n_a, n_b), dtype=np.uint64) if per_shard else None
             L.check(self.ctx.lib.fbk_query_read(self.ctx.h, self.h, tot.ctypes.data, ps.ctypes.data if ps is not None else None))
             return (tot, ps) if per_shard else tot
-        if self.kind == "fold":
+        if self.kind in ("fold", "rows"):  # counts per group / cardinalities of the result rows
             out = np.zeros(self.shape[0], dtype=np.uint64)
             L.check(self.ctx.lib.fbk_query_read(self.ctx.h, self.h, out.ctypes.data, None))
             return out
+        if self.kind == "topn":  # (row indexes, counts) of the results
+            cap = self.shape[0]
+            idx, cnt = np.zeros(1 + cap, dtype=np.uint32), np.zeros(max(cap, 1), dtype=np.uint64)
+            L.check(self.ctx.lib.fbk_query_read(self.ctx.h, self.h, idx.ctypes.data, cnt.ctypes.data))
+            r = int(idx[0])
+            return idx[1 : 1 + r].copy(), cnt[:r].copy()
         sums, counts = np.zeros(self.shape[0], dtype=np.int64), np.zeros(self.shape[0], dtype=np.uint64)
         L.check(self.ctx.lib.fbk_query_read(self.ctx.h, self.h, sums.ctypes.data, counts.ctypes.data))
         return sums, counts
+
+    def output(self) -> "Batch":
+        """The output batch of the last run (row-valued queries): BORROWED — do not free, valid until the next run."""
+        h = C.c_void_p()
+        L.check(self.ctx.lib.fbk_query_output(self.ctx.h, self.h, C.byref(h)))
+        b = Batch(self.ctx, h.value)
+        b.borrowed = True
+        return b
 
     def free(self) -> None:
         if self.h:
@@ -583,6 +597,29 @@ class Context:
         L.check(self.lib.fbk_query_bsi_sum(self.h, batch.h, base.ctypes.data, base.size, bit_depth, op, C.c_int64(predicate), filt.h if filt is not None else None,
                                            rf.ctypes.data if rf is not None else None, C.byref(h)))
         return Query(self, h.value, "bsi", (base.size,))
+
+    def prepare_bsi_range(self, batch: Batch, base_rows, op: int, bit_depth: int, predicate: int) -> Query:
+        """Row(v op predicate) with the result rows kept on the device (Query.output()); read() = their cardinalities"""
+        base = np.ascontiguousarray(base_rows, dtype=np.uint32)
+        h = C.c_void_p()
+        L.check(self.lib.fbk_query_bsi_range(self.h, batch.h, base.ctypes.data, base.size, op, bit_depth, C.c_int64(predicate), C.byref(h)))
+        return Query(self, h.value, "rows", (base.size,))
+
+    def prepare_fold(self, op: int, batch: Batch, groups, flags: int = 0) -> Query:
+        """The materialised n-way Union / Xor / Difference (fbk_fold_n) as a launch-only query; read() = cardinalities"""
+        g = np.ascontiguousarray(groups, dtype=np.uint32)
+        h = C.c_void_p()
+        L.check(self.lib.fbk_query_fold(self.h, op, batch.h, g.ctypes.data, g.shape[0], g.shape[1], flags, C.byref(h)))
+        return Query(self, h.value, "rows", (g.shape[0],))
+
+    def prepare_topn(self, a: Batch, rows_a, n: int = 0, filt: Optional[Batch] = None, rows_f=None, min_threshold: int = 0, tanimoto_threshold: int = 0) -> Query:
+        ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
+        n_shards, n_a = ra.shape
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        h = C.c_void_p()
+        L.check(self.lib.fbk_query_topn(self.h, a.h, ra.ctypes.data, n_a, filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None, n_shards, n,
+                                        min_threshold, tanimoto_threshold, C.byref(h)))
+        return Query(self, h.value, "topn", (min(n, n_a) if n else n_a,))
 
     # -- BSI -----------------------------------------------------------------------------
     def bsi_sum(self, batch: Batch, base_rows, bit_depth: int, filt: Optional[Batch] = None, rows_f=None):

@@ -372,7 +372,24 @@ int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_bat
  *   fbk_query_read(q, out0, out1)       synchronise; copy the last run's result to the host:
  *                                       count matrix: out0 = total [n_a * n_b] uint64, out1 = per-shard
  *                                       [n_shards][n_a * n_b] (or NULL); fold: out0 = counts [n_groups];
- *                                       BSI: out0 = int64 sums [n_shards], out1 = uint64 counts [n_shards]. */
+ *                                       BSI: out0 = int64 sums [n_shards], out1 = uint64 counts [n_shards].
+ *
+ * Queries with a ROW result keep the rows on the device too (round 4: the one-shot forms paid 40-80 us of
+ * host work around a 130 us kernel for allocating the output batch, uploading the plane program and
+ * downloading descriptors that nobody reads when the rows only feed the next operator):
+ *   fbk_query_bsi_range                 Row(v op predicate), fragment.rangeOp (fragment.go:937-1303), arguments
+ *                                       as fbk_bsi_range (8 KiB cells).  run = memset + k_bsi_range_slot;
+ *                                       read: out0 = uint64 cardinalities [n_shards]
+ *   fbk_query_fold                      the materialised n-way Union / Xor / Difference (fbk_fold_n; flags =
+ *                                       FBK_SETOP_OPTIMIZE: Container.optimize() in the kernel's epilogue).
+ *                                       run = memset + ONE launch; read: out0 = uint64 cardinalities [n_groups]
+ *   fbk_query_output(q, &batch)         the output batch of the last run, BORROWED: owned by the query, rewritten
+ *                                       by its next run, freed with it.  A valid operand of any later call on the
+ *                                       same context (the filter of fbk_bsi_sum / fbk_query_bsi_sum, a plan's row).
+ *   fbk_query_topn                      fbk_topn with the per-shard counts, the totals AND the ordering (device
+ *                                       radix sort, scratch sized at prepare) launch-only; read: out0 = uint32
+ *                                       {number of results r, r row indexes} (capacity 1 + min(n, n_a), n = 0:
+ *                                       1 + n_a), out1 = uint64 counts [r].  device_out must be NULL. */
 typedef struct fbk_query fbk_query;
 #define FBK_QUERY_ACCUMULATE 1u
 int32_t fbk_query_count_matrix(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a, const fbk_batch* b,
@@ -382,6 +399,14 @@ int32_t fbk_query_fold_intersection_count(fbk_ctx* ctx, int32_t op, const fbk_ba
                                           uint32_t k, const fbk_batch* filter, const uint32_t* rows_f, fbk_query** out_query);
 int32_t fbk_query_bsi_sum(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards, uint32_t bit_depth,
                           int32_t op, int64_t predicate, const fbk_batch* filter, const uint32_t* rows_f, fbk_query** out_query);
+int32_t fbk_query_bsi_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* base_rows, uint32_t n_shards, int32_t op,
+                            uint32_t bit_depth, int64_t predicate, fbk_query** out_query);
+int32_t fbk_query_fold(fbk_ctx* ctx, int32_t op, const fbk_batch* batch, const uint32_t* rows, uint64_t n_groups, uint32_t k,
+                       uint32_t flags, fbk_query** out_query);
+int32_t fbk_query_topn(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a, const fbk_batch* filter,
+                       const uint32_t* rows_f, uint32_t n_shards, uint32_t n, uint64_t min_threshold, uint64_t tanimoto_threshold,
+                       fbk_query** out_query);
+int32_t fbk_query_output(fbk_ctx* ctx, fbk_query* query, fbk_batch** out_batch);
 int32_t fbk_query_run(fbk_ctx* ctx, fbk_query* query, void* device_out, uint32_t flags);
 int32_t fbk_query_result(fbk_ctx* ctx, fbk_query* query, void** out_device_ptr, uint64_t* out_bytes);
 int32_t fbk_query_read(fbk_ctx* ctx, fbk_query* query, void* out0, void* out1);

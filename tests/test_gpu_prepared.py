@@ -146,3 +146,118 @@ def test_prepared_query_argument_errors(gpu_ctx, mixed):
     other.close()
     q.free()
     batch.free()
+
+
+def _words_of(batch):
+    """bit content of every row of a batch: [n_rows, 16, 1024] uint64"""
+    rows = batch.download()
+    w = np.zeros((len(rows), 16, 1024), dtype=np.uint64)
+    for r, row in enumerate(rows):
+        for k, c in row.items():
+            w[r, k & 15] = c.words()
+    return w
+
+
+def test_prepared_bsi_range_rows_stay_on_the_device(gpu_ctx):
+    """fbk_query_bsi_range: Row(v op k) as a launch-only query whose result rows feed the next operator without leaving the
+    device — Range(> k) then Sum(filter = that row), BASELINE config 5's pipeline, both prepared."""
+    n_shards, depth = 6, 20
+    rng = D.rng_for(8401)
+    w = rng.integers(0, 2**64, (n_shards, depth + 2, 16, 1024), dtype=np.uint64)
+    w[:, 0] |= rng.integers(0, 2**64, (n_shards, 16, 1024), dtype=np.uint64)
+    w[-1, 0, 9:] = 0
+    w[:, 1:] &= w[:, :1]
+    batch = gpu_ctx.upload_dense(w.reshape(-1))
+    OA = PB.RowSet.from_dense(w.reshape(-1, 16, 1024))
+    base, idx = np.arange(n_shards) * (depth + 2), np.arange(n_shards)
+    for op, pred in ((L.BSI_GT, 4321), (L.BSI_LTE, -99), (L.BSI_EQ, 77), (L.BSI_NEQ, 0), (L.BSI_LT, -(1 << 30)), (L.BSI_GTE, 0)):
+        R, ecnt = PB.bsi_range(OA, base, depth, op, pred)
+        q = gpu_ctx.prepare_bsi_range(batch, base, op, depth, pred)
+        with pytest.raises(L.FbkError):
+            q.output()  # no run yet
+        for _ in range(2):  # every run rewrites the same output batch
+            q.run()
+        assert (q.read() == ecnt).all(), (op, pred)
+        out = q.output()
+        assert (_words_of(out) == R.words()).all(), (op, pred)
+        # the borrowed rows as the filter of a prepared Sum and of the one-shot call
+        es, ec = PB.bsi_sum(OA, base, depth, R, idx)
+        s, c = gpu_ctx.bsi_sum(batch, base, depth, out, idx)
+        assert (s == es).all() and (c == ec).all(), (op, pred)
+        qs = gpu_ctx.prepare_bsi_sum(batch, base, depth, filt=out, rows_f=idx)
+        q.run()
+        qs.run()
+        s, c = qs.read()
+        assert (s == es).all() and (c == ec).all(), (op, pred)
+        # the one-shot call agrees
+        o1, c1 = gpu_ctx.bsi_range(batch, base, op, depth, pred)
+        assert (c1 == ecnt).all() and (_words_of(o1) == R.words()).all()
+        o1.free()
+        qs.free()
+        q.free()
+    with pytest.raises(L.FbkError):
+        gpu_ctx.prepare_bsi_range(batch, base, 9, depth, 1)  # ErrInvalidRangeOperation
+    with pytest.raises(L.FbkError):
+        gpu_ctx.prepare_bsi_range(batch, base + 10**6, L.BSI_GT, depth, 1)
+    batch.free()
+
+
+@pytest.mark.parametrize("flags", [0, L.SETOP_OPTIMIZE])
+def test_prepared_fold_materialised(gpu_ctx, mixed, flags):
+    """fbk_query_fold: Union / Xor / Difference of k rows per group, the result rows kept on the device; with FBK_SETOP_OPTIMIZE
+    the descriptors and payload bytes equal the one-shot fbk_fold_n's."""
+    rows, g, filt, OA, OF = mixed
+    batch = gpu_ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
+    eu, ucnt = PB.union_n(OA, g)
+    q = gpu_ctx.prepare_fold(L.OP_OR, batch, g, flags)
+    for _ in range(2):
+        q.run()
+    assert (q.read() == ucnt).all()
+    out = q.output()
+    assert (_words_of(out) == eu.words()).all()
+    for op in (L.OP_OR, L.OP_XOR, L.OP_ANDNOT):
+        qq = gpu_ctx.prepare_fold(op, batch, g[:, :5], flags)
+        qq.run()
+        o1, c1 = gpu_ctx.fold_n(op, batch, g[:, :5], flags)
+        assert (qq.read() == c1).all()
+        d0, p0, _ = qq.output().download_flat()
+        d1, p1, _ = o1.download_flat()
+        assert d0.tobytes() == d1.tobytes() and p0.tobytes() == p1.tobytes(), op
+        assert qq.output().to_roaring() == o1.to_roaring()
+        o1.free()
+        qq.free()
+    q.free()
+    with pytest.raises(L.FbkError):
+        gpu_ctx.prepare_fold(L.OP_AND, batch, g, flags)
+    batch.free()
+
+
+def test_prepared_topn_orders_on_the_device(gpu_ctx, mixed):
+    """fbk_query_topn against the one-shot fbk_topn (both ordering paths of which are tied to the oracle in test_gpu_topn.py)
+    and the oracle's per-shard counts: thresholds, n, with and without a source row, repeated runs."""
+    rows, g, filt, OA, OF = mixed
+    n = g.shape[0]
+    batch = gpu_ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
+    F = gpu_ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
+    fidx = np.arange(n)
+    exp_counts = PB.topk_counts(OA, g, OF, fidx).sum(axis=0)
+    for use_f in (True, False):
+        for top, mt, tt in ((0, 0, 0), (5, 0, 0), (1, 0, 0), (0, 3000, 0), (4, 0, 30), (0, 0, 90)):
+            if tt and not use_f:
+                continue
+            fa = (F, fidx) if use_f else (None, None)
+            e_idx, e_cnt = gpu_ctx.topn(batch, g, top, *fa, min_threshold=mt, tanimoto_threshold=tt)
+            q = gpu_ctx.prepare_topn(batch, g, top, *fa, min_threshold=mt, tanimoto_threshold=tt)
+            for _ in range(2):
+                q.run()
+            idx, cnt = q.read()
+            assert idx.tolist() == e_idx.tolist() and cnt.tolist() == e_cnt.tolist(), (use_f, top, mt, tt)
+            if use_f and not mt and not tt:
+                assert all(int(c) == int(exp_counts[i]) for i, c in zip(idx, cnt))
+                if top == 0:
+                    assert len(idx) == int((exp_counts != 0).sum())
+            q.free()
+    with pytest.raises(L.FbkError):
+        gpu_ctx.prepare_topn(batch, g, 3, F, fidx, tanimoto_threshold=101)
+    batch.free()
+    F.free()

@@ -1278,3 +1278,81 @@ def test_bsi_add_reference_cases(gpu_ctx, oracle):
         assert got == {p: x + y for p, x, y in zip(pos, a, b) if x + y}, g
     for bt in (out, X, Y):
         bt.free()
+
+
+def test_fold_optimize_in_the_epilogue_equals_the_separate_pass(gpu_ctx, oracle):
+    """Union / Xor / Difference of k rows + optimize(): the fold kernel's own epilogue (option fold_encode=1, the default) and
+    the separate re-encode pass over 8 KiB cells (fold_encode=0) produce the same descriptors and payload bytes — and the
+    same Pilosa-roaring image (Bitmap.WriteTo, roaring.go:1730-1817) — and every container has optimize()'s encoding of the
+    oracle's result.  Rows are chosen to land on every outcome: nil, short / long arrays (incl. 4095 values), run lists of
+    1 .. 2048 intervals (incl. runs spanning the two halves of a cell and runs ending at 65535), bitmaps, full containers."""
+    O = oracle
+    rng = D.rng_for(4242)
+
+    def cont(kind):
+        if kind == "full":
+            return O.OContainer.run([(0, 65535)])
+        if kind == "runs":
+            nr = int(rng.choice([1, 2, 7, 64, 700, 2048]))
+            per = 65536 // nr
+            st = np.arange(nr) * per + rng.integers(0, max(1, per // 3), nr)
+            ln = rng.integers(1, max(2, per // 2), nr)
+            return O.OContainer.run([(int(s), int(min(s + l, 65535))) for s, l in zip(st, ln)])
+        if kind == "edge":  # a run across the middle of the cell and one up to the last value
+            return O.OContainer.run([(32700, 32900), (65500, 65535)])
+        if kind == "arr":
+            n = int(rng.choice([1, 5, 300, 2047, 4095]))
+            return O.OContainer.array(np.sort(rng.choice(65536, n, replace=False)))
+        return O.OContainer.bitmap(D.words_of(np.sort(rng.choice(65536, int(rng.choice([5000, 30000, 65000])), replace=False))))
+
+    kinds = ["full", "runs", "edge", "arr", "bm", "runs", "arr"]
+    n_groups, k = 12, 5
+    rows, groups = [], []
+    for g in range(n_groups):
+        ids = []
+        for _ in range(k):
+            row = {}
+            for s in range(16):
+                if rng.random() < 0.25:
+                    continue
+                # groups 0-3: sparse operands only (array / run results); others: everything
+                kind = kinds[int(rng.integers(3 if g < 4 else 0, len(kinds)))] if g >= 4 else ["arr", "runs", "edge"][int(rng.integers(0, 3))]
+                row[g * 16 + s] = cont(kind)
+            ids.append(len(rows))
+            rows.append(row)
+        groups.append(ids)
+    groups = np.array(groups, dtype=np.uint32)
+    batch = gpu_ctx.upload([D.to_fbk_row(r) for r in rows])
+
+    def fold(op, bms):
+        if op == L.OP_OR:
+            return bms[0].union(*bms[1:])
+        if op == L.OP_ANDNOT:
+            return bms[0].difference(*bms[1:])
+        acc = bms[0]
+        for b in bms[1:]:
+            acc = acc.xor(b)
+        return acc
+
+    try:
+        for op in (L.OP_OR, L.OP_XOR, L.OP_ANDNOT):
+            got = {}
+            for mode in (1, 0):
+                gpu_ctx.set_option("fold_encode", mode)
+                out, cnt = gpu_ctx.fold_n(op, batch, groups, L.SETOP_OPTIMIZE)
+                d, p, n_rows = out.download_flat()
+                got[mode] = (d.copy(), p.copy(), cnt.copy(), out.to_roaring(), out.download())
+                out.free()
+            (d1, p1, c1, img1, res1), (d0, p0, c0, img0, _) = got[1], got[0]
+            assert (c1 == c0).all() and d1.tobytes() == d0.tobytes() and p1.tobytes() == p0.tobytes() and img1 == img0, op
+            types = set()
+            for g, ids in enumerate(groups):
+                exp = fold(op, [O.OBitmap.from_containers(list(rows[i].items())) for i in ids])
+                assert int(c1[g]) == exp.count(), (op, g)
+                assert (row_words(res1[g]) == bitmap_words(exp)).all(), (op, g)
+                assert_optimized_like_oracle(O, res1[g], exp)
+                types |= {c.typ for c in res1[g].values()}
+            assert types >= {L.TYPE_ARRAY, L.TYPE_BITMAP, L.TYPE_RUN}, (op, types)  # every encoding was produced
+    finally:
+        gpu_ctx.set_option("fold_encode", 1)
+    batch.free()
