@@ -46,7 +46,7 @@ def test_the_hand_counted_kernels_are_in_the_binary(kernels):
     for k in ("k_bsi_range_sum_halfILb0ELi3", "k_bsi_range_sum_halfILb1ELi4", "k_bsi_between_sum_partILi8ELi3", "k_bsi_between_sum_partILi8ELi4", "k_fold_scatterILi1", "k_rows_vs_filter"):
         assert k in names, k
     # and they do contain hand-written waits with loads in flight behind them
-    for k in ("k_bsi_range_sum_halfILb0ELi3", "k_fold_scatterILi1ELb0"):
+    for k in ("k_bsi_range_sum_halfILb0ELi3", "k_fold_scatterILi1ELi0"):
         insns = next(v for n, v in funcs.items() if k in n)
         assert any(i.kind == "wait" and i.vm_wait not in (None, 0) for i in insns), k
 
