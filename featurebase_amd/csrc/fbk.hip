@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -98,6 +99,8 @@ struct FbkOptions {
   int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)
   int64_t bsi_half_waves = 1;            // dense BSI batches: the one-pass Range + Sum runs half a container per wavefront; 0: one wavefront per container (A/B runs)
   int64_t bsi_planes_ahead = 3;          // one-pass BSI kernels on dense batches: planes in flight per wavefront (3 or 4)
+  int64_t upload_threads = 0;            // host threads that fill the pinned upload buffers (0: min(8, cores / 2))
+  int64_t upload_chunk_mb = 64;          // size of each of the two pinned upload buffers
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
@@ -145,6 +148,11 @@ struct fbk_ctx {
   // uses it synchronises the stream before returning).
   uint8_t* h_stage = nullptr;
   uint64_t h_stage_cap = 0, h_stage_used = 0;
+  // Bulk uploads (fbk_batch_upload / _dense): two pinned buffers, one being filled by host threads while the other's DMA
+  // runs (staged_h2d).  Allocated on the first bulk upload, kept for the context's lifetime.
+  uint8_t* up_ring[2] = {nullptr, nullptr};
+  hipEvent_t up_ev[2] = {nullptr, nullptr};
+  uint64_t up_cap = 0;
   // option time_kernels: events around the dominant kernel of the last query-level call
   hipEvent_t kt0 = nullptr, kt1 = nullptr;
   bool kt_armed = false;
@@ -659,6 +667,8 @@ const OptionDesc kOptions[] = {
     {"bsi_range_sum_two_pass", &FbkOptions::bsi_range_sum_two_pass, 0, 1},
     {"bsi_half_waves", &FbkOptions::bsi_half_waves, 0, 1},
     {"bsi_planes_ahead", &FbkOptions::bsi_planes_ahead, 3, 4},
+    {"upload_threads", &FbkOptions::upload_threads, 0, 64},
+    {"upload_chunk_mb", &FbkOptions::upload_chunk_mb, 1, 1024},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
@@ -759,6 +769,10 @@ int32_t fbk_close(fbk_ctx* ctx) {
   if (!ctx->root) cache_release_all(ctx);
   pool_release_all(ctx);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->up_ring[k]) (void)hipHostFree(ctx->up_ring[k]);
+    if (ctx->up_ev[k]) (void)hipEventDestroy(ctx->up_ev[k]);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->root) ctx->root->children.fetch_sub(1);
   delete ctx;
@@ -828,7 +842,68 @@ int32_t fbk_batch_free(fbk_ctx* ctx, fbk_batch* b) {
   return FBK_OK;
 }
 
-static int32_t validate_container(const fbk_container_desc& d, const uint8_t* payload, uint64_t payload_len,
+// ---- bulk host -> device copies -----------------------------------------------------------------------------------
+// `total` bytes of an image the caller describes by fill(off, len, dst): "write bytes [off, off + len) of the image to dst".
+// The image goes through two pinned buffers: while the DMA of one runs, a few host threads fill the other (each its own
+// slice, so fill must be safe to call concurrently on disjoint ranges).  hipMemcpy from pageable memory stages through the
+// runtime's own bounce buffers on ONE thread: 1.3 GB/s for the 581 MB of config 3's rows when the host-side validation and
+// the assembly of the arena were counted in, 7.9 GB/s for a plain 256 MiB copy (round-3 bench line).  Leaves the copies
+// enqueued on the context's stream; the caller synchronises.
+extern "C++" {
+template <class Fill>
+hipError_t staged_h2d(fbk_ctx* ctx, uint8_t* d_dst, uint64_t total, Fill fill) {
+  if (total == 0) return hipSuccess;
+  const uint64_t want = uint64_t(ctx->opt.upload_chunk_mb) << 20;
+  if (ctx->up_cap != want) {
+    for (int k = 0; k < 2; ++k) {
+      if (ctx->up_ring[k]) (void)hipHostFree(ctx->up_ring[k]);
+      ctx->up_ring[k] = nullptr;
+    }
+    ctx->up_cap = 0;
+    for (int k = 0; k < 2; ++k) {
+      void* p = nullptr;
+      hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+      if (e == hipSuccess && !ctx->up_ev[k]) e = hipEventCreateWithFlags(&ctx->up_ev[k], hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+      ctx->up_ring[k] = static_cast<uint8_t*>(p);
+    }
+    ctx->up_cap = want;
+  }
+  unsigned nt = ctx->opt.upload_threads ? unsigned(ctx->opt.upload_threads) : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+  bool used[2] = {false, false};
+  uint64_t c = 0;
+  for (uint64_t off = 0; off < total; off += ctx->up_cap, ++c) {
+    const int k = int(c & 1);
+    const uint64_t len = std::min<uint64_t>(ctx->up_cap, total - off);
+    if (used[k]) {
+      const hipError_t e = hipEventSynchronize(ctx->up_ev[k]);  // the DMA that last read this buffer
+      if (e != hipSuccess) return e;
+    }
+    uint8_t* dst = ctx->up_ring[k];
+    const uint64_t per = ((len + nt - 1) / nt + 4095) & ~uint64_t(4095);
+    const unsigned parts = unsigned((len + per - 1) / per);
+    if (parts <= 1) {
+      fill(off, len, dst);
+    } else {
+      std::vector<std::thread> th;
+      th.reserve(parts - 1);
+      for (unsigned t = 1; t < parts; ++t) {
+        const uint64_t a = uint64_t(t) * per, n = std::min<uint64_t>(per, len - a);
+        th.emplace_back([&fill, off, a, n, dst] { fill(off + a, n, dst + a); });
+      }
+      fill(off, std::min<uint64_t>(per, len), dst);
+      for (std::thread& x : th) x.join();
+    }
+    hipError_t e = hipMemcpyAsync(d_dst + off, dst, len, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->up_ev[k], ctx->stream);
+    if (e != hipSuccess) return e;
+    used[k] = true;
+  }
+  return hipSuccess;
+}
+}  // extern "C++"
+
+static int32_t validate_container(const fbk_container_desc& d, const uint8_t* /*payload*/, uint64_t payload_len,
                                   uint64_t* bytes) {
   uint64_t need;
   switch (d.type) {
@@ -849,27 +924,10 @@ static int32_t validate_container(const fbk_container_desc& d, const uint8_t* pa
   }
   if (d.off > payload_len || need > payload_len - d.off) return fail(FBK_E_INVALID, "container payload out of bounds");
   if (d.n < -1 || d.n > 65536) return fail(FBK_E_INVALID, "container n out of range");
-  const uint8_t* p = payload + d.off;
-  if (d.type == FBK_TYPE_ARRAY) {
-    // must be strictly ascending (sorted []uint16, roaring.go:53-58)
-    uint16_t prev = 0;
-    for (uint32_t i = 0; i < d.len; ++i) {
-      uint16_t v;
-      std::memcpy(&v, p + 2 * i, 2);
-      if (i && v <= prev) return fail(FBK_E_INVALID, "array container not strictly ascending");
-      prev = v;
-    }
-    if (d.n >= 0 && uint32_t(d.n) != d.len) return fail(FBK_E_INVALID, "array container n != len");
-  } else if (d.type == FBK_TYPE_RUN) {
-    int64_t prev_last = -1;
-    for (uint32_t i = 0; i < d.len; ++i) {
-      uint16_t s, l;
-      std::memcpy(&s, p + 4 * i, 2);
-      std::memcpy(&l, p + 4 * i + 2, 2);
-      if (l < s || int64_t(s) <= prev_last) return fail(FBK_E_INVALID, "run container intervals overlap or are unordered");
-      prev_last = l;
-    }
-  }
+  // The CONTENT rules — arrays strictly ascending (sorted []uint16, roaring.go:53-58), runs ordered and non-overlapping — are
+  // checked on the device after the copy (k_validate_recount, one wavefront per container): walking 581 MB value by value
+  // on one host thread was most of the 0.44 s the round-3 bench line reports for the upload of config 3's rows.
+  if (d.type == FBK_TYPE_ARRAY && d.n >= 0 && uint32_t(d.n) != d.len) return fail(FBK_E_INVALID, "array container n != len");
   *bytes = need;
   return FBK_OK;
 }
@@ -940,38 +998,60 @@ int32_t fbk_batch_upload(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t
   }
   b->arena_bytes = off;
   b->dense = dense;
-  std::vector<uint8_t> stage;
-  const uint8_t* h_src = nullptr;
-  try {
-    stage.assign(std::max<uint64_t>(off, 16), 0);
-  } catch (...) {
-    delete b;
-    return fail(FBK_E_NOMEM, "host staging allocation failed");
-  }
+  // the arena image in (row, slot) order: payload bytes, then zeros up to the next 16-byte boundary
+  struct Piece {
+    uint64_t at, bytes, src;
+  };
+  std::vector<Piece> pieces;
+  pieces.reserve(n_desc);
   for (uint64_t s = 0; s < n_slots; ++s)
-    if (src[s] >= 0) std::memcpy(stage.data() + b->h_slots[s].off, pay + descs[src[s]].off, nbytes[s]);
-  h_src = stage.data();
+    if (src[s] >= 0) pieces.push_back(Piece{b->h_slots[s].off, nbytes[s], descs[src[s]].off});
+  auto fill = [&pieces, pay](uint64_t a, uint64_t len, uint8_t* dst) {
+    const uint64_t e = a + len;
+    size_t i = size_t(std::upper_bound(pieces.begin(), pieces.end(), a, [](uint64_t v, const Piece& p) { return v < p.at; }) - pieces.begin());
+    if (i) --i;  // the piece that starts at or before a
+    for (; i < pieces.size() && pieces[i].at < e; ++i) {
+      const Piece& p = pieces[i];
+      const uint64_t pe = p.at + p.bytes, ze = p.at + align16(p.bytes);
+      if (pe > a) {
+        const uint64_t x0 = std::max(a, p.at), x1 = std::min(e, pe);
+        if (x1 > x0) std::memcpy(dst + (x0 - a), pay + p.src + (x0 - p.at), x1 - x0);
+      }
+      const uint64_t z0 = std::max(a, pe), z1 = std::min(e, ze);
+      if (z1 > z0) std::memset(dst + (z0 - a), 0, z1 - z0);
+    }
+  };
 
+  DevBuf dbad;
+  uint32_t h_bad = 0;
   hipError_t e = ctx_malloc(ctx, reinterpret_cast<void**>(&b->d_arena), std::max<uint64_t>(off, 16));
   if (e == hipSuccess) e = ctx_malloc(ctx, reinterpret_cast<void**>(&b->d_slots), std::max<uint64_t>(n_slots, 1) * sizeof(Slot));
-  if (e == hipSuccess && off) e = hipMemcpyAsync(b->d_arena, h_src, off, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = dbad.alloc(ctx, 16);
+  if (e == hipSuccess) e = hipMemsetAsync(dbad.p, 0, 4, ctx->stream);
   if (e == hipSuccess && n_slots)
     e = hipMemcpyAsync(b->d_slots, b->h_slots.data(), n_slots * sizeof(Slot), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && need_recount) {
+  if (e == hipSuccess) e = staged_h2d(ctx, b->d_arena, off, fill);
+  if (e == hipSuccess && n_slots) {
+    // content validation and the cardinalities in one pass over what has just landed (arrays: order; runs: order and n;
+    // bitmaps: n — the caller's n is not trusted: every `n == 65536` shortcut and every buffer sized from a cardinality
+    // depends on it, bitmapRepair roaring.go:4193-4206)
     const uint32_t blocks = uint32_t((n_slots + 3) / 4);
-    hipLaunchKernelGGL(fbk::k_recount, dim3(blocks), dim3(256), 0, ctx->stream, b->d_slots, b->d_arena, n_slots);
+    hipLaunchKernelGGL(fbk::k_validate_recount, dim3(blocks), dim3(256), 0, ctx->stream, b->d_slots, b->d_arena, n_slots, dbad.as<uint32_t>());
     e = hipGetLastError();
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(b->h_slots.data(), b->d_slots, n_slots * sizeof(Slot), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->h_slots.data(), b->d_slots, n_slots * sizeof(Slot), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, dbad.p, 4, hipMemcpyDeviceToHost, ctx->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) {
+  if (e != hipSuccess || h_bad) {
     (void)hipGetLastError();
+    (void)hipStreamSynchronize(ctx->stream);
     if (b->d_arena) (void)ctx_free(b->ctx, b->d_arena);
     if (b->d_slots) (void)ctx_free(b->ctx, b->d_slots);
     delete b;
-    return fail(e == hipErrorOutOfMemory ? FBK_E_NOMEM : FBK_E_HIP, std::string("batch upload: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FBK_E_NOMEM : FBK_E_HIP, std::string("batch upload: ") + hipGetErrorString(e));
+    return fail(FBK_E_INVALID, (h_bad & 1u) ? "array container not strictly ascending" : "run container intervals overlap or are unordered");
   }
+  need_recount = n_slots != 0;
   if (need_recount) {
     // containers that turned out empty become nil on both sides
     bool changed = false;
@@ -1019,7 +1099,17 @@ int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_r
   }
   hipError_t e = ctx_malloc(ctx, reinterpret_cast<void**>(&b->d_arena), std::max<uint64_t>(bytes, 16));
   if (e == hipSuccess) e = ctx_malloc(ctx, reinterpret_cast<void**>(&b->d_slots), std::max<uint64_t>(n_slots, 1) * sizeof(Slot));
-  if (e == hipSuccess && bytes) e = hipMemcpyAsync(b->d_arena, words, bytes, hipMemcpyDefault, ctx->stream);  // (host or device source)
+  if (e == hipSuccess && bytes) {
+    hipPointerAttribute_t at;
+    const bool on_device = hipPointerGetAttributes(&at, words) == hipSuccess && at.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();  // (an unregistered host pointer is reported as an error by some runtimes)
+    if (on_device) {
+      e = hipMemcpyAsync(b->d_arena, words, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    } else {
+      const uint8_t* src8 = reinterpret_cast<const uint8_t*>(words);
+      e = staged_h2d(ctx, b->d_arena, bytes, [src8](uint64_t a, uint64_t len, uint8_t* dst) { std::memcpy(dst, src8 + a, len); });
+    }
+  }
   if (e == hipSuccess && n_slots) {
     e = hipMemcpyAsync(b->d_slots, b->h_slots.data(), n_slots * sizeof(Slot), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
