@@ -370,8 +370,36 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         out.append(_entry(f"config3 rows, {pa.size} row pairs: Intersect materialised (8 KiB cells), launch-only plan", "k_setop2<AND>", rows.bytes + pa.size * 16 * 8192, g, w,
                           set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), **common))
         plan.free()
-        g, w = _timed_call(torch, stream, lambda: ctx.union_n(batch, groups, L.SETOP_OPTIMIZE)[0].free(), max(5, iters // 2))
-        out.append(_entry("config3 rows, Union-of-64 materialised + optimize() re-encode (one-shot call)", "k_fold_scatter<OR> + k_encode_*", nbytes, g, w, **common))
+        # Union-of-64 MATERIALISED + optimize(): the prepared query (group lists and the output batch resident: memset + one launch of the
+        # fold kernel, which encodes in its epilogue) beside the one-shot call; every result container compared with the oracle's
+        # union re-encoded by optimize() — encoding, cardinality and payload bytes
+        q_un = ctx.prepare_fold(L.OP_OR, batch, groups, L.SETOP_OPTIMIZE)
+        q_un.run()
+        un_counts = q_un.read()
+        un_bytes = q_un.output().info()[2]
+        if want_cpu:
+            eu, eu_cnt = PB.union_n(OA, groups)
+            assert (un_counts == eu_cnt).all(), "config 3 materialised union: cardinalities differ from the oracle"
+            du, pu, nru = q_un.output().download_flat()
+            assert (PB.RowSet.from_flat(du, pu, nru).words() == eu.words()).all(), "config 3 materialised union: bit content differs from the oracle"
+            eu.free()
+        g, w, kq = _timed_query(torch, stream, q_un, iters, ctx)
+        out.append(_entry("config3 rows, Union-of-64 materialised + optimize(): prepared query, Container.optimize() in the fold kernel's epilogue", "k_fold_scatter<OR, optimize>",
+                          nbytes + un_bytes, g, w, kq, output_payload_bytes=un_bytes,
+                          call_us=call_us(lambda: ctx.union_n(batch, groups, L.SETOP_OPTIMIZE)[0].free()), **common))
+        q_un.free()
+        # TopN with its ordering on the device (radix sort of the 64 totals; the count matrix entry above stops at the per-shard counts)
+        q_tn = ctx.prepare_topn(batch, groups, 10, F, fidx)
+        q_tn.run()
+        tn_idx, tn_cnt = q_tn.read()
+        if want_cpu:
+            tot_e = PB.topk_counts(OA, groups, OF, fidx).sum(axis=0)
+            order = sorted([i for i in range(64) if tot_e[i]], key=lambda i: (-int(tot_e[i]), i))[:10]
+            assert tn_idx.tolist() == order and [int(c) for c in tn_cnt] == [int(tot_e[i]) for i in order], "config 3 TopN: GPU and oracle disagree"
+        g, w, kq = _timed_query(torch, stream, q_tn, iters, ctx)
+        out.append(_entry("config3 rows, TopN(n = 10) of 64 rows against the filter row: counts, sum over shards and ordering on the device, prepared query", "k_rows_vs_filter", nbytes + 8 * 64 * n3,
+                          g, w, kq, call_us=call_us(lambda: ctx.topn(batch, groups, 10, F, fidx)), **common))
+        q_tn.free()
         for q in (q_fold, q_top, q_gb):
             q.free()
         batch.free()
@@ -452,9 +480,14 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             e_rng.free()
             OA.free()
         par5 = f"every one of the {n5} shards bit-exact against the oracle" if want_cpu else "unchecked"
-        g, wl, kq = _timed_call(torch, stream, lambda: ctx.bsi_range(batch, base, L.BSI_GT, depth, kk)[0].free(), iters, ctx=ctx)
-        out.append(_entry(f"config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense (one-shot call: the result row is a new batch)", "k_bsi_range_slot",
-                          plane_bytes * (depth + 3), g, wl, kq, shards=n5, cpu_baseline=cpu5, parity=par5))
+        q_rng = ctx.prepare_bsi_range(batch, base, L.BSI_GT, depth, kk)
+        q_rng.run()
+        assert (q_rng.read() == rng_cnt).all(), "config 5: prepared Range differs from the one-shot call"
+        g, wl, kq = _timed_query(torch, stream, q_rng, iters, ctx)
+        out.append(_entry(f"config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense: prepared query, the result rows stay on the device", "k_bsi_range_slot",
+                          plane_bytes * (depth + 3), g, wl, kq, shards=n5, cpu_baseline=cpu5, parity=par5, timing=timing_note,
+                          call_us=_timed_call(torch, stream, lambda: ctx.bsi_range(batch, base, L.BSI_GT, depth, kk)[0].free(), 5)[0]))
+        q_rng.free()
         g, wl, kq = _timed_query(torch, stream, q_sum, iters, ctx)
         out.append(_entry("config5: BSI Sum(filter = the Range result)", "k_bsi_sum_slot", plane_bytes * (depth + 3), g, wl, kq, shards=n5, parity=par5, timing=timing_note,
                           call_us=_timed_call(torch, stream, lambda: ctx.bsi_sum(batch, base, depth, rng_out, idx5), 5)[0]))

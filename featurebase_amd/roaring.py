@@ -228,7 +228,7 @@ class Query:
         h = C.c_void_p()
         L.check(self.ctx.lib.fbk_query_output(self.ctx.h, self.h, C.byref(h)))
         b = Batch(self.ctx, h.value)
-        b.borrowed = True
+        b.owned = False  # free() on the wrapper is a no-op: the query owns the batch
         return b
 
     def free(self) -> None:
