@@ -193,3 +193,32 @@ def test_corrupt_trees_and_untrusted_headers(gpu_ctx, oracle):
                     gpu_ctx.upload_rbf(bytes(swapped), root)
                 return
     raise AssertionError("no array cell found")
+
+
+def test_image_written_by_the_restated_reference_writer(gpu_ctx, oracle):
+    """fbk_rbf_find_root + fbk_batch_upload_rbf on a database image produced by the line-by-line restatement of the
+    reference's page WRITER (oracle/pyrbf_writer.py, pinned byte for byte to the file the reference ships): a three-level
+    b-tree whose root turned into a branch of branches, leaf pages left by putLeafCell's splits and in-place rewrites, RLE
+    and BitmapPtr cells, bitmap pages reused after a free, root records chained over an overflow page.  The device result
+    must equal the oracle's page reader AND what was put in (the cursor-level contents)."""
+    from oracle import pyrbf
+    from test_oracle_rbf import build_multi_page_db
+
+    db, expect = build_multi_page_db(oracle, n_names=60)
+    img = db.image()
+    for name, conts in expect.items():
+        root = gpu_ctx.rbf_find_root(img, name)  # (names on the second root-record page included)
+        assert root == pyrbf.find_root(img, name) == db.records[name]
+        ref = pyrbf.read_bitmap(img, root)
+        batch, ids = gpu_ctx.upload_rbf(img, root)
+        assert ids.tolist() == sorted({k >> 4 for k in conts})
+        got = {k: c for row in batch.download() for k, c in row.items()}
+        assert sorted(got) == sorted(conts) == [k for k, _, _, _ in ref]
+        for k, t, n, payload in ref:
+            c = got[k]
+            assert (c.typ, c.n) == (t, n), (name, k)
+            assert np.array_equal(np.asarray(c.data).reshape(-1), np.asarray(payload).reshape(-1)), (name, k)
+            assert c.n == conts[k].n and (c.words() == conts[k].words()).all(), (name, k)
+        batch.free()
+    types = {t for _, t, _, _ in pyrbf.read_bitmap(img, db.records["i/f/standard/0"])}
+    assert types == {1, 2, 3}

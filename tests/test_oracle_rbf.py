@@ -93,3 +93,181 @@ def test_writer_reader_round_trip(oracle):
     # the 40-row tree needs branch pages above the leaves at this fan-out
     root = pyrbf.find_root(f, "i/f/standard/0")
     assert struct.unpack_from(">I", f, root * 8192 + 4)[0] == pyrbf.BRANCH
+
+
+# ---- the restated WRITER (oracle/pyrbf_writer.py) -------------------------------------------------------------------
+def test_writer_restatement_reproduces_the_reference_written_file():
+    """createBitmap("x") + Add(100) + Commit through the restated write path = the database file the reference ships
+    (ctl/testdata/ok/data): meta page (page count 4, WAL id 4, root-record page 1, freelist page 2), root-record page
+    {3, "x"}, the empty freelist leaf and the leaf page with the one array cell — every byte the fixture holds."""
+    from oracle import pyrbf_writer as W
+
+    db = W.RbfDb()
+    db.create_bitmap("x")
+    assert db.add("x", 100) and not db.add("x", 100)
+    db.commit()
+    img = db.image()
+    ref = file_image("ok")
+    assert len(img) == len(ref) == 4 * 8192
+    for pg, h in enumerate(FIX["files"]["ok"]["pages_hex_prefix"]):
+        want = bytes.fromhex(h)
+        assert img[pg * 8192 : pg * 8192 + len(want)] == want, pg
+        assert img[pg * 8192 + len(want) : (pg + 1) * 8192] == bytes(8192 - len(want)), pg  # (the fixture keeps each page up to its last non-zero byte)
+
+
+def test_writer_restatement_add_roaring_sequences(oracle):
+    """Cursor.AddRoaring through the restated writer, read back with the oracle READER.  Cursor.merge compares the union
+    with the INCOMING container (`res.N() != data.N()`, cursor.go:1367): an incoming SUPERSET of what is stored is reported
+    "unchanged" and NOT written (the reference's behaviour, restated as it is), an incoming subset rewrites the cell."""
+    from oracle import pyrbf, pyrbf_writer as W
+
+    O = oracle
+
+    def cells(db):
+        img = db.image()
+        return [(k, t, n, p.tolist()) for k, t, n, p in pyrbf.read_bitmap(img, pyrbf.find_root(img, "x"))]
+
+    db = W.RbfDb()
+    db.create_bitmap("x")
+    assert db.add_roaring("x", [(0, O.OContainer.array([1, 2]))])
+    assert not db.add_roaring("x", [(0, O.OContainer.array([1, 2, 3]))])   # union N = 3 = incoming N: not written
+    assert cells(db) == [(0, 1, 2, [1, 2])]
+    assert db.add_roaring("x", [(0, O.OContainer.array([7]))])             # union N = 3 != 1: written
+    assert cells(db) == [(0, 1, 3, [1, 2, 7])]
+    assert db.add_roaring("x", [(0, O.OContainer.array([2, 3, 4, 5, 6]))])  # {1..7}: roaring.Union optimize()s into one run
+    assert cells(db) == [(0, 3, 7, [[1, 7]])]
+    # a bitmap container: BitmapPtr cell + a raw bitmap page; an array merged into it: still a bitmap page, more bits
+    db = W.RbfDb()
+    db.create_bitmap("x")
+    assert db.add_roaring("x", [(0, O.OContainer.bitmap(D.words_of(np.arange(0, 65536, 2))))])
+    page_n = db.page_n
+    assert db.add_roaring("x", [(0, O.OContainer.array([1, 3, 5]))])
+    assert db.page_n == page_n  # the bitmap page is rewritten in place (cursor.go:460-473)
+    db.commit()
+    img = db.image()
+    (k, t, n, p), = pyrbf.read_bitmap(img, pyrbf.find_root(img, "x"))
+    assert (k, t, n) == (0, 2, 32771) and (p == D.words_of(np.union1d(np.arange(0, 65536, 2), [1, 3, 5]))).all()
+    # ... and a run that swallows it: the cell becomes RLE and the bitmap page goes to the freelist (FB-1239, cursor.go:444-458)
+    assert db.add_roaring("x", [(0, O.OContainer.run([(0, 65000)]))])
+    assert db.free == [page_n - 1]
+    db.commit()
+    assert db.page_n == page_n - 1 and db.free == []  # Commit truncates a free page at the end of the file (tx.go:155-208)
+    assert cells(db) == [(0, 3, 65268, [[0, 65000]] + [[v, v] for v in range(65002, 65536, 2)])]
+    # RLE conversion at the cell limit (TestCursor_RLEConversion :601-640): 2039 runs stay RLE, 2040 become a bitmap page
+    for nr, want_t in ((2039, 3), (2040, 2)):
+        db = W.RbfDb()
+        db.create_bitmap("x")
+        assert db.add_roaring("x", [(7, O.OContainer.run([(16 * i, 16 * i + 9) for i in range(nr)]))])
+        db.commit()
+        img = db.image()
+        (k, t, n, p), = pyrbf.read_bitmap(img, pyrbf.find_root(img, "x"))
+        assert (k, t, n) == (7, want_t, 10 * nr)
+    # array at the cell limit: 4079 values an array cell, 4080 a bitmap page (ArrayMaxSize, rbf.go:37-39)
+    for nv, want_t in ((4079, 1), (4080, 2)):
+        db = W.RbfDb()
+        db.create_bitmap("x")
+        assert db.add_roaring("x", [(1, O.OContainer.array(np.arange(nv) * 3))])
+        db.commit()
+        img = db.image()
+        (k, t, n, p), = pyrbf.read_bitmap(img, pyrbf.find_root(img, "x"))
+        assert (k, t, n) == (1, want_t, nv)
+
+
+def build_multi_page_db(oracle, n_names=3):
+    """A database image with everything the reader has to get right, written by the restated writer: a fragment of 2600
+    containers (arrays, RLE cells, BitmapPtr cells) added in three AddRoaring calls that interleave keys — leaf pages
+    split, the root turns into a branch page, the branch itself splits (three levels) — plus enough bitmaps with long
+    names that the root records spill into a chained overflow page."""
+    from oracle import pyrbf_writer as W
+
+    O = oracle
+    rng = D.rng_for(4711)
+    db = W.RbfDb()
+    names = [f"idx/field-{i:04d}/" + "v" * 150 + f"/standard/{i}" for i in range(n_names)]
+    expect = {}
+    for i, name in enumerate(names):
+        db.create_bitmap(name)
+    frag = "i/f/standard/0"
+    db.create_bitmap(frag)
+    conts = {}
+    keys = list(range(0, 5200, 2))
+    for rnd in range(3):
+        items = []
+        for key in keys[rnd::3]:
+            kind = int(rng.integers(0, 5))
+            if kind == 0:
+                c = O.OContainer.array(np.sort(rng.choice(65536, int(rng.integers(1, 40)), replace=False)))
+            elif kind == 1:
+                c = O.OContainer.array(np.sort(rng.choice(65536, int(rng.integers(300, 1500)), replace=False)))
+            elif kind == 2:
+                st = np.sort(rng.choice(4000, int(rng.integers(1, 300)), replace=False)) * 16
+                c = O.OContainer.run([(int(s), int(s) + int(rng.integers(2, 14))) for s in st])
+            elif kind == 3:
+                c = O.OContainer.bitmap(D.words_of(np.sort(rng.choice(65536, 20000, replace=False))))
+            else:
+                c = O.OContainer.run([(0, 65535)])
+            items.append((key, c))
+            conts[key] = c
+        assert db.add_roaring(frag, items)
+        db.commit()
+    # a second pass merges into a third of the keys (type changes: array -> bitmap page, bitmap page -> full run frees its page)
+    items = []
+    for key in keys[::3]:
+        extra = O.OContainer.run([(0, 65535)]) if key % 4 == 0 else O.OContainer.array(np.sort(rng.choice(65536, 3000, replace=False)))
+        items.append((key, extra))
+        res = O.optimize(O.union(extra, conts[key]))
+        if res.n != extra.n:  # Cursor.merge's rule (cursor.go:1367): an incoming superset is not written
+            conts[key] = res
+    db.add_roaring(frag, items)
+    db.commit()
+    # the other bitmaps get one small container each
+    for i, name in enumerate(names):
+        c = O.OContainer.array([i, i + 7])
+        db.add_roaring(name, [(i, c)])
+        expect[name] = {i: c}
+    db.commit()
+    expect[frag] = conts
+    return db, expect
+
+
+def test_writer_restatement_multi_page_image_structure(oracle):
+    from oracle import pyrbf, pyrbf_writer as W
+
+    db, expect = build_multi_page_db(oracle, n_names=60)
+    img = db.image()
+    assert len(img) == db.page_n * 8192
+    # root records: chained through the overflow pointer (60 names of ~180 bytes do not fit one page)
+    first = struct.unpack_from(">I", img, 20)[0]
+    nxt = struct.unpack_from(">I", img, first * 8192 + 8)[0]
+    assert nxt != 0 and struct.unpack_from(">I", img, nxt * 8192 + 4)[0] == pyrbf.ROOT_RECORD
+    # the fragment's root kept its page number and is a branch whose children are branches (three levels)
+    root = pyrbf.find_root(img, "i/f/standard/0")
+    assert root == db.records["i/f/standard/0"]
+    assert struct.unpack_from(">I", img, root * 8192 + 4)[0] == pyrbf.BRANCH
+    kids = W.read_branch_cells(img[root * 8192 : (root + 1) * 8192])
+    assert len(kids) >= 2 and all(struct.unpack_from(">I", img, c * 8192 + 4)[0] == pyrbf.BRANCH for _, _, c in kids)
+    # every cell type occurs; every page the writer produced respects the page size and the 8-byte alignment of its cells
+    types = set()
+
+    def walk(pgno):
+        page = img[pgno * 8192 : (pgno + 1) * 8192]
+        if W.read_flags(page) == pyrbf.BRANCH:
+            cells = W.read_branch_cells(page)
+            assert cells and [k for k, _, _ in cells] == sorted(k for k, _, _ in cells)
+            for _, _, c in cells:
+                walk(c)
+            return
+        n = W.read_cell_n(page)
+        assert n >= 1 and all(W.read_cell_offset(page, i) % 8 == 0 for i in range(n))
+        assert W.leaf_page_size(page) <= 8192
+        types.update(W.read_leaf_cell(page, i).typ for i in range(n))
+
+    walk(root)
+    assert types == {W.T_ARRAY, W.T_RLE, W.T_BITMAP_PTR}
+    # and the oracle reader gets back exactly what was put in (ConvertToLeafArgs' encodings of the merged containers)
+    for name, conts in expect.items():
+        back = pyrbf.read_bitmap(img, pyrbf.find_root(img, name))
+        assert [k for k, _, _, _ in back] == sorted(conts)
+        for k, t, n, p in back:
+            c = conts[k]
+            assert n == c.n and (pyrbf.leaf_to_container((k, t, n, p)).words() == c.words()).all(), (name, k)

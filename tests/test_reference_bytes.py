@@ -229,3 +229,27 @@ def test_cursor_policy_image_through_upload_rbf(gpu_ctx, oracle):
     assert c10.typ == 2 and c10.n == META["ArrayMaxSize"] + 2 and (c10.words() == D.words_of(np.arange(META["ArrayMaxSize"] + 2))).all()
     b2.free()
     batch.free()
+
+
+def test_cursor_add_roaring_table_through_the_restated_writer(oracle):
+    """The same (name, wantChanged) table of TestCursor_AddRoaring, this time through the line-by-line restatement of
+    the reference's page WRITER (oracle/pyrbf_writer.py: Seek, putLeafCell fast and slow paths, bitmap-page allocation
+    and release, merge): every call reports what the reference's test expects, and the pages it leaves hold the cells the
+    policy model predicts — read back by the oracle's page reader."""
+    from oracle import pyrbf, pyrbf_writer as W
+
+    want = {c["name"]: c["wantChanged"] for c in META["cursor_add_roaring"]["cases"]}
+    db = W.RbfDb()
+    db.create_bitmap("x")
+    for name, key, cont in _add_roaring_cases(oracle):
+        assert db.add_roaring("x", [(key, cont)]) == want[name], name
+    db.commit()
+    img = db.image()
+    back = pyrbf.read_bitmap(img, pyrbf.find_root(img, "x"))
+    model = build_cursor_model(oracle)
+    assert [(k, t, n) for k, t, n, _ in back] == [(k, t, n) for k, t, n, _ in model.containers()]
+    for (_, _, _, p0), (_, _, _, p1) in zip(model.containers(), back):
+        assert np.array_equal(np.asarray(p0).reshape(-1), p1.reshape(-1))
+    # "too Big Array" took a bitmap page that "too Big RLE" (the union is an RLE cell) gave back: it is on the freelist or
+    # was truncated off the end of the file by Commit
+    assert db.page_n <= 6
