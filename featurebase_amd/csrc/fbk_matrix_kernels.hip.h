@@ -271,13 +271,6 @@ struct DensifySrc {
 struct DensifyArgs {
   DensifySrc src[3];
 };
-// 0, 1, 2, ... : the row list of densified temporaries (made on the device: a prepared query's run must not
-// leave a host staging copy in flight when it returns)
-__global__ void __launch_bounds__(256) k_iota_u32(uint32_t* __restrict__ out, uint64_t n) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = (uint32_t)i;
-}
-
 __global__ void __launch_bounds__(256) k_densify_rows(DensifyArgs args) {
   __shared__ u64 lds[4][kWords];
   const int lane = threadIdx.x & 63;

@@ -279,6 +279,35 @@ __global__ void __launch_bounds__(256) k_iota_u32(uint32_t* __restrict__ v, uint
   if (i < n) v[i] = i;
 }
 
+// The ordering of TopK / TopN for a field of up to kRankSortMax rows in ONE launch: row i's position is the number of rows
+// that come before it — a larger count, or the same count and a smaller index (count descending, row index ascending:
+// BSIData.PivotDescending, bsi.go:18-62) — and it writes itself there.  O(n^2) compares, tiles of 256 counts through LDS.
+// *nz (zeroed by the caller) receives the number of rows with a non-zero count.
+constexpr uint32_t kRankSortMax = 4096;
+__global__ void __launch_bounds__(256) k_rank_sort_desc(const u64* __restrict__ counts, uint32_t n, u64* __restrict__ out_counts, uint32_t* __restrict__ out_index,
+                                                       uint32_t* __restrict__ nz) {
+  __shared__ u64 tile[256];
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const u64 mine = i < n ? counts[i] : 0;
+  uint32_t rank = 0;
+  for (uint32_t j0 = 0; j0 < n; j0 += 256) {
+    __syncthreads();
+    tile[threadIdx.x] = j0 + threadIdx.x < n ? counts[j0 + threadIdx.x] : 0;
+    __syncthreads();
+    const uint32_t m = min(256u, n - j0);
+    for (uint32_t k = 0; k < m; ++k) {
+      const u64 c = tile[k];
+      rank += (c > mine || (c == mine && j0 + k < i)) ? 1u : 0u;
+    }
+  }
+  if (i < n) {
+    out_counts[rank] = mine;
+    out_index[rank] = i;
+  }
+  const u64 any = __ballot(i < n && mine != 0);
+  if ((threadIdx.x & 63) == 0 && any) atomicAdd(nz, (uint32_t)__popcll(any));
+}
+
 // number of leading non-zero keys of a descending sequence (binary search by one thread)
 __global__ void k_count_nonzero_desc(const u64* __restrict__ keys, uint32_t n, uint32_t* __restrict__ out) {
   uint32_t lo = 0, hi = n;  // first index with key == 0
