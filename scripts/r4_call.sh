@@ -9,6 +9,7 @@ STEPS=${STEPS:-"pytest pairs ctops"}
 for s in $STEPS; do
 case $s in
 pytest) (timeout ${PYTEST_TIMEOUT:-900} python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} 2>&1 | tail -25) > $O/pytest.log ;;
+pytest_sel) (timeout ${PYTEST_TIMEOUT:-900} python -m pytest ${PYTEST_SEL} -m gpu -x -q 2>&1 | tail -25) > $O/pytest_sel.log ;;
 pytest_full) (timeout 600 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q --durations=10 2>&1 | tail -40) > $O/pytest_full.log ;;
 pairs) timeout 300 python scripts/bench_pairs.py --out $O/pairs.json ${PAIRS_ARGS:-} > $O/pairs.txt 2> $O/pairs.err ;;
 ctops_small) timeout 400 python scripts/bench_ctops.py --rows 1024 --iters 20 --out $O/ctops_small.json --only Empty,Ary1,Ary16,Ary256,Ary512,BM4096,RunFull,Run16,Run256 2>&1 | grep -v amdgpu.ids | tail -40 > $O/ctops_small.txt ;;
@@ -23,10 +24,11 @@ bsi) (timeout 200 python scripts/bsi_bench.py 2>&1 | grep -v amdgpu.ids > $O/bsi
 pmc_hbm) (cd /tmp; export TMPDIR=/tmp; BA="--steps 20 --warmup 2 --repeats 2 --no-cpu-baseline --cold-sets 1 --shards4 128 --shards4-total 0"; timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o b -- python $R/bench.py $BA > /dev/null 2>&1; timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o b -- python $R/bench.py $BA > /dev/null 2>&1; python3 $R/scripts/pmc_hbm_summary.py $O "bench.py $BA (round 4)" > $O/pmc_hbm_bytes.txt 2>&1) ;;
 pmc_scatter) bash scripts/fused_pmc.sh $TAG/pmc_scatter 256 0 scatter_pmc.py ${KF:-k_} > $O/pmc_scatter.txt 2>&1 ;;
 spbsweep) timeout 300 python scripts/matrix_spb_sweep.py ${SWEEP_ARGS:-1024 6} 2> $O/spb_sweep.err | grep -v amdgpu.ids > $O/spb_sweep.json ;;
+small) timeout 300 python scripts/small_shapes_ab.py ${SMALL_ARGS:-64 7} 2> $O/small_shapes.err | grep -v amdgpu.ids > $O/small_shapes.json ;;
 fused) timeout 400 python scripts/fused_bench.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_bench.txt ;;
 fusedprof) timeout 300 python scripts/fused_prof.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_prof.txt ;;
 *) echo "unknown step $s" ;;
 esac
 done
 ls -R $O | head -40
-for f in $O/pytest.log $O/pytest_full.log $O/bench_n1.err $O/bench_n2.err; do [ -f $f ] && tail -60 $f; done
+for f in $O/pytest.log $O/pytest_sel.log $O/pytest_full.log $O/bench_n1.err $O/bench_n2.err; do [ -f $f ] && tail -60 $f; done
