@@ -1241,8 +1241,7 @@ int32_t fbk_count_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* ro
   DevBuf drows, dcnt;
   if (int32_t rc = upload_rows(ctx, rows, n, b->n_rows, drows)) return rc;
   HIP_TRY(dcnt.alloc(ctx, n * 8));
-  HIP_TRY(hipMemsetAsync(dcnt.p, 0, n * 8, ctx->stream));
-  hipLaunchKernelGGL(fbk::k_count_range, dim3(uint32_t(n * fbk::kSlots / 4)), dim3(256), 0, ctx->stream, b->d_slots,
+  hipLaunchKernelGGL(fbk::k_count_range, dim3(uint32_t((n + 3) / 4)), dim3(256), 0, ctx->stream, b->d_slots,
                      b->d_arena, drows.as<uint32_t>(), n, uint32_t(start), uint32_t(end), dcnt.as<u64>(),
                      uint32_t(ctx->opt.count_range_reference_quirk));
   HIP_TRY(hipGetLastError());
