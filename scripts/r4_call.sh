@@ -25,6 +25,7 @@ pmc_hbm) (cd /tmp; export TMPDIR=/tmp; BA="--steps 20 --warmup 2 --repeats 2 --n
 pmc_scatter) bash scripts/fused_pmc.sh $TAG/pmc_scatter 256 0 scatter_pmc.py ${KF:-k_} > $O/pmc_scatter.txt 2>&1 ;;
 spbsweep) timeout 300 python scripts/matrix_spb_sweep.py ${SWEEP_ARGS:-1024 6} 2> $O/spb_sweep.err | grep -v amdgpu.ids > $O/spb_sweep.json ;;
 small) timeout 300 python scripts/small_shapes_ab.py ${SMALL_ARGS:-64 7} 2> $O/small_shapes.err | grep -v amdgpu.ids > $O/small_shapes.json ;;
+scatter_ab) (for i in 1 2; do for lib in "" build_variants/${AB_VARIANT:-r4_container_dealing}/libfbk.so; do FBK_LIB_PATH=${lib:+$R/$lib} timeout 200 python scripts/scatter_ab.py 2>> $O/scatter_ab.err | grep "^{" >> $O/scatter_ab.jsonl; done; done) ;;
 fused) timeout 400 python scripts/fused_bench.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_bench.txt ;;
 fusedprof) timeout 300 python scripts/fused_prof.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_prof.txt ;;
 *) echo "unknown step $s" ;;
