@@ -262,43 +262,43 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
       }
     }
     {
-      // ---- chunk-granular ring over the BLOCK's containers as one sequence of 1 KiB chunks, dealt to the four waves chunk by
-      //      chunk (wave w takes chunks w, w + 4, ...).  Round 4: dealing whole containers (wave w: rows w, w + 4, ...) left the
-      //      waves of a block with unequal bytes — config 3's rows 0..5 are 8 KiB bitmaps, so two waves of every block carried
-      //      two of them and two waves one, +-11 % around the mean — and a block lives as long as its slowest wave. ----
+      // ---- chunk-granular ring: the wave's containers as ONE sequence of 1 KiB chunks ----
       constexpr int NCH = 6;
       typedef uint32_t Chunk __attribute__((ext_vector_type(4)));
       Chunk C[NCH];
       // chunks of lane l's container (0: nil / empty / beyond 8 KiB, not part of the sequence)
       const uint32_t my_bytes = payload_bytes(mine.tn >> 24, mine.len);
       const uint32_t nr = ((mine.tn & 0xFFFFFFu) != 0 && my_bytes <= 8192u) ? (my_bytes + 1023u) >> 10 : 0u;
-      const uint32_t incl = wave_incl_scan(nr);  // chunks of the containers 0 .. l
-      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-      // producer (next chunk to load) and consumer (next chunk to scatter): position g in the sequence plus the descriptor
-      // of the container it falls into, held in scalar registers and refreshed only when the container changes
+      auto next_valid = [&](uint32_t i) {
+        while (i < cnt && __builtin_amdgcn_readlane(nr, (int)(i & 63)) == 0) i += 4;
+        return i;
+      };
+      // producer (next chunk to load) and consumer (next chunk to scatter): position in the
+      // sequence plus the descriptor of the current container, held in scalar registers and
+      // refreshed only when the container changes (8 v_readlane per chunk otherwise)
       struct Cursor {
-        uint32_t g, i, j, nr, len, tn, bytes;
+        uint32_t i, j, nr, len, tn, bytes;
         u64 off;
       };
-      auto locate = [&](Cursor& k) {
-        if (k.g < total) {
-          k.i = (uint32_t)__popcll(__ballot(incl <= k.g));  // the first container whose chunks reach past g
+      auto fetch = [&](Cursor& k) {
+        k.j = 0;
+        if (k.i < cnt) {
           meta(k.i, k.off, k.len, k.tn);
           k.bytes = payload_bytes(k.tn >> 24, k.len);
           k.nr = (k.bytes + 1023u) >> 10;
-          k.j = k.g - ((uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(k.i & 63)) - k.nr);
         }
       };
       auto advance = [&](Cursor& k) {
-        k.g += 4;
-        k.j += 4;
-        if (k.j >= k.nr) locate(k);
+        if (++k.j == k.nr) {
+          k.i = next_valid(k.i + 4);
+          fetch(k);
+        }
       };
       Cursor P, Q;
-      P.g = (uint32_t)wv;
-      P.i = P.j = P.nr = P.len = P.tn = P.bytes = 0;
+      P.i = next_valid(wv);
+      P.nr = P.len = P.tn = P.bytes = 0;
       P.off = 0;
-      locate(P);
+      fetch(P);
       Q = P;
       // Exactly ONE load instruction per step, written as asm, so that "the chunk issued NCH steps
       // ago has landed" is the constant s_waitcnt vmcnt(NCH - 1): left to the compiler, the
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
       const uint32_t lane16 = lane * 16u;
       auto load_chunk = [&](Chunk& c) {
         const uint8_t* p = arena;
-        if (P.g < total) {
+        if (P.i < cnt) {
           const uint32_t b0 = P.j * 1024u + lane16;
           p = arena + P.off + (b0 < P.bytes ? b0 : 0u);
           advance(P);
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
       };
 #pragma unroll
       for (int q = 0; q < NCH; ++q) load_chunk(C[q]);
-      while (Q.g < total) {
+      while (Q.i < cnt) {
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
           // Every slot of a lap waits and reloads whether or not the sequence still has a chunk for it (an exhausted
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
           // follows the control flow and not the values, can verify.  (With the whole slot behind "if (Q.i < cnt)" it has to
           // assume a slot running after an earlier one was skipped, one load short; at most NCH - 1 idle slots per wave.)
           asm volatile("s_waitcnt vmcnt(%1)" : "+v"(C[q]) : "n"(NCH - 1));
-          if (Q.g < total) {
+          if (Q.i < cnt) {
             const uint32_t d[4] = {C[q][0], C[q][1], C[q][2], C[q][3]};
             scatter_chunk<OP>(d, Q.tn >> 24, Q.len, Q.j, lane, acc32);
             advance(Q);

@@ -31,7 +31,6 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
   __shared__ u64 F[kWords];         // the filter container as a bitmap
   __shared__ uint32_t rank[kWords + 1];  // rank[w] = popcount(F[0..w))
   __shared__ uint32_t s_part[4];
-  __shared__ uint32_t rowcnt[64];  // the counts of the 64 rows of one pass, added up over the block's four waves
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -147,54 +146,50 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
         if (lane == 0 && c) atomicAdd(&out_shard[(uint64_t)shard * nA + base + i], (u64)c);
       }
     }
-    // ---- the other containers: the BLOCK's containers as one sequence of 1 KiB chunks through a register ring, dealt to the
-    //      four waves chunk by chunk (wave w: chunks w, w + 4, ...; round 4 — whole containers per wave left the waves of a
-    //      block with unequal bytes, see k_fold_scatter); a row's count is added up over the waves in LDS ----
+    // ---- the other containers: one sequence of 1 KiB chunks through a register ring ----
     constexpr int NCH = 6;
     typedef uint32_t Chunk __attribute__((ext_vector_type(4)));
     Chunk C[NCH];
-    if (t < 64) rowcnt[t] = 0;
-    __syncthreads();
     const uint32_t nr = (my_n != 0 && !trivial && my_bytes <= 8192u) ? (my_bytes + 1023u) >> 10 : 0u;  // chunks of lane l's container
-    const uint32_t incl = wave_incl_scan(nr);  // chunks of the containers 0 .. l
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    // producer (next chunk to load) and consumer (next chunk to count): position g in the sequence
-    // plus the descriptor of the container it falls into, held in scalar registers and refreshed only
-    // when the container changes
+    auto next_valid = [&](uint32_t i) {
+      while (i < cnt && __builtin_amdgcn_readlane(nr, (int)(i & 63)) == 0) i += 4;
+      return i;
+    };
+    // producer (next chunk to load) and consumer (next chunk to count): position in the sequence
+    // plus the descriptor of the current container, held in scalar registers and refreshed only
+    // when the container changes (8 v_readlane per chunk otherwise)
     struct Cursor {
-      uint32_t g, i, j, nr, len, tn, bytes;
+      uint32_t i, j, nr, len, tn, bytes;
       u64 off;
     };
-    auto locate = [&](Cursor& k) {
-      if (k.g < total) {
-        k.i = (uint32_t)__popcll(__ballot(incl <= k.g));  // the first container whose chunks reach past g
+    auto fetch = [&](Cursor& k) {
+      k.j = 0;
+      if (k.i < cnt) {
         meta(k.i, k.off, k.len, k.tn);
         k.bytes = payload_bytes(k.tn >> 24, k.len);
         k.nr = (k.bytes + 1023u) >> 10;
-        k.j = k.g - ((uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(k.i & 63)) - k.nr);
       }
     };
-    auto advance = [&](Cursor& k) -> bool {  // true: this wave's share of the container is finished
-      k.g += 4;
-      k.j += 4;
-      if (k.j >= k.nr) {
-        locate(k);
+    auto advance = [&](Cursor& k) -> bool {  // true: the container is finished
+      if (++k.j == k.nr) {
+        k.i = next_valid(k.i + 4);
+        fetch(k);
         return true;
       }
       return false;
     };
     Cursor P, Q;
-    P.g = (uint32_t)wv;
-    P.i = P.j = P.nr = P.len = P.tn = P.bytes = 0;
+    P.i = next_valid(wv);
+    P.nr = P.len = P.tn = P.bytes = 0;
     P.off = 0;
-    locate(P);
+    fetch(P);
     Q = P;
     // exactly one load instruction per step (see fbk_fold_kernels.hip.h): lanes past the end of a
     // payload re-read its first 16 bytes, an exhausted producer the first 16 bytes of the arena
     const uint32_t lane16 = lane * 16u;
     auto load_chunk = [&](Chunk& c) {
       const uint8_t* p = arenaA;
-      if (P.g < total) {
+      if (P.i < cnt) {
         const uint32_t b0 = P.j * 1024u + lane16;
         p = arenaA + P.off + (b0 < P.bytes ? b0 : 0u);
         advance(P);
@@ -238,12 +233,12 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
 #pragma unroll
     for (int q = 0; q < NCH; ++q) load_chunk(C[q]);
     uint32_t c = 0;
-    while (Q.g < total) {
+    while (Q.i < cnt) {
 #pragma unroll
       for (int q = 0; q < NCH; ++q) {
         // (every slot of a lap waits and reloads, only the counting is conditional: see k_fold_scatter)
         asm volatile("s_waitcnt vmcnt(%1)" : "+v"(C[q]) : "n"(NCH - 1));
-        if (Q.g < total) {
+        if (Q.i < cnt) {
           const uint32_t d[4] = {C[q][0], C[q][1], C[q][2], C[q][3]};
           c += count_chunk(d, Q.tn >> 24, Q.len, Q.j);
           const uint32_t row = Q.i;
@@ -253,7 +248,7 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
             c = wave_rows_sum(c);
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)c, 0) + (uint32_t)__builtin_amdgcn_readlane((int)c, 16) +
                                  (uint32_t)__builtin_amdgcn_readlane((int)c, 32) + (uint32_t)__builtin_amdgcn_readlane((int)c, 48);
-            if (lane == 0 && tot) atomicAdd(&rowcnt[row], tot);
+            if (lane == 0 && tot) atomicAdd(&out_shard[(uint64_t)shard * nA + base + row], (u64)tot);
             c = 0;
           }
         }
@@ -262,9 +257,6 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
     }
     // loads still in flight target registers the compiler is about to reuse
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if ((uint32_t)t < cnt && rowcnt[t]) atomicAdd(&out_shard[(uint64_t)shard * nA + base + t], (u64)rowcnt[t]);
-    __syncthreads();  // (rowcnt is cleared again by the next pass)
   }
 }
 
