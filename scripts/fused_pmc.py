@@ -6,21 +6,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
-import _experiments  # noqa: E402
-
-_experiments.use()  # the -DFBK_EXPERIMENTS build: the ablation / cycle-stamp options do not exist in the product library
 import numpy as np  # noqa: E402
 
 import datagen as D  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 ablate = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if ablate:  # parts of the kernel switched off: the -DFBK_EXPERIMENTS build (the option does not exist in the product library)
+    import _experiments  # noqa: E402
+
+    _experiments.use()
 rows, groups, filt = D.config3_flat(n, mp="fork")
 from featurebase_amd.roaring import Context  # noqa: E402
 
 ctx = Context(0)
 batch = ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
 F = ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
-ctx.set_option("matrix_fused_ablate", ablate)
+if ablate:
+    ctx.set_option("matrix_fused_ablate", ablate)
 for _ in range(3):
     ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, np.arange(n))

@@ -16,8 +16,8 @@ ctops_small) timeout 400 python scripts/bench_ctops.py --rows 1024 --iters 20 --
 ctops) timeout 600 python scripts/bench_ctops.py --rows 1024 --iters 20 --out $O/ctops.json 2>&1 | grep -v amdgpu.ids | tail -80 > $O/ctops.txt ;;
 bench) timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err ;;
 bench2) timeout 400 python bench.py --gpus 2 --steps 100 > $O/bench_n2.json 2> $O/bench_n2.err ;;
-misc) (cd /tmp; export TMPDIR=/tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/misc -o misc -- python $R/scripts/profile_misc.py 64 > $O/misc.json 2> /dev/null) ;;
-benchprof) (cd /tmp; export TMPDIR=/tmp; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --repeats 5 --no-cpu-baseline > $O/bench_prof.json 2> /dev/null) ;;
+misc) (cd /tmp; export TMPDIR=/tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/misc -o misc -- python $R/scripts/profile_misc.py 64 > $O/misc.json 2> /dev/null; python3 $R/scripts/kernel_trace_by_grid.py $O/misc/misc_kernel_trace.csv 1 > $O/misc_kernel_trace_by_grid.csv) ;;
+benchprof) (cd /tmp; export TMPDIR=/tmp; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --repeats 5 --no-cpu-baseline > $O/bench_prof.json 2> /dev/null; python3 $R/scripts/kernel_trace_by_grid.py $O/kt/bench_kernel_trace.csv 3 > $O/kernel_trace_by_grid.csv) ;;
 pmc_pairs) KF=${KF:-icount}; bash scripts/fused_pmc.sh $TAG/pmc_v1 64 pair_kernels=1 pairs_pmc.py $KF > $O/pmc_pairs_v1.txt 2>&1; bash scripts/fused_pmc.sh $TAG/pmc_v2 64 pair_kernels=2,pair_spw=2 pairs_pmc.py $KF > $O/pmc_pairs_v2.txt 2>&1 ;;
 bsi_ahead) (for a in 3 4; do FBK_BSI_PLANES_AHEAD=$a timeout 200 python scripts/bsi_bench.py 2>&1 | grep -i "one pass\|half_waves\|Sum()" > $O/bsi_ahead$a.txt; done) ;;
 bsi) (timeout 200 python scripts/bsi_bench.py 2>&1 | grep -v amdgpu.ids > $O/bsi_bench.txt) ;;
@@ -26,6 +26,8 @@ pmc_scatter) bash scripts/fused_pmc.sh $TAG/pmc_scatter 256 0 scatter_pmc.py ${K
 spbsweep) timeout 300 python scripts/matrix_spb_sweep.py ${SWEEP_ARGS:-1024 6} 2> $O/spb_sweep.err | grep -v amdgpu.ids > $O/spb_sweep.json ;;
 small) timeout 300 python scripts/small_shapes_ab.py ${SMALL_ARGS:-64 7} 2> $O/small_shapes.err | grep -v amdgpu.ids > $O/small_shapes.json ;;
 scatter_ab) (for i in 1 2; do for lib in "" build_variants/${AB_VARIANT:-r4_container_dealing}/libfbk.so; do FBK_LIB_PATH=${lib:+$R/$lib} timeout 200 python scripts/scatter_ab.py 2>> $O/scatter_ab.err | grep "^{" >> $O/scatter_ab.jsonl; done; done) ;;
+pmc_fused) bash scripts/fused_pmc.sh $TAG/pmc_fused 256 0 fused_pmc.py count_matrix_fused > $O/pmc_fused_shipped.txt 2>&1 ;;
+fuzz) bash scripts/fuzz_parity.sh $O ${FUZZ_SEEDS:-0x5eed4001 0x5eed4002 0x5eed4003} > /dev/null 2>&1 ;;
 fused) timeout 400 python scripts/fused_bench.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_bench.txt ;;
 fusedprof) timeout 300 python scripts/fused_prof.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_prof.txt ;;
 *) echo "unknown step $s" ;;

@@ -67,6 +67,18 @@ def test_group_rccl_reduce_one_member(gpu_ctx):
     tot = grp.count_matrix([dict(a=A, rows_a=rows[:, :3], b=A, rows_b=rows[:, 3:], filt=None, rows_f=None)], 3, 3)
     ref = c.count_matrix(A, rows[:, :3], A, rows[:, 3:])
     assert (tot == ref).all()
+    # the group forms of TopN (two passes) and BSI Sum over the same communicator
+    idx, cnt = grp.topn([dict(a=A, rows_a=rows, filt=None, rows_f=None)], 6, 3)
+    e_idx, e_cnt = c.topn(A, rows, 3)
+    assert idx.tolist() == e_idx.tolist() and cnt.tolist() == e_cnt.tolist()
+    wb = D.dense_rows(2 * 10, 0.5, 2231)
+    wb[0::10] |= wb[1::10]  # exists rows cover the sign rows
+    wb[np.arange(20) % 10 != 0] &= np.repeat(wb[0::10], 9, axis=0)
+    Bb = c.upload_dense(wb)
+    base = np.array([0, 10], dtype=np.uint32)
+    s1, c1 = c.bsi_sum(Bb, base, 8)
+    assert grp.bsi_sum([dict(batch=Bb, base_rows=base, filt=None, rows_f=None)], 8) == (int(s1.sum()), int(c1.sum()))
+    Bb.free()
     plan.free()
     A.free()
     grp.close()
