@@ -106,7 +106,6 @@ struct FbkOptions {
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
   int64_t pair_spw = 0;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4; 0 and 3 are read as 1 and 2): next slot's payload in flight while the current one is decoded
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
-  int64_t pair_probe_max = 128;          // k_icount2, array x bitmap: arrays of up to this many values probe the bitmap in global memory (gather loads) instead of copying it into the wave's LDS table first (0 .. 1024)
   int64_t pair_resolve = 1;              // k_icount2 reads the plan's resolved item records and stores one count per wave (0: row index -> descriptor per wave, atomics; A/B runs)
 #ifdef FBK_EXPERIMENTS
   int64_t pair_stamp = 0;                // timing experiment on k_icount2: waves report shader cycles of a phase instead of counts (WRONG results)
@@ -679,7 +678,6 @@ const OptionDesc kOptions[] = {
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
 #endif
     {"pair_resolve", &FbkOptions::pair_resolve, 0, 1},
-    {"pair_probe_max", &FbkOptions::pair_probe_max, 0, 1024},
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
 };
@@ -1465,9 +1463,9 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
       // slots per wave: 1 (also the meaning of 0), 2 or 4 — normalised ONCE, the launch and k_sum_wave_counts below must agree
       const int spw = ctx->opt.pair_spw == 4 ? 4 : ctx->opt.pair_spw >= 2 ? 2 : 1, wpb = pair_wpb_for(ctx, p->a, p->b);
 #ifdef FBK_EXPERIMENTS
-      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16) | (uint32_t(ctx->opt.pair_probe_max / 8) << 24);
+      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16);
 #else
-      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_probe_max / 8) << 24);
+      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths);
 #endif
       if (wpb == 4) {
         switch (spw) {

@@ -526,40 +526,15 @@ __device__ __forceinline__ uint32_t bitmap_table_probe(const uint8_t* __restrict
 }
 
 // values (<= 128: one dword of two values per lane, in v[0]) of an array that are set in a bitmap container in
-// global memory
+// global memory.  (Round 4 tried the same for up to 1024 values — 16 gather loads per lane instead of copying the bitmap's
+// 8 KiB through the wave's table: 167.3 / 166.9 / 170.4 us for thresholds 128 / 512 / 1024 on config 3's 8192 row pairs,
+// profiles/r04_pairs_probe_max_ab.json — no gain, removed again.)
 __device__ __forceinline__ uint32_t array_probe_global(const uint32_t (&v)[kPairBatch], uint32_t len, const uint8_t* __restrict__ pbm, int lane) {
   const uint32_t* bm = reinterpret_cast<const uint32_t*>(pbm);
   const uint32_t i2 = 2u * (uint32_t)lane, lo = v[0] & 0xFFFFu, hi = v[0] >> 16;
   uint32_t h = 0;
   if (i2 < len) h += (bm[lo >> 5] >> (lo & 31u)) & 1u;
   if (i2 + 1u < len) h += (bm[hi >> 5] >> (hi & 31u)) & 1u;
-  return h;
-}
-
-// the same for up to 1024 values (batch 0 of the array, already in registers): the bitmap's 8 KiB never go through the wave's
-// table — no 8 x 16-byte copy into registers, no 8 LDS stores, no wait for the whole container before the first probe; the
-// probes are gather loads (each lane its own dword), which touch the container's lines once each from HBM all the same.
-// Threshold: option pair_probe_max.
-__device__ __forceinline__ uint32_t array_probe_global_batch(const uint32_t (&v)[kPairBatch], uint32_t len, const uint8_t* __restrict__ pbm, int lane) {
-  const uint32_t* bm = reinterpret_cast<const uint32_t*>(pbm);
-  uint32_t w[2 * kPairBatch];
-#pragma unroll
-  for (int k = 0; k < kPairBatch; ++k) {  // all the gathers first, then the bit tests
-    const uint32_t i2 = 2u * ((uint32_t)k * kWave + (uint32_t)lane), lo = v[k] & 0xFFFFu, hi = v[k] >> 16;
-    w[2 * k] = i2 < len ? bm[lo >> 5] : 0u;
-    w[2 * k + 1] = i2 + 1u < len ? bm[hi >> 5] : 0u;
-    if (128u * (uint32_t)(k + 1) >= len) {  // wave-uniform: the rest of the batch is past the end
-#pragma unroll
-      for (int r = k + 1; r < kPairBatch; ++r) w[2 * r] = w[2 * r + 1] = 0u;
-      break;
-    }
-  }
-  uint32_t h = 0;
-#pragma unroll
-  for (int k = 0; k < kPairBatch; ++k) {
-    const uint32_t i2 = 2u * ((uint32_t)k * kWave + (uint32_t)lane);
-    h += (i2 < len ? __builtin_amdgcn_ubfe(w[2 * k], v[k], 1u) : 0u) + (i2 + 1u < len ? __builtin_amdgcn_ubfe(w[2 * k + 1], v[k] >> 16, 1u) : 0u);
-  }
   return h;
 }
 
@@ -574,7 +549,6 @@ __device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __res
   asm volatile("" : "+v"(lane));
   const uint32_t na = slot_n(sa), nb = slot_n(sb);
   const uint32_t ta = slot_type(sa), tb = slot_type(sb);
-  const uint32_t probe_max = (sparse_paths & 1u) ? min(8u * (sparse_paths >> 24), (uint32_t)(2 * kPairBatch * kWave)) : 0u;  // option pair_probe_max (0: off)
   // timing experiments (option pair_ablate, WRONG results): 2 = no item is decoded, 8 = items with a run are skipped,
   // 16 = array x array items are skipped, 32 = bitmap x array items are skipped
   if (sparse_paths & 0x200u) return;
@@ -616,11 +590,9 @@ __device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __res
     }
   } else if (ta == kTypeArray && tb == kTypeBitmap) {
     if ((sparse_paths & 1u) && sa.len <= kProbeArray) part += array_probe_global(va, sa.len, pb, lane);
-    else if (sa.len <= probe_max) part += array_probe_global_batch(va, sa.len, pb, lane);
     else part += bitmap_table_probe(pb, pa, sa.len, va, lane, table);
   } else if (ta == kTypeBitmap && tb == kTypeArray) {
     if ((sparse_paths & 1u) && sb.len <= kProbeArray) part += array_probe_global(vb, sb.len, pa, lane);
-    else if (sb.len <= probe_max) part += array_probe_global_batch(vb, sb.len, pa, lane);
     else part += bitmap_table_probe(pa, pb, sb.len, vb, lane, table);
   } else {
     // a run on at least one side: both operands 1 KiB at a time out of the table, one clear
@@ -659,7 +631,7 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
   __shared__ u64 lds[WPB][kWords];
   __shared__ uint32_t mini[WPB][2 * kMiniDwords];
 #ifndef FBK_EXPERIMENTS
-  sparse_paths &= 0xFF0000FFu;  // the ablation / cycle-stamp bits (8..23) exist in experiment builds only: every branch on them below folds away
+  sparse_paths &= 0xFFu;  // the ablation / cycle-stamp bits (8..23) exist in experiment builds only: every branch on them below folds away
 #endif
   const u64 t0 = ((sparse_paths >> 16) & 7u) ? __builtin_readcyclecounter() : 0;
   constexpr int kWavesPerPair = kSlots / SPW;

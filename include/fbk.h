@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FBK_ABI_VERSION 3
+#define FBK_ABI_VERSION 4 /* 4 (round 4): + fbk_query_bsi_range / _fold / _topn / _output, fbk_group_bsi_sum / _topn; nothing removed or changed */
 
 /* status codes */
 #define FBK_OK 0

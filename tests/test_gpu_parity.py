@@ -13,19 +13,15 @@ from featurebase_amd import lib as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(1, 128), (2, 128), (0, 128), (2, 1024), (2, 0)],
-                ids=["pair-kernels-r2", "pair-kernels-r3", "pair-kernels-auto", "pair-kernels-r3-probe1024", "pair-kernels-r3-probe0"], autouse=True)
+@pytest.fixture(params=[1, 2, 0], ids=["pair-kernels-r2", "pair-kernels-r3", "pair-kernels-auto"], autouse=True)
 def pair_kernel_generation(request, gpu_ctx):
     """Every test of this file runs with the round-2 pair kernels (k_icount / k_setop), with the round-3 ones (k_icount2 /
     k_setop2: table + probe, interior-map run decode, one-wave blocks) and with the library's own choice by payload size:
     each generation is checked against the oracle on every input of the file, not only on the rows the dispatch would
-    hand it.  The round-3 count kernel additionally with every array x bitmap item probing the bitmap in global memory
-    (option pair_probe_max = 1024) and with none doing so (0)."""
-    gpu_ctx.set_option("pair_kernels", request.param[0])
-    gpu_ctx.set_option("pair_probe_max", request.param[1])
-    yield request.param[0]
+    hand it."""
+    gpu_ctx.set_option("pair_kernels", request.param)
+    yield request.param
     gpu_ctx.set_option("pair_kernels", 0)
-    gpu_ctx.set_option("pair_probe_max", 128)
 
 OPS = [(L.OP_AND, "intersect"), (L.OP_OR, "union"), (L.OP_XOR, "xor"), (L.OP_ANDNOT, "difference")]
 ZERO = np.zeros(1024, dtype=np.uint64)
