@@ -28,6 +28,7 @@ small) timeout 300 python scripts/small_shapes_ab.py ${SMALL_ARGS:-64 7} 2> $O/s
 scatter_ab) (for i in 1 2; do for lib in "" build_variants/${AB_VARIANT:-r4_container_dealing}/libfbk.so; do FBK_LIB_PATH=${lib:+$R/$lib} timeout 200 python scripts/scatter_ab.py 2>> $O/scatter_ab.err | grep "^{" >> $O/scatter_ab.jsonl; done; done) ;;
 pmc_fused) bash scripts/fused_pmc.sh $TAG/pmc_fused 256 0 fused_pmc.py count_matrix_fused > $O/pmc_fused_shipped.txt 2>&1 ;;
 fuzz) bash scripts/fuzz_parity.sh $O ${FUZZ_SEEDS:-0x5eed4001 0x5eed4002 0x5eed4003} > /dev/null 2>&1 ;;
+fused_spb) timeout 300 python scripts/fused_spb_sweep.py ${SWEEP_ARGS:-256 5} 2> $O/fused_spb.err | grep -v amdgpu.ids > $O/fused_spb.json ;;
 fused) timeout 400 python scripts/fused_bench.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_bench.txt ;;
 fusedprof) timeout 300 python scripts/fused_prof.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_prof.txt ;;
 *) echo "unknown step $s" ;;
