@@ -369,6 +369,19 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         g, w = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND), iters)
         out.append(_entry(f"config3 rows, {pa.size} row pairs: Intersect materialised (8 KiB cells), launch-only plan", "k_setop2<AND>", rows.bytes + pa.size * 16 * 8192, g, w,
                           set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), **common))
+        # ... and with Container.optimize() applied inside the set-op kernel (round 4): the encoded containers are the only bytes written
+        plan.setop(L.OP_AND, L.SETOP_OPTIMIZE)
+        so_counts = plan.read()
+        so_bytes = plan.output().info()[2]
+        if want_cpu:
+            eo, eo_cnt = PB.setop(PB.OP_AND, OA, pa, OA, pb)
+            assert (so_counts == eo_cnt).all(), "config 3 row pairs, Intersect + optimize: cardinalities differ from the oracle"
+            ds, ps_, nrs = plan.output().download_flat()
+            assert (PB.RowSet.from_flat(ds, ps_, nrs).words() == eo.words()).all(), "config 3 row pairs, Intersect + optimize: bit content differs from the oracle"
+            eo.free()
+        g, w = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND, L.SETOP_OPTIMIZE), iters)
+        out.append(_entry(f"config3 rows, {pa.size} row pairs: Intersect materialised + optimize() inside the kernel, launch-only plan", "k_setop2<AND> (optimize)", rows.bytes + so_bytes, g, w,
+                          set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), output_payload_bytes=so_bytes, **common))
         plan.free()
         # Union-of-64 MATERIALISED + optimize(): the prepared query (group lists and the output batch resident: memset + one launch of the
         # fold kernel, which encodes in its epilogue) beside the one-shot call; every result container compared with the oracle's

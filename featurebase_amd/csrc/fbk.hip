@@ -102,7 +102,7 @@ struct FbkOptions {
   int64_t upload_threads = 0;            // host threads that fill the pinned upload buffers (0: min(8, cores / 2))
   int64_t upload_chunk_mb = 64;          // size of each of the two pinned upload buffers
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
-  int64_t setop_direct_encode = 1;       // 0: materialising ops always write 8 KiB cells first (A/B runs)
+  int64_t setop_direct_encode = 2;       // pair set-ops with optimize(): 2 the kernel applies Container.optimize() itself (encoded bytes into the head of the cell; no re-encode pass), 1 results of <= 1024 values leave the kernel as arrays and the re-encode pass does the rest (round 2), 0 always 8 KiB cells first (A/B runs, cross-checks)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
   int64_t pair_spw = 0;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4; 0 and 3 are read as 1 and 2): next slot's payload in flight while the current one is decoded
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
@@ -670,7 +670,7 @@ const OptionDesc kOptions[] = {
     {"upload_threads", &FbkOptions::upload_threads, 0, 64},
     {"upload_chunk_mb", &FbkOptions::upload_chunk_mb, 1, 1024},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
-    {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 1},
+    {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
     {"pair_spw", &FbkOptions::pair_spw, 0, 4},
 #ifdef FBK_EXPERIMENTS
@@ -1323,21 +1323,23 @@ int pair_wpb_for(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* b) {
 template <int OP>
 void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
   const uint32_t blocks = uint32_t(p->n_pairs * fbk::kSlots / 4);
+  // (the in-kernel optimize() — mode 2 — only when the caller asked for optimize(): plain set-ops keep their bitmap cells)
+  const uint32_t direct = want_runs ? uint32_t(p->ctx->opt.setop_direct_encode) : 0u;
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
                        p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, p->d_counts);
   else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT) && pair_wpb_for(p->ctx, p->a, p->b) == 4)
     hipLaunchKernelGGL((fbk::k_setop2<OP, 4>), dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
+                       want_runs ? p->d_runs : nullptr, p->d_counts, direct);
   else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT))
     hipLaunchKernelGGL((fbk::k_setop2<OP, 1>), dim3(uint32_t(p->n_pairs * fbk::kSlots)), dim3(64), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
+                       want_runs ? p->d_runs : nullptr, p->d_counts, direct);
   else
     hipLaunchKernelGGL(fbk::k_setop<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, p->d_counts, uint32_t(p->ctx->opt.setop_direct_encode));
+                       want_runs ? p->d_runs : nullptr, p->d_counts, direct);
 }
 
 void free_batch_storage(fbk_batch* b) {
@@ -1600,11 +1602,12 @@ int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags)
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   if (op < 0 || op > 3) return fail(FBK_E_INVALID, "unknown set operation");
   if (flags & ~FBK_SETOP_OPTIMIZE) return fail(FBK_E_INVALID, "unknown flags");
-  if (flags & FBK_SETOP_OPTIMIZE)
-    return fail(FBK_E_INVALID, "FBK_SETOP_OPTIMIZE needs a synchronisation point (the re-encode sizes its output on the host): use fbk_setop");
+  const bool opt = (flags & FBK_SETOP_OPTIMIZE) != 0;
+  if (opt && ctx->opt.setop_direct_encode != 2)
+    return fail(FBK_E_INVALID, "FBK_SETOP_OPTIMIZE on a plan needs option setop_direct_encode = 2 (optimize() inside the kernel); the separate re-encode pass sizes its output on the host: use fbk_setop");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
-  return plan_setop_enqueue_locked(ctx, plan, op, false);
+  return plan_setop_enqueue_locked(ctx, plan, op, opt);
 }
 
 int32_t fbk_plan_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null) {
@@ -1691,7 +1694,7 @@ int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* 
     hipError_t e = hipMemcpyAsync(out_counts, p->d_counts, n_pairs * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
     if (e != hipSuccess) rc = fail(FBK_E_HIP, std::string("setop: ") + hipGetErrorString(e));
   }
-  if (!rc && opt) rc = optimize_cells(ctx, p->out, p->d_runs);
+  if (!rc && opt && ctx->opt.setop_direct_encode != 2) rc = optimize_cells(ctx, p->out, p->d_runs);  // (mode 2: the kernel has encoded already)
   if (!rc) rc = refresh_slots(p->out);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (!rc && e != hipSuccess) rc = fail(FBK_E_HIP, std::string("setop: ") + hipGetErrorString(e));

@@ -285,6 +285,76 @@ __device__ __forceinline__ uint32_t frag_count_runs(const u64 (&w)[kWordsPerLane
   return r;
 }
 
+// The wave's result fragment written the way Container.optimize() encodes it (roaring.go:3412-3461: runs when runs <= 2048
+// and runs <= n / 2, an array when n < 4096, else the bitmap), exactly the encoded bytes, into `dst` (the head of the
+// result's 8 KiB cell).  n and r (bitmapCountRuns of the fragment) are wave-uniform, n != 0.  Arrays and interval lists
+// are staged in `stage` (8 KiB of LDS owned by this wave, free at this point) in value order — word 128 j + 2 lane + h sits
+// in register 2 j + h, so a lane's first position in group j is the count of the earlier groups plus an exclusive scan
+// over the lanes — and leave as coalesced 16-byte stores (peeling straight into global memory with 2-byte stores tripled
+// the set-op kernels' time in round 2, which is why their own right-sized path stopped at 1024 values).
+__device__ __forceinline__ void frag_store_encoded(const u64 (&w)[kWordsPerLane], uint32_t n, uint32_t r, int lane, u64* stage,
+                                                   uint8_t* __restrict__ dst, uint32_t& out_type, uint32_t& out_len) {
+  if (!(r <= 2048u && r <= n / 2u) && n >= 4096u) {
+    frag_store_bitmap(dst, lane, w);
+    out_type = kTypeBitmap;
+    out_len = kWords;
+    return;
+  }
+  uint16_t* s16 = reinterpret_cast<uint16_t*>(stage);
+  const bool as_run = r <= 2048u && r <= n / 2u;
+  if (!as_run) {
+    uint32_t before = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t mine = (uint32_t)__popcll(w[2 * j]) + (uint32_t)__popcll(w[2 * j + 1]);
+      const uint32_t incl = wave_incl_scan(mine);
+      uint32_t pos = before + incl - mine;
+      const uint32_t base = (128u * j + 2u * (uint32_t)lane) * 64u;
+      for (u64 x = w[2 * j]; x; x &= x - 1) s16[pos++] = (uint16_t)(base + (uint32_t)__builtin_ctzll(x));
+      for (u64 x = w[2 * j + 1]; x; x &= x - 1) s16[pos++] = (uint16_t)(base + 64u + (uint32_t)__builtin_ctzll(x));
+      before += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+  } else {
+    // {start, last} pairs: start at 2k, last at 2k + 1 (bitmapToRun, roaring.go:3859)
+    uint32_t sbase = 0, ebase = 0;
+    uint32_t prev_top = 0;  // top bit of the word before this group's first word
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const u64 w0 = w[2 * j], w1 = w[2 * j + 1];
+      const uint32_t top1 = (uint32_t)(w1 >> 63);
+      uint32_t left = __shfl_up(top1, 1, kWave);
+      if (lane == 0) left = prev_top;
+      // bit 0 of the word after this lane's w1: the next lane's w0, or the next group's lane-0 w0
+      uint32_t next0 = (uint32_t)(__shfl_down((unsigned)(w0 & 1ull), 1, kWave));
+      const uint32_t n0 = j < 7 ? (uint32_t)__shfl((unsigned)(w[j < 7 ? 2 * j + 2 : 0] & 1ull), 0, kWave) : 0u;
+      if (lane == 63) next0 = n0;
+      u64 st0 = w0 & ~((w0 << 1) | (u64)left);
+      u64 st1 = w1 & ~((w1 << 1) | (w0 >> 63));
+      u64 en0 = w0 & ~((w0 >> 1) | ((w1 & 1ull) << 63));
+      u64 en1 = w1 & ~((w1 >> 1) | ((u64)next0 << 63));
+      const uint32_t cs = (uint32_t)__popcll(st0) + (uint32_t)__popcll(st1), ce = (uint32_t)__popcll(en0) + (uint32_t)__popcll(en1);
+      const uint32_t is = wave_incl_scan(cs), ie = wave_incl_scan(ce);
+      uint32_t as = sbase + is - cs, ae = ebase + ie - ce;
+      const uint32_t base = (128u * j + 2u * (uint32_t)lane) * 64u;
+      for (; st0; st0 &= st0 - 1) s16[2 * (as++)] = (uint16_t)(base + (uint32_t)__builtin_ctzll(st0));
+      for (; st1; st1 &= st1 - 1) s16[2 * (as++)] = (uint16_t)(base + 64u + (uint32_t)__builtin_ctzll(st1));
+      for (; en0; en0 &= en0 - 1) s16[2 * (ae++) + 1] = (uint16_t)(base + (uint32_t)__builtin_ctzll(en0));
+      for (; en1; en1 &= en1 - 1) s16[2 * (ae++) + 1] = (uint16_t)(base + 64u + (uint32_t)__builtin_ctzll(en1));
+      sbase += (uint32_t)__builtin_amdgcn_readlane((int)is, 63);
+      ebase += (uint32_t)__builtin_amdgcn_readlane((int)ie, 63);
+      prev_top = (uint32_t)__shfl((int)top1, 63, kWave);
+    }
+  }
+  wave_lds_sync();
+  const uint32_t chunks = ((as_run ? 4u * r : 2u * n) + 15u) >> 4;  // <= 512
+  const ulonglong2* src = reinterpret_cast<const ulonglong2*>(stage);
+  ulonglong2* q = reinterpret_cast<ulonglong2*>(dst);
+  for (uint32_t k = (uint32_t)lane; k < chunks; k += kWave) st_stream(&q[k], src[k]);
+  wave_lds_sync();
+  out_type = as_run ? kTypeRun : kTypeArray;
+  out_len = as_run ? r : n;
+}
+
 // ---- kernels -------------------------------------------------------------------------
 
 // Cardinality of every container of a batch whose n is unknown (the analogue of
@@ -716,7 +786,7 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
     }
     return;
   }
-  if (OP == 0 && direct && outRuns) {
+  if (OP == 0 && direct && (outRuns || direct == 2u)) {
     // Right-sized output (option setop_direct_encode, only when the caller asked for optimize()):
     // an intersection with a small array is a subset of that array — written as an ARRAY of <= 64
     // values into the cell (<= 128 bytes instead of 8 KiB; intersectArrayArray / intersectArrayBitmap,
@@ -736,20 +806,23 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
     if (handled) {  // wave-uniform
       const u64 below = lane ? (mm & (~0ull >> (64 - lane))) : 0ull;
       const bool mine = (mm >> lane) & 1ull;
-      if (mine) reinterpret_cast<uint16_t*>(arenaO + so.off)[__popcll(below)] = (uint16_t)v;
       // a run starts at every survivor whose predecessor among the survivors is not value - 1
       const int prev = below ? 63 - __builtin_clzll(below) : 0;
       const uint32_t vprev = (uint32_t)__shfl((int)v, prev, kWave);
       const uint32_t r = (uint32_t)__popcll(__ballot(mine && (below == 0 || vprev + 1u != v)));
       const uint32_t c = (uint32_t)__popcll(mm);
-      if (lane == 0) {
-        so.len = c;
-        so.tn = make_tn(c ? kTypeArray : kTypeNil, c);
-        outSlots[wslot] = so;
-        outRuns[wslot] = r;
-        if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
+      // (with the encoding decided HERE, survivors that optimize() would store as runs — r <= c / 2 — take the general path)
+      if (!(direct == 2u && c != 0 && r <= c / 2u)) {
+        if (mine) reinterpret_cast<uint16_t*>(arenaO + so.off)[__popcll(below)] = (uint16_t)v;
+        if (lane == 0) {
+          so.len = c;
+          so.tn = make_tn(c ? kTypeArray : kTypeNil, c);
+          outSlots[wslot] = so;
+          if (outRuns) outRuns[wslot] = r;
+          if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
+        }
+        return;
       }
-      return;
     }
   }
   u64 wa[kWordsPerLane], wb[kWordsPerLane];
@@ -765,7 +838,21 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
   }
   uint32_t c = wave_reduce_add(frag_popcount(wa));
   uint32_t r = 0;
-  if (outRuns) r = wave_reduce_add(frag_count_runs(wa, lane));
+  if (outRuns || direct == 2u) r = wave_reduce_add(frag_count_runs(wa, lane));
+  if (direct == 2u && c != 0) {
+    // option setop_direct_encode = 2 (round 4, the default when optimize() is asked for): Container.optimize() applied here,
+    // the encoded container written into the head of the cell — no re-encode pass, no compaction, no host round trip
+    uint32_t t_out, l_out;
+    frag_store_encoded(wa, c, r, lane, lds[wv], arenaO + so.off, t_out, l_out);
+    if (lane == 0) {
+      so.len = l_out;
+      so.tn = make_tn(t_out, c);
+      outSlots[wslot] = so;
+      if (outRuns) outRuns[wslot] = r;
+      if (out_counts) atomicAdd(&out_counts[pair], (u64)c);
+    }
+    return;
+  }
   bool as_array = false;
   if (direct && outRuns && c != 0 && c <= kDirectArrayMax) {
     // Right-sized output for ANY operation (only when the caller asked for optimize()): a result of at most
@@ -786,7 +873,7 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
       for (u64 x = wa[2 * j + 1]; x; x &= x - 1) o16[pos++] = (uint16_t)(base + 64u + (uint32_t)__builtin_ctzll(x));
       before += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
-  } else {
+  } else if (direct != 2u) {  // (direct == 2 gets here only with an empty result: nil, nothing to write)
     frag_store_bitmap(arenaO + so.off, lane, wa);
   }
   if (lane == 0) {

@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
     }
     return;
   }
-  if (OP == 0 && direct && outRuns) {
+  if (OP == 0 && direct && (outRuns || direct == 2u)) {
     // intersection with a small array, written as an array (see k_setop)
     const uint32_t ta = slot_type(sa), tb = slot_type(sb);
     u64 mm = 0;
@@ -785,19 +785,21 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
     if (handled) {  // wave-uniform
       const u64 below = lane ? (mm & (~0ull >> (64 - lane))) : 0ull;
       const bool mine = (mm >> lane) & 1ull;
-      if (mine) reinterpret_cast<uint16_t*>(arenaO + so.off)[__popcll(below)] = (uint16_t)v;
       const int prev = below ? 63 - __builtin_clzll(below) : 0;
       const uint32_t vprev = (uint32_t)__shfl((int)v, prev, kWave);
       const uint32_t r = (uint32_t)__popcll(__ballot(mine && (below == 0 || vprev + 1u != v)));
       const uint32_t c = (uint32_t)__popcll(mm);
-      if (lane == 0) {
-        so.len = c;
-        so.tn = make_tn(c ? kTypeArray : kTypeNil, c);
-        outSlots[wslot] = so;
-        outRuns[wslot] = r;
-        if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
+      if (!(direct == 2u && c != 0 && r <= c / 2u)) {  // (survivors optimize() would store as runs take the general path)
+        if (mine) reinterpret_cast<uint16_t*>(arenaO + so.off)[__popcll(below)] = (uint16_t)v;
+        if (lane == 0) {
+          so.len = c;
+          so.tn = make_tn(c ? kTypeArray : kTypeNil, c);
+          outSlots[wslot] = so;
+          if (outRuns) outRuns[wslot] = r;
+          if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
+        }
+        return;
       }
-      return;
     }
   }
   u64 wa[kWordsPerLane], wb[kWordsPerLane];
@@ -809,7 +811,19 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
   }
   uint32_t c = wave_reduce_add(frag_popcount(wa));
   uint32_t r = 0;
-  if (outRuns) r = wave_reduce_add(frag_count_runs(wa, lane));
+  if (outRuns || direct == 2u) r = wave_reduce_add(frag_count_runs(wa, lane));
+  if (direct == 2u && c != 0) {  // Container.optimize() applied here (see k_setop / frag_store_encoded)
+    uint32_t t_out, l_out;
+    frag_store_encoded(wa, c, r, lane, lds[wv], arenaO + so.off, t_out, l_out);
+    if (lane == 0) {
+      so.len = l_out;
+      so.tn = make_tn(t_out, c);
+      outSlots[wslot] = so;
+      if (outRuns) outRuns[wslot] = r;
+      if (out_counts) atomicAdd(&out_counts[pair], (u64)c);
+    }
+    return;
+  }
   bool as_array = false;
   if (direct && outRuns && c != 0 && c <= kDirectArrayMax) {
     as_array = true;
@@ -825,7 +839,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
       for (u64 x = wa[2 * j + 1]; x; x &= x - 1) o16[pos++] = (uint16_t)(base + 64u + (uint32_t)__builtin_ctzll(x));
       before += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
-  } else {
+  } else if (direct != 2u) {  // (direct == 2 gets here only with an empty result: nil, nothing to write)
     frag_store_bitmap(arenaO + so.off, lane, wa);
   }
   if (lane == 0) {

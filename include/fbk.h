@@ -331,7 +331,10 @@ int32_t fbk_plan_intersection_count_accumulate(fbk_ctx* ctx, fbk_plan* plan, voi
 /* Enqueue out row i = A.rows_a[i] <op> B.rows_b[i] and counts[i] = its cardinality
  * (Bitmap.Intersect/Union/Xor/Difference + Count, roaring.go:736,1272,1598,1564;
  * executeCount's mapFn, executor.go:5871-5876).  The output batch is owned by the plan
- * and overwritten by the next enqueue.  Asynchronous. */
+ * and overwritten by the next enqueue.  Asynchronous.  flags = FBK_SETOP_OPTIMIZE (round 4): the
+ * kernel applies Container.optimize() itself and writes the encoded container into the head of each
+ * result cell — still launch-only (option setop_direct_encode = 2, the default; with 0 / 1 the
+ * re-encode is a separate pass that sizes its output on the host, which only fbk_setop can run). */
 int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags);
 
 /* Enqueue total = sum_i counts[i] (executeCount reduceFn, executor.go:5880) into the

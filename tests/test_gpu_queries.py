@@ -1356,3 +1356,78 @@ def test_fold_optimize_in_the_epilogue_equals_the_separate_pass(gpu_ctx, oracle)
     finally:
         gpu_ctx.set_option("fold_encode", 1)
     batch.free()
+
+
+def test_setop_optimize_inside_the_kernel_equals_the_separate_pass(gpu_ctx, oracle):
+    """Pair set-ops + optimize(): option setop_direct_encode = 2 (round 4: Container.optimize() applied by the set-op kernel,
+    the encoded container written into the head of its cell), 1 (round 2: small results as arrays, then the re-encode pass) and
+    0 (bitmap cells, then the re-encode pass) give the same descriptors, payload bytes and roaring image, for both generations
+    of the pair kernels; every container has optimize()'s encoding of the oracle's result.  Also as a PLAN: launch-only with
+    mode 2, refused with the others."""
+    O = oracle
+    rng = D.rng_for(4343)
+
+    def cont():
+        k = int(rng.integers(0, 8))
+        if k == 0:
+            return O.OContainer.run([(0, 65535)])
+        if k == 1:
+            nr = int(rng.choice([1, 3, 40, 900, 2048]))
+            per = 65536 // nr
+            st = np.arange(nr) * per + rng.integers(0, max(1, per // 3), nr)
+            ln = rng.integers(1, max(2, per // 2), nr)
+            return O.OContainer.run([(int(s), int(min(s + l, 65535))) for s, l in zip(st, ln)])
+        if k == 2:
+            return O.OContainer.run([(32700, 32900), (65500, 65535)])
+        if k in (3, 4):
+            return O.OContainer.array(np.sort(rng.choice(65536, int(rng.choice([1, 7, 60, 300, 2047, 4095])), replace=False)))
+        if k == 5:  # consecutive values: optimize() turns the intersection of arrays into runs
+            s0 = int(rng.integers(0, 60000))
+            return O.OContainer.array(np.arange(s0, s0 + int(rng.integers(2, 50))))
+        return O.OContainer.bitmap(D.words_of(np.sort(rng.choice(65536, int(rng.choice([5000, 30000, 65000])), replace=False))))
+
+    n = 40
+    rows_a = [{r * 16 + s: cont() for s in range(16) if rng.random() > 0.15} for r in range(n)]
+    rows_b = [{r * 16 + s: cont() for s in range(16) if rng.random() > 0.15} for r in range(n)]
+    A, Bt = gpu_ctx.upload([D.to_fbk_row(r) for r in rows_a]), gpu_ctx.upload([D.to_fbk_row(r) for r in rows_b])
+    idx = np.arange(n)
+    try:
+        for pk in (1, 2):
+            gpu_ctx.set_option("pair_kernels", pk)
+            for op, name in [(L.OP_AND, "intersect"), (L.OP_OR, "union"), (L.OP_XOR, "xor"), (L.OP_ANDNOT, "difference")]:
+                got = {}
+                for mode in (2, 1, 0):
+                    gpu_ctx.set_option("setop_direct_encode", mode)
+                    out, cnt = gpu_ctx.setop(op, A, idx, Bt, idx, flags=L.SETOP_OPTIMIZE)
+                    d, p, _ = out.download_flat()
+                    got[mode] = (d.tobytes(), p.tobytes(), cnt.copy(), out.to_roaring(), out.download())
+                    out.free()
+                for mode in (1, 0):
+                    assert got[2][0] == got[mode][0] and got[2][1] == got[mode][1] and (got[2][2] == got[mode][2]).all() and got[2][3] == got[mode][3], (pk, name, mode)
+                types = set()
+                for r in range(n):
+                    a = O.OBitmap.from_containers(list(rows_a[r].items()))
+                    b = O.OBitmap.from_containers(list(rows_b[r].items()))
+                    e = {"intersect": a.intersect, "union": a.union, "xor": a.xor, "difference": a.difference}[name](b)
+                    assert_optimized_like_oracle(O, got[2][4][r], e)
+                    assert int(got[2][2][r]) == e.count()
+                    types |= {c.typ for c in got[2][4][r].values()}
+                assert types == {L.TYPE_ARRAY, L.TYPE_BITMAP, L.TYPE_RUN}, (pk, name, types)
+        # the plan form: launch-only with the in-kernel optimize, refused when the re-encode would be a separate pass
+        gpu_ctx.set_option("pair_kernels", 0)
+        gpu_ctx.set_option("setop_direct_encode", 2)
+        plan = gpu_ctx.plan(A, idx, Bt, idx)
+        ref, rcnt = gpu_ctx.setop(L.OP_XOR, A, idx, Bt, idx, flags=L.SETOP_OPTIMIZE)
+        for _ in range(2):
+            plan.setop(L.OP_XOR, L.SETOP_OPTIMIZE)
+        assert (plan.read() == rcnt).all() and plan.output().to_roaring() == ref.to_roaring()
+        gpu_ctx.set_option("setop_direct_encode", 1)
+        with pytest.raises(L.FbkError):
+            plan.setop(L.OP_XOR, L.SETOP_OPTIMIZE)
+        plan.free()
+        ref.free()
+    finally:
+        gpu_ctx.set_option("pair_kernels", 0)
+        gpu_ctx.set_option("setop_direct_encode", 2)
+    A.free()
+    Bt.free()
