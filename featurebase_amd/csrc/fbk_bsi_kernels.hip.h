@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(64) k_bsi_range_slot(const Slot* __restrict__ 
                                                       const uint32_t* __restrict__ base, uint32_t n_shards,
                                                       const uint32_t* __restrict__ prog, uint32_t prog_len, uint32_t n_rows_frag,
                                                       uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
-                                                      uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts) {
+                                                      uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts, uint32_t encode) {
   __shared__ u64 lds[kWords];
   __shared__ Slot tab[kBsiDescCap];
   __shared__ u64 save[kWords];  // S lives in LDS (only BETWEEN programs use it): 32 registers fewer, two wavefronts per SIMD
@@ -363,9 +363,16 @@ __global__ void __launch_bounds__(64) k_bsi_range_slot(const Slot* __restrict__ 
   so.off = cell * 8192ull;
   so.len = kWords;
   so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
-  if (c) frag_store_bitmap(arenaO + so.off, lane, X);
   uint32_t rr = 0;
-  if (outRuns) rr = wave_reduce_add(frag_count_runs(X, lane));  // bitmapCountRuns (roaring.go:3372-3380)
+  if (outRuns || encode) rr = wave_reduce_add(frag_count_runs(X, lane));  // bitmapCountRuns (roaring.go:3372-3380)
+  if (encode && c) {  // Container.optimize() applied here (frag_store_encoded, fbk_kernels.hip.h): the scratch is free now
+    uint32_t t_out, l_out;
+    frag_store_encoded(X, c, rr, lane, lds, arenaO + so.off, t_out, l_out);
+    so.len = l_out;
+    so.tn = make_tn(t_out, c);
+  } else if (c) {
+    frag_store_bitmap(arenaO + so.off, lane, X);
+  }
   if (lane == 0) {
     outSlots[cell] = so;
     if (outRuns) outRuns[cell] = rr;

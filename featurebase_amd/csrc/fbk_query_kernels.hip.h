@@ -667,7 +667,7 @@ constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 __global__ void __launch_bounds__(256) k_shift(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
                                               const uint32_t* __restrict__ rows, const uint32_t* __restrict__ carry_rows,
                                               uint64_t n_rows, uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
-                                              uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts) {
+                                              uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts, uint32_t encode) {
   __shared__ u64 lds[4][kWords];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -715,12 +715,15 @@ __global__ void __launch_bounds__(256) k_shift(const Slot* __restrict__ slots, c
     w[2 * j] = (even << 1) | in;
     w[2 * j + 1] = (w[2 * j + 1] << 1) | (even >> 63);
   }
-  frag_store_bitmap(arenaO + so.off, lane, w);
   const uint32_t c = wave_reduce_add(frag_popcount(w));
   uint32_t r = 0;
-  if (outRuns) r = wave_reduce_add(frag_count_runs(w, lane));
+  if (outRuns || encode) r = wave_reduce_add(frag_count_runs(w, lane));
+  uint32_t t_out = c ? kTypeBitmap : kTypeNil, l_out = kWords;
+  if (encode && c) frag_store_encoded(w, c, r, lane, lds[wv], arenaO + so.off, t_out, l_out);  // optimize() applied here
+  else if (c) frag_store_bitmap(arenaO + so.off, lane, w);
   if (lane == 0) {
-    so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
+    so.len = l_out;
+    so.tn = make_tn(t_out, c);
     outSlots[wslot] = so;
     if (outRuns) outRuns[wslot] = r;
     if (out_counts && c) atomicAdd(&out_counts[i], (u64)c);
@@ -734,7 +737,7 @@ __global__ void __launch_bounds__(256) k_shift(const Slot* __restrict__ slots, c
 __global__ void __launch_bounds__(256) k_flip(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
                                              const uint32_t* __restrict__ rows, uint64_t n_rows, uint32_t start, uint32_t end_incl,
                                              uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
-                                             u64* __restrict__ out_counts) {
+                                             u64* __restrict__ out_counts, uint32_t encode) {
   __shared__ u64 lds[4][kWords];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -767,11 +770,14 @@ __global__ void __launch_bounds__(256) k_flip(const Slot* __restrict__ slots, co
       }
   }
   const uint32_t c = wave_reduce_add(frag_popcount(w));
-  if (c) frag_store_bitmap(arenaO + so.off, lane, w);
   uint32_t r = 0;
-  if (outRuns) r = wave_reduce_add(frag_count_runs(w, lane));
+  if (outRuns || encode) r = wave_reduce_add(frag_count_runs(w, lane));
+  uint32_t t_out = c ? kTypeBitmap : kTypeNil, l_out = kWords;
+  if (encode && c) frag_store_encoded(w, c, r, lane, lds[wv], arenaO + so.off, t_out, l_out);  // optimize() applied here
+  else if (c) frag_store_bitmap(arenaO + so.off, lane, w);
   if (lane == 0) {
-    so.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
+    so.len = l_out;
+    so.tn = make_tn(t_out, c);
     outSlots[wslot] = so;
     if (outRuns) outRuns[wslot] = r;
     if (out_counts && c) atomicAdd(&out_counts[i], (u64)c);
