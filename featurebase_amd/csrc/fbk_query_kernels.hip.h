@@ -134,7 +134,7 @@ __device__ __forceinline__ void frag_from_raw(const Raw& r, uint32_t type, uint3
 //               (executor.go:2950-2983) / Bitmap.Difference(others...) (roaring.go:1564-1595).
 // With a filter batch: counts[g] += |result ∩ F.rows_f[g]| (Bitmap.IntersectionCount of
 // the result against the filter row), else counts[g] += |result|.
-template <int OP, bool WRITE>
+template <int OP, int WRITE>  // WRITE: 0 counts only, 1 the result as a bitmap cell (+ run count), 2 Container.optimize() applied here (frag_store_encoded)
 __global__ void __launch_bounds__(256) k_fold_n(const Slot* __restrict__ slots, const uint8_t* __restrict__ arena,
                                                const uint32_t* __restrict__ rows, uint64_t n_groups, uint32_t k,
                                                const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,
@@ -273,9 +273,16 @@ __global__ void __launch_bounds__(256) k_fold_n(const Slot* __restrict__ slots, 
     so.off = cell * 8192ull;
     so.len = kWords;
     so.tn = make_tn(cu ? kTypeBitmap : kTypeNil, cu);
-    if (cu) frag_store_bitmap(arenaO + so.off, lane, acc);
     uint32_t r = 0;
-    if (outRuns) r = wave_reduce_add(frag_count_runs(acc, lane));
+    if (outRuns || WRITE == 2) r = wave_reduce_add(frag_count_runs(acc, lane));
+    if (WRITE == 2 && cu) {  // (wave 0's scratch is free: every partial has been read)
+      uint32_t t_out, l_out;
+      frag_store_encoded(acc, cu, r, lane, lds[0], arenaO + so.off, t_out, l_out);
+      so.len = l_out;
+      so.tn = make_tn(t_out, cu);
+    } else if (cu) {
+      frag_store_bitmap(arenaO + so.off, lane, acc);
+    }
     if (lane == 0) {
       outSlots[cell] = so;
       if (outRuns) outRuns[cell] = r;

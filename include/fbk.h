@@ -383,7 +383,7 @@ int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_bat
  *   fbk_query_bsi_range                 Row(v op predicate), fragment.rangeOp (fragment.go:937-1303), arguments
  *                                       as fbk_bsi_range (8 KiB cells).  run = memset + k_bsi_range_slot;
  *                                       read: out0 = uint64 cardinalities [n_shards]
- *   fbk_query_fold                      the materialised n-way Union / Xor / Difference (fbk_fold_n; flags =
+ *   fbk_query_fold                      the materialised n-way fold of any of the four operations (fbk_fold_n; flags =
  *                                       FBK_SETOP_OPTIMIZE: Container.optimize() in the kernel's epilogue).
  *                                       run = memset + ONE launch; read: out0 = uint64 cardinalities [n_groups]
  *   fbk_query_output(q, &batch)         the output batch of the last run, BORROWED: owned by the query, rewritten
