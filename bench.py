@@ -380,6 +380,12 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             assert (PB.RowSet.from_flat(ds, ps_, nrs).words() == eo.words()).all(), "config 3 row pairs, Intersect + optimize: bit content differs from the oracle"
             eo.free()
         g, w = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND, L.SETOP_OPTIMIZE), iters)
+        # A/B in the same process: option setop_probe = 0 decodes both operands of every item into 8 KiB fragments (the form every
+        # other type pair takes); 1 (shipped) lets an array operand probe the other's table and writes the survivors as they come
+        ctx.set_option("setop_probe", 0)
+        g_frag, _ = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND, L.SETOP_OPTIMIZE), iters)
+        ctx.set_option("setop_probe", 1)
+        plan.setop(L.OP_AND, L.SETOP_OPTIMIZE)
         # for scale: the one-shot call with optimize() inside the kernel, and with the round-2/3 pipeline (bitmap / small-array cells,
         # then the separate re-encode pass: plan, two scans, a host round trip for the arena size, write)
         c_in = call_us(lambda: ctx.setop(L.OP_AND, batch, pa, batch, pb, L.SETOP_OPTIMIZE)[0].free())
@@ -388,7 +394,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         ctx.set_option("setop_direct_encode", 2)
         out.append(_entry(f"config3 rows, {pa.size} row pairs: Intersect materialised + optimize() inside the kernel (only the encoded containers are written), launch-only plan", "k_setop2<AND> (optimize)",
                           rows.bytes + so_bytes, g, w, set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), output_payload_bytes=so_bytes, call_us=c_in,
-                          call_us_with_the_separate_reencode_pass=c_sep, **common))
+                          call_us_with_the_separate_reencode_pass=c_sep, launch_us_with_both_operands_decoded_into_fragments=g_frag, **common))
         plan.free()
         # Union-of-64 MATERIALISED + optimize(): the prepared query (group lists and the output batch resident: memset + one launch of the
         # fold kernel, which encodes in its epilogue) beside the one-shot call; every result container compared with the oracle's

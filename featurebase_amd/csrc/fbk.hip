@@ -111,6 +111,7 @@ struct FbkOptions {
   int64_t pair_stamp = 0;                // timing experiment on k_icount2: waves report shader cycles of a phase instead of counts (WRONG results)
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
 #endif
+  int64_t setop_probe = 1;               // k_setop2 with in-kernel optimize(): Intersect / Difference whose result is a subset of an array operand by table + probe, survivors written as the array (0: both operands decoded into fragments, as for every other type pair; same bytes)
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
 
@@ -255,9 +256,27 @@ void ctx_free(fbk_ctx* ctx, void* p) {
     if (it != ctx->pool_live.end()) {
       const uint64_t bucket = it->second;
       ctx->pool_live.erase(it);
-      if (ctx->pool_cached_bytes + bucket <= ctx->pool_cap_bytes) {
+      if (bucket <= ctx->pool_cap_bytes) {
+        // the block just returned is the likeliest to be asked for again: keep it, and when the cache is over its cap give
+        // back the largest blocks cached before it (other sizes first) until it fits
+        std::vector<void*> drop;
+        while (ctx->pool_cached_bytes + bucket > ctx->pool_cap_bytes) {
+          uint64_t victim = 0;
+          for (auto& kv : ctx->pool_free_lists)
+            if (!kv.second.empty() && kv.first != bucket && kv.first > victim) victim = kv.first;
+          if (!victim) {
+            auto own = ctx->pool_free_lists.find(bucket);
+            if (own == ctx->pool_free_lists.end() || own->second.empty()) break;
+            victim = bucket;
+          }
+          auto& fl = ctx->pool_free_lists[victim];
+          drop.push_back(fl.front());
+          fl.erase(fl.begin());
+          ctx->pool_cached_bytes -= victim;
+        }
         ctx->pool_free_lists[bucket].push_back(p);
         ctx->pool_cached_bytes += bucket;
+        for (void* d : drop) (void)hipFree(d);
         return;
       }
     }
@@ -671,6 +690,7 @@ const OptionDesc kOptions[] = {
     {"upload_chunk_mb", &FbkOptions::upload_chunk_mb, 1, 1024},
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
+    {"setop_probe", &FbkOptions::setop_probe, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
     {"pair_spw", &FbkOptions::pair_spw, 0, 4},
 #ifdef FBK_EXPERIMENTS
@@ -732,6 +752,8 @@ int32_t open_on_device(int32_t device, fbk_ctx* root, fbk_ctx** out_ctx) {
     root->children.fetch_add(1);
   } else {
     // the only place the environment is read
+    // cached (freed, reusable) device blocks: an eighth of the device, at least 8 GiB; given back on an allocation failure
+    ctx->pool_cap_bytes = std::max<uint64_t>(ctx->pool_cap_bytes, uint64_t(prop.totalGlobalMem) / 8);
     if (const char* cap = getenv("FBK_POOL_MAX_BYTES")) ctx->pool_cap_bytes = strtoull(cap, nullptr, 10);
     options_from_env(ctx->opt);
   }
@@ -1325,17 +1347,18 @@ void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
   const uint32_t blocks = uint32_t(p->n_pairs * fbk::kSlots / 4);
   // (the in-kernel optimize() — mode 2 — only when the caller asked for optimize(): plain set-ops keep their bitmap cells)
   const uint32_t direct = want_runs ? uint32_t(p->ctx->opt.setop_direct_encode) : 0u;
+  const uint32_t direct2 = direct | (p->ctx->opt.setop_probe ? 0x100u : 0u);  // k_setop2 only
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
                        p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, p->d_counts);
   else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT) && pair_wpb_for(p->ctx, p->a, p->b) == 4)
     hipLaunchKernelGGL((fbk::k_setop2<OP, 4>), dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, p->d_counts, direct);
+                       want_runs ? p->d_runs : nullptr, p->d_counts, direct2);
   else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT))
     hipLaunchKernelGGL((fbk::k_setop2<OP, 1>), dim3(uint32_t(p->n_pairs * fbk::kSlots)), dim3(64), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, p->d_counts, direct);
+                       want_runs ? p->d_runs : nullptr, p->d_counts, direct2);
   else
     hipLaunchKernelGGL(fbk::k_setop<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,

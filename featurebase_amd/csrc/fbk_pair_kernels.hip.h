@@ -733,6 +733,109 @@ __global__ void __launch_bounds__(256) k_resolve_items(const Slot* __restrict__ 
 // decoded — was built and measured this round: 64 us against 46 for the 2048 config-3 pairs (128 registers, static striding
 // over items of very different cost).  Removed; the one-wave blocks above give the hardware's dispatcher that job.)
 
+// ---- Intersect / Difference whose result is a subset of an ARRAY operand, by the count kernel's table + probe -------
+//
+// intersectArrayArray / intersectArrayBitmap / differenceArrayArray / differenceArrayBitmap (roaring.go:4632-4700,
+// 5339-5420) walk the array and keep the values found (not found) in the other container.  The materialising kernel did
+// that by decoding BOTH operands into 8 KiB fragments whatever their size (frag_load_pair: a table clear, a scatter and a
+// read-back per sparse operand), then popcount, run count, and an encode pass through the LDS — ~310 us for config 3's
+// 8192 sparse row pairs where counting the same intersections takes 176.  Here the other operand becomes the wave's
+// table exactly as in k_icount2 (shorter array scattered into the cleared table / bitmap copied in), the array PROBES it,
+// and the survivors are written straight into the output cell as the sorted array they already are: positions from two
+// ballots per dword row, the run count of the result (for Container.optimize()'s rule) from each survivor's predecessor.
+struct ProbeEmit {
+  uint32_t before = 0;             // survivors written so far (wave-uniform)
+  uint32_t runs = 0;               // this lane's survivors that start a run
+  uint32_t last_val = 0x7FFFFFFFu; // the array element in front of lane 0's of the coming dword row, and whether it
+  uint32_t last_kept = 0;          // survived (wave-uniform)
+};
+
+// one batch of the probing array: KEEP = 1 keeps the values set in the table, 0 those that are not
+template <int KEEP>
+__device__ __forceinline__ void array_probe_emit_batch(uint32_t tb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch],
+                                                       uint16_t* __restrict__ o16, ProbeEmit& e) {
+  const u64 lane_lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int k = 0; k < kPairBatch; ++k) {
+    if ((base + (uint32_t)k * kWave) * 2u >= len) break;  // (wave-uniform: no value in this dword row or after it)
+    const uint32_t i2 = (base + (uint32_t)k * kWave + (uint32_t)lane) * 2u;
+    const uint32_t lo = v[k] & 0xFFFFu, hi = v[k] >> 16;
+    const uint32_t t_lo = table_bit_lo(tb, v[k]), t_hi = table_bit_hi(tb, v[k]);  // (junk lanes read word 0: in bounds)
+    const bool k_lo = i2 < len && t_lo == (uint32_t)KEEP;
+    const bool k_hi = i2 + 1u < len && t_hi == (uint32_t)KEEP;
+    const u64 m_lo = __ballot(k_lo), m_hi = __ballot(k_hi);
+    // the element in front of this lane's `lo` is the previous lane's `hi` (lane 0: the previous row's last)
+    uint32_t pv = (uint32_t)__shfl_up((int)hi, 1, kWave);
+    if (lane == 0) pv = e.last_val;
+    const bool pk = (((m_hi << 1) | (u64)e.last_kept) >> lane) & 1ull;
+    const uint32_t pos = e.before + (uint32_t)__popcll(m_lo & lane_lt) + (uint32_t)__popcll(m_hi & lane_lt);
+    if (k_lo) o16[pos] = (uint16_t)lo;
+    if (k_hi) o16[pos + (k_lo ? 1u : 0u)] = (uint16_t)hi;
+    e.runs += ((k_lo && !(pk && pv + 1u == lo)) ? 1u : 0u) + ((k_hi && !(k_lo && lo + 1u == hi)) ? 1u : 0u);
+    e.before += (uint32_t)__popcll(m_lo) + (uint32_t)__popcll(m_hi);
+    e.last_val = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+    e.last_kept = (uint32_t)(m_hi >> 63);
+  }
+}
+
+// the whole probing array (batch 0 in v0, batches 1..3 in the tail requested before the table was built)
+template <int KEEP>
+__device__ __forceinline__ void array_probe_emit_all(const uint8_t* __restrict__ p, uint32_t len, int lane, uint32_t tb, const uint32_t (&v0)[kPairBatch],
+                                                     const ProbeTail& t, uint16_t* __restrict__ o16, uint32_t& n_out, uint32_t& runs_out) {
+  const uint32_t n_units = (len + 1u) >> 1;
+  constexpr uint32_t B = kPairBatch * kWave;
+  ProbeEmit e;
+  array_probe_emit_batch<KEEP>(tb, len, 0, lane, v0, o16, e);
+  if (n_units > B) array_probe_emit_batch<KEEP>(tb, len, B, lane, t.v1, o16, e);
+  if (n_units > 2 * B) array_probe_emit_batch<KEEP>(tb, len, 2 * B, lane, t.v2, o16, e);
+  if (n_units > 3 * B) array_probe_emit_batch<KEEP>(tb, len, 3 * B, lane, t.v3, o16, e);
+  for (uint32_t base = 4 * B; base < n_units; base += B) {  // a probing array beyond 4096 values (roaring.go:5054; the survivors still fit: the caller checked the bound)
+    uint32_t v[kPairBatch];
+    sparse_load(p, n_units, base, lane, v);
+    array_probe_emit_batch<KEEP>(tb, len, base, lane, v, o16, e);
+  }
+  n_out = e.before;
+  runs_out = wave_reduce_add(e.runs);
+}
+
+// probing array (pp, lp <= 4095 values, batch 0 in vp) against an ARRAY operand (pt, lt, batch 0 in vt)
+template <int KEEP>
+__device__ __forceinline__ void array_vs_array_emit(const uint8_t* __restrict__ pt, uint32_t lt, uint32_t (&vt)[kPairBatch], const uint8_t* __restrict__ pp,
+                                                    uint32_t lp, const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint16_t* __restrict__ o16,
+                                                    uint32_t& n_out, uint32_t& runs_out) {
+  ProbeTail tail;
+  probe_tail_load(pp, lp, lane, tail);
+  const uint32_t tbase = lds_table_base(table);
+  lds_zero(table, lane);
+  wave_lds_sync();
+  sparse_xor_all(kTypeArray, pt, lt, lane, tbase, vt);
+  wave_lds_sync();
+  array_probe_emit_all<KEEP>(pp, lp, lane, tbase, vp, tail, o16, n_out, runs_out);
+  wave_lds_sync();
+}
+
+// probing array against a BITMAP operand (copied into the table, no clear)
+template <int KEEP>
+__device__ __forceinline__ void array_vs_bitmap_emit(const uint8_t* __restrict__ pbm, const uint8_t* __restrict__ pp, uint32_t lp,
+                                                     const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint16_t* __restrict__ o16, uint32_t& n_out,
+                                                     uint32_t& runs_out) {
+  u64 wb[kWordsPerLane];
+  frag_load_bitmap(pbm, lane, wb);
+  ProbeTail tail;
+  probe_tail_load(pp, lp, lane, tail);
+  ulonglong2* q = reinterpret_cast<ulonglong2*>(table);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ulonglong2 x;
+    x.x = wb[2 * j];
+    x.y = wb[2 * j + 1];
+    q[j * kWave + lane] = x;  // fragment layout -> natural word order in the table
+  }
+  wave_lds_sync();
+  array_probe_emit_all<KEEP>(pp, lp, lane, lds_table_base(table), vp, tail, o16, n_out, runs_out);
+  wave_lds_sync();
+}
+
 // Materialising A <op> B, one wave per (pair, slot): k_setop's outputs and right-sized array paths
 // (fbk_kernels.hip.h) behind the pair loader above.
 template <int OP, int WPB>
@@ -745,6 +848,8 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
   __shared__ uint32_t mini[WPB][2 * kMiniDwords];
   const int lane = threadIdx.x & 63;
   const int wv = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: descriptors become scalar loads (see k_icount2)
+  const bool probe = (direct & 0x100u) != 0;  // option setop_probe: Intersect / Difference of an array by table + probe (A/B: both forms give the same bytes)
+  direct &= 0xFFu;
   const uint64_t wslot = (uint64_t)blockIdx.x * WPB + (uint64_t)wv;
   const uint64_t pair = wslot >> 4;
   const uint32_t slot = wslot & 15;
@@ -800,6 +905,44 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
         }
         return;
       }
+    }
+  }
+  if ((OP == 0 || OP == 3) && direct == 2u && probe) {
+    // the result is a subset of an array operand: table + probe, survivors written as the array they are (see above).
+    // (Arrays beyond 4095 values — oversized intermediates, roaring.go:5054 — could overflow the cell: general path.)
+    const uint32_t ta = slot_type(sa), tb = slot_type(sb);
+    const uint8_t* pa = arenaA + sa.off;
+    const uint8_t* pb = arenaB + sb.off;
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(arenaO + so.off);
+    uint32_t c = 0, r = 0;
+    bool done = false;
+    if (ta == kTypeArray && tb == kTypeArray && (OP == 3 ? sa.len : min(sa.len, sb.len)) <= 4095u) {
+      uint32_t va[kPairBatch], vb[kPairBatch];
+      sparse_load(pa, (sa.len + 1u) >> 1, 0, lane, va);
+      sparse_load(pb, (sb.len + 1u) >> 1, 0, lane, vb);
+      if (OP == 3 || sa.len > sb.len) array_vs_array_emit<OP == 0>(pb, sb.len, vb, pa, sa.len, va, lane, lds[wv], o16, c, r);  // A probes B's table
+      else array_vs_array_emit<1>(pa, sa.len, va, pb, sb.len, vb, lane, lds[wv], o16, c, r);  // (Intersect: the longer array probes)
+      done = true;
+    } else if (ta == kTypeArray && tb == kTypeBitmap && sa.len <= 4095u) {
+      uint32_t va[kPairBatch];
+      sparse_load(pa, (sa.len + 1u) >> 1, 0, lane, va);
+      array_vs_bitmap_emit<OP == 0>(pb, pa, sa.len, va, lane, lds[wv], o16, c, r);
+      done = true;
+    } else if (OP == 0 && ta == kTypeBitmap && tb == kTypeArray && sb.len <= 4095u) {
+      uint32_t vb[kPairBatch];
+      sparse_load(pb, (sb.len + 1u) >> 1, 0, lane, vb);
+      array_vs_bitmap_emit<1>(pa, pb, sb.len, vb, lane, lds[wv], o16, c, r);
+      done = true;
+    }
+    if (done && !(c != 0 && r <= c / 2u)) {  // (survivors optimize() would store as runs take the general path below and overwrite the cell)
+      if (lane == 0) {
+        so.len = c;
+        so.tn = make_tn(c ? kTypeArray : kTypeNil, c);
+        outSlots[wslot] = so;
+        if (outRuns) outRuns[wslot] = r;
+        if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
+      }
+      return;
     }
   }
   u64 wa[kWordsPerLane], wb[kWordsPerLane];

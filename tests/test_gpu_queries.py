@@ -1397,13 +1397,16 @@ def test_setop_optimize_inside_the_kernel_equals_the_separate_pass(gpu_ctx, orac
             gpu_ctx.set_option("pair_kernels", pk)
             for op, name in [(L.OP_AND, "intersect"), (L.OP_OR, "union"), (L.OP_XOR, "xor"), (L.OP_ANDNOT, "difference")]:
                 got = {}
-                for mode in (2, 1, 0):
-                    gpu_ctx.set_option("setop_direct_encode", mode)
+                # (mode 2 with and without option setop_probe: Intersect / Difference of an array operand by table + probe, survivors
+                # written as the array they are, against both operands decoded into fragments — "2f")
+                for mode in (2, "2f", 1, 0):
+                    gpu_ctx.set_option("setop_direct_encode", 2 if mode == "2f" else mode)
+                    gpu_ctx.set_option("setop_probe", 0 if mode == "2f" else 1)
                     out, cnt = gpu_ctx.setop(op, A, idx, Bt, idx, flags=L.SETOP_OPTIMIZE)
                     d, p, _ = out.download_flat()
                     got[mode] = (d.tobytes(), p.tobytes(), cnt.copy(), out.to_roaring(), out.download())
                     out.free()
-                for mode in (1, 0):
+                for mode in ("2f", 1, 0):
                     assert got[2][0] == got[mode][0] and got[2][1] == got[mode][1] and (got[2][2] == got[mode][2]).all() and got[2][3] == got[mode][3], (pk, name, mode)
                 types = set()
                 for r in range(n):
@@ -1430,5 +1433,6 @@ def test_setop_optimize_inside_the_kernel_equals_the_separate_pass(gpu_ctx, orac
     finally:
         gpu_ctx.set_option("pair_kernels", 0)
         gpu_ctx.set_option("setop_direct_encode", 2)
+        gpu_ctx.set_option("setop_probe", 1)
     A.free()
     Bt.free()

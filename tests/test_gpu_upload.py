@@ -81,3 +81,30 @@ def test_malformed_content_is_refused_by_the_device_check(gpu_ctx):
     b = gpu_ctx.upload([{0: c}])
     assert int(b.count([0])[0]) == 7
     b.free()
+
+
+def test_a_pool_cap_smaller_than_the_working_set_evicts_and_stays_correct(monkeypatch):
+    """FBK_POOL_MAX_BYTES: freed device blocks are cached up to the cap; the block just freed is kept and older, larger ones are
+    given back.  With a cap of a few MiB every call below frees more than fits, so blocks are evicted and re-allocated
+    between calls; the results must not change."""
+    from featurebase_amd.roaring import Context
+
+    monkeypatch.setenv("FBK_POOL_MAX_BYTES", str(6 << 20))
+    ctx = Context(0)
+    try:
+        want = None
+        for it in range(6):
+            n = 24 + 8 * (it % 3)  # 3, 4, 5 MiB of bitmap cells: different pool buckets on successive calls
+            w = D.dense_rows(n, 0.5, 9300 + (it % 3))
+            b = ctx.upload_dense(w)
+            out, counts = ctx.setop(L.OP_AND, b, np.arange(n - 1), b, np.arange(1, n))
+            ref = np.bitwise_count(w[:-1] & w[1:]).sum(axis=(1, 2))
+            assert (counts == ref).all(), it
+            if it % 3 == 0:
+                if want is None:
+                    want = counts.copy()
+                assert (counts == want).all()
+            out.free()
+            b.free()
+    finally:
+        ctx.close()
