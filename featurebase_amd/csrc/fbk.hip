@@ -112,6 +112,7 @@ struct FbkOptions {
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
 #endif
   int64_t setop_probe = 1;               // k_setop2 with in-kernel optimize(): Intersect / Difference whose result is a subset of an array operand by table + probe, survivors written as the array (0: both operands decoded into fragments, as for every other type pair; same bytes)
+  int64_t setop_count_atomics = 0;       // 1: the materialising pair kernels add every container's cardinality onto the pair's count with an atomic (rounds 1-3); 0: k_sum_slot_n sums the descriptors they wrote (no memset, no atomics)
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
 
@@ -691,6 +692,7 @@ const OptionDesc kOptions[] = {
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
     {"setop_probe", &FbkOptions::setop_probe, 0, 1},
+    {"setop_count_atomics", &FbkOptions::setop_count_atomics, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
     {"pair_spw", &FbkOptions::pair_spw, 0, 4},
 #ifdef FBK_EXPERIMENTS
@@ -1145,6 +1147,7 @@ int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_r
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
     (void)hipGetLastError();
+    (void)hipStreamSynchronize(ctx->stream);  // (copies out of the pinned buffers / into the arena may still be in flight)
     if (b->d_arena) (void)ctx_free(b->ctx, b->d_arena);
     if (b->d_slots) (void)ctx_free(b->ctx, b->d_slots);
     delete b;
@@ -1342,27 +1345,56 @@ int pair_wpb_for(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* b) {
   return std::min(batch_avg_payload(a), batch_avg_payload(b)) < 256 ? 4 : 1;
 }
 
+// The plan's item records: {A's descriptor, B's descriptor} per (pair, slot), resolved on the device once per version of the
+// two batches (k_resolve_items) — the pair kernels then start with ONE scalar round trip instead of row index -> descriptor.
+// Allocated with the per-wave count vector of the count kernel: both buffers or neither (a plan that got only the first, out
+// of memory on the second, must not take the resolved path next time).
+int32_t plan_resolve_items(fbk_ctx* ctx, fbk_plan* p) {
+  const uint64_t n_items = p->n_pairs * fbk::kSlots;
+  if (!p->d_items || !p->d_wave_counts) {
+    Slot* di = nullptr;
+    uint32_t* dw = nullptr;
+    HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&di), std::max<uint64_t>(n_items, 1) * 2 * sizeof(Slot)));
+    if (hipError_t e = ctx_malloc(ctx, reinterpret_cast<void**>(&dw), std::max<uint64_t>(n_items, 1) * sizeof(uint32_t)); e != hipSuccess) {
+      ctx_free(ctx, di);
+      HIP_TRY(e);
+    }
+    p->d_items = di;
+    p->d_wave_counts = dw;
+    p->items_va = p->items_vb = ~0ull;
+  }
+  if (n_items && (p->items_va != p->a->version || p->items_vb != p->b->version)) {
+    hipLaunchKernelGGL(fbk::k_resolve_items, dim3(uint32_t((n_items + 255) / 256)), dim3(256), 0, ctx->stream, p->a->d_slots, p->d_rows_a, p->b->d_slots,
+                       p->d_rows_b, p->n_pairs, p->d_items);
+    HIP_TRY(hipGetLastError());
+    p->items_va = p->a->version;
+    p->items_vb = p->b->version;
+  }
+  return FBK_OK;
+}
+
 template <int OP>
-void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs) {
+void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs, const Slot* items) {
   const uint32_t blocks = uint32_t(p->n_pairs * fbk::kSlots / 4);
   // (the in-kernel optimize() — mode 2 — only when the caller asked for optimize(): plain set-ops keep their bitmap cells)
   const uint32_t direct = want_runs ? uint32_t(p->ctx->opt.setop_direct_encode) : 0u;
   const uint32_t direct2 = direct | (p->ctx->opt.setop_probe ? 0x100u : 0u);  // k_setop2 only
+  u64* const counts = p->ctx->opt.setop_count_atomics ? p->d_counts : nullptr;  // (nullptr: k_sum_slot_n after the launch, see the caller)
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
-                       p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, p->d_counts);
+                       p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, counts);
   else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT) && pair_wpb_for(p->ctx, p->a, p->b) == 4)
     hipLaunchKernelGGL((fbk::k_setop2<OP, 4>), dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, p->d_counts, direct2);
+                       want_runs ? p->d_runs : nullptr, counts, direct2, (const Slot*)nullptr);
   else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT))
     hipLaunchKernelGGL((fbk::k_setop2<OP, 1>), dim3(uint32_t(p->n_pairs * fbk::kSlots)), dim3(64), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, p->d_counts, direct2);
+                       want_runs ? p->d_runs : nullptr, counts, direct2, items);
   else
     hipLaunchKernelGGL(fbk::k_setop<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, p->d_counts, direct);
+                       want_runs ? p->d_runs : nullptr, counts, direct);
 }
 
 void free_batch_storage(fbk_batch* b) {
@@ -1457,28 +1489,8 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
     // (resolved item records + a count per wave pay for their second launch only where the items are heavy: one-wave blocks)
     const bool resolved = pk2 && ctx->opt.pair_resolve && pair_wpb_for(ctx, p->a, p->b) == 1;
     if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
-    if (resolved) {
-      const uint64_t n_items = p->n_pairs * fbk::kSlots;
-      if (!p->d_items || !p->d_wave_counts) {
-        // both buffers or neither: a plan that got only the first (out of memory on the second) must not take the resolved path next time
-        Slot* di = nullptr;
-        uint32_t* dw = nullptr;
-        HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&di), n_items * 2 * sizeof(Slot)));
-        if (hipError_t e = ctx_malloc(ctx, reinterpret_cast<void**>(&dw), n_items * sizeof(uint32_t)); e != hipSuccess) {
-          ctx_free(ctx, di);
-          HIP_TRY(e);
-        }
-        p->d_items = di;
-        p->d_wave_counts = dw;
-        p->items_va = p->items_vb = ~0ull;
-      }
-      if (p->items_va != p->a->version || p->items_vb != p->b->version) {
-        hipLaunchKernelGGL(fbk::k_resolve_items, dim3(uint32_t((n_items + 255) / 256)), dim3(256), 0, ctx->stream, p->a->d_slots, p->d_rows_a, p->b->d_slots,
-                           p->d_rows_b, p->n_pairs, p->d_items);
-        p->items_va = p->a->version;
-        p->items_vb = p->b->version;
-      }
-    }
+    if (resolved)
+      if (int32_t rc = plan_resolve_items(ctx, p)) return rc;
     if (pk2) {
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
@@ -1555,13 +1567,22 @@ int32_t plan_setop_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, int32_t op, bool wa
   if (want_runs && !p->d_runs) HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_runs), std::max<uint64_t>(n_slots, 1) * 4));
   if (p->n_pairs == 0) return FBK_OK;
   const bool dense = p->a->dense && p->b->dense && !want_runs;
-  HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
-  switch (op) {
-    case FBK_OP_AND: launch_setop<0>(dense, p, ctx->stream, want_runs); break;
-    case FBK_OP_OR: launch_setop<1>(dense, p, ctx->stream, want_runs); break;
-    case FBK_OP_XOR: launch_setop<2>(dense, p, ctx->stream, want_runs); break;
-    default: launch_setop<3>(dense, p, ctx->stream, want_runs); break;
+  // the one-wave-block pair kernels start from the plan's resolved item records (as the count does)
+  const Slot* items = nullptr;
+  if (!dense && ctx->opt.pair_resolve && use_pair_kernels2(ctx, p->a, p->b, op) && pair_wpb_for(ctx, p->a, p->b) == 1) {
+    if (int32_t rc = plan_resolve_items(ctx, p)) return rc;
+    items = p->d_items;
   }
+  if (ctx->opt.setop_count_atomics) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
+  switch (op) {
+    case FBK_OP_AND: launch_setop<0>(dense, p, ctx->stream, want_runs, items); break;
+    case FBK_OP_OR: launch_setop<1>(dense, p, ctx->stream, want_runs, items); break;
+    case FBK_OP_XOR: launch_setop<2>(dense, p, ctx->stream, want_runs, items); break;
+    default: launch_setop<3>(dense, p, ctx->stream, want_runs, items); break;
+  }
+  // the pair's cardinality = the sum of the n its 16 output descriptors carry
+  if (!ctx->opt.setop_count_atomics)
+    hipLaunchKernelGGL(fbk::k_sum_slot_n, dim3(uint32_t((p->n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, p->out->d_slots, p->n_pairs, p->d_counts);
   HIP_TRY(hipGetLastError());
   // dense kernels write the dense layout (an all-zero result cell stays an all-zero
   // bitmap in the arena, its slot says nil): the output can feed the dense kernels again

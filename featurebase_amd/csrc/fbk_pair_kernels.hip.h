@@ -728,6 +728,19 @@ __global__ void __launch_bounds__(256) k_resolve_items(const Slot* __restrict__ 
   items[2 * i + 1] = slotsB[(uint64_t)rowsB[pair] * kSlots + slot];
 }
 
+// out[pair] = the cardinality of output row `pair`: the sum of the n its 16 cells' descriptors carry.  The materialising
+// kernels used to add every wave's count onto out[pair] with a uint64 atomic (16 waves of a pair, from up to 8 XCDs: executed
+// at the memory side, plus the memset in front); the descriptors they write anyway hold the same numbers.
+__global__ void __launch_bounds__(256) k_sum_slot_n(const Slot* __restrict__ outSlots, uint64_t n_pairs, u64* __restrict__ out) {
+  const uint64_t pair = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pair >= n_pairs) return;
+  const Slot* s = outSlots + pair * kSlots;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k) acc += slot_n(s[k]);
+  out[pair] = acc;
+}
+
 // (A PERSISTENT form — a grid as large as the device holds, every wave striding through the items as a four-stage
 // software pipeline: row indexes of item u + 3 W, descriptors of u + 2 W, payload batch 0 of u + W in flight while item u is
 // decoded — was built and measured this round: 64 us against 46 for the 2048 config-3 pairs (128 registers, static striding
@@ -750,9 +763,21 @@ struct ProbeEmit {
   uint32_t last_kept = 0;          // survived (wave-uniform)
 };
 
-// one batch of the probing array: KEEP = 1 keeps the values set in the table, 0 those that are not
-template <int KEEP>
-__device__ __forceinline__ void array_probe_emit_batch(uint32_t tb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch],
+// bit (value >> 5) of a 2048-bit map at LDS byte offset mb: one bit per DWORD of the table (the interior map of a run
+// container after its parity prefix, see run_fill_batch); value in bits [15:0] / [31:16] of x
+__device__ __forceinline__ uint32_t map_bit_lo(uint32_t mb, uint32_t x) {
+  const uint32_t w = *(const lds_u32*)(uintptr_t)(mb + (__builtin_amdgcn_ubfe(x, 10u, 6u) << 2));
+  return __builtin_amdgcn_ubfe(w, x >> 5, 1u);  // (bit-field offsets use bits [4:0] only)
+}
+__device__ __forceinline__ uint32_t map_bit_hi(uint32_t mb, uint32_t x) {
+  const uint32_t w = *(const lds_u32*)(uintptr_t)(mb + ((x >> 26) << 2));
+  return __builtin_amdgcn_ubfe(w, x >> 21, 1u);
+}
+
+// one batch of the probing array: KEEP = 1 keeps the values set in the table, 0 those that are not; MAP: the table holds a
+// run container as boundary masks, its full dwords are in the map at mb
+template <int KEEP, bool MAP>
+__device__ __forceinline__ void array_probe_emit_batch(uint32_t tb, uint32_t mb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch],
                                                        uint16_t* __restrict__ o16, ProbeEmit& e) {
   const u64 lane_lt = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
@@ -760,7 +785,11 @@ __device__ __forceinline__ void array_probe_emit_batch(uint32_t tb, uint32_t len
     if ((base + (uint32_t)k * kWave) * 2u >= len) break;  // (wave-uniform: no value in this dword row or after it)
     const uint32_t i2 = (base + (uint32_t)k * kWave + (uint32_t)lane) * 2u;
     const uint32_t lo = v[k] & 0xFFFFu, hi = v[k] >> 16;
-    const uint32_t t_lo = table_bit_lo(tb, v[k]), t_hi = table_bit_hi(tb, v[k]);  // (junk lanes read word 0: in bounds)
+    uint32_t t_lo = table_bit_lo(tb, v[k]), t_hi = table_bit_hi(tb, v[k]);  // (junk lanes read word 0: in bounds)
+    if (MAP) {
+      t_lo |= map_bit_lo(mb, v[k]);
+      t_hi |= map_bit_hi(mb, v[k]);
+    }
     const bool k_lo = i2 < len && t_lo == (uint32_t)KEEP;
     const bool k_hi = i2 + 1u < len && t_hi == (uint32_t)KEEP;
     const u64 m_lo = __ballot(k_lo), m_hi = __ballot(k_hi);
@@ -778,22 +807,18 @@ __device__ __forceinline__ void array_probe_emit_batch(uint32_t tb, uint32_t len
   }
 }
 
-// the whole probing array (batch 0 in v0, batches 1..3 in the tail requested before the table was built)
-template <int KEEP>
-__device__ __forceinline__ void array_probe_emit_all(const uint8_t* __restrict__ p, uint32_t len, int lane, uint32_t tb, const uint32_t (&v0)[kPairBatch],
-                                                     const ProbeTail& t, uint16_t* __restrict__ o16, uint32_t& n_out, uint32_t& runs_out) {
+// the whole probing array of <= 4095 values (batch 0 in v0, batches 1..3 in the tail requested before the table was built)
+template <int KEEP, bool MAP = false>
+__device__ __forceinline__ void array_probe_emit_all(const uint8_t* __restrict__ /*p*/, uint32_t len, int lane, uint32_t tb, const uint32_t (&v0)[kPairBatch],
+                                                     const ProbeTail& t, uint16_t* __restrict__ o16, uint32_t& n_out, uint32_t& runs_out, uint32_t mb = 0) {
   const uint32_t n_units = (len + 1u) >> 1;
   constexpr uint32_t B = kPairBatch * kWave;
   ProbeEmit e;
-  array_probe_emit_batch<KEEP>(tb, len, 0, lane, v0, o16, e);
-  if (n_units > B) array_probe_emit_batch<KEEP>(tb, len, B, lane, t.v1, o16, e);
-  if (n_units > 2 * B) array_probe_emit_batch<KEEP>(tb, len, 2 * B, lane, t.v2, o16, e);
-  if (n_units > 3 * B) array_probe_emit_batch<KEEP>(tb, len, 3 * B, lane, t.v3, o16, e);
-  for (uint32_t base = 4 * B; base < n_units; base += B) {  // a probing array beyond 4096 values (roaring.go:5054; the survivors still fit: the caller checked the bound)
-    uint32_t v[kPairBatch];
-    sparse_load(p, n_units, base, lane, v);
-    array_probe_emit_batch<KEEP>(tb, len, base, lane, v, o16, e);
-  }
+  array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 0, lane, v0, o16, e);
+  if (n_units > B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, B, lane, t.v1, o16, e);
+  if (n_units > 2 * B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 2 * B, lane, t.v2, o16, e);
+  if (n_units > 3 * B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 3 * B, lane, t.v3, o16, e);
+  // (len <= 4095 — the caller's condition: the survivors must fit the cell — is at most four batches)
   n_out = e.before;
   runs_out = wave_reduce_add(e.runs);
 }
@@ -836,6 +861,39 @@ __device__ __forceinline__ void array_vs_bitmap_emit(const uint8_t* __restrict__
   wave_lds_sync();
 }
 
+// probing array against a RUN operand of <= kRunFillMax intervals (batch 0 in vr): the runs as boundary masks in the
+// cleared table + the map of full dwords (run_fill_batch), the array probes both (intersectArrayRun / differenceArrayRun,
+// roaring.go:4702-4740, 5421-5470, walk the two lists; here neither list is walked)
+template <int KEEP>
+__device__ __forceinline__ void array_vs_run_emit(const uint8_t* __restrict__ pr, uint32_t lr, uint32_t (&vr)[kPairBatch], const uint8_t* __restrict__ pp,
+                                                  uint32_t lp, const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint32_t* mini,
+                                                  uint16_t* __restrict__ o16, uint32_t& n_out, uint32_t& runs_out) {
+  ProbeTail tail;
+  probe_tail_load(pp, lp, lane, tail);
+  const uint32_t tbase = lds_table_base(table);
+  const uint32_t mbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)mini);
+  lds_zero(table, lane);
+  mini[lane] = 0;
+  wave_lds_sync();
+  run_fill_all(pr, lr, lane, tbase, mbase, vr);
+  wave_lds_sync();
+  {  // toggles -> filled: the parity prefix of the 2048-bit map, one dword per lane (as run_finish_init)
+    uint32_t x = mini[lane];
+    x ^= x << 1;
+    x ^= x << 2;
+    x ^= x << 4;
+    x ^= x << 8;
+    x ^= x << 16;
+    const u64 odd = __ballot((x >> 31) != 0);
+    const u64 lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (__popcll(odd & lane_lt) & 1) x = ~x;
+    mini[lane] = x;
+  }
+  wave_lds_sync();
+  array_probe_emit_all<KEEP, true>(pp, lp, lane, tbase, vp, tail, o16, n_out, runs_out, mbase);
+  wave_lds_sync();
+}
+
 // Materialising A <op> B, one wave per (pair, slot): k_setop's outputs and right-sized array paths
 // (fbk_kernels.hip.h) behind the pair loader above.
 template <int OP, int WPB>
@@ -843,7 +901,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
                                                     const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
                                                     const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
                                                     uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
-                                                    u64* __restrict__ out_counts, uint32_t direct) {
+                                                    u64* __restrict__ out_counts, uint32_t direct, const Slot* __restrict__ items) {
   __shared__ u64 lds[WPB][kWords];
   __shared__ uint32_t mini[WPB][2 * kMiniDwords];
   const int lane = threadIdx.x & 63;
@@ -854,9 +912,15 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
   const uint64_t pair = wslot >> 4;
   const uint32_t slot = wslot & 15;
   if (pair >= n_pairs) return;
-  const uint32_t ra = rowsA[pair], rb = rowsB[pair];
-  const Slot sa = slotsA[(uint64_t)ra * kSlots + slot];
-  const Slot sb = slotsB[(uint64_t)rb * kSlots + slot];
+  Slot sa, sb;
+  if (items) {  // the plan's resolved item records (k_resolve_items): one scalar round trip instead of row index -> descriptor
+    sa = items[2 * wslot];
+    sb = items[2 * wslot + 1];
+  } else {
+    const uint32_t ra = rowsA[pair], rb = rowsB[pair];
+    sa = slotsA[(uint64_t)ra * kSlots + slot];
+    sb = slotsB[(uint64_t)rb * kSlots + slot];
+  }
   const uint32_t na = slot_n(sa), nb = slot_n(sb);
   Slot so;
   so.off = wslot * 8192ull;
@@ -916,23 +980,35 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
     uint16_t* o16 = reinterpret_cast<uint16_t*>(arenaO + so.off);
     uint32_t c = 0, r = 0;
     bool done = false;
-    if (ta == kTypeArray && tb == kTypeArray && (OP == 3 ? sa.len : min(sa.len, sb.len)) <= 4095u) {
-      uint32_t va[kPairBatch], vb[kPairBatch];
-      sparse_load(pa, (sa.len + 1u) >> 1, 0, lane, va);
-      sparse_load(pb, (sb.len + 1u) >> 1, 0, lane, vb);
-      if (OP == 3 || sa.len > sb.len) array_vs_array_emit<OP == 0>(pb, sb.len, vb, pa, sa.len, va, lane, lds[wv], o16, c, r);  // A probes B's table
-      else array_vs_array_emit<1>(pa, sa.len, va, pb, sb.len, vb, lane, lds[wv], o16, c, r);  // (Intersect: the longer array probes)
-      done = true;
-    } else if (ta == kTypeArray && tb == kTypeBitmap && sa.len <= 4095u) {
-      uint32_t va[kPairBatch];
-      sparse_load(pa, (sa.len + 1u) >> 1, 0, lane, va);
-      array_vs_bitmap_emit<OP == 0>(pb, pa, sa.len, va, lane, lds[wv], o16, c, r);
-      done = true;
-    } else if (OP == 0 && ta == kTypeBitmap && tb == kTypeArray && sb.len <= 4095u) {
-      uint32_t vb[kPairBatch];
-      sparse_load(pb, (sb.len + 1u) >> 1, 0, lane, vb);
-      array_vs_bitmap_emit<1>(pa, pb, sb.len, vb, lane, lds[wv], o16, c, r);
-      done = true;
+    // who probes: the array the result is a subset of (Difference: A; Intersect: the LONGER array, so that the shorter one is
+    // the table; against a bitmap or a run: the array).  Wave-uniform; batch 0 of both payloads is requested after the roles
+    // are known, so each type pair has ONE instance of the probe loop.
+    const bool a_arr = ta == kTypeArray, b_arr = tb == kTypeArray;
+    const bool a_probes = a_arr && (OP == 3 || !b_arr || sa.len > sb.len);
+    const bool b_probes = OP == 0 && b_arr && !a_probes;
+    if (a_probes || b_probes) {
+      const uint8_t* pp = a_probes ? pa : pb;   // the probing array
+      const uint8_t* pt = a_probes ? pb : pa;   // the operand that becomes the table
+      const uint32_t lp = a_probes ? sa.len : sb.len, lt = a_probes ? sb.len : sa.len;
+      const uint32_t tt = a_probes ? tb : ta;
+      if (lp <= 4095u) {
+        uint32_t vp[kPairBatch], vt[kPairBatch];
+        if (tt == kTypeArray) {
+          sparse_load(pp, (lp + 1u) >> 1, 0, lane, vp);
+          sparse_load(pt, (lt + 1u) >> 1, 0, lane, vt);
+          array_vs_array_emit<OP == 0>(pt, lt, vt, pp, lp, vp, lane, lds[wv], o16, c, r);
+          done = true;
+        } else if (tt == kTypeBitmap) {
+          sparse_load(pp, (lp + 1u) >> 1, 0, lane, vp);
+          array_vs_bitmap_emit<OP == 0>(pt, pp, lp, vp, lane, lds[wv], o16, c, r);
+          done = true;
+        } else if (tt == kTypeRun && lt <= kRunFillMax) {
+          sparse_load(pp, (lp + 1u) >> 1, 0, lane, vp);
+          sparse_load(pt, lt, 0, lane, vt);
+          array_vs_run_emit<OP == 0>(pt, lt, vt, pp, lp, vp, lane, lds[wv], mini[wv], o16, c, r);
+          done = true;
+        }
+      }
     }
     if (done && !(c != 0 && r <= c / 2u)) {  // (survivors optimize() would store as runs take the general path below and overwrite the cell)
       if (lane == 0) {
