@@ -336,13 +336,23 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         def call_us(fn, n=max(5, iters // 2)):
             return _timed_call(torch, stream, fn, n)[0]
 
+        # (A/B in the same process: option query_resolve = 0 — the kernel gathers its 64 descriptors through the row list, as the one-shot
+        # call does — against the prepared query's resolved row records, k_resolve_rows)
+        def without_records(q):
+            ctx.set_option("query_resolve", 0)
+            r = _timed_query(torch, stream, q, iters, ctx)[2]
+            ctx.set_option("query_resolve", 1)
+            q.run()
+            return r
+
         g, w, kq = _timed_query(torch, stream, q_fold, iters, ctx)
         out.append(_entry("config3: Union-of-64 rows then IntersectionCount(filter), fused, mixed array/run/bitmap rows (rank-law density 0.001-0.5)",
                           "k_fold_scatter<OR>", nbytes + 8 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), cpu_baseline=cpu3,
-                          call_us=call_us(lambda: ctx.union_n_intersection_count(batch, groups, F, fidx)), **common))
+                          call_us=call_us(lambda: ctx.union_n_intersection_count(batch, groups, F, fidx)), kernel_us_without_row_records=without_records(q_fold), **common))
         g, w, kq = _timed_query(torch, stream, q_top, iters, ctx)
         out.append(_entry("config3 rows, TopN/TopK shape: 64 rows x 1 filter row per shard", "k_rows_vs_filter", nbytes + 8 * 64 * n3, g, w, kq,
-                          set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), call_us=call_us(lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1))), **common))
+                          set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), call_us=call_us(lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1))),
+                          kernel_us_without_row_records=without_records(q_top), **common))
         g, w, kq = _timed_query(torch, stream, q_gb, max(5, iters // 2), ctx)
         # heavy containers (run containers, arrays of more than 2048 values) are read through dense shadows the library builds per
         # batch on the first count matrix (option matrix_shadow, fbk.hip heavy_shadow): what that costs in memory and traffic

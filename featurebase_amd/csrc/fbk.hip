@@ -112,6 +112,7 @@ struct FbkOptions {
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
 #endif
   int64_t setop_probe = 1;               // k_setop2 with in-kernel optimize(): Intersect / Difference whose result is a subset of an array operand by table + probe, survivors written as the array (0: both operands decoded into fragments, as for every other type pair; same bytes)
+  int64_t query_resolve = 1;             // prepared folds / TopN: the row descriptors of every (group / shard, slot) resolved into contiguous records once per version of the batch (0: the kernels gather them through the row lists, as the one-shot calls do)
   int64_t setop_count_atomics = 0;       // 1: the materialising pair kernels add every container's cardinality onto the pair's count with an atomic (rounds 1-3); 0: k_sum_slot_n sums the descriptors they wrote (no memset, no atomics)
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
@@ -693,6 +694,7 @@ const OptionDesc kOptions[] = {
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
     {"setop_probe", &FbkOptions::setop_probe, 0, 1},
     {"setop_count_atomics", &FbkOptions::setop_count_atomics, 0, 1},
+    {"query_resolve", &FbkOptions::query_resolve, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
     {"pair_spw", &FbkOptions::pair_spw, 0, 4},
 #ifdef FBK_EXPERIMENTS

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
                                                      const Slot* __restrict__ fslots, const uint8_t* __restrict__ farena,
                                                      const uint32_t* __restrict__ frows, uint8_t* __restrict__ arenaO,
                                                      Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
-                                                     u64* __restrict__ out_counts) {
+                                                     u64* __restrict__ out_counts, const Slot* __restrict__ recs) {
   static_assert(OP == 1 || OP == 2 || OP == 3, "scatter fold handles OR, XOR and ANDNOT");
   __shared__ u64 acc[kWords];  // the union / xor of the group's containers at this slot
   __shared__ u64 aux[kWords];  // decode scratch for the filter row and for r0 of a difference
@@ -185,6 +185,9 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
   }
   __syncthreads();
   const uint32_t* grow = rows + g * k;
+  // a prepared query's resolved row records (k_resolve_rows): the k descriptors of this (group, slot) side by side — one
+  // coalesced load instead of row index -> descriptor gathered from k rows
+  const Slot* grec = recs ? recs + cell * (uint64_t)k : nullptr;
   // The filter container (and r0 of a difference) is needed only in the epilogue, but its
   // address hangs off a chain of dependent loads (row index -> descriptor -> payload): start
   // it now, in the block layout (thread t: chunks t and t+256), so it has landed by then.
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
   u64 p0[4] = {0, 0, 0, 0};
   bool r0_ready = false;
   if (OP == 3) {
-    s0 = slots[(uint64_t)grow[0] * kSlots + slot];
+    s0 = grec ? grec[0] : slots[(uint64_t)grow[0] * kSlots + slot];
     if (slot_n(s0) != 0 && slot_type(s0) == kTypeBitmap) {
       const ulonglong2* q = reinterpret_cast<const ulonglong2*>(arena + s0.off);
       const ulonglong2 v0 = ld_stream(&q[t]), v1 = ld_stream(&q[256 + t]);
@@ -230,7 +233,7 @@ __global__ void __launch_bounds__(256, 8) k_fold_scatter(const Slot* __restrict_
     mine.off = 0;
     mine.len = 0;
     mine.tn = 0;
-    if (base + lane < k) mine = slots[(uint64_t)grow[base + lane] * kSlots + slot];
+    if (base + lane < k) mine = grec ? grec[base + lane] : slots[(uint64_t)grow[base + lane] * kSlots + slot];
     if (OP == 3 && base + lane == 0) mine.tn = 0;  // r0 is not one of the subtrahends
     const uint32_t cnt = min(64u, k - base);
     if (OP != 2 && __ballot(slot_n(mine) == 65536u) != 0) {

@@ -23,11 +23,25 @@
 
 namespace fbk {
 
+// Row records of a prepared query: recs[(unit * 16 + slot) * n_per + i] = the descriptor of slot `slot` of row
+// rows[unit * n_per + i] (unit = a group of a fold / a shard of a TopN).  Resolved once per version of the batch; the
+// scatter kernels then read the descriptors of a (unit, slot) as ONE contiguous piece.
+__global__ void __launch_bounds__(256) k_resolve_rows(const Slot* __restrict__ slots, const uint32_t* __restrict__ rows, uint64_t n_units, uint32_t n_per,
+                                                     Slot* __restrict__ recs) {
+  const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_units * kSlots * n_per) return;
+  const uint32_t i = (uint32_t)(idx % n_per);
+  const uint64_t us = idx / n_per;
+  const uint32_t slot = (uint32_t)(us & 15u);
+  const uint64_t unit = us >> 4;
+  recs[idx] = slots[(uint64_t)rows[unit * n_per + i] * kSlots + slot];
+}
+
 __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
                                                           const uint32_t* __restrict__ rowsA, uint32_t nA,
                                                           const Slot* __restrict__ slotsF, const uint8_t* __restrict__ arenaF,
                                                           const uint32_t* __restrict__ rowsF, uint32_t n_shards,
-                                                          uint32_t rows_per_block, u64* __restrict__ out_shard) {
+                                                          uint32_t rows_per_block, u64* __restrict__ out_shard, const Slot* __restrict__ recs) {
   __shared__ u64 F[kWords];         // the filter container as a bitmap
   __shared__ uint32_t rank[kWords + 1];  // rank[w] = popcount(F[0..w))
   __shared__ uint32_t s_part[4];
@@ -49,7 +63,9 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
   first_mine.off = 0;
   first_mine.len = 0;
   first_mine.tn = 0;
-  if (i_begin + lane < i_end) first_mine = slotsA[(uint64_t)arow[i_begin + lane] * kSlots + slot];
+  // (a prepared query's resolved row records, k_resolve_rows: the nA descriptors of this (shard, slot) side by side)
+  const Slot* srec = recs ? recs + ((uint64_t)shard * kSlots + slot) * nA : nullptr;
+  if (i_begin + lane < i_end) first_mine = srec ? srec[i_begin + lane] : slotsA[(uint64_t)arow[i_begin + lane] * kSlots + slot];
   const Slot sf = slotsF[(uint64_t)rowsF[shard] * kSlots + slot];
   const uint32_t nf = slot_n(sf);
   if (nf == 0) return;  // nothing can intersect at this slot (block-uniform)
@@ -100,7 +116,7 @@ __global__ void __launch_bounds__(256, 8) k_rows_vs_filter(const Slot* __restric
       mine.off = 0;
       mine.len = 0;
       mine.tn = 0;
-      if (base + lane < i_end) mine = slotsA[(uint64_t)arow[base + lane] * kSlots + slot];
+      if (base + lane < i_end) mine = srec ? srec[base + lane] : slotsA[(uint64_t)arow[base + lane] * kSlots + slot];
     }
     const uint32_t cnt = min(64u, i_end - base);
     auto meta = [&](uint32_t i, u64& off, uint32_t& len, uint32_t& tn) {
