@@ -60,7 +60,8 @@ def main():
     exp = PB.intersection_count(OA, pa, OA, pb)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     res = {"shards": args.shards, "pairs": int(n_pairs), "encoded_bytes": int(rows.bytes), "type_pairs (n nil, a array, b bitmap, r run)": mix, "variants": {}}
-    ops = [("intersectionCount", None), ("intersect", L.OP_AND), ("union", L.OP_OR), ("difference", L.OP_ANDNOT), ("xor", L.OP_XOR)]
+    ops = [("intersectionCount", None), ("intersect", L.OP_AND), ("union", L.OP_OR), ("difference", L.OP_ANDNOT), ("xor", L.OP_XOR),
+           ("intersect + optimize()", (L.OP_AND, L.SETOP_OPTIMIZE)), ("difference + optimize()", (L.OP_ANDNOT, L.SETOP_OPTIMIZE))]
     if args.only_count:
         ops = ops[:1]
     ref_counts = {}
@@ -71,7 +72,10 @@ def main():
         plan = ctx.plan(batch, pa, batch, pb)
         out = {}
         for name, op in ops:
-            fn = plan.intersection_count if op is None else (lambda o=op: plan.setop(o))
+            flags = 0
+            if isinstance(op, tuple):
+                op, flags = op
+            fn = plan.intersection_count if op is None else (lambda o=op, f=flags: plan.setop(o, f))
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
@@ -91,11 +95,12 @@ def main():
             elif op is None:
                 assert (counts == exp).all(), f"pair_kernels={var}: intersectionCount differs from the oracle"
             else:
-                if name not in ref_counts:
+                name_ref = name.split(" +")[0]
+                if name_ref not in ref_counts:
                     _, ecnt = PB.setop({L.OP_AND: PB.OP_AND, L.OP_OR: PB.OP_OR, L.OP_XOR: PB.OP_XOR, L.OP_ANDNOT: PB.OP_ANDNOT}[op], OA, pa, OA, pb)
-                    ref_counts[name] = ecnt
-                assert ablated or (counts == ref_counts[name]).all(), f"pair_kernels={var}: {name} cardinalities differ from the oracle"
-            nbytes = rows.bytes + (0 if op is None else n_pairs * 16 * 8192)
+                    ref_counts[name_ref] = ecnt
+                assert ablated or (counts == ref_counts[name_ref]).all(), f"pair_kernels={var}: {name} cardinalities differ from the oracle"
+            nbytes = rows.bytes + (0 if op is None else plan.output().info()[2] if flags else n_pairs * 16 * 8192)
             out[name] = {"us": us, "min_us": min(samples), "algorithmic_bytes": int(nbytes), "TBps": nbytes / us / 1e6, "frac_of_8TBps": nbytes / us / 1e6 / 8.0,
                          "pairs_per_s": n_pairs * 16 / (us * 1e-6)}
         plan.free()
