@@ -395,11 +395,6 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         ctx.set_option("setop_probe", 0)
         g_frag, _ = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND, L.SETOP_OPTIMIZE), iters)
         ctx.set_option("setop_probe", 1)
-        # ... and option setop_count_atomics = 1: every wave adds its container's cardinality onto the pair's count with a uint64 atomic
-        # (rounds 1-3) instead of k_sum_slot_n summing the 16 descriptors of the pair afterwards
-        ctx.set_option("setop_count_atomics", 1)
-        g_atom, _ = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND, L.SETOP_OPTIMIZE), iters)
-        ctx.set_option("setop_count_atomics", 0)
         plan.setop(L.OP_AND, L.SETOP_OPTIMIZE)
         # for scale: the one-shot call with optimize() inside the kernel, and with the round-2/3 pipeline (bitmap / small-array cells,
         # then the separate re-encode pass: plan, two scans, a host round trip for the arena size, write)
@@ -409,7 +404,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         ctx.set_option("setop_direct_encode", 2)
         out.append(_entry(f"config3 rows, {pa.size} row pairs: Intersect materialised + optimize() inside the kernel (only the encoded containers are written), launch-only plan", "k_setop2<AND> (optimize)",
                           rows.bytes + so_bytes, g, w, set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), output_payload_bytes=so_bytes, call_us=c_in,
-                          call_us_with_the_separate_reencode_pass=c_sep, launch_us_with_both_operands_decoded_into_fragments=g_frag, launch_us_with_count_atomics=g_atom, **common))
+                          call_us_with_the_separate_reencode_pass=c_sep, launch_us_with_both_operands_decoded_into_fragments=g_frag, **common))
         plan.free()
         # Union-of-64 MATERIALISED + optimize(): the prepared query (group lists and the output batch resident: memset + one launch of the
         # fold kernel, which encodes in its epilogue) beside the one-shot call; every result container compared with the oracle's

@@ -105,7 +105,7 @@ struct FbkOptions {
   int64_t setop_direct_encode = 2;       // pair set-ops with optimize(): 2 the kernel applies Container.optimize() itself (encoded bytes into the head of the cell; no re-encode pass), 1 results of <= 1024 values leave the kernel as arrays and the re-encode pass does the rest (round 2), 0 always 8 KiB cells first (A/B runs, cross-checks)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
   int64_t pair_spw = 0;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4; 0 and 3 are read as 1 and 2): next slot's payload in flight while the current one is decoded
-  int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends), 2 or 4; 0 = by the rows' payload size
+  int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
   int64_t pair_resolve = 1;              // k_icount2 reads the plan's resolved item records and stores one count per wave (0: row index -> descriptor per wave, atomics; A/B runs)
 #ifdef FBK_EXPERIMENTS
   int64_t pair_stamp = 0;                // timing experiment on k_icount2: waves report shader cycles of a phase instead of counts (WRONG results)
@@ -113,7 +113,6 @@ struct FbkOptions {
 #endif
   int64_t setop_probe = 1;               // k_setop2 with in-kernel optimize(): Intersect / Difference whose result is a subset of an array operand by table + probe, survivors written as the array (0: both operands decoded into fragments, as for every other type pair; same bytes)
   int64_t query_resolve = 1;             // prepared folds / TopN: the row descriptors of every (group / shard, slot) resolved into contiguous records once per version of the batch (0: the kernels gather them through the row lists, as the one-shot calls do)
-  int64_t setop_count_atomics = 0;       // 1: the materialising pair kernels add every container's cardinality onto the pair's count with an atomic (rounds 1-3); 0: k_sum_slot_n sums the descriptors they wrote (no memset, no atomics)
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
 
@@ -693,7 +692,6 @@ const OptionDesc kOptions[] = {
     {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
     {"setop_probe", &FbkOptions::setop_probe, 0, 1},
-    {"setop_count_atomics", &FbkOptions::setop_count_atomics, 0, 1},
     {"query_resolve", &FbkOptions::query_resolve, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
     {"pair_spw", &FbkOptions::pair_spw, 0, 4},
@@ -1343,7 +1341,7 @@ bool use_pair_kernels2(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* 
 // moment IT ends, which is what heterogeneous items (runs next to arrays) need; when one side's containers are tiny the
 // items are all alike and short, and four waves per block quarter the number of blocks to launch.
 int pair_wpb_for(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* b) {
-  if (ctx->opt.pair_wpb) return ctx->opt.pair_wpb >= 4 ? 4 : ctx->opt.pair_wpb >= 2 ? 2 : 1;  // (normalised once: 1, 2 or 4)
+  if (ctx->opt.pair_wpb) return ctx->opt.pair_wpb >= 4 ? 4 : 1;  // (normalised once: 1 or 4.  Two-wave blocks were built and measured in round 4: count 182 against 166-173 us, set-ops equal — profiles/r04_pairs_wpb_ab.json — and removed)
   return std::min(batch_avg_payload(a), batch_avg_payload(b)) < 256 ? 4 : 1;
 }
 
@@ -1381,26 +1379,21 @@ void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs, const
   // (the in-kernel optimize() — mode 2 — only when the caller asked for optimize(): plain set-ops keep their bitmap cells)
   const uint32_t direct = want_runs ? uint32_t(p->ctx->opt.setop_direct_encode) : 0u;
   const uint32_t direct2 = direct | (p->ctx->opt.setop_probe ? 0x100u : 0u);  // k_setop2 only
-  u64* const counts = p->ctx->opt.setop_count_atomics ? p->d_counts : nullptr;  // (nullptr: k_sum_slot_n after the launch, see the caller)
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
-                       p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots, counts);
+                       p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots);
   else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT) && pair_wpb_for(p->ctx, p->a, p->b) == 4)
     hipLaunchKernelGGL((fbk::k_setop2<OP, 4>), dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, counts, direct2, (const Slot*)nullptr);
-  else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT) && pair_wpb_for(p->ctx, p->a, p->b) == 2)
-    hipLaunchKernelGGL((fbk::k_setop2<OP, 2>), dim3(uint32_t(p->n_pairs * fbk::kSlots / 2)), dim3(128), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
-                       p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, counts, direct2, items);
+                       want_runs ? p->d_runs : nullptr, direct2, (const Slot*)nullptr);
   else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT))
     hipLaunchKernelGGL((fbk::k_setop2<OP, 1>), dim3(uint32_t(p->n_pairs * fbk::kSlots)), dim3(64), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, counts, direct2, items);
+                       want_runs ? p->d_runs : nullptr, direct2, items);
   else
     hipLaunchKernelGGL(fbk::k_setop<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, counts, direct);
+                       want_runs ? p->d_runs : nullptr, direct);
 }
 
 void free_batch_storage(fbk_batch* b) {
@@ -1493,7 +1486,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
   } else {
     const bool pk2 = use_pair_kernels2(ctx, p->a, p->b, -1);
     // (resolved item records + a count per wave pay for their second launch only where the items are heavy: one-wave blocks)
-    const bool resolved = pk2 && ctx->opt.pair_resolve && pair_wpb_for(ctx, p->a, p->b) <= 2;
+    const bool resolved = pk2 && ctx->opt.pair_resolve && pair_wpb_for(ctx, p->a, p->b) == 1;
     if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     if (resolved)
       if (int32_t rc = plan_resolve_items(ctx, p)) return rc;
@@ -1516,8 +1509,6 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
           case 4: FBK_LAUNCH_ICOUNT2(4, 4); break;
           default: FBK_LAUNCH_ICOUNT2(2, 4); break;
         }
-      } else if (wpb == 2 && spw == 1) {  // (two-wave blocks exist for one slot per wave only)
-        FBK_LAUNCH_ICOUNT2(1, 2);
       } else {
         switch (spw) {
           case 1: FBK_LAUNCH_ICOUNT2(1, 1); break;
@@ -1577,20 +1568,19 @@ int32_t plan_setop_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, int32_t op, bool wa
   const bool dense = p->a->dense && p->b->dense && !want_runs;
   // the one-wave-block pair kernels start from the plan's resolved item records (as the count does)
   const Slot* items = nullptr;
-  if (!dense && ctx->opt.pair_resolve && use_pair_kernels2(ctx, p->a, p->b, op) && pair_wpb_for(ctx, p->a, p->b) <= 2) {
+  if (!dense && ctx->opt.pair_resolve && use_pair_kernels2(ctx, p->a, p->b, op) && pair_wpb_for(ctx, p->a, p->b) == 1) {
     if (int32_t rc = plan_resolve_items(ctx, p)) return rc;
     items = p->d_items;
   }
-  if (ctx->opt.setop_count_atomics) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
   switch (op) {
     case FBK_OP_AND: launch_setop<0>(dense, p, ctx->stream, want_runs, items); break;
     case FBK_OP_OR: launch_setop<1>(dense, p, ctx->stream, want_runs, items); break;
     case FBK_OP_XOR: launch_setop<2>(dense, p, ctx->stream, want_runs, items); break;
     default: launch_setop<3>(dense, p, ctx->stream, want_runs, items); break;
   }
-  // the pair's cardinality = the sum of the n its 16 output descriptors carry
-  if (!ctx->opt.setop_count_atomics)
-    hipLaunchKernelGGL(fbk::k_sum_slot_n, dim3(uint32_t((p->n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, p->out->d_slots, p->n_pairs, p->d_counts);
+  // the pair's cardinality = the sum of the n its 16 output descriptors carry (rounds 1-3: a uint64 atomic per wave onto a
+  // zeroed vector; measured equal within 1 % on config 3's 8192 row pairs, and one launch instead of memset + atomics)
+  hipLaunchKernelGGL(fbk::k_sum_slot_n, dim3(uint32_t((p->n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, p->out->d_slots, p->n_pairs, p->d_counts);
   HIP_TRY(hipGetLastError());
   // dense kernels write the dense layout (an all-zero result cell stays an all-zero
   // bitmap in the arena, its slot says nil): the output can feed the dense kernels again

@@ -632,14 +632,13 @@ __global__ void __launch_bounds__(256) k_icount_dense(const uint8_t* __restrict_
 
 // A <op> B for dense rows, materialised as dense rows, cardinality fused in the same
 // pass (roaring.go:4971-4974).  out row `pair` is written at out + pair*128 KiB and
-// per-slot cardinalities into outSlots.
+// per-slot cardinalities into outSlots (the pair's cardinality is their sum: k_sum_slot_n).
 template <int OP>
 __global__ void __launch_bounds__(256) k_setop_dense(const uint8_t* __restrict__ arenaA,
                                                     const uint32_t* __restrict__ rowsA,
                                                     const uint8_t* __restrict__ arenaB,
                                                     const uint32_t* __restrict__ rowsB,
-                                                    uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
-                                                    u64* __restrict__ out_counts) {
+                                                    uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots) {
   // one wave per container slot; 4 slots per block
   const int lane = threadIdx.x & 63;
   const uint32_t wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -659,7 +658,6 @@ __global__ void __launch_bounds__(256) k_setop_dense(const uint8_t* __restrict__
     s.len = kWords;
     s.tn = make_tn(c ? kTypeBitmap : kTypeNil, c);
     outSlots[wslot] = s;
-    if (out_counts) atomicAdd(&out_counts[pair], (u64)c);
   }
 }
 
@@ -760,7 +758,7 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
                                               const Slot* __restrict__ slotsB, const uint8_t* __restrict__ arenaB,
                                               const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
                                               uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots,
-                                              uint32_t* __restrict__ outRuns, u64* __restrict__ out_counts, uint32_t direct) {
+                                              uint32_t* __restrict__ outRuns, uint32_t direct) {
   __shared__ u64 lds[4][kWords];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -819,7 +817,6 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
           so.tn = make_tn(c ? kTypeArray : kTypeNil, c);
           outSlots[wslot] = so;
           if (outRuns) outRuns[wslot] = r;
-          if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
         }
         return;
       }
@@ -849,7 +846,6 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
       so.tn = make_tn(t_out, c);
       outSlots[wslot] = so;
       if (outRuns) outRuns[wslot] = r;
-      if (out_counts) atomicAdd(&out_counts[pair], (u64)c);
     }
     return;
   }
@@ -881,7 +877,6 @@ __global__ void __launch_bounds__(256) k_setop(const Slot* __restrict__ slotsA, 
     so.tn = make_tn(c ? (as_array ? kTypeArray : kTypeBitmap) : kTypeNil, c);
     outSlots[wslot] = so;
     if (outRuns) outRuns[wslot] = r;
-    if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
   }
 }
 

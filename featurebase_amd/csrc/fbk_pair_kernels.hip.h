@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
                                                     const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
                                                     const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
                                                     uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
-                                                    u64* __restrict__ out_counts, uint32_t direct, const Slot* __restrict__ items) {
+                                                    uint32_t direct, const Slot* __restrict__ items) {
   __shared__ u64 lds[WPB][kWords];
   __shared__ uint32_t mini[WPB][2 * kMiniDwords];
   const int lane = threadIdx.x & 63;
@@ -965,7 +965,6 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
           so.tn = make_tn(c ? kTypeArray : kTypeNil, c);
           outSlots[wslot] = so;
           if (outRuns) outRuns[wslot] = r;
-          if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
         }
         return;
       }
@@ -1016,7 +1015,6 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
         so.tn = make_tn(c ? kTypeArray : kTypeNil, c);
         outSlots[wslot] = so;
         if (outRuns) outRuns[wslot] = r;
-        if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
       }
       return;
     }
@@ -1039,7 +1037,6 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
       so.tn = make_tn(t_out, c);
       outSlots[wslot] = so;
       if (outRuns) outRuns[wslot] = r;
-      if (out_counts) atomicAdd(&out_counts[pair], (u64)c);
     }
     return;
   }
@@ -1066,7 +1063,6 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
     so.tn = make_tn(c ? (as_array ? kTypeArray : kTypeBitmap) : kTypeNil, c);
     outSlots[wslot] = so;
     if (outRuns) outRuns[wslot] = r;
-    if (out_counts && c) atomicAdd(&out_counts[pair], (u64)c);
   }
 }
 

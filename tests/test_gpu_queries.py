@@ -1399,16 +1399,14 @@ def test_setop_optimize_inside_the_kernel_equals_the_separate_pass(gpu_ctx, orac
                 got = {}
                 # (mode 2 with and without option setop_probe: Intersect / Difference of an array operand by table + probe, survivors
                 # written as the array they are, against both operands decoded into fragments — "2f")
-                # ("2a": the pair's cardinality by atomics from every wave, as rounds 1-3 did, instead of summing the output descriptors)
-                for mode in (2, "2f", "2a", 1, 0):
-                    gpu_ctx.set_option("setop_direct_encode", 2 if mode in ("2f", "2a") else mode)
+                for mode in (2, "2f", 1, 0):
+                    gpu_ctx.set_option("setop_direct_encode", 2 if mode == "2f" else mode)
                     gpu_ctx.set_option("setop_probe", 0 if mode == "2f" else 1)
-                    gpu_ctx.set_option("setop_count_atomics", 1 if mode == "2a" else 0)
                     out, cnt = gpu_ctx.setop(op, A, idx, Bt, idx, flags=L.SETOP_OPTIMIZE)
                     d, p, _ = out.download_flat()
                     got[mode] = (d.tobytes(), p.tobytes(), cnt.copy(), out.to_roaring(), out.download())
                     out.free()
-                for mode in ("2f", "2a", 1, 0):
+                for mode in ("2f", 1, 0):
                     assert got[2][0] == got[mode][0] and got[2][1] == got[mode][1] and (got[2][2] == got[mode][2]).all() and got[2][3] == got[mode][3], (pk, name, mode)
                 types = set()
                 for r in range(n):
@@ -1436,6 +1434,5 @@ def test_setop_optimize_inside_the_kernel_equals_the_separate_pass(gpu_ctx, orac
         gpu_ctx.set_option("pair_kernels", 0)
         gpu_ctx.set_option("setop_direct_encode", 2)
         gpu_ctx.set_option("setop_probe", 1)
-        gpu_ctx.set_option("setop_count_atomics", 0)
     A.free()
     Bt.free()
