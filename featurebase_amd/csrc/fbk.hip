@@ -112,6 +112,7 @@ struct FbkOptions {
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
 #endif
   int64_t setop_probe = 1;               // k_setop2 with in-kernel optimize(): Intersect / Difference whose result is a subset of an array operand by table + probe, survivors written as the array (0: both operands decoded into fragments, as for every other type pair; same bytes)
+  int64_t pair_run_probe = 1;            // k_icount2: array x run items by probing the run container's table (boundary masks + map of full dwords) instead of decoding both operands (0: pair_stream, as for run x run / run x bitmap)
   int64_t query_resolve = 1;             // prepared folds / TopN: the row descriptors of every (group / shard, slot) resolved into contiguous records once per version of the batch (0: the kernels gather them through the row lists, as the one-shot calls do)
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
@@ -693,6 +694,7 @@ const OptionDesc kOptions[] = {
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
     {"setop_probe", &FbkOptions::setop_probe, 0, 1},
     {"query_resolve", &FbkOptions::query_resolve, 0, 1},
+    {"pair_run_probe", &FbkOptions::pair_run_probe, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
     {"pair_spw", &FbkOptions::pair_spw, 0, 4},
 #ifdef FBK_EXPERIMENTS
@@ -1499,9 +1501,9 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
       // slots per wave: 1 (also the meaning of 0), 2 or 4 — normalised ONCE, the launch and k_sum_wave_counts below must agree
       const int spw = ctx->opt.pair_spw == 4 ? 4 : ctx->opt.pair_spw >= 2 ? 2 : 1, wpb = pair_wpb_for(ctx, p->a, p->b);
 #ifdef FBK_EXPERIMENTS
-      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16);
+      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (ctx->opt.pair_run_probe ? 2u : 0u) | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16);
 #else
-      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths);
+      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (ctx->opt.pair_run_probe ? 2u : 0u);
 #endif
       if (wpb == 4) {
         switch (spw) {

@@ -136,17 +136,37 @@ __device__ __forceinline__ void sparse_xor_all(uint32_t type, const uint8_t* __r
 __device__ __forceinline__ uint32_t table_bit_lo(uint32_t tb, uint32_t x) { return __builtin_amdgcn_ubfe(*table_dword_lo(tb, x), x, 1u); }
 __device__ __forceinline__ uint32_t table_bit_hi(uint32_t tb, uint32_t x) { return __builtin_amdgcn_ubfe(*table_dword_hi(tb, x), x >> 16, 1u); }
 
-// this lane's hits of one batch of array dwords against the table
-__device__ __forceinline__ uint32_t array_probe_batch(uint32_t tb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch]) {
+// bit (value >> 5) of a 2048-bit map at LDS byte offset mb: one bit per DWORD of the table (the interior map of a run
+// container after its parity prefix, see run_fill_batch); value in bits [15:0] / [31:16] of x
+__device__ __forceinline__ uint32_t map_bit_lo(uint32_t mb, uint32_t x) {
+  const uint32_t w = *(const lds_u32*)(uintptr_t)(mb + (__builtin_amdgcn_ubfe(x, 10u, 6u) << 2));
+  return __builtin_amdgcn_ubfe(w, x >> 5, 1u);  // (bit-field offsets use bits [4:0] only)
+}
+__device__ __forceinline__ uint32_t map_bit_hi(uint32_t mb, uint32_t x) {
+  const uint32_t w = *(const lds_u32*)(uintptr_t)(mb + ((x >> 26) << 2));
+  return __builtin_amdgcn_ubfe(w, x >> 21, 1u);
+}
+
+// this lane's hits of one batch of array dwords against the table (MAP: a run container as boundary masks in the table, its
+// full dwords in the map at mb — run_fill_batch)
+template <bool MAP = false>
+__device__ __forceinline__ uint32_t array_probe_batch(uint32_t tb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch], uint32_t mb = 0) {
   uint32_t hits = 0;
   if ((base + kPairBatch * kWave) * 2u <= len) {
 #pragma unroll
-    for (int k = 0; k < kPairBatch; ++k) hits += table_bit_lo(tb, v[k]) + table_bit_hi(tb, v[k]);
+    for (int k = 0; k < kPairBatch; ++k) {
+      if (MAP) hits += (table_bit_lo(tb, v[k]) | map_bit_lo(mb, v[k])) + (table_bit_hi(tb, v[k]) | map_bit_hi(mb, v[k]));
+      else hits += table_bit_lo(tb, v[k]) + table_bit_hi(tb, v[k]);
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < kPairBatch; ++k) {
       const uint32_t i2 = (base + (uint32_t)k * kWave + (uint32_t)lane) * 2u;
-      const uint32_t b0 = table_bit_lo(tb, v[k]), b1 = table_bit_hi(tb, v[k]);  // (junk lanes read word 0: in bounds)
+      uint32_t b0 = table_bit_lo(tb, v[k]), b1 = table_bit_hi(tb, v[k]);  // (junk lanes read word 0: in bounds)
+      if (MAP) {
+        b0 |= map_bit_lo(mb, v[k]);
+        b1 |= map_bit_hi(mb, v[k]);
+      }
       hits += (i2 < len ? b0 : 0u) + (i2 + 1u < len ? b1 : 0u);
     }
   }
@@ -168,18 +188,19 @@ __device__ __forceinline__ void probe_tail_load(const uint8_t* __restrict__ p, u
   if (n_units > 3 * B) sparse_load(p, n_units, 3 * B, lane, t.v3);
 }
 // number of this lane's array values that are set in the table
+template <bool MAP = false>
 __device__ __forceinline__ uint32_t array_probe_all(const uint8_t* __restrict__ p, uint32_t len, int lane, uint32_t tb,
-                                                    const uint32_t (&v0)[kPairBatch], const ProbeTail& t) {
+                                                    const uint32_t (&v0)[kPairBatch], const ProbeTail& t, uint32_t mb = 0) {
   const uint32_t n_units = (len + 1u) >> 1;
   constexpr uint32_t B = kPairBatch * kWave;
-  uint32_t hits = array_probe_batch(tb, len, 0, lane, v0);
-  if (n_units > B) hits += array_probe_batch(tb, len, B, lane, t.v1);
-  if (n_units > 2 * B) hits += array_probe_batch(tb, len, 2 * B, lane, t.v2);
-  if (n_units > 3 * B) hits += array_probe_batch(tb, len, 3 * B, lane, t.v3);
+  uint32_t hits = array_probe_batch<MAP>(tb, len, 0, lane, v0, mb);
+  if (n_units > B) hits += array_probe_batch<MAP>(tb, len, B, lane, t.v1, mb);
+  if (n_units > 2 * B) hits += array_probe_batch<MAP>(tb, len, 2 * B, lane, t.v2, mb);
+  if (n_units > 3 * B) hits += array_probe_batch<MAP>(tb, len, 3 * B, lane, t.v3, mb);
   for (uint32_t base = 4 * B; base < n_units; base += B) {  // arrays beyond 4096 values (roaring.go:5054)
     uint32_t v[kPairBatch];
     sparse_load(p, n_units, base, lane, v);
-    hits += array_probe_batch(tb, len, base, lane, v);
+    hits += array_probe_batch<MAP>(tb, len, base, lane, v, mb);
   }
   return hits;
 }
@@ -275,6 +296,44 @@ __device__ __forceinline__ void frag_or_interior(u64 (&w)[kWordsPerLane], uint32
     w[2 * j + 1] |= (u64)m2 | ((u64)m3 << 32);
   }
   wave_lds_sync();
+}
+
+// A run container of <= kRunFillMax intervals (batch 0 in vr) as something an array can PROBE: boundary masks in the cleared
+// table, and the map of the dwords that lie entirely inside a run (after its parity prefix: one bit per dword, 2048 bits in the
+// first 64 dwords of `mini`).  Value x is in the container iff its table bit or the map bit of its dword is set.
+__device__ __forceinline__ void run_table_build(const uint8_t* __restrict__ pr, uint32_t lr, uint32_t (&vr)[kPairBatch], int lane, u64* table, uint32_t* mini,
+                                                uint32_t& tbase, uint32_t& mbase) {
+  tbase = lds_table_base(table);
+  mbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)mini);
+  lds_zero(table, lane);
+  mini[lane] = 0;
+  wave_lds_sync();
+  run_fill_all(pr, lr, lane, tbase, mbase, vr);
+  wave_lds_sync();
+  uint32_t x = mini[lane];  // toggles -> filled: the parity prefix of the 2048-bit map, one dword per lane (as run_finish_init)
+  x ^= x << 1;
+  x ^= x << 2;
+  x ^= x << 4;
+  x ^= x << 8;
+  x ^= x << 16;
+  const u64 odd = __ballot((x >> 31) != 0);
+  const u64 lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  if (__popcll(odd & lane_lt) & 1) x = ~x;
+  mini[lane] = x;
+  wave_lds_sync();
+}
+
+// |array ∩ run container| by probing (intersectionCountArrayRun, roaring.go:4537-4557, walks both lists; pair_stream below
+// decodes both operands into 8 KiB): this lane's hits.  Round 4.
+__device__ __forceinline__ uint32_t run_table_probe(const uint8_t* __restrict__ pr, uint32_t lr, uint32_t (&vr)[kPairBatch], const uint8_t* __restrict__ pp,
+                                                    uint32_t lp, const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint32_t* mini) {
+  ProbeTail tail;
+  probe_tail_load(pp, lp, lane, tail);
+  uint32_t tbase, mbase;
+  run_table_build(pr, lr, vr, lane, table, mini, tbase, mbase);
+  const uint32_t h = array_probe_all<true>(pp, lp, lane, tbase, vp, tail, mbase);
+  wave_lds_sync();
+  return h;
 }
 
 // Both containers of an item as register fragments, batch 0 of the sparse ones already in va / vb: bitmaps stream to
@@ -594,6 +653,12 @@ __device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __res
   } else if (ta == kTypeBitmap && tb == kTypeArray) {
     if ((sparse_paths & 1u) && sb.len <= kProbeArray) part += array_probe_global(vb, sb.len, pa, lane);
     else part += bitmap_table_probe(pa, pb, sb.len, vb, lane, table);
+  } else if ((sparse_paths & 2u) && ((ta == kTypeArray && tb == kTypeRun && sb.len <= kRunFillMax) || (ta == kTypeRun && tb == kTypeArray && sa.len <= kRunFillMax))) {
+    // array x run: the run container becomes the table, the array probes it (option pair_run_probe).  (Two instances of the
+    // probe loop rather than the operands' batches copied into role-named registers: the copies cost 16 registers, and the
+    // compiler answered with 24 spilled ones.)
+    if (ta == kTypeArray) part += run_table_probe(pb, sb.len, vb, pa, sa.len, va, lane, table, mini);
+    else part += run_table_probe(pa, sa.len, va, pb, sb.len, vb, lane, table, mini);
   } else {
     // a run on at least one side: both operands 1 KiB at a time out of the table, one clear
     uint32_t acc = 0;
@@ -763,17 +828,6 @@ struct ProbeEmit {
   uint32_t last_kept = 0;          // survived (wave-uniform)
 };
 
-// bit (value >> 5) of a 2048-bit map at LDS byte offset mb: one bit per DWORD of the table (the interior map of a run
-// container after its parity prefix, see run_fill_batch); value in bits [15:0] / [31:16] of x
-__device__ __forceinline__ uint32_t map_bit_lo(uint32_t mb, uint32_t x) {
-  const uint32_t w = *(const lds_u32*)(uintptr_t)(mb + (__builtin_amdgcn_ubfe(x, 10u, 6u) << 2));
-  return __builtin_amdgcn_ubfe(w, x >> 5, 1u);  // (bit-field offsets use bits [4:0] only)
-}
-__device__ __forceinline__ uint32_t map_bit_hi(uint32_t mb, uint32_t x) {
-  const uint32_t w = *(const lds_u32*)(uintptr_t)(mb + ((x >> 26) << 2));
-  return __builtin_amdgcn_ubfe(w, x >> 21, 1u);
-}
-
 // one batch of the probing array: KEEP = 1 keeps the values set in the table, 0 those that are not; MAP: the table holds a
 // run container as boundary masks, its full dwords are in the map at mb
 template <int KEEP, bool MAP>
@@ -870,26 +924,8 @@ __device__ __forceinline__ void array_vs_run_emit(const uint8_t* __restrict__ pr
                                                   uint16_t* __restrict__ o16, uint32_t& n_out, uint32_t& runs_out) {
   ProbeTail tail;
   probe_tail_load(pp, lp, lane, tail);
-  const uint32_t tbase = lds_table_base(table);
-  const uint32_t mbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)mini);
-  lds_zero(table, lane);
-  mini[lane] = 0;
-  wave_lds_sync();
-  run_fill_all(pr, lr, lane, tbase, mbase, vr);
-  wave_lds_sync();
-  {  // toggles -> filled: the parity prefix of the 2048-bit map, one dword per lane (as run_finish_init)
-    uint32_t x = mini[lane];
-    x ^= x << 1;
-    x ^= x << 2;
-    x ^= x << 4;
-    x ^= x << 8;
-    x ^= x << 16;
-    const u64 odd = __ballot((x >> 31) != 0);
-    const u64 lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (__popcll(odd & lane_lt) & 1) x = ~x;
-    mini[lane] = x;
-  }
-  wave_lds_sync();
+  uint32_t tbase, mbase;
+  run_table_build(pr, lr, vr, lane, table, mini, tbase, mbase);
   array_probe_emit_all<KEEP, true>(pp, lp, lane, tbase, vp, tail, o16, n_out, runs_out, mbase);
   wave_lds_sync();
 }
