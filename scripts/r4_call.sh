@@ -22,6 +22,7 @@ pmc_pairs) KF=${KF:-icount}; bash scripts/fused_pmc.sh $TAG/pmc_v1 64 pair_kerne
 bsi_ahead) (for a in 3 4; do FBK_BSI_PLANES_AHEAD=$a timeout 200 python scripts/bsi_bench.py 2>&1 | grep -i "one pass\|half_waves\|Sum()" > $O/bsi_ahead$a.txt; done) ;;
 bsi) (timeout 200 python scripts/bsi_bench.py 2>&1 | grep -v amdgpu.ids > $O/bsi_bench.txt) ;;
 pmc_hbm) (cd /tmp; export TMPDIR=/tmp; BA="--steps 20 --warmup 2 --repeats 2 --no-cpu-baseline --cold-sets 1 --shards4 128 --shards4-total 0"; timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o b -- python $R/bench.py $BA > /dev/null 2>&1; timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o b -- python $R/bench.py $BA > /dev/null 2>&1; python3 $R/scripts/pmc_hbm_summary.py $O "bench.py $BA (round 4)" > $O/pmc_hbm_bytes.txt 2>&1) ;;
+pmc_pairs4) bash scripts/fused_pmc.sh $TAG/pmc_pairs ${PMC_SHARDS:-256} pair_kernels=2 pairs_pmc.py icount2 > $O/pmc_pairs_shipped.txt 2>&1 ;;
 pmc_scatter) bash scripts/fused_pmc.sh $TAG/pmc_scatter 256 0 scatter_pmc.py ${KF:-k_} > $O/pmc_scatter.txt 2>&1 ;;
 spbsweep) timeout 300 python scripts/matrix_spb_sweep.py ${SWEEP_ARGS:-1024 6} 2> $O/spb_sweep.err | grep -v amdgpu.ids > $O/spb_sweep.json ;;
 small) timeout 300 python scripts/small_shapes_ab.py ${SMALL_ARGS:-64 7} 2> $O/small_shapes.err | grep -v amdgpu.ids > $O/small_shapes.json ;;
