@@ -104,7 +104,6 @@ struct FbkOptions {
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 2;       // pair set-ops with optimize(): 2 the kernel applies Container.optimize() itself (encoded bytes into the head of the cell; no re-encode pass), 1 results of <= 1024 values leave the kernel as arrays and the re-encode pass does the rest (round 2), 0 always 8 KiB cells first (A/B runs, cross-checks)
   int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
-  int64_t pair_spw = 0;                  // slots of a row pair one wavefront of k_icount2 works through (1, 2 or 4; 0 and 3 are read as 1 and 2): next slot's payload in flight while the current one is decoded
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
   int64_t pair_resolve = 1;              // k_icount2 reads the plan's resolved item records and stores one count per wave (0: row index -> descriptor per wave, atomics; A/B runs)
 #ifdef FBK_EXPERIMENTS
@@ -696,7 +695,6 @@ const OptionDesc kOptions[] = {
     {"query_resolve", &FbkOptions::query_resolve, 0, 1},
     {"pair_run_probe", &FbkOptions::pair_run_probe, 0, 1},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
-    {"pair_spw", &FbkOptions::pair_spw, 0, 4},
 #ifdef FBK_EXPERIMENTS
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
@@ -1498,30 +1496,21 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
                      p->d_counts, pair_flags, resolved ? p->d_items : (const Slot*)nullptr,  \
                      resolved ? p->d_wave_counts : (uint32_t*)nullptr)
-      // slots per wave: 1 (also the meaning of 0), 2 or 4 — normalised ONCE, the launch and k_sum_wave_counts below must agree
-      const int spw = ctx->opt.pair_spw == 4 ? 4 : ctx->opt.pair_spw >= 2 ? 2 : 1, wpb = pair_wpb_for(ctx, p->a, p->b);
+      // One container slot per wave.  (The kernel is written for SPW slots per wave with the next slot's payload in flight while the
+      // current one is decoded; SPW = 2 / 4 measured 49.6 / 56 us against 46 in round 3 — fewer waves lose more than the prefetch
+      // gains — and are no longer instantiated.)
+      const int wpb = pair_wpb_for(ctx, p->a, p->b);
 #ifdef FBK_EXPERIMENTS
       const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (ctx->opt.pair_run_probe ? 2u : 0u) | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16);
 #else
       const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (ctx->opt.pair_run_probe ? 2u : 0u);
 #endif
-      if (wpb == 4) {
-        switch (spw) {
-          case 1: FBK_LAUNCH_ICOUNT2(1, 4); break;
-          case 4: FBK_LAUNCH_ICOUNT2(4, 4); break;
-          default: FBK_LAUNCH_ICOUNT2(2, 4); break;
-        }
-      } else {
-        switch (spw) {
-          case 1: FBK_LAUNCH_ICOUNT2(1, 1); break;
-          case 4: FBK_LAUNCH_ICOUNT2(4, 1); break;
-          default: FBK_LAUNCH_ICOUNT2(2, 1); break;
-        }
-      }
+      if (wpb == 4) FBK_LAUNCH_ICOUNT2(1, 4);
+      else FBK_LAUNCH_ICOUNT2(1, 1);
 #undef FBK_LAUNCH_ICOUNT2
       if (resolved)
         hipLaunchKernelGGL(fbk::k_sum_wave_counts, dim3(uint32_t((p->n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, p->d_wave_counts,
-                           uint32_t(fbk::kSlots / spw), p->n_pairs, p->d_counts);
+                           uint32_t(fbk::kSlots), p->n_pairs, p->d_counts);
     }
     else
       hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,

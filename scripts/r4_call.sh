@@ -18,7 +18,7 @@ bench) timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err ;;
 bench2) timeout 400 python bench.py --gpus 2 --steps 100 > $O/bench_n2.json 2> $O/bench_n2.err ;;
 misc) (cd /tmp; export TMPDIR=/tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/misc -o misc -- python $R/scripts/profile_misc.py 64 > $O/misc.json 2> /dev/null; python3 $R/scripts/kernel_trace_by_grid.py $O/misc/misc_kernel_trace.csv 1 > $O/misc_kernel_trace_by_grid.csv) ;;
 benchprof) (cd /tmp; export TMPDIR=/tmp; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --repeats 5 --no-cpu-baseline > $O/bench_prof.json 2> /dev/null; python3 $R/scripts/kernel_trace_by_grid.py $O/kt/bench_kernel_trace.csv 3 > $O/kernel_trace_by_grid.csv) ;;
-pmc_pairs) KF=${KF:-icount}; bash scripts/fused_pmc.sh $TAG/pmc_v1 64 pair_kernels=1 pairs_pmc.py $KF > $O/pmc_pairs_v1.txt 2>&1; bash scripts/fused_pmc.sh $TAG/pmc_v2 64 pair_kernels=2,pair_spw=2 pairs_pmc.py $KF > $O/pmc_pairs_v2.txt 2>&1 ;;
+pmc_pairs) KF=${KF:-icount}; bash scripts/fused_pmc.sh $TAG/pmc_v1 64 pair_kernels=1 pairs_pmc.py $KF > $O/pmc_pairs_v1.txt 2>&1; bash scripts/fused_pmc.sh $TAG/pmc_v2 64 pair_kernels=2 pairs_pmc.py $KF > $O/pmc_pairs_v2.txt 2>&1 ;;
 bsi_ahead) (for a in 3 4; do FBK_BSI_PLANES_AHEAD=$a timeout 200 python scripts/bsi_bench.py 2>&1 | grep -i "one pass\|half_waves\|Sum()" > $O/bsi_ahead$a.txt; done) ;;
 bsi) (timeout 200 python scripts/bsi_bench.py 2>&1 | grep -v amdgpu.ids > $O/bsi_bench.txt) ;;
 pmc_hbm) (cd /tmp; export TMPDIR=/tmp; BA="--steps 20 --warmup 2 --repeats 2 --no-cpu-baseline --cold-sets 1 --shards4 128 --shards4-total 0"; timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o b -- python $R/bench.py $BA > /dev/null 2>&1; timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o b -- python $R/bench.py $BA > /dev/null 2>&1; python3 $R/scripts/pmc_hbm_summary.py $O "bench.py $BA (round 4)" > $O/pmc_hbm_bytes.txt 2>&1) ;;

@@ -81,7 +81,7 @@ def _fuzz_pairwise_and_folds(gpu_ctx, oracle, it):
     Y, WY = (X, WX) if rng.random() < 0.3 else make_batch(gpu_ctx, rng, int(rng.integers(1, 50)))
     n = int(rng.integers(1, 120))
     ia, ib = rng.integers(0, len(WX), n), rng.integers(0, len(WY), n)
-    for name, val in (("sparse_paths", int(rng.integers(0, 2))), ("setop_direct_encode", int(rng.integers(0, 3))), ("setop_probe", int(rng.integers(0, 2))), ("pair_run_probe", int(rng.integers(0, 2))), ("dense_spb", int(rng.choice([1, 2, 4, 8, 16])))):
+    for name, val in (("sparse_paths", int(rng.integers(0, 2))), ("setop_direct_encode", int(rng.integers(0, 3))), ("setop_probe", int(rng.integers(0, 2))), ("pair_run_probe", int(rng.integers(0, 2))), ("pair_wpb", int(rng.choice([0, 1, 4]))), ("pair_resolve", int(rng.integers(0, 2))), ("dense_spb", int(rng.choice([1, 2, 4, 8, 16])))):
         gpu_ctx.set_option(name, val)
     try:
         got = gpu_ctx.intersection_count(X, ia, Y, ib)
@@ -130,7 +130,7 @@ def _fuzz_pairwise_and_folds(gpu_ctx, oracle, it):
         out.free()
         F.free()
     finally:
-        for name, val in (("sparse_paths", 1), ("setop_direct_encode", 2), ("setop_probe", 1), ("pair_run_probe", 1), ("dense_spb", 16), ("fold_register", 0)):
+        for name, val in (("sparse_paths", 1), ("setop_direct_encode", 2), ("setop_probe", 1), ("pair_run_probe", 1), ("pair_wpb", 0), ("pair_resolve", 1), ("dense_spb", 16), ("fold_register", 0)):
             gpu_ctx.set_option(name, val)
         if Y is not X:
             Y.free()
