@@ -111,6 +111,7 @@ struct FbkOptions {
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
 #endif
   int64_t setop_probe = 1;               // k_setop2 with in-kernel optimize(): Intersect / Difference whose result is a subset of an array operand by table + probe, survivors written as the array (0: both operands decoded into fragments, as for every other type pair; same bytes)
+  int64_t pair_lean = 0;                 // 1 / 4: a count plan that runs again sorts its items by class on the host and gives the array x array items of <= 1024 / 2048 values to k_icount_aa (4 KiB table, 32 waves per CU; 1 or 4 waves per block); 0: k_icount2 for every item
   int64_t pair_run_probe = 1;            // k_icount2: array x run items by probing the run container's table (boundary masks + map of full dwords) instead of decoding both operands (0: pair_stream, as for run x run / run x bitmap)
   int64_t query_resolve = 1;             // prepared folds / TopN: the row descriptors of every (group / shard, slot) resolved into contiguous records once per version of the batch (0: the kernels gather them through the row lists, as the one-shot calls do)
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
@@ -694,6 +695,7 @@ const OptionDesc kOptions[] = {
     {"setop_probe", &FbkOptions::setop_probe, 0, 1},
     {"query_resolve", &FbkOptions::query_resolve, 0, 1},
     {"pair_run_probe", &FbkOptions::pair_run_probe, 0, 1},
+    {"pair_lean", &FbkOptions::pair_lean, 0, 4},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
 #ifdef FBK_EXPERIMENTS
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
@@ -1302,6 +1304,12 @@ struct fbk_plan {
   Slot* d_items = nullptr;
   uint32_t* d_wave_counts = nullptr;
   uint64_t items_va = ~0ull, items_vb = ~0ull;
+  // round 4 (option pair_lean): from its second run on a plan sorts its items by class on the host — the lean array x array
+  // items first (k_icount_aa), then the rest (k_icount2) — records in that order + the item each record stands for
+  Slot* d_items_sorted = nullptr;
+  uint32_t* d_item_ids = nullptr;
+  uint64_t n_lean = 0, sorted_va = ~0ull, sorted_vb = ~0ull;
+  uint64_t count_runs = 0;
 };
 
 namespace {
@@ -1373,6 +1381,64 @@ int32_t plan_resolve_items(fbk_ctx* ctx, fbk_plan* p) {
   return FBK_OK;
 }
 
+// The plan's items sorted by class (see k_icount_aa): false = not available for this run (a batch whose descriptors were
+// rewritten on the device and not read back yet, or no memory) — the caller launches the one kernel over all items.
+bool plan_sort_items(fbk_ctx* ctx, fbk_plan* p) {
+  const fbk_batch *a = p->a, *b = p->b;
+  if (a->slots_stale || b->slots_stale) return false;
+  const uint64_t n_items = p->n_pairs * fbk::kSlots;
+  if (n_items == 0 || n_items > (1ull << 31)) return false;
+  if (p->d_items_sorted && p->sorted_va == a->version && p->sorted_vb == b->version) return true;
+  std::vector<uint8_t> lean(n_items);
+  uint64_t n_lean = 0;
+  for (uint64_t i = 0; i < p->n_pairs; ++i)
+    for (int s = 0; s < fbk::kSlots; ++s) {
+      const Slot& sa = a->h_slots[uint64_t(p->h_rows_a[i]) * fbk::kSlots + s];
+      const Slot& sb = b->h_slots[uint64_t(p->h_rows_b[i]) * fbk::kSlots + s];
+      const bool l = fbk::slot_n(sa) != 0 && fbk::slot_n(sb) != 0 && fbk::slot_type(sa) == fbk::kTypeArray && fbk::slot_type(sb) == fbk::kTypeArray &&
+                     std::min(sa.len, sb.len) <= fbk::kLeanShortMax && std::max(sa.len, sb.len) <= fbk::kLeanLongMax;
+      lean[i * fbk::kSlots + s] = l;
+      n_lean += l;
+    }
+  std::vector<Slot> recs(2 * n_items);
+  std::vector<uint32_t> ids(n_items);
+  uint64_t pl = 0, pg = n_lean;
+  for (uint64_t i = 0; i < p->n_pairs; ++i)
+    for (int s = 0; s < fbk::kSlots; ++s) {
+      const uint64_t it = i * fbk::kSlots + s, at = lean[it] ? pl++ : pg++;
+      recs[2 * at] = a->h_slots[uint64_t(p->h_rows_a[i]) * fbk::kSlots + s];
+      recs[2 * at + 1] = b->h_slots[uint64_t(p->h_rows_b[i]) * fbk::kSlots + s];
+      ids[at] = uint32_t(it);
+    }
+  if (!p->d_items_sorted) {
+    Slot* di = nullptr;
+    uint32_t* dd = nullptr;
+    if (ctx_malloc(ctx, reinterpret_cast<void**>(&di), n_items * 2 * sizeof(Slot)) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    if (ctx_malloc(ctx, reinterpret_cast<void**>(&dd), n_items * sizeof(uint32_t)) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx_free(ctx, di);
+      return false;
+    }
+    p->d_items_sorted = di;
+    p->d_item_ids = dd;
+  }
+  // (synchronous copies out of pageable vectors, once per version of the two batches; earlier launches of this plan that
+  // read the previous records are drained first)
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(p->d_items_sorted, recs.data(), recs.size() * sizeof(Slot), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->d_item_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    p->sorted_va = p->sorted_vb = ~0ull;
+    return false;
+  }
+  p->n_lean = n_lean;
+  p->sorted_va = a->version;
+  p->sorted_vb = b->version;
+  return true;
+}
+
 template <int OP>
 void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs, const Slot* items) {
   const uint32_t blocks = uint32_t(p->n_pairs * fbk::kSlots / 4);
@@ -1416,6 +1482,8 @@ void free_plan_storage(fbk_plan* p) {
   if (p->d_runs) (void)ctx_free(p->ctx, p->d_runs);
   if (p->d_items) (void)ctx_free(p->ctx, p->d_items);
   if (p->d_wave_counts) (void)ctx_free(p->ctx, p->d_wave_counts);
+  if (p->d_items_sorted) (void)ctx_free(p->ctx, p->d_items_sorted);
+  if (p->d_item_ids) (void)ctx_free(p->ctx, p->d_item_ids);
   free_batch_storage(p->out);
   delete p;
 }
@@ -1490,12 +1558,16 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
     if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     if (resolved)
       if (int32_t rc = plan_resolve_items(ctx, p)) return rc;
+    // a plan that runs again is worth sorting: the lean items to k_icount_aa, the others to k_icount2, both adding into the
+    // per-item counts that k_sum_wave_counts folds per pair
+    const bool sorted = resolved && ctx->opt.pair_lean && p->count_runs >= 1 && plan_sort_items(ctx, p);
+    ++p->count_runs;
     if (pk2) {
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
                      p->d_counts, pair_flags, resolved ? p->d_items : (const Slot*)nullptr,  \
-                     resolved ? p->d_wave_counts : (uint32_t*)nullptr)
+                     resolved ? p->d_wave_counts : (uint32_t*)nullptr, (const uint32_t*)nullptr)
       // One container slot per wave.  (The kernel is written for SPW slots per wave with the next slot's payload in flight while the
       // current one is decoded; SPW = 2 / 4 measured 49.6 / 56 us against 46 in round 3 — fewer waves lose more than the prefetch
       // gains — and are no longer instantiated.)
@@ -1505,7 +1577,21 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #else
       const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (ctx->opt.pair_run_probe ? 2u : 0u);
 #endif
-      if (wpb == 4) FBK_LAUNCH_ICOUNT2(1, 4);
+      if (sorted) {
+        const uint64_t n_items = p->n_pairs * fbk::kSlots, n_gen = n_items - p->n_lean;
+        if (p->n_lean) {
+          if (ctx->opt.pair_lean == 4)
+            hipLaunchKernelGGL((fbk::k_icount_aa<4>), dim3(uint32_t((p->n_lean + 3) / 4)), dim3(256), 0, ctx->stream, p->d_items_sorted, uint32_t(p->n_lean), p->a->d_arena,
+                               p->b->d_arena, p->d_item_ids, p->d_wave_counts);
+          else
+            hipLaunchKernelGGL((fbk::k_icount_aa<1>), dim3(uint32_t(p->n_lean)), dim3(64), 0, ctx->stream, p->d_items_sorted, uint32_t(p->n_lean), p->a->d_arena,
+                               p->b->d_arena, p->d_item_ids, p->d_wave_counts);
+        }
+        if (n_gen)  // (one record per block; "pairs" = sixteenths of the record list, only a bound here)
+          hipLaunchKernelGGL((fbk::k_icount2<1, 1>), dim3(uint32_t(n_gen)), dim3(64), 0, ctx->stream, p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots,
+                             p->b->d_arena, p->d_rows_b, (n_gen + fbk::kSlots - 1) / fbk::kSlots, p->d_counts, pair_flags, p->d_items_sorted + 2 * p->n_lean, p->d_wave_counts,
+                             p->d_item_ids + p->n_lean);
+      } else if (wpb == 4) FBK_LAUNCH_ICOUNT2(1, 4);
       else FBK_LAUNCH_ICOUNT2(1, 1);
 #undef FBK_LAUNCH_ICOUNT2
       if (resolved)

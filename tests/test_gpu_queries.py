@@ -1436,3 +1436,85 @@ def test_setop_optimize_inside_the_kernel_equals_the_separate_pass(gpu_ctx, orac
         gpu_ctx.set_option("setop_probe", 1)
     A.free()
     Bt.free()
+
+
+def test_pair_count_with_the_items_sorted_by_class(gpu_ctx, oracle):
+    """Option pair_lean: a count plan that runs again sorts its items by class on the host — array x array items of <= 1024 /
+    <= 2048 values go to k_icount_aa (a 4 KiB table for half the value range, used twice), the rest to k_icount2 — and the two
+    launches add into the same per-item counts.  Same results as the single kernel and as the oracle, for arrays on both
+    sides of every limit (row boundaries of 128 values, the 32768 split inside a row, the class limits), with 1 and 4 waves
+    per block, on the first (unsorted) and the later runs; a plan over a batch that was written on the device falls back."""
+    O = oracle
+    rng = D.rng_for(4545)
+
+    def arr(n, mode):
+        if mode == 1:
+            v = np.sort(rng.choice(32768, min(n, 32768), replace=False))
+        elif mode == 2:
+            v = np.sort(rng.choice(32768, min(n, 32768), replace=False)) + 32768
+        elif mode == 3:
+            s0 = int(rng.integers(32768 - n, 32768)) if n < 32768 else 0
+            v = np.arange(s0, s0 + n)
+        else:
+            v = np.sort(rng.choice(65536, n, replace=False))
+        return O.OContainer.array(v)
+
+    def cont():
+        k = int(rng.integers(0, 10))
+        if k == 0:
+            return O.OContainer.bitmap(D.words_of(np.sort(rng.choice(65536, int(rng.choice([5000, 40000])), replace=False))))
+        if k == 1:
+            nr = int(rng.choice([1, 7, 300]))
+            per = 65536 // nr
+            st = np.arange(nr) * per + rng.integers(0, max(1, per // 3), nr)
+            ln = rng.integers(1, max(2, per // 2), nr)
+            return O.OContainer.run([(int(s), int(min(s + l, 65535))) for s, l in zip(st, ln)])
+        n = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 4095, int(rng.integers(1, 2049))]))
+        return arr(n, int(rng.integers(0, 4)))
+
+    n = 48
+    rows_a = [{r * 16 + s: cont() for s in range(16) if rng.random() > 0.1} for r in range(n)]
+    rows_b = [{r * 16 + s: cont() for s in range(16) if rng.random() > 0.1} for r in range(n)]
+    for r in range(0, n, 5):  # shared values: real intersections between long arrays
+        for s in range(16):
+            k = r * 16 + s
+            if k in rows_a[r] and k in rows_b[r] and rows_a[r][k].typ == L.TYPE_ARRAY and rows_b[r][k].typ == L.TYPE_ARRAY:
+                va, vb = rows_a[r][k].values(), rows_b[r][k].values()
+                rows_b[r][k] = O.OContainer.array(np.unique(np.concatenate([vb, va[::2]]))[: max(len(vb), 1)])
+    A, Bt = gpu_ctx.upload([D.to_fbk_row(r) for r in rows_a]), gpu_ctx.upload([D.to_fbk_row(r) for r in rows_b])
+    ia, ib = np.arange(n), (np.arange(n) * 7) % n
+    ia = np.concatenate([ia, ia])
+    ib = np.concatenate([ib, np.arange(n)])
+    exp = [sum(O.intersection_count(rows_a[a][ka], rows_b[b][b * 16 + (ka & 15)]) for ka in rows_a[a] if b * 16 + (ka & 15) in rows_b[b]) for a, b in zip(ia, ib)]
+    try:
+        gpu_ctx.set_option("pair_kernels", 2)
+        for lean in (0, 1, 4):
+            gpu_ctx.set_option("pair_lean", lean)
+            plan = gpu_ctx.plan(A, ia, Bt, ib)
+            for run in range(3):
+                plan.intersection_count()
+                assert plan.read().tolist() == exp, (lean, run)
+            plan.free()
+        # a batch written on the device (a plan's output): its host descriptors are stale, the plan keeps the one kernel
+        p0 = gpu_ctx.plan(A, ia, Bt, ib)
+        p0.setop(L.OP_OR)
+        out = p0.output()
+        m = len(ia)
+        gpu_ctx.set_option("pair_lean", 0)
+        ref = gpu_ctx.intersection_count(out, np.arange(m), Bt, ib)
+        gpu_ctx.set_option("pair_lean", 1)
+        plan = gpu_ctx.plan(out, np.arange(m), Bt, ib)
+        for run in range(3):
+            plan.intersection_count()
+            assert plan.read().tolist() == ref.tolist(), run
+        out.download()  # (reads the descriptors back: from now on the plan may sort)
+        for run in range(2):
+            plan.intersection_count()
+            assert plan.read().tolist() == ref.tolist(), run
+        plan.free()
+        p0.free()
+    finally:
+        gpu_ctx.set_option("pair_lean", 0)
+        gpu_ctx.set_option("pair_kernels", 0)
+    A.free()
+    Bt.free()
