@@ -374,8 +374,16 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         if want_cpu:
             assert (pc == PB.intersection_count(OA, pa, OA, pb)).all(), "config 3 row pairs: GPU and oracle disagree"
         g, w = _timed_call(torch, stream, plan.intersection_count, iters)
+        # A/B in the same process: option pair_lean = 4 — the plan sorts its items by class on the host (once) and the array x array
+        # items of <= 1024 / 2048 values go to the lean kernel k_icount_aa (4 KiB table, 32 waves per CU), the rest to k_icount2.
+        # Off by default: ~1 ms of host work per plan to save a few microseconds per run
+        ctx.set_option("pair_lean", 4)
+        g_lean, _ = _timed_call(torch, stream, plan.intersection_count, iters)
+        assert (plan.read() == pc).all(), "config 3 row pairs: the class-sorted launch pair and the single kernel disagree"
+        ctx.set_option("pair_lean", 0)
+        plan.intersection_count()
         out.append(_entry(f"config3 rows, {pa.size} row pairs (rows 0..31 x rows 32..63 of every shard): IntersectionCount, launch-only plan", "k_icount2", rows.bytes, g, w,
-                          set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), **common))
+                          set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), launch_us_with_the_items_sorted_by_class=g_lean, **common))
         g, w = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND), iters)
         out.append(_entry(f"config3 rows, {pa.size} row pairs: Intersect materialised (8 KiB cells), launch-only plan", "k_setop2<AND>", rows.bytes + pa.size * 16 * 8192, g, w,
                           set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), **common))
