@@ -136,9 +136,10 @@ int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
  * dense_spb, fold_register, matrix_valu, matrix_spb, matrix_pass_kb, matrix_densify, matrix_fused,
  * matrix_fp4, matrix_shadow (1: the count matrix over encoded rows reads run containers and arrays of more
  * than matrix_shadow_array values through dense shadows built per batch on first use — up to
- * matrix_shadow_max_mb of device memory per batch; 0: every container is decoded in every query),
+ * matrix_shadow_max_mb of device memory per batch, matrix_shadow_apref array items loaded a stage ahead; 0: every container
+ * is decoded in every query),
  * bsi_range_sum_two_pass, bsi_half_waves, bsi_planes_ahead, topk_device_sort, sparse_paths,
- * setop_direct_encode, setop_probe, fold_encode, pair_kernels, pair_wpb, pair_resolve, pair_run_probe,
+ * setop_direct_encode, setop_probe, fold_encode, pair_kernels, pair_wpb, pair_resolve, pair_run_probe, pair_lean,
  * query_resolve, upload_chunk_mb, upload_threads, count_range_reference_quirk.  Every value of every option gives
  * the same results (the tests run them against each other); they select between kernels, not between semantics —
  * except count_range_reference_quirk, which is a documented divergence of the reference itself.

@@ -83,3 +83,24 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower(), f"{f} mentions the oracle"
+
+
+def test_option_names_in_the_header_are_the_library_s():
+    """The list of tuning knobs in include/fbk.h (the comment above fbk_set_option) names exactly the options the library
+    registers (kOptions in fbk.hip), the three experiment-only ones aside: a knob that was removed or added without the header
+    following is a documentation bug a maintainer trips over."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hip = open(os.path.join(root, "featurebase_amd", "csrc", "fbk.hip")).read()
+    table = hip[hip.index("const OptionDesc kOptions[] = {"):]
+    table = table[: table.index("};")]
+    registered = set(re.findall(r'\{"([a-z_0-9]+)", &FbkOptions::', table))
+    experiments = {"pair_ablate", "pair_stamp", "matrix_fused_ablate"}
+    header = open(os.path.join(root, "include", "fbk.h")).read()
+    doc = header[header.index("Tuning / test knobs"): header.index("int32_t fbk_set_option")]
+    words = set(re.findall(r"\b[a-z]+(?:_[a-z0-9]+)+\b", doc))
+    missing = sorted((registered - experiments) - words)
+    assert not missing, f"options the header does not name: {missing}"
+    stale = sorted(w for w in words if (w.startswith(("pair_", "matrix_", "bsi_", "setop_", "fold_", "upload_", "query_", "dense_", "topk_")) and w not in registered))
+    assert not stale, f"names in the header that are not options (any more): {stale}"
