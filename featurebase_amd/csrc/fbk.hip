@@ -185,7 +185,9 @@ struct fbk_batch {
   // dense shadows of the heavy containers (run containers, long arrays), built on the first count matrix over mixed rows
   // (heavy_shadow): a copy of the descriptor table in which those containers are bitmaps in a shadow arena.  The matrix-core
   // kernel with in-kernel decode then streams them like any bitmap row instead of decoding them in every query.  Under win_mu,
-  // dropped with the window index.  shadow_state: 0 not looked at, 1 built, 2 nothing heavy / over the memory cap
+  // dropped with the window index.  shadow_state: 0 not looked at, 1 built, 2 nothing heavy / over the memory cap.  The
+  // parameters (options matrix_shadow, matrix_shadow_array, the cap) are those of the context whose count matrix touched the
+  // batch FIRST: a batch shared between contexts keeps that decision until its containers are rewritten
   mutable uint8_t* d_shadow_arena = nullptr;
   mutable Slot* d_shadow_slots = nullptr;
   mutable uint64_t shadow_bytes = 0;
@@ -1385,10 +1387,19 @@ int32_t plan_resolve_items(fbk_ctx* ctx, fbk_plan* p) {
 // rewritten on the device and not read back yet, or no memory) — the caller launches the one kernel over all items.
 bool plan_sort_items(fbk_ctx* ctx, fbk_plan* p) {
   const fbk_batch *a = p->a, *b = p->b;
-  if (a->slots_stale || b->slots_stale) return false;
   const uint64_t n_items = p->n_pairs * fbk::kSlots;
   if (n_items == 0 || n_items > (1ull << 31)) return false;
   if (p->d_items_sorted && p->sorted_va == a->version && p->sorted_vb == b->version) return true;
+  // the host descriptors are read under the batches' own locks (another context of the device may be refreshing them:
+  // refresh_slots); both at once through std::lock — a plan over (b, a) on another context takes them in the other order
+  std::unique_lock<std::mutex> la(const_cast<fbk_batch*>(a)->slots_mu, std::defer_lock), lb;
+  if (b != a) {
+    lb = std::unique_lock<std::mutex>(const_cast<fbk_batch*>(b)->slots_mu, std::defer_lock);
+    std::lock(la, lb);
+  } else {
+    la.lock();
+  }
+  if (a->slots_stale || b->slots_stale) return false;
   std::vector<uint8_t> lean(n_items);
   uint64_t n_lean = 0;
   for (uint64_t i = 0; i < p->n_pairs; ++i)
