@@ -57,6 +57,64 @@ def reduce_count_vector(local: np.ndarray, device: Optional[str] = None) -> np.n
     return t.cpu().numpy().view(np.uint64)
 
 
+def order_totals(totals: np.ndarray, n: int = 0):
+    """(row indexes, counts) of a totals vector in the order TopN reports them: count descending, row index ascending inside
+    one count (Pairs sorted by count, executor.go:2823; the tie rule is fbk_topn's), rows with a zero count dropped, the
+    first n (0: all)."""
+    t = np.asarray(totals, dtype=np.uint64)
+    idx = np.nonzero(t)[0]
+    idx = idx[np.lexsort((idx, -t[idx].astype(np.int64)))] if idx.size else idx
+    if n:
+        idx = idx[:n]
+    return idx.astype(np.uint32), t[idx]
+
+
+def topn_two_pass(local_totals: np.ndarray, n: int = 0, device: Optional[str] = None):
+    """executeTopN's two passes (executor.go:2779-2827) for the one-process-per-GPU deployment — the multi-process form of
+    fbk_group_topn.  local_totals[i] = this rank's total of row i over the shards IT owns, thresholds already applied per
+    shard (what fbk_topn / a prepared fbk_query_topn leave on the device; a rank without shards passes zeros).
+      pass 1  the rank's own first n rows are its candidates (executeTopNShards :2829-2864);
+      merge   the candidate ids of all ranks, sorted and de-duplicated (:2814-2816): ONE all_gather of n ids per rank;
+      pass 2  the totals of exactly those rows summed over the ranks (Pairs.Add, cache.go:463): ONE all_reduce of
+              |candidates| words; ordered, trimmed to n (:2823-2825).
+    Returns (row indexes, counts), identical on every rank.  n = 0 (or n >= the number of rows): every row is a candidate,
+    the result is exact and costs one all_reduce of the whole vector.  Like the reference's, a row that is in no rank's
+    local top n is not returned even if its global total would qualify."""
+    import torch
+    import torch.distributed as dist
+
+    t = np.ascontiguousarray(local_totals, dtype=np.uint64)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not multi:
+        return order_totals(t, n)
+    if n == 0 or n >= t.size:
+        return order_totals(reduce_count_vector(t, device), n)
+    world = dist.get_world_size()
+    mine, _ = order_totals(t, n)
+    ids = torch.full((n,), -1, dtype=torch.int64)
+    ids[: mine.size] = torch.from_numpy(mine.astype(np.int64))
+    if device:
+        ids = ids.to(device)
+    gathered = [torch.empty_like(ids) for _ in range(world)]
+    dist.all_gather(gathered, ids)
+    cand = np.unique(torch.cat(gathered).cpu().numpy())
+    cand = cand[cand >= 0]
+    if cand.size == 0:
+        return np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint64)
+    tot = reduce_count_vector(t[cand], device)
+    k, c = order_totals(tot, n)
+    return cand[k].astype(np.uint32), c
+
+
+def bsi_sum_reduce(psum: int, nsum: int, count: int, device: Optional[str] = None):
+    """Sum(field) over all ranks (executeSum's reduce, ValCount.Add, executor.go:8438): every rank passes the {psum, nsum,
+    count} of the shards it owns (fbk_bsi_sum folded over its shards; uint64 sums wrap exactly as the reference's); returns
+    (int64(psum) - int64(nsum) with that wrap-around, count) — roaring/filter.go:1103-1108.  The caller adds count * Base."""
+    v = reduce_count_vector(np.array([psum, nsum, count], dtype=np.uint64), device)
+    s = (int(v[0]) - int(v[1])) & 0xFFFFFFFFFFFFFFFF
+    return (s - (1 << 64) if s >= (1 << 63) else s), int(v[2])
+
+
 class BucketedCountReducer:
     """Cross-GPU sum of per-step partial counts with ONE collective per `bucket` steps.
 

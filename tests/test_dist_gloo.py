@@ -250,3 +250,76 @@ def test_per_query_reducer_without_a_process_group():
         assert red.reduce() == k % 2
     bufs = red.flush()
     assert red.collectives == 0 and bufs.tolist() == [[4, 5, 6], [3, 4, 5]]
+
+
+def _topn_worker(rank: int, world: int, port: int, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from featurebase_amd import dist as fd
+    from oracle import pytopn as T
+
+    fd.init("gloo")
+    out = []
+    for case in range(12):
+        rng = np.random.default_rng(3100 + case)
+        n_rows, n_shards = int(rng.integers(3, 40)), int(rng.integers(1, 9))
+        # shard s: row id -> columns; src = the filter row of the shard.  Every rank builds ALL shards (same seed) and owns s mod world
+        shards = [{r: sorted(set(rng.integers(0, 64, int(rng.integers(0, 30))).tolist())) for r in range(n_rows)} for _ in range(n_shards)]
+        srcs = [sorted(set(rng.integers(0, 64, int(rng.integers(1, 40))).tolist())) for _ in range(n_shards)]
+        mt = int(rng.integers(0, 4)) if case % 3 == 0 else 0
+        n = int(rng.choice([0, 1, 2, 5, n_rows, n_rows + 3]))
+        ids = list(range(n_rows))
+        mine = fd.shards_for_rank(n_shards, rank, world)
+        local = np.zeros(n_rows, dtype=np.uint64)
+        if mine:
+            for r, c in T.top_exact([shards[s] for s in mine], ids, 0, [srcs[s] for s in mine], mt, 0):
+                local[r] = c
+        idx, cnt = fd.topn_two_pass(local, n)
+        node_shards = [[shards[s] for s in fd.shards_for_rank(n_shards, m, world)] for m in range(world)]
+        node_srcs = [[srcs[s] for s in fd.shards_for_rank(n_shards, m, world)] for m in range(world)]
+        exp = T.top_two_pass(node_shards, ids, n, node_srcs, mt, 0)
+        out.append(([(int(i), int(c)) for i, c in zip(idx, cnt)], [(int(r), int(c)) for r, c in exp]))
+    # BSI Sum: {psum, nsum, count} per rank, with a negative total and a wrap-around of the uint64 partial sums
+    parts = [(5, 1 << 63, 3), ((1 << 64) - 7, (1 << 63) + 10, 4)]
+    s, c = fd.bsi_sum_reduce(*parts[rank])
+    q.put((rank, out, (s, c)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_topn_two_pass_and_bsi_sum_two_ranks():
+    """featurebase_amd.dist.topn_two_pass / bsi_sum_reduce (the one-process-per-GPU forms of fbk_group_topn / fbk_group_bsi_sum)
+    on two gloo ranks against oracle/pytopn.top_two_pass (executeTopN, executor.go:2779-2827) and ValCount.Add's arithmetic:
+    the same pairs on every rank, including the reference's approximation (a row in no rank's own first n is lost)."""
+    import torch.multiprocessing as mp
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_topn_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = [q.get(timeout=240) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    total = (5 + (1 << 64) - 7) % (1 << 64) - ((1 << 63) + (1 << 63) + 10) % (1 << 64)
+    total &= (1 << 64) - 1
+    total = total - (1 << 64) if total >= (1 << 63) else total
+    for rank, cases, (s, c) in results:
+        for got, exp in cases:
+            assert got == exp, (rank, got, exp)
+        assert (s, c) == (total, 7)
+
+
+def test_topn_two_pass_without_a_process_group():
+    sys.path.insert(0, ROOT)
+    from featurebase_amd import dist as fd
+
+    idx, cnt = fd.topn_two_pass(np.array([3, 0, 9, 3, 1], dtype=np.uint64), 3)
+    assert idx.tolist() == [2, 0, 3] and cnt.tolist() == [9, 3, 3]  # count descending, row index ascending inside a count, zeros dropped
+    idx, cnt = fd.topn_two_pass(np.zeros(4, dtype=np.uint64), 0)
+    assert idx.size == 0 and cnt.size == 0
+    assert fd.bsi_sum_reduce(7, 9, 2) == (-2, 2)
