@@ -237,7 +237,9 @@ def _timed_call(torch, stream, fn, iters, warm=2, ctx=None):
 
 def _entry(name, kernel, alg_bytes, gpu_us, wall_us, kernel_us=None, **extra):
     t = gpu_us["median"] * 1e-6
+    ident, _, name = name.rpartition("|")  # "short id|descriptive name": the id is what the compact stdout line carries (bench_line.py)
     out = {
+        "id": ident or None,
         "name": name,
         "kernel": kernel,
         "algorithmic_bytes": int(alg_bytes),
@@ -346,11 +348,11 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             return r
 
         g, w, kq = _timed_query(torch, stream, q_fold, iters, ctx)
-        out.append(_entry("config3: Union-of-64 rows then IntersectionCount(filter), fused, mixed array/run/bitmap rows (rank-law density 0.001-0.5)",
+        out.append(_entry("c3.union64_icount|config3: Union-of-64 rows then IntersectionCount(filter), fused, mixed array/run/bitmap rows (rank-law density 0.001-0.5)",
                           "k_fold_scatter<OR>", nbytes + 8 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), cpu_baseline=cpu3,
                           call_us=call_us(lambda: ctx.union_n_intersection_count(batch, groups, F, fidx)), kernel_us_without_row_records=without_records(q_fold), **common))
         g, w, kq = _timed_query(torch, stream, q_top, iters, ctx)
-        out.append(_entry("config3 rows, TopN/TopK shape: 64 rows x 1 filter row per shard", "k_rows_vs_filter", nbytes + 8 * 64 * n3, g, w, kq,
+        out.append(_entry("c3.rows_vs_filter|config3 rows, TopN/TopK shape: 64 rows x 1 filter row per shard", "k_rows_vs_filter", nbytes + 8 * 64 * n3, g, w, kq,
                           set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), call_us=call_us(lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1))),
                           kernel_us_without_row_records=without_records(q_top), **common))
         g, w, kq = _timed_query(torch, stream, q_gb, max(5, iters // 2), ctx)
@@ -359,7 +361,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         dd = d3
         heavy = int((((dd["type"] == 3) & (dd["n"] != 0)) | ((dd["type"] == 1) & (dd["len"] > 2048))).sum())
         heavy_payload = int((dd["len"][(dd["type"] == 3) & (dd["n"] != 0)].astype(np.int64) * 4).sum() + (dd["len"][(dd["type"] == 1) & (dd["len"] > 2048)].astype(np.int64) * 2).sum())
-        out.append(_entry("config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel, heavy containers through dense shadows (default)", "k_count_matrix_fused",
+        out.append(_entry("c3.groupby32x32|config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel, heavy containers through dense shadows (default)", "k_count_matrix_fused",
                           nbytes + 8 * 1024 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
                           call_us=call_us(lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx)),
                           heavy_row_shadows={"containers": heavy, "resident_bytes": heavy * 8192 + 16 * 16 * rows.n_rows, "built": "once per batch, on the first count matrix that reads it",
@@ -382,10 +384,10 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         assert (plan.read() == pc).all(), "config 3 row pairs: the class-sorted launch pair and the single kernel disagree"
         ctx.set_option("pair_lean", 0)
         plan.intersection_count()
-        out.append(_entry(f"config3 rows, {pa.size} row pairs (rows 0..31 x rows 32..63 of every shard): IntersectionCount, launch-only plan", "k_icount2", rows.bytes, g, w,
+        out.append(_entry(f"c3.pairs_icount|config3 rows, {pa.size} row pairs (rows 0..31 x rows 32..63 of every shard): IntersectionCount, launch-only plan", "k_icount2", rows.bytes, g, w,
                           set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), launch_us_with_the_items_sorted_by_class=g_lean, **common))
         g, w = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND), iters)
-        out.append(_entry(f"config3 rows, {pa.size} row pairs: Intersect materialised (8 KiB cells), launch-only plan", "k_setop2<AND>", rows.bytes + pa.size * 16 * 8192, g, w,
+        out.append(_entry(f"c3.pairs_intersect_cells|config3 rows, {pa.size} row pairs: Intersect materialised (8 KiB cells), launch-only plan", "k_setop2<AND>", rows.bytes + pa.size * 16 * 8192, g, w,
                           set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), **common))
         # ... and with Container.optimize() applied inside the set-op kernel (round 4): the encoded containers are the only bytes written
         plan.setop(L.OP_AND, L.SETOP_OPTIMIZE)
@@ -410,7 +412,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         ctx.set_option("setop_direct_encode", 1)
         c_sep = call_us(lambda: ctx.setop(L.OP_AND, batch, pa, batch, pb, L.SETOP_OPTIMIZE)[0].free())
         ctx.set_option("setop_direct_encode", 2)
-        out.append(_entry(f"config3 rows, {pa.size} row pairs: Intersect materialised + optimize() inside the kernel (only the encoded containers are written), launch-only plan", "k_setop2<AND> (optimize)",
+        out.append(_entry(f"c3.pairs_intersect_optimize|config3 rows, {pa.size} row pairs: Intersect materialised + optimize() inside the kernel (only the encoded containers are written), launch-only plan", "k_setop2<AND> (optimize)",
                           rows.bytes + so_bytes, g, w, set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), output_payload_bytes=so_bytes, call_us=c_in,
                           call_us_with_the_separate_reencode_pass=c_sep, launch_us_with_both_operands_decoded_into_fragments=g_frag, **common))
         plan.free()
@@ -428,7 +430,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             assert (PB.RowSet.from_flat(du, pu, nru).words() == eu.words()).all(), "config 3 materialised union: bit content differs from the oracle"
             eu.free()
         g, w, kq = _timed_query(torch, stream, q_un, iters, ctx)
-        out.append(_entry("config3 rows, Union-of-64 materialised + optimize(): prepared query, Container.optimize() in the fold kernel's epilogue", "k_fold_scatter<OR, optimize>",
+        out.append(_entry("c3.union64_optimize|config3 rows, Union-of-64 materialised + optimize(): prepared query, Container.optimize() in the fold kernel's epilogue", "k_fold_scatter<OR, optimize>",
                           nbytes + un_bytes, g, w, kq, output_payload_bytes=un_bytes,
                           call_us=call_us(lambda: ctx.union_n(batch, groups, L.SETOP_OPTIMIZE)[0].free()), **common))
         q_un.free()
@@ -441,7 +443,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             order = sorted([i for i in range(64) if tot_e[i]], key=lambda i: (-int(tot_e[i]), i))[:10]
             assert tn_idx.tolist() == order and [int(c) for c in tn_cnt] == [int(tot_e[i]) for i in order], "config 3 TopN: GPU and oracle disagree"
         g, w, kq = _timed_query(torch, stream, q_tn, iters, ctx)
-        out.append(_entry("config3 rows, TopN(n = 10) of 64 rows against the filter row: counts, sum over shards and ordering on the device, prepared query", "k_rows_vs_filter", nbytes + 8 * 64 * n3,
+        out.append(_entry("c3.topn10|config3 rows, TopN(n = 10) of 64 rows against the filter row: counts, sum over shards and ordering on the device, prepared query", "k_rows_vs_filter", nbytes + 8 * 64 * n3,
                           g, w, kq, call_us=call_us(lambda: ctx.topn(batch, groups, 10, F, fidx)), **common))
         q_tn.free()
         for q in (q_fold, q_top, q_gb):
@@ -478,7 +480,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
                 o.free()
         nbytes = n4 * (n_a + n_b + 1) * 16 * 8192
         g, w, kq = _timed_query(torch, stream, q4, max(5, iters // 2), ctx)
-        out.append(_entry(f"config4 slice: {n4} shards x (32 x 32 rows + filter), dense bitmaps, IntersectionCount matrix", "k_count_matrix_mfma",
+        out.append(_entry(f"c4.dense_slice|config4 slice: {n4} shards x (32 x 32 rows + filter), dense bitmaps, IntersectionCount matrix", "k_count_matrix_mfma",
                           nbytes + 8 * n_a * n_b * n4, g, w, kq, shards=n4, host_gen_s=gen_s, set_ops_per_s=n4 * 16 * n_a * n_b / (g["median"] * 1e-6),
                           pair_bits_scanned_GBps=n4 * n_a * n_b * 2 * 16 * 8192 / (g["median"] * 1e-6) / 1e9, cpu_baseline=cpu4, timing=timing_note,
                           call_us=_timed_call(torch, stream, lambda: ctx.count_matrix(A, ra, B, rb, F, rf), 5)[0],
@@ -528,15 +530,15 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         q_rng.run()
         assert (q_rng.read() == rng_cnt).all(), "config 5: prepared Range differs from the one-shot call"
         g, wl, kq = _timed_query(torch, stream, q_rng, iters, ctx)
-        out.append(_entry(f"config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense: prepared query, the result rows stay on the device", "k_bsi_range_slot",
+        out.append(_entry(f"c5.range|config5: BSI Range(> 2^62), {n5} shards x (64 planes + exists + sign), dense: prepared query, the result rows stay on the device", "k_bsi_range_slot",
                           plane_bytes * (depth + 3), g, wl, kq, shards=n5, cpu_baseline=cpu5, parity=par5, timing=timing_note,
                           call_us=_timed_call(torch, stream, lambda: ctx.bsi_range(batch, base, L.BSI_GT, depth, kk)[0].free(), 5)[0]))
         q_rng.free()
         g, wl, kq = _timed_query(torch, stream, q_sum, iters, ctx)
-        out.append(_entry("config5: BSI Sum(filter = the Range result)", "k_bsi_sum_slot", plane_bytes * (depth + 3), g, wl, kq, shards=n5, parity=par5, timing=timing_note,
+        out.append(_entry("c5.sum|config5: BSI Sum(filter = the Range result)", "k_bsi_sum_slot", plane_bytes * (depth + 3), g, wl, kq, shards=n5, parity=par5, timing=timing_note,
                           call_us=_timed_call(torch, stream, lambda: ctx.bsi_sum(batch, base, depth, rng_out, idx5), 5)[0]))
         g, wl, kq = _timed_query(torch, stream, q_fused, iters, ctx)
-        out.append(_entry("config5 fused: Sum(Range(> 2^62)) of the same field, one pass over the planes", "k_bsi_range_sum_half", plane_bytes * (depth + 2), g, wl, kq, shards=n5,
+        out.append(_entry("c5.range_sum_fused|config5 fused: Sum(Range(> 2^62)) of the same field, one pass over the planes", "k_bsi_range_sum_half", plane_bytes * (depth + 2), g, wl, kq, shards=n5,
                           timing=timing_note, call_us=_timed_call(torch, stream, lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, kk), 5)[0],
                           parity="equal to the Range-then-Sum totals of the entry above (oracle-checked), every shard"))
         q_sum.free()
@@ -660,6 +662,7 @@ def main():
     ap.add_argument("--secondary-iters", type=int, default=20)
     ap.add_argument("--shards4-total", type=int, default=8192, help="BASELINE configs[3], strong scaling: this many shards in total, split over the ranks (0 = skip)")
     ap.add_argument("--queries4", type=int, default=10, help="timed queries per reduce mode of the strong-scaling section")
+    ap.add_argument("--detail", default="bench_detail.json", help="file name (under the repo root, and gpurun_out/ when present) of the verbose result object; stdout carries the compact line")
     ap.add_argument("--cold-sets", type=int, default=4, help="distinct resident data sets cycled for the L3-cold roofline (1 = skip)")
     args = ap.parse_args()
 
@@ -1095,8 +1098,14 @@ def main():
                 pass
         if cb is not None:
             out["cpu_baseline"] = cb
+        # stdout: ONE compact line (bench_line.py: <= 6 KB, the driver could not parse round 4's 21.6 KB line); the full
+        # object goes to bench_detail.json (beside this file and under gpurun_out/) and to stderr
+        import bench_line
+
+        out["detail_files"] = bench_line.write_detail(out, ROOT, args.detail)
+        print("[bench] detail: " + json.dumps(out), file=sys.stderr, flush=True)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.write(json_fd, (bench_line.dumps_line(out, args.detail) + "\n").encode())
 
     plan.free()
     A.free()
