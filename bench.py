@@ -489,6 +489,43 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         for b in (A, B, F):
             b.free()
         del wa, wb, wf
+    # ---- config 4 on the input SURVEY.md 8d specifies: densities LOG-UNIFORM in [0.001, 0.5] (2/3 of the rows are array rows) ----
+    n4m = args.shards4_mixed
+    if n4m:
+        import datagen as D
+
+        t0 = time.perf_counter()
+        d4, p4, nr4, g4, fd4, fp4, nbytes = D.config3_flat_subprocess(n4m, n_a + n_b, 4000, config4=True)
+        gen_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        batch4, F4 = ctx.upload_flat(d4, p4, nr4), ctx.upload_flat(fd4, fp4, n4m)
+        up_s = time.perf_counter() - t0
+        ga, gb, fidx = np.ascontiguousarray(g4[:, :n_a]), np.ascontiguousarray(g4[:, n_a:]), np.arange(n4m)
+        q4m = ctx.prepare_count_matrix(batch4, ga, batch4, gb, F4, fidx, keep_per_shard=True)
+        q4m.run()
+        tot, ps4 = q4m.read(per_shard=True)
+        cpu4m = None
+        if want_cpu:
+            OA, OF = PB.RowSet.from_flat(d4, p4, nr4), PB.RowSet.from_flat(fd4, fp4, n4m)
+            t0 = time.perf_counter()
+            e4 = PB.count_matrix(OA, ga, OA, gb, OF, fidx)
+            t_cpu = time.perf_counter() - t0
+            assert (ps4 == e4).all() and (tot == e4.sum(axis=0)).all(), "config 4 (log-uniform rows): GPU and oracle disagree"
+            cpu4m = {"kind": "port", "cores": PB.threads(), "sample": f"all {n4m} shards (32 x 32 log-uniform rows + filter), oracle groupByIterator counts, one shard per host thread",
+                     "value": n4m * 16 * n_a * n_b / t_cpu, "unit": "set-ops/s", "all_shards_s": t_cpu}
+            OA.free()
+            OF.free()
+        types = np.bincount(d4["type"], minlength=4)
+        g, w, kq = _timed_query(torch, stream, q4m, max(5, iters // 2), ctx)
+        out.append(_entry(f"c4.loguniform_slice|config4 slice as SURVEY 8d writes it: {n4m} shards x (32 x 32 rows, densities log-uniform [0.001, 0.5] + filter p = 0.5), IntersectionCount matrix on ENCODED rows",
+                          "k_count_matrix_fused", nbytes + 8 * n_a * n_b * n4m, g, w, kq, shards=n4m, host_gen_s=gen_s, upload_s=up_s, set_ops_per_s=n4m * 16 * n_a * n_b / (g["median"] * 1e-6),
+                          containers={"array": int(types[1]), "bitmap": int(types[2]), "run": int(types[3])}, cpu_baseline=cpu4m, timing=timing_note,
+                          note="frac is quoted on the ENCODED bytes (arrays 2 n, bitmaps 8192: the algorithmic bytes of SURVEY 8d); the dense-only slice above reads 2.1 x these bytes per shard",
+                          parity=f"every one of the {n4m} per-shard matrices bit-exact against the oracle" if want_cpu else "unchecked (--no-cpu-baseline)"))
+        q4m.free()
+        for b in (batch4, F4):
+            b.free()
+        del d4, p4
     # ---- config 5: BSI Range(> k) + Sum, 64 bit planes + exists + sign, 100 M columns = 96 shards ----
     n5, depth = args.shards5, 64
     if n5:
@@ -610,7 +647,93 @@ def config4_strong(torch, dist, fdist, dev, ctx, stream, rank, world, args, cpu_
     q.free()
     for b in (A, B, F):
         b.free()
+    torch.cuda.empty_cache()
+    out["variants"] = [{"id": "dense", "rows": out["rows"], "ms_per_query_pipelined": res["pipelined_s_per_query"] * 1e3, "kernel": "k_count_matrix_mfma", "kernel_us": k_us["median"],
+                        "kernel_frac": out["kernel_frac_of_8TBps"], "parity": parity, "shards_this_rank": ns}]
+    if args.shards4_mixed_total:
+        out["variants"].append(config4_strong_mixed(torch, dist, fdist, dev, ctx, stream, rank, world, args, cpu_group, want_cpu))
     return out
+
+
+def config4_strong_mixed(torch, dist, fdist, dev, ctx, stream, rank, world, args, cpu_group, want_cpu):
+    """configs[3] strong-scaled on the input SURVEY.md 8d specifies (fields A and B: 32 rows each, densities log-uniform in
+    [0.001, 0.5]: two thirds array rows; filter p = 0.5; encodings by optimize()).  The rank owns a contiguous block of
+    shards (SURVEY 8e allows either dealing; the rows are i.i.d.), generated on the host in slices of <= 1024 shards — one
+    batch and one prepared query per slice, a "query" runs them back to back accumulating into one 1024-cell matrix — so
+    that the host never holds more than one slice (4.3 GB) of the 34 GB an N = 1 run makes resident."""
+    import datagen as D
+
+    total, n_a, n_b = args.shards4_mixed_total, 32, 32
+    per = [total // world + (1 if r < total % world else 0) for r in range(world)]
+    first, ns = sum(per[:rank]), per[rank]
+    t0 = time.perf_counter()
+    qs, keep, nbytes, types = [], [], 0, np.zeros(4, dtype=np.int64)
+    local = np.zeros((n_a, n_b), dtype=np.uint64)
+    t_chk, PB = 0.0, None
+    if want_cpu:
+        from oracle import pybatch as PB
+    for s0 in range(0, ns, 1024):
+        m = min(1024, ns - s0)
+        d, p, nr, g, fd, fp, nb = D.config3_flat_subprocess(m, n_a + n_b, 4000, config4=True, first_shard=first + s0)
+        batch, F = ctx.upload_flat(d, p, nr), ctx.upload_flat(fd, fp, m)
+        ga, gb, fidx = np.ascontiguousarray(g[:, :n_a]), np.ascontiguousarray(g[:, n_a:]), np.arange(m)
+        q = ctx.prepare_count_matrix(batch, ga, batch, gb, F, fidx, keep_per_shard=True)
+        q.run()
+        tot, ps = q.read(per_shard=True)
+        if want_cpu:  # EVERY shard of the slice against the oracle
+            t1 = time.perf_counter()
+            OA, OF = PB.RowSet.from_flat(d, p, nr), PB.RowSet.from_flat(fd, fp, m)
+            e = PB.count_matrix(OA, ga, OA, gb, OF, fidx)
+            assert (ps == e).all(), f"config 4 strong (log-uniform rows): GPU and oracle disagree in shards {first + s0}.. of rank {rank}"
+            OA.free()
+            OF.free()
+            t_chk += time.perf_counter() - t1
+        local += tot
+        nbytes += nb
+        types += np.bincount(d["type"], minlength=4)[:4]
+        qs.append(q)
+        keep += [batch, F]
+        del d, p
+    resident_s = time.perf_counter() - t0
+    parity = (f"every one of this rank's {ns} shards bit-exact against the oracle ({t_chk:.1f} s, {PB.threads()} host threads)" if want_cpu else "unchecked (--no-cpu-baseline)")
+    expected = torch.from_numpy(local.view(np.int64).reshape(-1).copy()).to(dev)
+    if world > 1:
+        dist.all_reduce(expected)
+    expected = expected.cpu().numpy().view(np.uint64)
+
+    def run_local(cell):
+        if not qs:
+            cell.zero_()  # (fewer shards than ranks: this rank contributes nothing)
+        for i, q in enumerate(qs):
+            q.run(cell.data_ptr(), accumulate=i > 0)
+
+    # the kernels alone: the sum over the slices' launches (HIP events by the library around each)
+    k_us = []
+    if qs:
+        ctx.set_option("time_kernels", 1)
+        for _ in range(5):
+            t = 0.0
+            for q in qs:
+                q.run()
+                torch.cuda.synchronize()
+                t += ctx.get_option("last_kernel_ns") / 1e3
+            k_us.append(t)
+        ctx.set_option("time_kernels", 0)
+    k_med = sorted(k_us)[len(k_us) // 2] if k_us else 0.0
+    res = fdist.strong_scaling_queries(run_local, n_a * n_b, args.queries4, dev, expected=expected, sync=torch.cuda.synchronize, depth=4, cpu_group=cpu_group)
+    tv = torch.tensor([res["pipelined_s_per_query"], k_med], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+    tv = tv.tolist()
+    for q in qs:
+        q.free()
+    for b in keep:
+        b.free()
+    return {"id": "loguniform", "rows": f"{n_a} x {n_b} + filter row per shard, densities log-uniform [0.001, 0.5] (SURVEY 8d), encoded: {int(types[1])} array / {int(types[2])} bitmap / {int(types[3])} run containers on this rank",
+            "shards_total": total, "shards_this_rank": ns, "slices": len(qs), "resident_bytes_this_rank": int(nbytes), "make_resident_s": resident_s,
+            "ms_per_query_pipelined": tv[0] * 1e3, "set_ops_per_s": total * 16 * n_a * n_b / tv[0] if tv[0] else None, "kernel": "k_count_matrix_fused", "kernel_us": k_med,
+            "kernel_us_max_over_ranks": tv[1], "kernel_frac": (nbytes / (k_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) if k_med else None, "parity": parity,
+            "collectives": res["collectives"], "latency_s": res["latency_s"]}
 
 
 def group_in_process(ctx_lib_path, wa, wb, expected, steps):
@@ -658,6 +781,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 3, 4, 5 (N = 1 only anyway)")
     ap.add_argument("--shards3", type=int, default=256)
     ap.add_argument("--shards4", type=int, default=1024)
+    ap.add_argument("--shards4-mixed", type=int, default=1024, help="BASELINE configs[3] per-GPU slice on SURVEY 8d's log-uniform density rows (0 = skip)")
+    ap.add_argument("--shards4-mixed-total", type=int, default=8192, help="strong-scaling variant of configs[3] on the log-uniform rows: this many shards in total (0 = skip)")
     ap.add_argument("--shards5", type=int, default=96)
     ap.add_argument("--secondary-iters", type=int, default=20)
     ap.add_argument("--shards4-total", type=int, default=8192, help="BASELINE configs[3], strong scaling: this many shards in total, split over the ranks (0 = skip)")
@@ -958,6 +1083,11 @@ def main():
                     "kernel_us_max_over_ranks": tv[3],
                     "rank0": mine4,
                 }
+                vs = mine4.pop("variants", [])
+                vs[0].update(ms_per_query_pipelined=tv[0] * 1e3, set_ops_per_s=total_ops / tv[0], kernel_us_max_over_ranks=tv[3])
+                strong["variants"] = vs
+                if len(vs) > 1:
+                    strong["workload"] += "; variant 'loguniform': the same query on SURVEY 8d's log-uniform density rows (encoded array / bitmap rows)"
             except Exception as e:  # noqa: BLE001 — the headline is measured already
                 import traceback
 

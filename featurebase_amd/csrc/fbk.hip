@@ -103,7 +103,8 @@ struct FbkOptions {
   int64_t upload_chunk_mb = 64;          // size of each of the two pinned upload buffers
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 2;       // pair set-ops with optimize(): 2 the kernel applies Container.optimize() itself (encoded bytes into the head of the cell; no re-encode pass), 1 results of <= 1024 values leave the kernel as arrays and the re-encode pass does the rest (round 2), 0 always 8 KiB cells first (A/B runs, cross-checks)
-  int64_t count_range_reference_quirk = 0;  // 1: fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227)
+  int64_t count_range_reference_quirk = 1;  // 1 (default: identical to the reference): fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227); 0: the arithmetically right count
+  int64_t topn_semantics = 1;            // fbk_topn / fbk_query_topn / fbk_group_topn / fbk_topn_partials with n > 0: 1 (default) the reference's two passes — candidates = the union over the SHARDS of fragment.top(N = n) (k_topn_candidates), then their exact totals (executeTopN, executor.go:2779-2864); 0: the exact top n of all rows
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
   int64_t pair_resolve = 1;              // k_icount2 reads the plan's resolved item records and stores one count per wave (0: row index -> descriptor per wave, atomics; A/B runs)
 #ifdef FBK_EXPERIMENTS
@@ -706,6 +707,7 @@ const OptionDesc kOptions[] = {
     {"pair_resolve", &FbkOptions::pair_resolve, 0, 1},
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
+    {"topn_semantics", &FbkOptions::topn_semantics, 0, 1},
 };
 
 int32_t option_set(FbkOptions& o, const char* name, int64_t v) {

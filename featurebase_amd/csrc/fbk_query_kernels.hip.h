@@ -819,6 +819,156 @@ __global__ void __launch_bounds__(256) k_topn_filter(u64* __restrict__ counts, c
   if (!ok) counts[i] = 0;
 }
 
+// ---- TopN candidates: pass 1 of executeTopN (executor.go:2779-2864), per SHARD ------------------------
+// fragment.top (fragment.go:1317-1437) with N = n walks the shard's rows in rank-cache order (cardinality descending; rows
+// of one cardinality in row-index order — Go sorts the cache with an unstable sort, the tie order is fixed here): the first n rows that pass
+// the thresholds fill the heap ("P"); with a source row every LATER row whose cardinality passes the cnt-level test and
+// whose count reaches T = the smallest count in P is pushed as well, without evicting (:1404-1425: the heap only grows,
+// so its minimum stays T; "cnt < threshold -> break" skips rows that could not reach T anyway); without a source row the
+// walk stops at n (:1398-1401).  Every id a shard returns is a candidate of the second pass (:2812-2818).
+//
+// One block per shard, no sort: the n-th qualifying row in rank order is found by two-level histogram selection on
+// (2^22 - 1 - cnt) and then, among the rows of that cardinality, on the row index (both < 2^22: 2048 x 2048 bins).
+// counts[s][i] = |row i ∩ src_s| BEFORE k_topn_filter (= cards without a source row), cards[s][i] = the row's
+// cardinality, src_counts[s] = |src_s|.  cand[i] is set to 1 for every candidate row (all shards write the same value).
+struct TopnRule {
+  u64 min_threshold, tanimoto, src;
+  bool tani;
+  __device__ __forceinline__ bool cnt_ok(u64 cnt) const {
+    if (cnt == 0) return false;
+    if (tani) return !(cnt * 100 <= src * tanimoto || cnt * tanimoto >= src * 100);
+    return cnt >= min_threshold;
+  }
+  __device__ __forceinline__ bool count_ok(u64 cnt, u64 count) const {
+    if (count == 0) return false;
+    if (tani) {
+      const u64 den = cnt + src - count;
+      return (count * 100 + den - 1) / den > tanimoto;
+    }
+    return count >= min_threshold;
+  }
+};
+
+// the k-th smallest (k >= 1) 22-bit key among the rows i < n_a with pred(i); returns the key, *below = the number of
+// flagged rows with a smaller key.  Requires k <= the number of flagged rows.  hist: 2048 uint32 of LDS; sel: 4 uint32.
+template <typename Pred, typename Key>
+__device__ __forceinline__ uint32_t block_kth_smallest(uint32_t n_a, uint32_t k, Pred pred, Key key, uint32_t* hist, uint32_t* sel, uint32_t* below) {
+  uint32_t base = 0, prefix = 0;  // rows below the current bin; the key bits fixed so far
+  for (int level = 0; level < 2; ++level) {
+    for (uint32_t b = threadIdx.x; b < 2048; b += 256) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_a; i += 256) {
+      if (!pred(i)) continue;
+      const uint32_t kk = key(i);
+      if (level == 0) atomicAdd(&hist[kk >> 11], 1u);
+      else if ((kk >> 11) == prefix) atomicAdd(&hist[kk & 2047], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // wave 0: lane l owns bins [32 l, 32 l + 32)
+      const int lane = threadIdx.x;
+      uint32_t mine = 0;
+      for (int j = 0; j < 32; ++j) mine += hist[lane * 32 + j];
+      uint32_t incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      const uint32_t excl = incl - mine;
+      if (base + excl < k && k <= base + incl) {  // exactly one lane
+        uint32_t run = base + excl;
+        for (int j = 0; j < 32; ++j) {
+          const uint32_t h = hist[lane * 32 + j];
+          if (k <= run + h) {
+            sel[0] = uint32_t(lane * 32 + j);
+            sel[1] = run;
+            break;
+          }
+          run += h;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t bin = sel[0];
+    base = sel[1];
+    __syncthreads();
+    prefix = level == 0 ? bin : ((prefix << 11) | bin);
+  }
+  *below = base;
+  return prefix;
+}
+
+__global__ void __launch_bounds__(256) k_topn_candidates(const u64* __restrict__ counts, const u64* __restrict__ cards, const u64* __restrict__ src_counts,
+                                                        uint32_t n_a, uint32_t top_n, u64 min_threshold, u64 tanimoto_threshold, int has_src,
+                                                        u64* __restrict__ cand) {
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t sel[4];
+  __shared__ unsigned long long red[4];
+  const uint64_t s = blockIdx.x;
+  counts += s * n_a;
+  cards += s * n_a;
+  TopnRule rule;
+  rule.min_threshold = min_threshold;
+  rule.tanimoto = tanimoto_threshold;
+  rule.src = (has_src && src_counts) ? src_counts[s] : 0;
+  rule.tani = tanimoto_threshold > 0 && has_src;
+  constexpr uint32_t kTop = (1u << 22) - 1;
+  auto qualifies = [&](uint32_t i) {
+    const u64 cnt = cards[i];
+    return rule.cnt_ok(cnt) && rule.count_ok(cnt, counts[i]);
+  };
+  // ---- how many rows qualify at all
+  uint32_t q = 0;
+  for (uint32_t i = threadIdx.x; i < n_a; i += 256) q += qualifies(i) ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += (uint32_t)__shfl_xor((int)q, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+  __syncthreads();
+  const uint32_t n_qual = uint32_t(red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();
+  if (n_qual < top_n) {  // the heap never fills: every qualifying row is returned, nothing else is looked at
+    for (uint32_t i = threadIdx.x; i < n_a; i += 256)
+      if (qualifies(i)) cand[i] = 1;
+    return;
+  }
+  // ---- the n-th qualifying row in rank order: cardinality v, and among the rows of cardinality v the row index id_cut
+  uint32_t above = 0;
+  const uint32_t vkey = block_kth_smallest(n_a, top_n, qualifies, [&](uint32_t i) { return kTop - uint32_t(cards[i]); }, hist, sel, &above);
+  const u64 v = kTop - vkey;
+  uint32_t dummy = 0;
+  const uint32_t id_cut = block_kth_smallest(n_a, top_n - above, [&](uint32_t i) { return cards[i] == v && qualifies(i); }, [&](uint32_t i) { return i; }, hist, sel, &dummy);
+  auto in_p = [&](uint32_t i) {
+    const u64 cnt = cards[i];
+    return (cnt > v || (cnt == v && i <= id_cut)) && qualifies(i);
+  };
+  // ---- T = the smallest count in P
+  unsigned long long t = ~0ull;
+  for (uint32_t i = threadIdx.x; i < n_a; i += 256)
+    if (in_p(i)) t = counts[i] < t ? counts[i] : t;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long x = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(t >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)t, o, 64);
+    t = x < t ? x : t;
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  unsigned long long T = red[0];
+  for (int w = 1; w < 4; ++w) T = red[w] < T ? red[w] : T;
+  const bool later = has_src && T >= min_threshold;  // (:1409: "threshold < MinThreshold -> break")
+  for (uint32_t i = threadIdx.x; i < n_a; i += 256) {
+    const u64 cnt = cards[i];
+    bool c = in_p(i);
+    if (!c && later && (cnt < v || (cnt == v && i > id_cut))) c = rule.cnt_ok(cnt) && counts[i] >= T;
+    if (c) cand[i] = 1;
+  }
+}
+
+// totals of the rows that are no candidate of any shard do not exist in the reference's second pass
+__global__ void __launch_bounds__(256) k_topn_mask(u64* __restrict__ totals, const u64* __restrict__ cand, uint32_t n_a) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_a && cand[i] == 0) totals[i] = 0;
+}
+
 __global__ void __launch_bounds__(256) k_max_u64(const u64* __restrict__ v, uint64_t n, u64* __restrict__ out) {
   u64 m = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) m = v[i] > m ? v[i] : m;

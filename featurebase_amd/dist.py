@@ -69,41 +69,31 @@ def order_totals(totals: np.ndarray, n: int = 0):
     return idx.astype(np.uint32), t[idx]
 
 
-def topn_two_pass(local_totals: np.ndarray, n: int = 0, device: Optional[str] = None):
-    """executeTopN's two passes (executor.go:2779-2827) for the one-process-per-GPU deployment — the multi-process form of
-    fbk_group_topn.  local_totals[i] = this rank's total of row i over the shards IT owns, thresholds already applied per
-    shard (what fbk_topn / a prepared fbk_query_topn leave on the device; a rank without shards passes zeros).
-      pass 1  the rank's own first n rows are its candidates (executeTopNShards :2829-2864);
-      merge   the candidate ids of all ranks, sorted and de-duplicated (:2814-2816): ONE all_gather of n ids per rank;
-      pass 2  the totals of exactly those rows summed over the ranks (Pairs.Add, cache.go:463): ONE all_reduce of
-              |candidates| words; ordered, trimmed to n (:2823-2825).
-    Returns (row indexes, counts), identical on every rank.  n = 0 (or n >= the number of rows): every row is a candidate,
-    the result is exact and costs one all_reduce of the whole vector.  Like the reference's, a row that is in no rank's
-    local top n is not returned even if its global total would qualify."""
-    import torch
+def topn_reduce(local_totals: np.ndarray, local_candidates: Optional[np.ndarray] = None, n: int = 0, device: Optional[str] = None):
+    """TopN for the one-process-per-GPU deployment — the multi-process form of fbk_group_topn.  Every rank passes what
+    fbk_topn_partials (Context.topn_partials) returned for the shards IT owns: local_totals[i] = its total of row i
+    (thresholds applied per shard), local_candidates[i] != 0 iff one of its shards lists row i in the reference's first
+    pass (fragment.top with N = n per SHARD, executor.go:2869-2944; a rank without shards passes zeros).  ONE all_reduce
+    of [totals | candidates] (2 n_a words): in the reference a node returns its shards' merged pairs untrimmed
+    (executeTopNShards :2829-2864), so the candidate set is the union over all shards wherever they live, and the second
+    pass (:2812-2818) is the totals of those rows — which every rank already holds.  Rows no rank flagged are dropped, the
+    rest ordered (count descending, row index ascending) and trimmed to n (:2823-2825).  local_candidates = None: no
+    candidate pass (n = 0, or the exact semantics): one all_reduce of n_a words.  Identical on every rank, and identical
+    to fbk_topn over all shards on one context."""
     import torch.distributed as dist
 
     t = np.ascontiguousarray(local_totals, dtype=np.uint64)
+    c = None if local_candidates is None else np.ascontiguousarray(local_candidates, dtype=np.uint64)
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    if not multi:
-        return order_totals(t, n)
-    if n == 0 or n >= t.size:
-        return order_totals(reduce_count_vector(t, device), n)
-    world = dist.get_world_size()
-    mine, _ = order_totals(t, n)
-    ids = torch.full((n,), -1, dtype=torch.int64)
-    ids[: mine.size] = torch.from_numpy(mine.astype(np.int64))
-    if device:
-        ids = ids.to(device)
-    gathered = [torch.empty_like(ids) for _ in range(world)]
-    dist.all_gather(gathered, ids)
-    cand = np.unique(torch.cat(gathered).cpu().numpy())
-    cand = cand[cand >= 0]
-    if cand.size == 0:
-        return np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint64)
-    tot = reduce_count_vector(t[cand], device)
-    k, c = order_totals(tot, n)
-    return cand[k].astype(np.uint32), c
+    if multi:
+        if c is None:
+            t = reduce_count_vector(t, device)
+        else:
+            both = reduce_count_vector(np.concatenate([t, c]), device)
+            t, c = both[: t.size], both[t.size:]
+    if c is not None:
+        t = np.where(c != 0, t, np.uint64(0))
+    return order_totals(t, n)
 
 
 def bsi_sum_reduce(psum: int, nsum: int, count: int, device: Optional[str] = None):

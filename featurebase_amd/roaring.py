@@ -492,6 +492,20 @@ class Context:
         )
         return idx[: got.value].copy(), cnt[: got.value].copy()
 
+    def topn_partials(self, a: Optional[Batch], rows_a, n_a: int, n: int = 0, filt: Optional[Batch] = None, rows_f=None, min_threshold: int = 0,
+                      tanimoto_threshold: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        """fbk_topn_partials: (totals [n_a], candidate flags [n_a]) of THIS context's shards — what a rank of the
+        one-process-per-GPU deployment hands to featurebase_amd.dist.topn_reduce.  a = None / no rows: zeros."""
+        tot, cand = np.zeros(n_a, dtype=np.uint64), np.zeros(n_a, dtype=np.uint64)
+        if a is None or rows_a is None or len(rows_a) == 0:
+            return tot, cand
+        ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
+        assert ra.ndim == 2 and ra.shape[1] == n_a
+        rf = np.ascontiguousarray(rows_f, dtype=np.uint32) if filt is not None else None
+        L.check(self.lib.fbk_topn_partials(self.h, a.h, ra.ctypes.data, n_a, filt.h if filt is not None else None, rf.ctypes.data if rf is not None else None,
+                                           ra.shape[0], n, min_threshold, tanimoto_threshold, tot.ctypes.data, cand.ctypes.data))
+        return tot, cand
+
     def topk_bsi(self, a: Batch, rows_a, filt: Optional[Batch] = None, rows_f=None, flags: int = 0) -> Tuple[Batch, int]:
         """The TopK counts as BSI planes over the row indices (bsiBuilder, bsi.go:251): (batch of depth rows, depth)."""
         ra = np.ascontiguousarray(rows_a, dtype=np.uint32)
@@ -804,7 +818,8 @@ class Group:
 
     def topn(self, per_member: Sequence[Optional[dict]], n_a: int, n: int = 0, min_threshold: int = 0, tanimoto_threshold: int = 0):
         """per_member[m]: None or dict(a=Batch, rows_a=[n_shards, n_a], filt=Batch|None, rows_f=[n_shards]).
-        Returns (row indexes, counts) of the two-pass TopN over all members (fbk_group_topn)."""
+        Returns (row indexes, counts) of the TopN over the shards of all members (fbk_group_topn: fbk_topn's answer,
+        however the shards are dealt)."""
         args = (L.TopnArgs * len(self.members))()
         keep = []
         for m, pm in enumerate(per_member):

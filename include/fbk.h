@@ -51,7 +51,23 @@
 extern "C" {
 #endif
 
-#define FBK_ABI_VERSION 4 /* 4 (round 4): + fbk_query_bsi_range / _fold / _topn / _output, fbk_group_bsi_sum / _topn; nothing removed or changed */
+#define FBK_ABI_VERSION 5
+/* ABI history.
+ *   5 (round 5): + fbk_topn_partials, options topn_semantics, matrix_shadow_arena_x.  CHANGED: fbk_topn / fbk_query_topn /
+ *      fbk_group_topn with 0 < n < n_a return the reference's two-pass answer by default (topn_semantics = 1; = 0 restores
+ *      round 4's exact top n of fbk_topn; round 4's per-member candidate rule of fbk_group_topn is gone — it was neither);
+ *      count_range_reference_quirk defaults to 1 (the reference's number).
+ *   4 (round 4): + fbk_query_bsi_range / _fold / _topn / _output, fbk_group_bsi_sum / _topn.  Also changed in that round
+ *      (not said at the time): option pair_spw REMOVED (fbk_set_option fails, FBK_PAIR_SPW is ignored); pair_wpb accepts
+ *      0 / 1 / 4 only; the default of matrix_shadow_max_mb went from 65536 to 16384; fbk_plan_setop(FBK_SETOP_OPTIMIZE)
+ *      succeeds (when setop_direct_encode == 2) where it was an error.
+ *
+ * Where the DEFAULT deliberately differs from the reference, and the option that restores identity:
+ *   (none since ABI 5.)  Before: CountRange on runs ending at `end` (count_range_reference_quirk = 1), TopN with n > 0
+ *   (topn_semantics = 1).  What remains different cannot be restored by an option because the reference itself leaves it
+ *   unspecified or depends on state off the path: the order of TopN pairs of EQUAL count (Go's unstable sort over map
+ *   order; here row index ascending) and the rank cache's size / staleness (cache.go: at most CacheSize rows, refreshed
+ *   lazily; here every row of the field is ranked, as after RecalculateCaches with CacheSize >= the field's rows). */
 
 /* status codes */
 #define FBK_OK 0
@@ -140,9 +156,10 @@ int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
  * is decoded in every query),
  * bsi_range_sum_two_pass, bsi_half_waves, bsi_planes_ahead, topk_device_sort, sparse_paths,
  * setop_direct_encode, setop_probe, fold_encode, pair_kernels, pair_wpb, pair_resolve, pair_run_probe, pair_lean,
- * query_resolve, upload_chunk_mb, upload_threads, count_range_reference_quirk.  Every value of every option gives
- * the same results (the tests run them against each other); they select between kernels, not between semantics —
- * except count_range_reference_quirk, which is a documented divergence of the reference itself.
+ * query_resolve, upload_chunk_mb, upload_threads, count_range_reference_quirk, topn_semantics.  Every value of every
+ * option gives the same results (the tests run them against each other); they select between kernels, not between
+ * semantics — except count_range_reference_quirk and topn_semantics, whose DEFAULTS (1) are the reference's results and
+ * whose other value (0) is the arithmetically exact one (see fbk_count_range, fbk_topn).
  * Measurement: time_kernels = 1 makes the query-level calls (count matrix, n-way fold, BSI range /
  * sum / min / max) record HIP events on the context's stream right before and after their dominant kernel;
  * fbk_get_option("last_kernel_ns") then returns that kernel's duration for the last such call. */
@@ -273,10 +290,9 @@ int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, ui
  * hold a run whose last value == end-1+1 (`iv.Last == end`), where RunCountRange's
  * "subset of range" and "overlaps end" branches both fire and over-count (roaring.go:3216-3227)
  * — a case the reference's own callers (container-aligned ranges) never produce.
- * DEFAULT: the bit count.  Option "count_range_reference_quirk" = 1 (fbk_set_option, or
- * FBK_COUNT_RANGE_REFERENCE_QUIRK=1 in the environment of fbk_open) makes the call reproduce
- * RunCountRange as written, over-count included, so that a Go caller can get the reference's number on
- * the same inputs; both modes are tested against the oracle (tests/test_gpu_parity.py). */
+ * DEFAULT (option "count_range_reference_quirk" = 1): RunCountRange as written, over-count included — the
+ * reference's number on the same inputs.  = 0 (fbk_set_option, or FBK_COUNT_RANGE_REFERENCE_QUIRK=0 in the
+ * environment of fbk_open): the bit count.  Both modes are tested against the oracle (tests/test_gpu_parity.py). */
 int32_t fbk_count_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n, uint64_t start,
                         uint64_t end, uint64_t* out_counts);
 
@@ -526,24 +542,42 @@ int32_t fbk_topk(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint3
                  const uint32_t* rows_f, uint32_t n_shards, uint32_t k, uint32_t* out_index, uint64_t* out_count, uint32_t cap,
                  uint32_t* out_n);
 
-/* TopN with the reference's qualification rules (fragment.top, fragment.go:1317-1437; executeTopN's
- * per-shard map): per shard s and row i, cnt = the row's stored cardinality and count = |row ∩ F_s|
- * (count = cnt without a filter = the `Src` row).  The row contributes count to totals[i] from that
- * shard iff cnt != 0, count != 0 and
+/* TopN (executeTopN, executor.go:2779-2864; per shard fragment.top, fragment.go:1317-1437).  Per shard s and row i,
+ * cnt = the row's stored cardinality and count = |row ∩ F_s| (count = cnt without a filter = the `Src` row).  The row
+ * QUALIFIES in that shard iff cnt != 0, count != 0 and
  *   tanimoto_threshold > 0 and a filter is given:
  *       src*T/100 < cnt < src*100/T   and   ceil(count*100 / (cnt + src - count)) > T     (:1334-1391;
  *       src = |F_s|, T = tanimoto_threshold, a percentage; evaluated in integer arithmetic, which equals
  *       the reference's float64 comparisons for every count a shard can hold)
- *   otherwise:  cnt >= min_threshold and count >= min_threshold                              (:1357, :1394)
- * Every row is counted exactly: the rank cache's early exits (:1404-1422) only skip rows that could
- * not qualify, its truncation to the first N cached rows is an approximation this path does not
- * need — so fbk_topn can return a row that the reference's cache (cache.go, rankCache: at most
- * CacheSize rows, refreshed lazily) had dropped or not yet ranked; on inputs whose rows all fit the
- * cache the two agree (tests/golden/topn_vectors.json).  Totals are summed over the shards (Pairs.Add, cache.go:463), ordered count descending /
- * row index ascending, at most n results (n = 0: all).  fbk_topk is fbk_topn with both thresholds 0. */
+ *   otherwise:  cnt >= min_threshold and count >= min_threshold                              (:1357, :1394;
+ *       the caller passes what executeTopNShard passes: 0 there becomes defaultMinThreshold = 1, the same rule)
+ * and totals[i] = the sum of count over the shards where row i qualifies (Pairs.Add, cache.go:463).
+ *
+ * n = 0 or n >= n_a: every row with a total is returned, ordered count descending / row index ascending.
+ * 0 < n < n_a, option topn_semantics = 1 (DEFAULT): the reference's two passes.  Pass 1: per SHARD, fragment.top with
+ *   N = n walks the rows in rank order (cnt descending; equal cnt: row index ascending) — the first n qualifying rows,
+ *   and with a filter every later row whose cnt passes the cnt-level test and whose count reaches the smallest count of
+ *   those n (the heap only grows, :1404-1425) — and the ids of all shards are merged, untrimmed (executeTopNShards
+ *   :2829-2864).  Pass 2: the totals of exactly those candidates (:2812-2818), ordered, trimmed to n (:2823-2825).  A row
+ *   outside every shard's own list is not returned even if its total would rank: that IS the reference's answer
+ *   (TestExecutor_Execute_TopN_fill_small, tests/golden/executor_topn_vectors.json).  One kernel (k_topn_candidates,
+ *   one block per shard, histogram selection — no sort) next to the counting the call does anyway.
+ * 0 < n < n_a, topn_semantics = 0: the exact top n of totals.
+ * The rank cache itself (cache.go: at most CacheSize rows per fragment, refreshed lazily) is not modelled: every row given
+ * in rows_a is ranked.  fbk_topk (executeTopK, an exact operator in the reference too) is fbk_topn with both thresholds 0
+ * and no candidate pass. */
 int32_t fbk_topn(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a, const fbk_batch* filter,
                  const uint32_t* rows_f, uint32_t n_shards, uint32_t n, uint64_t min_threshold, uint64_t tanimoto_threshold,
                  uint32_t* out_index, uint64_t* out_count, uint32_t cap, uint32_t* out_n);
+
+/* One member's share of a TopN for the one-process-per-GPU deployment (featurebase_amd/dist.py topn_reduce): totals[i] as
+ * fbk_topn computes them over THIS context's shards and candidates[i] != 0 iff some shard here lists row i in pass 1
+ * (without a candidate pass — n = 0, n >= n_a, topn_semantics = 0 — every row with a total).  The ranks all-reduce
+ * [totals | candidates] (2 n_a words, ONE collective), drop the rows no rank flagged, order and trim: the same answer
+ * as fbk_topn over all shards, however they are dealt.  n_shards = 0: zeros.  Both outputs hold n_a uint64. */
+int32_t fbk_topn_partials(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, uint32_t n_a, const fbk_batch* filter,
+                          const uint32_t* rows_f, uint32_t n_shards, uint32_t n, uint64_t min_threshold, uint64_t tanimoto_threshold,
+                          uint64_t* out_totals, uint64_t* out_candidates);
 
 /* The TopK counts in the form executeTopKShard hands to its reducer: BSI planes over the ROW IDS
  * (bsiBuilder.Insert(rowID, count), bsi.go:251-284; merged across shards with AddBSI = fbk_bsi_add,
@@ -716,14 +750,12 @@ typedef struct fbk_bsi_args {
 int32_t fbk_group_bsi_sum(fbk_group* group, const fbk_bsi_args* per_member, uint32_t bit_depth, int64_t* out_sum,
                           uint64_t* out_count);
 
-/* TopN over the shards of all members, in the reference's two passes (executeTopN, executor.go:2779-2827):
- * (1) every member counts its shards as fbk_topn does and orders its own totals — its first n rows are its
- * candidates (what a node returns to the coordinator, executeTopNShards :2829-2864); (2) the sorted union of the
- * candidate row ids goes back to every member ("ids", :2814-2818), whose totals of exactly those rows are reduced
- * over the members (Pairs.Add) in ONE collective of |candidates| words; the result is ordered count descending /
- * row index ascending and trimmed to n (:2823-2825).  As in the reference, a row outside every member's local
- * top n is not returned; n = 0 makes every row a candidate (exact).  per_member[m] are member m's arguments of
- * fbk_topn; outputs as fbk_topn. */
+/* TopN over the shards of all members: fbk_topn's answer over the union of the members' shards (the same two passes
+ * under topn_semantics = 1, exact under 0), independent of how the shards are dealt — in the reference a node returns its
+ * shards' merged pairs UNTRIMMED (executeTopNShards :2829-2864), the truncation to n happens per shard inside fragment.top.
+ * Every member counts its shards and flags its shards' candidates; ONE reduce of [totals | candidate flags] (2 n_a words;
+ * n_a without a candidate pass) over the members, then order and trim on the host.  per_member[m] are member m's
+ * arguments of fbk_topn; outputs as fbk_topn.  The first member's topn_semantics decides for the group. */
 typedef struct fbk_topn_args {
   const fbk_batch* a;
   const uint32_t* rows_a;  /* [n_shards][n_a] */

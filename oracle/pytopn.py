@@ -8,9 +8,13 @@ unspecified are fixed here so that the function is deterministic: rows of equal 
 ascending id order (Go sorts a map's entries with an unstable sort), and nothing else.  It is pinned
 to the reference's own known answers (tests/golden/topn_vectors.json, extracted mechanically).
 
-`top_exact` is the specification the GPU path implements (include/fbk.h fbk_topn): the same
-threshold rules applied to EVERY row (no rank-cache early exits, which are an optimisation that
-never changes which rows qualify), ordered count descending / id ascending."""
+`execute_topn` composes it per SHARD into executeTopN's two passes (executor.go:2779-2864) and is pinned to the
+expectations of TestExecutor_Execute_TopN, _TopN_fill, _TopN_fill_small and _TopN_Src
+(tests/golden/executor_topn_vectors.json, extracted mechanically): this is what fbk_topn / fbk_group_topn return under
+option topn_semantics = 1 (reference, the default).
+
+`top_exact` is the specification of option topn_semantics = 0 (include/fbk.h fbk_topn): the same
+threshold rules applied to EVERY row of every shard, no candidate pass, ordered count descending / id ascending."""
 from __future__ import annotations
 
 import math
@@ -146,27 +150,61 @@ def top_exact(shards: Sequence[Dict[int, Iterable[int]]], ids: Sequence[int], n:
     return out[:n] if n else out
 
 
-def top_two_pass(node_shards: Sequence[Sequence[Dict[int, Iterable[int]]]], ids: Sequence[int], n: int = 0,
-                 node_srcs: Optional[Sequence[Optional[Sequence[Iterable[int]]]]] = None, min_threshold: int = 0,
-                 tanimoto_threshold: int = 0) -> List[Tuple[int, int]]:
-    """executeTopN (executor.go:2779-2827) over several nodes, with the exact per-shard counting of top_exact in place of
-    the rank cache: node_shards[m] = the shards node m owns (node_srcs[m] their filter rows).
-      pass 1 (:2795): every node's answer is its own merged, sorted list (executeTopNShards :2829-2864) — here its first
-              n rows by (count descending, id ascending); a node without shards answers nothing;
-      ids    (:2814-2816): the keys of all answers, sorted;
-      pass 2 (:2818): every node's totals of exactly those ids (fragment.top does not truncate when ids are given,
-              fragment.go:1324-1327), added up over the nodes (Pairs.Add, cache.go:463), sorted, trimmed to n (:2823)."""
-    per_node = []
-    for m, shards in enumerate(node_shards):
-        if not shards:
-            per_node.append({})
+def pairs_add(p: Dict[int, int], other: Sequence[Tuple[int, int]]) -> Dict[int, int]:
+    """Pairs.Add (cache.go:463-483): counts of equal ids added up (the map form; the slice order it returns is Go's map
+    order, i.e. unspecified — every caller sorts afterwards)."""
+    for r, c in other:
+        p[r] = p.get(r, 0) + c
+    return p
+
+
+def pairs_sorted(p: Dict[int, int]) -> List[Tuple[int, int]]:
+    """sort.Sort(Pairs) (Less = Count >, cache.go:434): count descending; Go's sort is not stable and the input order is a
+    map's, so ties are unspecified in the reference — fixed here (and in fbk_topn) as row id ascending."""
+    return sorted(p.items(), key=lambda q: (-q[1], q[0]))
+
+
+DEFAULT_MIN_THRESHOLD = 1  # executor.go:40-42
+
+
+def execute_topn_shards(shards: Sequence[Dict[int, Iterable[int]]], n: int, srcs: Optional[Sequence[Optional[Iterable[int]]]], row_ids: Optional[Sequence[int]],
+                        min_threshold: int, tanimoto_threshold: int) -> List[Tuple[int, int]]:
+    """executeTopNShards (executor.go:2829-2864): fragment.top of EVERY shard with the call's own n (executeTopNShard
+    :2869-2944 — MinThreshold 0 becomes 1, :2918-2920), merged with Pairs.Add in the reduce — nothing is trimmed here, by
+    shard beyond fragment.top's own rule or by node — then sorted."""
+    if min_threshold == 0:
+        min_threshold = DEFAULT_MIN_THRESHOLD
+    merged: Dict[int, int] = {}
+    for s, rows in enumerate(shards):
+        if not rows:  # no fragment for this shard (:2911-2913): an empty PairsField
             continue
-        srcs = node_srcs[m] if node_srcs is not None else None
-        per_node.append(dict(top_exact(shards, ids, 0, srcs, min_threshold, tanimoto_threshold)))
-    cand = set()
-    for tot in per_node:
-        first = sorted(tot.items(), key=lambda p: (-p[1], p[0]))
-        cand.update(r for r, _ in (first[:n] if n else first))
-    merged = {r: sum(tot.get(r, 0) for tot in per_node) for r in sorted(cand)}
-    out = sorted([(r, c) for r, c in merged.items() if c], key=lambda p: (-p[1], p[0]))
-    return out[:n] if n else out
+        src = srcs[s] if srcs is not None else None
+        pairs_add(merged, fragment_top(rows, n, src, row_ids, min_threshold, tanimoto_threshold))
+    return pairs_sorted(merged)
+
+
+def execute_topn(shards: Sequence[Dict[int, Iterable[int]]], n: int = 0, srcs: Optional[Sequence[Optional[Iterable[int]]]] = None,
+                 ids_arg: Optional[Sequence[int]] = None, min_threshold: int = 0, tanimoto_threshold: int = 0) -> List[Tuple[int, int]]:
+    """executeTopN (executor.go:2779-2827) on the coordinating node.  shards[s] = row id -> columns of shard s (how the
+    shards are dealt to nodes does not matter: a remote node runs executeTopNShards over ITS shards with opt.Remote and
+    returns the merged, untrimmed list (:2800-2806), and Pairs.Add is associative).
+      pass 1 (:2795)       executeTopNShards with the call as written: per SHARD, fragment.top(N = n);
+      early out (:2802)    no pairs, or the call named ids: the pass-1 list is the answer (NOT trimmed to n);
+      ids (:2812-2816)     the keys of the pass-1 pairs, sorted;
+      pass 2 (:2818)       the same call with those ids: fragment.top sets N = 0 when ids are given (fragment.go:1324-1327),
+                           so every shard reports every id that passes the thresholds there;
+      trim (:2823-2825)    the first n of the sorted merge."""
+    pairs = execute_topn_shards(shards, n, srcs, ids_arg, min_threshold, tanimoto_threshold)
+    if not pairs or ids_arg:
+        return pairs
+    ids = sorted(r for r, _ in pairs)
+    trimmed = execute_topn_shards(shards, n, srcs, ids, min_threshold, tanimoto_threshold)
+    if n != 0 and n < len(trimmed):
+        trimmed = trimmed[:n]
+    return trimmed
+
+
+def topn_candidates(shards: Sequence[Dict[int, Iterable[int]]], n: int, srcs: Optional[Sequence[Optional[Iterable[int]]]] = None, min_threshold: int = 0,
+                    tanimoto_threshold: int = 0) -> List[int]:
+    """The sorted candidate ids of execute_topn's pass 1 (what fbk_topn_partials reports per member, as flags)."""
+    return sorted(r for r, _ in execute_topn_shards(shards, n, srcs, None, min_threshold, tanimoto_threshold))

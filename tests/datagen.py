@@ -288,31 +288,52 @@ def bernoulli_words(rng, d: float, shape) -> np.ndarray:
 
 
 def _config3_chunk(args):
-    s0, s1, k, seed_idx = args
-    rows, _, filt = config3_flat(s1 - s0, k, seed_idx, first_shard=s0, workers=1)
+    s0, s1, k, seed_idx, dens, run_frac = args
+    rows, _, filt = config3_flat(s1 - s0, k, seed_idx, first_shard=s0, workers=1, densities=dens, run_frac=run_frac)
     return rows, filt
 
 
-def config3_flat(n_shards: int, k: int = 64, seed_idx: int = 3000, first_shard: int = 0, workers: int = 0, mp: str = "spawn"):
+def config4_densities(n_rows: int = 64, seed_idx: int = 4000):
+    """SURVEY.md 8d, configs[3] as written: "field A: 32 rows, field B: 32 rows, densities log-uniform [0.001, 0.5]" — one
+    density per FIELD ROW (the same in every shard: a row of a field is one attribute value), drawn once from the seeded
+    generator.  i.i.d. bits at density d never make a run container (runs ~ n (1 - d) > n / 2) and make an array below
+    4096 / 65536 = 0.0625, so ln(62.5) / ln(500) = 66.5 % of the rows are ARRAY rows — the mix the dense-only runs of rounds
+    1-4 never touched."""
+    rng = rng_for(seed_idx, 0xD5)
+    return np.exp(rng.uniform(np.log(0.001), np.log(0.5), n_rows)).tolist()
+
+
+def config4_flat(n_shards: int, n_a: int = 32, n_b: int = 32, seed_idx: int = 4000, first_shard: int = 0, workers: int = 0, mp: str = "spawn"):
+    """BASELINE.json configs[3] on SURVEY 8d's input: per shard n_a rows of field A then n_b rows of field B (row r of
+    the shard = field row r; rows 0 .. n_a-1 are A), densities config4_densities, encodings by optimize()'s rule, plus
+    one filter row of density 0.5.  Returns (rows FlatRows, rows_a [n_shards, n_a], rows_b [n_shards, n_b], filter
+    FlatRows, densities)."""
+    dens = config4_densities(n_a + n_b, seed_idx)
+    rows, groups, filt = config3_flat(n_shards, n_a + n_b, seed_idx, first_shard, workers, mp, densities=dens, run_frac=0.0)
+    return rows, np.ascontiguousarray(groups[:, :n_a]), np.ascontiguousarray(groups[:, n_a:]), filt, dens
+
+
+def config3_flat(n_shards: int, k: int = 64, seed_idx: int = 3000, first_shard: int = 0, workers: int = 0, mp: str = "spawn", densities=None, run_frac: float = 0.25):
     """BASELINE.json configs[2]: per shard k rows of rank-law density clamp(0.5 (r+1)^-1.1, 0.001, 0.5)
     — a quarter of the containers run-structured — plus one filter row of density 0.5.
     Returns (rows FlatRows, groups [n_shards, k], filter FlatRows).  Shard s is seeded by (seed_idx,
-    s), so the data does not depend on how the shards are split over `workers` processes."""
+    s), so the data does not depend on how the shards are split over `workers` processes.
+    densities / run_frac: the same generator on another density law (config4_flat)."""
     rows, filt = FlatRows(), FlatRows()
     groups = np.arange(n_shards * k, dtype=np.uint32).reshape(n_shards, k)
     if workers == 0:
         import os
 
-        workers = max(1, min(16, (os.cpu_count() or 1) // 2, n_shards // 8))
+        workers = max(1, min(16 if n_shards < 1024 else 64, (os.cpu_count() or 1) // 2, n_shards // 8))
     if workers > 1:
         import multiprocessing
         from concurrent.futures import ProcessPoolExecutor
 
         per = (n_shards + workers - 1) // workers
-        jobs = [(first_shard + a, first_shard + min(n_shards, a + per), k, seed_idx) for a in range(0, n_shards, per)]
+        jobs = [(first_shard + a, first_shard + min(n_shards, a + per), k, seed_idx, densities, run_frac) for a in range(0, n_shards, per)]
         # mp="fork" only before the process has initialised the HIP runtime (bench.py generates first)
         with ProcessPoolExecutor(max_workers=workers, mp_context=multiprocessing.get_context(mp)) as ex:
-            for (a, _, _, _), (r, f) in zip(jobs, ex.map(_config3_chunk, jobs)):
+            for (a, *_), (r, f) in zip(jobs, ex.map(_config3_chunk, jobs)):
                 rows.extend(r, (a - first_shard) * k)
                 filt.extend(f, a - first_shard)
         rows.n_rows, filt.n_rows = n_shards * k, n_shards
@@ -321,9 +342,9 @@ def config3_flat(n_shards: int, k: int = 64, seed_idx: int = 3000, first_shard: 
         s = first_shard + s_local
         rng = rng_for(seed_idx, s)
         for r in range(k):
-            d = zipf_density(r)
+            d = zipf_density(r) if densities is None else float(densities[r])
             row = s_local * k + r
-            is_run = rng.random(SLOTS) < 0.25
+            is_run = rng.random(SLOTS) < run_frac
             plain = np.nonzero(~is_run)[0]
             if plain.size:
                 if d >= 0.07:  # bitmaps (n >= 4096 with overwhelming probability)
@@ -363,21 +384,22 @@ def config3_flat(n_shards: int, k: int = 64, seed_idx: int = 3000, first_shard: 
     return rows, groups, filt
 
 
-def config3_flat_subprocess(n_shards: int, k: int = 64, seed_idx: int = 3000):
-    """config3_flat run in a child process (which forks its generator workers): for callers that have
-    already initialised the HIP runtime, where a fork of THIS process would be unsafe and a spawn would
-    re-import the caller's main module.  Returns (descs, payload, n_rows, groups, fdescs, fpayload,
-    encoded_bytes)."""
+def config3_flat_subprocess(n_shards: int, k: int = 64, seed_idx: int = 3000, config4: bool = False, first_shard: int = 0):
+    """config3_flat (config4 = True: config4_flat with k = n_a + n_b rows, half each) run in a child process (which forks
+    its generator workers): for callers that have already initialised the HIP runtime, where a fork of THIS process
+    would be unsafe and a spawn would re-import the caller's main module.  Returns (descs, payload, n_rows, groups,
+    fdescs, fpayload, encoded_bytes)."""
     import subprocess
     import sys
     import tempfile
 
     with tempfile.TemporaryDirectory(prefix="fbk_cfg3_") as tmp:
+        gen = (f"rows, _, _, filt, _ = D.config4_flat({n_shards}, {k // 2}, {k - k // 2}, {seed_idx}, first_shard={first_shard}, mp='fork')\n" if config4 else
+               f"rows, groups, filt = D.config3_flat({n_shards}, {k}, {seed_idx}, first_shard={first_shard}, mp='fork')\n")
         code = (
             "import sys, numpy as np\n"
             f"sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})\n"
-            "import datagen as D\n"
-            f"rows, groups, filt = D.config3_flat({n_shards}, {k}, {seed_idx}, mp='fork')\n"
+            "import datagen as D\n" + gen +
             f"np.save({tmp!r} + '/d.npy', rows.descs()); np.save({tmp!r} + '/p.npy', rows.payload())\n"
             f"np.save({tmp!r} + '/fd.npy', filt.descs()); np.save({tmp!r} + '/fp.npy', filt.payload())\n"
         )

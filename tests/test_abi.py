@@ -50,7 +50,7 @@ def test_struct_layout_matches_header(lib):
 
 
 def test_abi_version(lib):
-    assert lib.load().fbk_abi_version() == 4
+    assert lib.load().fbk_abi_version() == 5
 
 
 def test_no_device_fails_loudly(lib):

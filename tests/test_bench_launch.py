@@ -42,7 +42,7 @@ def test_gpus_2_line_schema_on_the_gpu_box():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     detail = "bench_detail_test_n2.json"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3", "--shards", "128", "--repeats", "2", "--cold-sets", "1",
-           "--shards4-total", "48", "--queries4", "3", "--detail", detail]
+           "--shards4-total", "48", "--shards4-mixed-total", "20", "--queries4", "3", "--detail", detail]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=850)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stderr[-2000:])
@@ -59,6 +59,8 @@ def test_gpus_2_line_schema_on_the_gpu_box():
     assert "error" not in s, s
     assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["backend"] == r["config"]["backend"] and s["rank0"]["shards_total"] == 48 and s["rank0"]["shards_this_rank"] == 24
     assert s["ms_per_query_pipelined"] > 0 and s["ms_per_query_host_add"] > 0 and s["rank0"]["collectives"] == 2 + 3 + 3
+    assert [v["id"] for v in s["variants"]] == ["dense", "loguniform"] and s["variants"][1]["shards_total"] == 20 and s["variants"][1]["shards_this_rank"] == 10
+    assert s["variants"][1]["parity"].startswith("every one of this rank's 10 shards bit-exact") and s["variants"][1]["kernel_us"] > 0
     g = r["group_api"]
     assert g["members"] == 2 and "host" in g["modes"] and g["count_matrix"]["scaling"] == "strong" and sum(g["count_matrix"]["shards_per_member"]) == 48
     # the CPU leg is part of EVERY line (same keys as at N = 1): rank 0 times it while the other ranks sleep
@@ -78,6 +80,7 @@ def _check_compact(c, n, steps, shards4_total):
     s = c["strong_scaling"]
     assert "error" not in s, s
     assert s["n_gpus"] == n and s["ms_per_query"] > 0 and s["rank0"]["shards_total"] == shards4_total
+    assert [v["id"] for v in s["variants"]] == ["dense", "loguniform"] and all(v["ms_per_query"] > 0 and v["parity"].startswith("exact") for v in s["variants"])
     assert c["throughput_mode_bucketed"]["steps_per_collective"] == 16 and c["per_query"]["one_cell_ms_per_step"] > 0
     g = c["group_api"]
     assert g["members"] == n and "host" in g["modes"] and g["count_matrix"]["scaling"] == "strong"

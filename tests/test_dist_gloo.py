@@ -269,18 +269,22 @@ def _topn_worker(rank: int, world: int, port: int, q):
         shards = [{r: sorted(set(rng.integers(0, 64, int(rng.integers(0, 30))).tolist())) for r in range(n_rows)} for _ in range(n_shards)]
         srcs = [sorted(set(rng.integers(0, 64, int(rng.integers(1, 40))).tolist())) for _ in range(n_shards)]
         mt = int(rng.integers(0, 4)) if case % 3 == 0 else 0
+        tt = int(rng.choice([10, 30])) if case % 4 == 1 else 0
         n = int(rng.choice([0, 1, 2, 5, n_rows, n_rows + 3]))
         ids = list(range(n_rows))
         mine = fd.shards_for_rank(n_shards, rank, world)
-        local = np.zeros(n_rows, dtype=np.uint64)
+        # what fbk_topn_partials returns for this rank's shards (tests/test_gpu_topn.py checks the device against exactly this)
+        local, cand = np.zeros(n_rows, dtype=np.uint64), np.zeros(n_rows, dtype=np.uint64)
         if mine:
-            for r, c in T.top_exact([shards[s] for s in mine], ids, 0, [srcs[s] for s in mine], mt, 0):
+            for r, c in T.top_exact([shards[s] for s in mine], ids, 0, [srcs[s] for s in mine], mt, tt):
                 local[r] = c
-        idx, cnt = fd.topn_two_pass(local, n)
-        node_shards = [[shards[s] for s in fd.shards_for_rank(n_shards, m, world)] for m in range(world)]
-        node_srcs = [[srcs[s] for s in fd.shards_for_rank(n_shards, m, world)] for m in range(world)]
-        exp = T.top_two_pass(node_shards, ids, n, node_srcs, mt, 0)
+            cand[T.topn_candidates([shards[s] for s in mine], n, [srcs[s] for s in mine], mt, tt)] = 1
+        idx, cnt = fd.topn_reduce(local, cand, n)
+        exp = T.execute_topn(shards, n, srcs, None, mt, tt)  # ALL shards, wherever they live
+        exact_idx, exact_cnt = fd.topn_reduce(local, None, n)
+        exact = T.top_exact(shards, ids, n, srcs, mt, tt)
         out.append(([(int(i), int(c)) for i, c in zip(idx, cnt)], [(int(r), int(c)) for r, c in exp]))
+        out.append(([(int(i), int(c)) for i, c in zip(exact_idx, exact_cnt)], [(int(r), int(c)) for r, c in exact]))
     # BSI Sum: {psum, nsum, count} per rank, with a negative total and a wrap-around of the uint64 partial sums
     parts = [(5, 1 << 63, 3), ((1 << 64) - 7, (1 << 63) + 10, 4)]
     s, c = fd.bsi_sum_reduce(*parts[rank])
@@ -290,10 +294,11 @@ def _topn_worker(rank: int, world: int, port: int, q):
 
 
 @pytest.mark.timeout(300)
-def test_topn_two_pass_and_bsi_sum_two_ranks():
-    """featurebase_amd.dist.topn_two_pass / bsi_sum_reduce (the one-process-per-GPU forms of fbk_group_topn / fbk_group_bsi_sum)
-    on two gloo ranks against oracle/pytopn.top_two_pass (executeTopN, executor.go:2779-2827) and ValCount.Add's arithmetic:
-    the same pairs on every rank, including the reference's approximation (a row in no rank's own first n is lost)."""
+def test_topn_reduce_and_bsi_sum_two_ranks():
+    """featurebase_amd.dist.topn_reduce / bsi_sum_reduce (the one-process-per-GPU forms of fbk_group_topn / fbk_group_bsi_sum)
+    on two gloo ranks against oracle/pytopn.execute_topn over ALL shards (executeTopN, executor.go:2779-2864: per-SHARD
+    candidates, so the answer does not depend on which rank owns which shard) and ValCount.Add's arithmetic; without the
+    candidate flags the reduce gives the exact top n (top_exact)."""
     import torch.multiprocessing as mp
 
     world = 2
@@ -314,12 +319,14 @@ def test_topn_two_pass_and_bsi_sum_two_ranks():
         assert (s, c) == (total, 7)
 
 
-def test_topn_two_pass_without_a_process_group():
+def test_topn_reduce_without_a_process_group():
     sys.path.insert(0, ROOT)
     from featurebase_amd import dist as fd
 
-    idx, cnt = fd.topn_two_pass(np.array([3, 0, 9, 3, 1], dtype=np.uint64), 3)
+    idx, cnt = fd.topn_reduce(np.array([3, 0, 9, 3, 1], dtype=np.uint64), None, 3)
     assert idx.tolist() == [2, 0, 3] and cnt.tolist() == [9, 3, 3]  # count descending, row index ascending inside a count, zeros dropped
-    idx, cnt = fd.topn_two_pass(np.zeros(4, dtype=np.uint64), 0)
+    idx, cnt = fd.topn_reduce(np.array([3, 0, 9, 3, 1], dtype=np.uint64), np.array([1, 1, 0, 0, 1], dtype=np.uint64), 3)
+    assert idx.tolist() == [0, 4] and cnt.tolist() == [3, 1]  # rows 2 and 3 are nobody's candidates
+    idx, cnt = fd.topn_reduce(np.zeros(4, dtype=np.uint64), None, 0)
     assert idx.size == 0 and cnt.size == 0
     assert fd.bsi_sum_reduce(7, 9, 2) == (-2, 2)

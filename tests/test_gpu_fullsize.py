@@ -146,6 +146,43 @@ def test_config4_count_matrix_every_shard_vs_oracle(gpu_ctx):
         b.free()
 
 
+def test_config4_as_surveyed_mixed_rows_every_shard_vs_oracle(gpu_ctx):
+    """configs[3] on the input SURVEY.md 8d specifies: fields A and B of 32 rows each with densities LOG-UNIFORM in
+    [0.001, 0.5] (two thirds of the rows are array rows; tests/datagen.py config4_flat), filter row p = 0.5, the 1024
+    shards one GPU of eight owns.  Every per-shard 32 x 32 matrix against the restated groupByIterator
+    (executor.go:8880-8934, oracle/batch_oracle.c), with and without the filter, one-shot call and prepared query, in every
+    kernel the cost model can pick for encoded rows (fused / generic pairs)."""
+    n_shards, n_a, n_b = 1024, 32, 32
+    d, p, n_rows, groups, fd, fp, nbytes = D.config3_flat_subprocess(n_shards, n_a + n_b, 4000, config4=True)
+    types = np.bincount(d["type"], minlength=4)
+    assert types[3] == 0 and 0.55 < types[1] / (types[1] + types[2]) < 0.8, types  # ~2/3 arrays, no run containers
+    OA, OF = PB.RowSet.from_flat(d, p, n_rows), PB.RowSet.from_flat(fd, fp, n_shards)
+    batch, F = gpu_ctx.upload_flat(d, p, n_rows), gpu_ctx.upload_flat(fd, fp, n_shards)
+    ga, gb, fidx = groups[:, :n_a], groups[:, n_a:], np.arange(n_shards)
+    exp = PB.count_matrix(OA, ga, OA, gb, OF, fidx)
+    exp_nf = PB.count_matrix(OA, ga, OA, gb)
+    try:
+        for fused in (-1, 1, 0):
+            gpu_ctx.set_option("matrix_fused", fused)
+            sl = slice(None) if fused != 0 else slice(0, 64)  # (the generic pair kernel: a slice is enough)
+            tot, ps = gpu_ctx.count_matrix(batch, ga[sl], batch, gb[sl], F, fidx[sl], per_shard=True)
+            assert (ps == exp[sl]).all() and (tot == exp[sl].sum(axis=0)).all(), fused
+            assert (gpu_ctx.count_matrix(batch, ga[sl], batch, gb[sl], per_shard=True)[1] == exp_nf[sl]).all(), fused
+        gpu_ctx.set_option("matrix_fused", -1)
+        q = gpu_ctx.prepare_count_matrix(batch, ga, batch, gb, F, fidx, keep_per_shard=True)
+        for _ in range(2):
+            q.run()
+            tot, ps = q.read(per_shard=True)
+            assert (ps == exp).all() and (tot == exp.sum(axis=0)).all()
+        q.free()
+    finally:
+        gpu_ctx.set_option("matrix_fused", -1)
+    for b in (batch, F):
+        b.free()
+    for o in (OA, OF):
+        o.free()
+
+
 def test_config5_bsi_every_shard_vs_oracle(gpu_ctx):
     n_shards, depth = 96, 64
     w = D.dense_rows(n_shards * (depth + 2), 0.5, 5001).reshape(n_shards, depth + 2, 16, 1024)

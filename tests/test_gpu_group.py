@@ -235,9 +235,10 @@ def test_group_bsi_sum_matches_the_sum_of_the_shards(gpu_ctx, oracle):
     grp.close()
 
 
-def test_group_topn_two_passes(gpu_ctx):
-    """fbk_group_topn against the two-pass restatement of executeTopN (oracle/pytopn.top_two_pass): candidates = every
-    member's own first n rows, their totals reduced over the members; n = 0 is the exact TopN of all shards."""
+def test_group_topn_is_fbk_topn_over_all_shards(gpu_ctx):
+    """fbk_group_topn against oracle/pytopn.execute_topn over ALL shards (executeTopN, executor.go:2779-2864: candidates per
+    SHARD, merged untrimmed — the dealing of shards to members does not matter), under topn_semantics = 0 against
+    top_exact; two different dealings of the same shards must give the same answer, and fbk_topn on one context too."""
     from oracle import pytopn as T
     from test_gpu_topn import row_of_columns
 
@@ -248,37 +249,56 @@ def test_group_topn_two_passes(gpu_ctx):
         rows = {}
         for r in range(n_a):
             k = int(rng.integers(0, 4))
-            # member-dependent skew: the rows a member ranks first differ between the members
+            # shard-dependent skew: the rows a shard ranks first differ between the shards
             m = [0, int(rng.integers(1, 30)), int(rng.integers(100, 3000)), int(rng.integers(5000, 30000))][k] * (1 + ((r + s) % G == 0))
             rows[r] = sorted(set(rng.integers(0, 1 << 17, m).tolist()))
         shards.append(rows)
         srcs.append(sorted(set(rng.integers(0, 1 << 17, 20000).tolist())))
+    ids = list(range(n_a))
     grp = Group([0] * G)
-    per, keep, node_shards, node_srcs = [], [], [], []
-    for m, c in enumerate(grp.members):
-        mine = list(range(m, n_shards, G))
-        a = c.upload([row_of_columns(shards[s][r]) for s in mine for r in range(n_a)])
-        f = c.upload([row_of_columns(srcs[s]) for s in mine])
-        keep += [a, f]
-        per.append(dict(a=a, rows_a=np.arange(len(mine) * n_a).reshape(len(mine), n_a), filt=f, rows_f=np.arange(len(mine))))
-        node_shards.append([shards[s] for s in mine])
-        node_srcs.append([srcs[s] for s in mine])
-    nofilt = [dict(p, filt=None, rows_f=None) for p in per]
-    for mode in (L.REDUCE_HOST, L.REDUCE_PEER):
-        grp.set_reduce(mode)
-        for use_src in (True, False):
-            for mt, tt, n in [(0, 0, 0), (0, 0, 3), (0, 0, 1), (5, 0, 6), (300, 0, 0), (0, 20, 4), (0, 60, 0)]:
-                if tt and not use_src:
-                    continue
-                exp = T.top_two_pass(node_shards, list(range(n_a)), n, node_srcs if use_src else None, mt, tt)
-                idx, cnt = grp.topn(per if use_src else nofilt, n_a, n, mt, tt)
-                assert list(zip(idx.tolist(), [int(x) for x in cnt])) == exp, (mode, use_src, mt, tt, n)
-                if n == 0:  # every row a candidate: the exact TopN over all shards
-                    assert exp == T.top_exact(shards, list(range(n_a)), 0, srcs if use_src else None, mt, tt)
-    # a member that owns no shard of the query
-    exp = T.top_two_pass([node_shards[0], [], node_shards[2]], list(range(n_a)), 5, [node_srcs[0], None, node_srcs[2]])
-    idx, cnt = grp.topn([per[0], None, per[2]], n_a, 5)
-    assert list(zip(idx.tolist(), [int(x) for x in cnt])) == exp
+    keep = []
+
+    def deal(owner):
+        per = []
+        for m, c in enumerate(grp.members):
+            mine = [s for s in range(n_shards) if owner(s) == m]
+            if not mine:
+                per.append(None)
+                continue
+            a = c.upload([row_of_columns(shards[s][r]) for s in mine for r in range(n_a)])
+            f = c.upload([row_of_columns(srcs[s]) for s in mine])
+            keep.extend([a, f])
+            per.append(dict(a=a, rows_a=np.arange(len(mine) * n_a).reshape(len(mine), n_a), filt=f, rows_f=np.arange(len(mine))))
+        return per
+
+    dealings = [deal(lambda s: s % G), deal(lambda s: 0 if s < 4 else 2)]  # round-robin; contiguous with an idle member
+    one = gpu_ctx.upload([row_of_columns(shards[s][r]) for s in range(n_shards) for r in range(n_a)])
+    onef = gpu_ctx.upload([row_of_columns(srcs[s]) for s in range(n_shards)])
+    keep += [one, onef]
+    ra1, rf1 = np.arange(n_shards * n_a).reshape(n_shards, n_a), np.arange(n_shards)
+    differ = 0
+    try:
+        for mode in (L.REDUCE_HOST, L.REDUCE_PEER):
+            grp.set_reduce(mode)
+            for use_src in (True, False):
+                for mt, tt, n in [(0, 0, 0), (0, 0, 3), (0, 0, 1), (5, 0, 6), (300, 0, 0), (0, 20, 4), (0, 60, 0), (0, 0, 2)]:
+                    if tt and not use_src:
+                        continue
+                    ss = srcs if use_src else None
+                    exp_ref, exp_exact = T.execute_topn(shards, n, ss, None, mt, tt), T.top_exact(shards, ids, n, ss, mt, tt)
+                    differ += exp_ref != exp_exact
+                    for sem, exp in ((1, exp_ref), (0, exp_exact)):
+                        for c in grp.members + [gpu_ctx]:
+                            c.set_option("topn_semantics", sem)
+                        for per in dealings:
+                            args = per if use_src else [None if p is None else dict(p, filt=None, rows_f=None) for p in per]
+                            idx, cnt = grp.topn(args, n_a, n, mt, tt)
+                            assert list(zip(idx.tolist(), [int(x) for x in cnt])) == exp, (mode, use_src, mt, tt, n, sem)
+                        idx, cnt = gpu_ctx.topn(one, ra1, n, onef if use_src else None, rf1 if use_src else None, min_threshold=mt, tanimoto_threshold=tt)
+                        assert list(zip(idx.tolist(), [int(x) for x in cnt])) == exp, ("one context", use_src, mt, tt, n, sem)
+    finally:
+        gpu_ctx.set_option("topn_semantics", 1)
+    assert differ >= 3
     for b in keep:
         b.free()
     grp.close()

@@ -58,11 +58,12 @@ def test_fragment_top_vectors_through_fbk_topn(gpu_ctx, c):
 
 
 def test_topn_thresholds_multi_shard_vs_oracle(gpu_ctx):
-    """Random rows over several shards: MinThreshold and Tanimoto rules applied per shard, counts summed
-    over shards, against oracle/pytopn.top_exact (itself tied to the line-by-line fragment.top in
-    tests/test_oracle_topn.py)."""
+    """Random rows over several shards: MinThreshold and Tanimoto rules applied per shard, counts summed over shards.
+    Under topn_semantics = 1 (default) against oracle/pytopn.execute_topn (executeTopN's two passes, pinned to the
+    reference's executor vectors), under 0 against top_exact; one-shot call, prepared query, and a member's partials."""
     from oracle import pytopn as T
 
+    differ = []
     rng = np.random.default_rng(77)
     n_shards, n_a = 4, 40
     shards, srcs = [], []
@@ -78,17 +79,84 @@ def test_topn_thresholds_multi_shard_vs_oracle(gpu_ctx):
     F = gpu_ctx.upload([row_of_columns(srcs[s]) for s in range(n_shards)])
     ra = np.arange(n_shards * n_a).reshape(n_shards, n_a)
     rf = np.arange(n_shards)
-    for use_src in (True, False):
-        for mt, tt, n in [(0, 0, 0), (5, 0, 0), (300, 0, 7), (2000, 0, 0), (0, 10, 0), (0, 30, 5), (0, 60, 0), (0, 100, 0), (7, 20, 0)]:
-            if tt and not use_src:
-                continue
-            exp = T.top_exact(shards, list(range(n_a)), n, srcs if use_src else None, mt, tt)
-            idx, cnt = gpu_ctx.topn(batch, ra, n, F if use_src else None, rf if use_src else None, min_threshold=mt, tanimoto_threshold=tt)
-            assert list(zip(idx.tolist(), [int(x) for x in cnt])) == exp, (use_src, mt, tt, n)
+    ids = list(range(n_a))
+    try:
+        for use_src in (True, False):
+            for mt, tt, n in [(0, 0, 0), (5, 0, 0), (300, 0, 7), (2000, 0, 0), (0, 10, 0), (0, 30, 5), (0, 60, 0), (0, 100, 0), (7, 20, 0), (0, 0, 1), (0, 0, 3), (40, 0, 2),
+                              (0, 20, 2), (0, 0, n_a - 1), (0, 0, n_a), (0, 0, n_a + 5)]:
+                if tt and not use_src:
+                    continue
+                ss = srcs if use_src else None
+                fa = (F, rf) if use_src else (None, None)
+                # topn_semantics = 1 (default): executeTopN's two passes, candidates per SHARD; = 0: the exact top n
+                exp_ref = T.execute_topn(shards, n, ss, None, mt, tt)
+                exp_exact = T.top_exact(shards, ids, n, ss, mt, tt)
+                for sem, exp in ((1, exp_ref), (0, exp_exact)):
+                    gpu_ctx.set_option("topn_semantics", sem)
+                    idx, cnt = gpu_ctx.topn(batch, ra, n, *fa, min_threshold=mt, tanimoto_threshold=tt)
+                    assert list(zip(idx.tolist(), [int(x) for x in cnt])) == exp, (use_src, mt, tt, n, sem)
+                    q = gpu_ctx.prepare_topn(batch, ra, n, *fa, min_threshold=mt, tanimoto_threshold=tt)
+                    for _ in range(2):
+                        q.run()
+                        qi, qc = q.read()
+                        assert list(zip(qi.tolist(), [int(x) for x in qc])) == exp, ("prepared", use_src, mt, tt, n, sem)
+                    q.free()
+                    # a member's share: totals of its shards + the candidate flags of its shards' first pass
+                    tot, cand = gpu_ctx.topn_partials(batch, ra[1:3], n_a, n, *((F, rf[1:3]) if use_src else (None, None)), min_threshold=mt, tanimoto_threshold=tt)
+                    sub, subsrc = shards[1:3], (srcs[1:3] if use_src else None)
+                    et = np.zeros(n_a, dtype=np.uint64)
+                    for r, c in T.top_exact(sub, ids, 0, subsrc, mt, tt):
+                        et[r] = c
+                    assert (tot == et).all(), ("partials", use_src, mt, tt, n, sem)
+                    if sem == 1 and 0 < n < n_a:
+                        assert np.nonzero(cand)[0].tolist() == T.topn_candidates(sub, n, subsrc, mt, tt), ("candidates", use_src, mt, tt, n)
+                    else:
+                        assert ((cand != 0) == (et != 0)).all()
+                if 0 < n < n_a and exp_ref != exp_exact:
+                    differ.append((use_src, mt, tt, n))
+    finally:
+        gpu_ctx.set_option("topn_semantics", 1)
+    assert differ, "the inputs never separated the reference's answer from the exact one"
     with pytest.raises(L.FbkError):
         gpu_ctx.topn(batch, ra, 0, F, rf, tanimoto_threshold=101)
     batch.free()
     F.free()
+
+
+EXEC = json.load(open(os.path.join(HERE, "golden", "executor_topn_vectors.json")))
+
+
+@pytest.mark.parametrize("c", EXEC["cases"], ids=lambda c: c["test"])
+def test_executor_topn_vectors_through_fbk_topn(gpu_ctx, c):
+    """TestExecutor_Execute_TopN / _fill / _fill_small / _Src (executor_test.go:1846-2200) through fbk_topn on the default
+    semantics: _fill_small's five shards each rank another row first, n = 1 -> the candidates are {0..4} -> {0: 5}.  Also
+    through a two-member group on one device (shards dealt round-robin) and the partials + reduce of the one-process-per-GPU
+    deployment: the answer must not depend on the dealing."""
+    from featurebase_amd import dist as fd
+    from featurebase_amd.roaring import Group
+
+    w = EXEC["shard_width"]
+    n_shards = max(col // w for _, col in c["bits"]) + 1
+    ids = sorted({r for r, _ in c["bits"]})
+    per = [[[] for _ in ids] for _ in range(n_shards)]
+    for r, col in c["bits"]:
+        per[col // w][ids.index(r)].append(col % w)
+    batch = gpu_ctx.upload([row_of_columns(per[s][i]) for s in range(n_shards) for i in range(len(ids))])
+    ra = np.arange(n_shards * len(ids)).reshape(n_shards, len(ids))
+    F, rf = None, None
+    if c["src_bits"] is not None:
+        F = gpu_ctx.upload([row_of_columns([x % w for x in c["src_bits"] if x // w == s]) for s in range(n_shards)])
+        rf = np.arange(n_shards)
+    idx, cnt = gpu_ctx.topn(batch, ra, c["n"], F, rf, min_threshold=1)
+    assert [[ids[i], int(x)] for i, x in zip(idx.tolist(), cnt.tolist())] == c["expected"], c["test"]
+    # two ranks' partials, reduced as featurebase_amd.dist.topn_reduce does without a process group: add them by hand
+    parts = [gpu_ctx.topn_partials(batch, ra[m::2], len(ids), c["n"], F, rf[m::2] if rf is not None else None, min_threshold=1) if ra[m::2].size else
+             (np.zeros(len(ids), dtype=np.uint64), np.zeros(len(ids), dtype=np.uint64)) for m in range(2)]
+    i2, c2 = fd.topn_reduce(parts[0][0] + parts[1][0], parts[0][1] + parts[1][1], c["n"])
+    assert [[ids[i], int(x)] for i, x in zip(i2.tolist(), c2.tolist())] == c["expected"], c["test"]
+    batch.free()
+    if F is not None:
+        F.free()
 
 
 def test_topk_counts_as_bsi_planes(gpu_ctx):

@@ -7,6 +7,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
 VEC = json.load(open(os.path.join(HERE, "golden", "topn_vectors.json")))["cases"]
 
 
@@ -50,18 +51,76 @@ def test_exact_specification_agrees_with_the_restatement():
         assert [p[1] for p in a] == [p[1] for p in b]  # both are in descending count order
 
 
-def test_two_pass_topn_restatement():
-    """oracle/pytopn.top_two_pass (executeTopN, executor.go:2779-2827): with one node or n = 0 it is top_exact; with several
-    nodes a row that is in no node's own first n is lost — the reference's known approximation, reproduced on purpose."""
+def _shards_of(bits, width):
+    """[(row, column)] -> one {row: [columns relative to the shard]} per shard, from shard 0 to the last one that has a bit"""
+    n = max(c // width for _, c in bits) + 1
+    out = [dict() for _ in range(n)]
+    for r, c in bits:
+        out[c // width].setdefault(r, []).append(c % width)
+    return out
+
+
+def test_execute_topn_against_the_reference_executor_vectors():
+    """oracle/pytopn.execute_topn (executeTopN, executor.go:2779-2864: per-SHARD fragment.top candidates, merged untrimmed,
+    re-counted, trimmed) reproduces TestExecutor_Execute_TopN / _fill / _fill_small / _Src (executor_test.go:1846-2200),
+    extracted by tests/golden/extract_executor_topn.py.  _fill_small is the cross-shard case: five shards whose own top-1
+    rows are 1, 2, 3, 4 and 0 -> candidates {0..4} -> {0: 5}."""
     from oracle import pytopn as T
 
-    # node 0 ranks row 0 first, node 1 ranks row 1 first; row 2 is second on both and has the largest total
-    n0 = [{0: range(10), 1: range(1), 2: range(9)}]
-    n1 = [{0: range(1), 1: range(10), 2: range(9)}]
-    ids = [0, 1, 2]
-    assert T.top_exact(n0 + n1, ids, 1) == [(2, 18)]
-    assert T.top_two_pass([n0, n1], ids, 1) == [(0, 11)]  # candidates {0, 1}: totals 11, 11 -> id ascending
-    assert T.top_two_pass([n0, n1], ids, 2) == [(2, 18), (0, 11)]
-    assert T.top_two_pass([n0, n1], ids, 0) == T.top_exact(n0 + n1, ids, 0)
-    assert T.top_two_pass([n0 + n1], ids, 1) == T.top_exact(n0 + n1, ids, 1)
-    assert T.top_two_pass([n0, []], ids, 2) == T.top_exact(n0, ids, 2)
+    g = json.load(open(os.path.join(GOLD, "executor_topn_vectors.json")))
+    w = g["shard_width"]
+    assert [c["test"] for c in g["cases"]] == ["TestExecutor_Execute_TopN/RowIDColumnID", "TestExecutor_Execute_TopN_fill", "TestExecutor_Execute_TopN_fill_small",
+                                                "TestExecutor_Execute_TopN_Src"]
+    for c in g["cases"]:
+        shards = _shards_of([tuple(b) for b in c["bits"]], w)
+        srcs = None
+        if c["src_bits"] is not None:
+            srcs = [[x % w for x in c["src_bits"] if x // w == s] for s in range(len(shards))]
+        got = T.execute_topn(shards, c["n"], srcs)
+        assert [list(p) for p in got] == c["expected"], (c["test"], got)
+    fs = [c for c in g["cases"] if c["test"].endswith("fill_small")][0]
+    assert T.topn_candidates(_shards_of([tuple(b) for b in fs["bits"]], w), 1) == [0, 1, 2, 3, 4]
+
+
+def test_execute_topn_is_neither_exact_nor_per_node():
+    """A constructed input on which the three candidate rules differ: the reference's (per shard), the exact top n, and
+    round 4's mistaken per-node rule (the first n of a node's MERGED totals)."""
+    from oracle import pytopn as T
+
+    # shards 0 and 1 live on one node, shard 2 on another.  Row 2 is second in every shard and has the largest total.
+    s0 = {0: range(10), 1: range(1), 2: range(9)}
+    s1 = {0: range(1), 1: range(10), 2: range(9)}
+    s2 = {3: range(5), 2: range(4)}
+    ids = [0, 1, 2, 3]
+    assert T.top_exact([s0, s1, s2], ids, 1) == [(2, 22)]
+    # per shard: top-1 rows are 0, 1, 3 -> candidates {0, 1, 3}; totals 11, 11, 5 -> (0, 11)
+    assert T.topn_candidates([s0, s1, s2], 1) == [0, 1, 3]
+    assert T.execute_topn([s0, s1, s2], 1) == [(0, 11)]
+    # (the per-node rule would have merged s0 + s1 first: totals 0: 11, 1: 11, 2: 18 -> candidate 2 -> (2, 22): not the reference's answer)
+    assert T.execute_topn([s0, s1, s2], 2) == [(2, 22), (0, 11)]  # n = 2: every shard's first two rows -> all four rows
+    assert T.execute_topn([s0, s1, s2], 0) == T.top_exact([s0, s1, s2], ids, 0)
+    # ids given: pass 1 is the answer, untrimmed (executor.go:2800-2806)
+    assert T.execute_topn([s0, s1, s2], 1, ids_arg=[1, 2]) == [(2, 22), (1, 11)]
+    # with a source row a shard can return MORE than n pairs: rows after the n-th whose count reaches the heap's minimum
+    # are pushed without evicting (fragment.go:1404-1425)
+    rows = {0: range(0, 10), 1: range(5, 14), 2: range(6, 14), 3: range(100, 101)}
+    src = range(5, 20)
+    assert T.fragment_top(rows, 1, src, None, 1, 0) == [(1, 9), (2, 8), (0, 5)]
+    assert T.execute_topn([rows], 1, [src]) == [(1, 9)]
+
+
+def test_execute_topn_random_against_the_candidate_definition():
+    """execute_topn == (candidates = union of the shards' fragment.top(n) ids) then top_exact over the candidates, trimmed."""
+    from oracle import pytopn as T
+
+    rng = np.random.default_rng(11)
+    for trial in range(150):
+        ns = int(rng.integers(1, 5))
+        shards = [{int(r): sorted(set(rng.integers(0, 50, int(rng.integers(0, 30))).tolist())) for r in range(10)} for _ in range(ns)]
+        srcs = [sorted(set(rng.integers(0, 50, int(rng.integers(1, 25))).tolist())) for _ in range(ns)] if trial % 3 else None
+        mt = int(rng.integers(0, 5)) if trial % 2 else 0
+        tt = int(rng.choice([0, 10, 30, 50])) if srcs is not None and trial % 4 == 0 else 0
+        n = int(rng.integers(1, 6))
+        cand = T.topn_candidates(shards, n, srcs, mt, tt)
+        exp = T.top_exact(shards, cand, n, srcs, max(mt, 1), tt)
+        assert T.execute_topn(shards, n, srcs, None, mt, tt) == exp, trial
