@@ -121,6 +121,8 @@ def compact_group(g):
     for name, m in (g.get("modes") or {}).items():
         if isinstance(m, dict):
             modes[name] = {k: _r(m[k]) for k in ("ms_per_step", "latency_ms_median", "set_ops_per_s", "matrix_ms") if isinstance(m.get(k), (int, float))}
+            if isinstance(m.get("latency_ms"), dict):  # (the in-process form of the N = 1 line)
+                modes[name]["latency_ms_median"] = _r(m["latency_ms"].get("median"))
             if "error" in m:
                 modes[name] = {"error": _short(m["error"], 120)}
     out["modes"] = modes

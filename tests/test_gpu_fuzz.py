@@ -131,7 +131,9 @@ def test_chained_ops_vs_bitset_model(gpu_ctx, oracle, seed):
             b2.free()
         else:  # count ranges
             s, e = sorted(int(x) for x in rng.integers(0, (1 << 20) + 1, size=2))
+            ctx.set_option("count_range_reference_quirk", 0)  # (the bit count; the reference-identical default is tested in test_gpu_parity.py)
             got = ctx.count_range(A, idx, s, e)
+            ctx.set_option("count_range_reference_quirk", 1)
             bits = np.unpackbits(ma.reshape(N_ROWS, -1).view(np.uint8), axis=1, bitorder="little")
             assert got.tolist() == bits[:, s:e].sum(axis=1).tolist(), ("count_range", step, s, e)
     for b, _ in pop:

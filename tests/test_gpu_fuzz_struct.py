@@ -204,7 +204,9 @@ def test_fuzz_row_transforms(gpu_ctx, oracle, it):
             a, b = sorted(int(v) for v in rng.integers(0, WIDTH + 1, 2))
             if rng.random() < 0.3:
                 a, b = (a >> 16) << 16, (b >> 16) << 16
+            gpu_ctx.set_option("count_range_reference_quirk", 0)  # (the bit count; the reference-identical default is tested in test_gpu_parity.py)
             got = gpu_ctx.count_range(X, rows, a, b)
+            gpu_ctx.set_option("count_range_reference_quirk", 1)
             mask = ((1 << b) - 1) ^ ((1 << a) - 1)
             assert got.tolist() == [bin(v & mask).count("1") for v in ints], (a, b)
         for _ in range(3):

@@ -252,6 +252,13 @@ def test_group_topn_is_fbk_topn_over_all_shards(gpu_ctx):
             # shard-dependent skew: the rows a shard ranks first differ between the shards
             m = [0, int(rng.integers(1, 30)), int(rng.integers(100, 3000)), int(rng.integers(5000, 30000))][k] * (1 + ((r + s) % G == 0))
             rows[r] = sorted(set(rng.integers(0, 1 << 17, m).tolist()))
+        # a local champion per shard (row s: by far the largest row of shard s, tiny elsewhere) and a row that is second
+        # everywhere but first in total (row 47): with n = 1 the reference's candidates are the champions, row 47 is lost
+        rows[s] = list(range(0, 60000))
+        rows[47] = list(range(0, 50000))
+        for o in range(n_shards):
+            if o != s:
+                rows[o] = rows[o][:3] if len(rows[o]) > 3 else rows[o]
         shards.append(rows)
         srcs.append(sorted(set(rng.integers(0, 1 << 17, 20000).tolist())))
     ids = list(range(n_a))

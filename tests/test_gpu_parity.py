@@ -425,23 +425,30 @@ def test_reference_bitmap_level_count_range_vectors_through_the_abi(gpu_ctx, ora
 
 
 def test_count_range_counts_bits_where_run_count_range_double_counts(gpu_ctx, oracle):
-    """The deliberate divergence from RunCountRange (roaring.go:3216-3227, pinned on the oracle in
-    tests/test_oracle_bitmap_vectors.py::test_run_count_range_overcount_is_pinned): the device counts
-    the bits of [start, end)."""
+    """RunCountRange's double count (roaring.go:3216-3227, pinned on the oracle in
+    tests/test_oracle_bitmap_vectors.py::test_run_count_range_overcount_is_pinned): the DEFAULT
+    (count_range_reference_quirk = 1, ABI 5) returns the reference's number on the same call, option = 0 the bits
+    of [start, end)."""
     from featurebase_amd.roaring import Container
 
     b = gpu_ctx.upload([{0: Container.run([(10, 20), (30, 40)])}])
-    assert gpu_ctx.count_range(b, [0], 15, 40).tolist() == [16]
     bm = oracle.OBitmap.from_containers([(0, oracle.OContainer.run([(10, 20), (30, 40)]))])
-    assert bm.count_range(15, 40) == 27  # the reference's answer for the same call
+    assert bm.count_range(15, 40) == 27  # the reference's answer
+    assert gpu_ctx.get_option("count_range_reference_quirk") == 1
+    assert gpu_ctx.count_range(b, [0], 15, 40).tolist() == [27]
+    gpu_ctx.set_option("count_range_reference_quirk", 0)
+    try:
+        assert gpu_ctx.count_range(b, [0], 15, 40).tolist() == [16]
+    finally:
+        gpu_ctx.set_option("count_range_reference_quirk", 1)
     assert gpu_ctx.count_range(b, [0], 12, 35).tolist() == [bm.count_range(12, 35)]
     b.free()
 
 
 def test_count_range_reference_quirk_mode_matches_the_reference_everywhere(gpu_ctx, oracle):
     """Option count_range_reference_quirk = 1: fbk_count_range returns what Bitmap.CountRange returns in the
-    reference ON THE SAME INPUTS, RunCountRange's over-count (roaring.go:3216-3227) included; the default
-    mode returns the number of bits in [start, end).  Random mixed rows and ranges chosen to hit run ends."""
+    reference ON THE SAME INPUTS, RunCountRange's over-count (roaring.go:3216-3227) included (the default since
+    ABI 5); = 0 returns the number of bits in [start, end).  Random mixed rows and ranges chosen to hit run ends."""
     from featurebase_amd.roaring import Container
 
     b = gpu_ctx.upload([{0: Container.run([(10, 20), (30, 40)])}])
@@ -480,7 +487,7 @@ def test_count_range_reference_quirk_mode_matches_the_reference_everywhere(gpu_c
         assert n_quirk > 0, "no range hit the quirk: the test does not exercise the strict mode"
         batch.free()
     finally:
-        gpu_ctx.set_option("count_range_reference_quirk", 0)
+        gpu_ctx.set_option("count_range_reference_quirk", 1)
 
 
 def _mask_range(w, s, e):
