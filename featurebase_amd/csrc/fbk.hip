@@ -26,6 +26,7 @@
 #include "fbk_matrix_kernels.hip.h"
 #include "fbk_matrix_mfma.hip.h"
 #include "fbk_matrix_fused.hip.h"
+#include "fbk_matrix_fusedp.hip.h"
 #include "fbk_wire_kernels.hip.h"
 
 using fbk::Slot;
@@ -92,6 +93,7 @@ struct FbkOptions {
   int64_t matrix_shadow_array = 2048;    //   arrays longer than this are heavy (run containers always are)
   int64_t matrix_shadow_max_mb = 16384;  //   no shadow for a batch that would need more than this (nor more than twice its arena, nor a quarter of the free device memory)
   int64_t matrix_shadow_apref = 2;       //   array items per group loaded a stage ahead when rows are shadowed (1 or 2; filtered queries: 323 vs 349 us, profiles/r03_fused_shadow_ab.txt)
+  int64_t matrix_fused_program = 1;      // count matrix over encoded rows: 1 the kernel runs a prepared program (k_fused_program: row tables + resolved array items per (shard, tile, slot), built once per prepared query / per one-shot call; fbk_matrix_fusedp.hip.h), 0 every block builds its work lists itself (round 4's kernel: cross-check, A/B runs)
 #ifdef FBK_EXPERIMENTS  // (scripts/ build their own variant with -DFBK_EXPERIMENTS into build_variants/; the product library has neither the options nor the device branches)
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
 #endif
@@ -555,6 +557,9 @@ struct KernelSpan {
     (void)hipEventRecord(c->kt1, c->stream);
     c->kt_armed = true;
   }
+  void restart() {  // what was enqueued so far inside the span was preparation (a prepared program built on its first run), not the kernel
+    if (c) (void)hipEventRecord(c->kt0, c->stream);
+  }
 };
 
 int32_t upload_rows(fbk_ctx* ctx, const uint32_t* rows, uint64_t n, uint32_t n_rows_limit, DevBuf& out) {
@@ -682,6 +687,7 @@ const OptionDesc kOptions[] = {
     {"matrix_shadow_array", &FbkOptions::matrix_shadow_array, 0, 65536},
     {"matrix_shadow_max_mb", &FbkOptions::matrix_shadow_max_mb, 0, 1 << 20},
     {"matrix_shadow_apref", &FbkOptions::matrix_shadow_apref, 1, 2},
+    {"matrix_fused_program", &FbkOptions::matrix_fused_program, 0, 1},
 #ifdef FBK_EXPERIMENTS
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
 #endif

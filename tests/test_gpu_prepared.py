@@ -299,16 +299,27 @@ def test_prepared_row_records_follow_a_rewritten_batch(gpu_ctx, mixed):
         og = np.arange(n * 6).reshape(n, 6)
         q = gpu_ctx.prepare_fold_intersection_count(L.OP_OR, O, og, F, fidx)
         qt = gpu_ctx.prepare_topn(O, og, 0, F, fidx)
+        qm = gpu_ctx.prepare_count_matrix(O, og, O, og[:, ::-1].copy(), F, fidx)  # 6 x 6 rows: the kernel with the prepared program
         for op in (L.OP_OR, L.OP_AND, L.OP_XOR):
             plan.setop(op)  # rewrites O in place
             q.run()
             qt.run()
+            # the count matrix's program (row tables, resolved array items: addresses INTO O's arena) follows the rewrite too
+            qm.run()
+            qm.run()
+            gpu_ctx.set_option("matrix_fused", 0)
+            try:
+                e_m = gpu_ctx.count_matrix(O, og, O, og[:, ::-1].copy(), F, fidx)
+            finally:
+                gpu_ctx.set_option("matrix_fused", -1)
+            assert (qm.read() == e_m).all(), op
             assert q.read().tolist() == gpu_ctx.fold_n_intersection_count(L.OP_OR, O, og, F, fidx).tolist(), op
             e_idx, e_cnt = gpu_ctx.topn(O, og, 0, F, fidx)
             idx, cnt = qt.read()
             assert idx.tolist() == e_idx.tolist() and cnt.tolist() == e_cnt.tolist(), op
         q.free()
         qt.free()
+        qm.free()
         plan.free()
     finally:
         gpu_ctx.set_option("query_resolve", 1)

@@ -510,8 +510,17 @@ def test_count_range_vs_oracle(gpu_ctx, oracle):
     ranges = [(0, 1 << 20), (0, 0), (65536, 131072), (5, 6), (100, 65536 + 77), (65535, 65537), (3 * 65536 + 12345, 9 * 65536 + 1),
               (1 << 19, 1 << 20), ((1 << 20) - 1, 1 << 20), (64, 128), (63, 129), (1000, 1000)]
     ranges += [tuple(sorted(int(x) for x in rng.integers(0, (1 << 20) + 1, size=2))) for _ in range(20)]
+    obms = [O.OBitmap.from_containers(sorted((k & 15, c) for k, c in r.items())) for r in rows]
     for s, e in ranges:
+        # the default is the reference's number (RunCountRange's double count included, roaring.go:3216-3227) ...
         got = gpu_ctx.count_range(batch, idx, s, e)
+        assert got.tolist() == [bm.count_range(s, e) for bm in obms], (s, e)
+        # ... option count_range_reference_quirk = 0 the bits of [s, e)
+        gpu_ctx.set_option("count_range_reference_quirk", 0)
+        try:
+            got = gpu_ctx.count_range(batch, idx, s, e)
+        finally:
+            gpu_ctx.set_option("count_range_reference_quirk", 1)
         for r in range(len(rows)):
             bits = np.unpackbits(words[r].reshape(-1).view(np.uint8), bitorder="little")
             truth = int(bits[s:e].sum())
@@ -655,18 +664,22 @@ def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
     batch.free()
 
 
-@pytest.fixture(params=[(1, 2048, 2), (1, 64, 1), (0, 2048, 2)], ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows"])
+@pytest.fixture(params=[(1, 2048, 2, 1), (1, 64, 1, 1), (0, 2048, 2, 1), (1, 2048, 2, 0), (0, 2048, 2, 0)],
+                ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows", "heavy-shadows-round4-kernel", "no-shadows-round4-kernel"])
 def shadow_mode(request, gpu_ctx):
     """Count matrix over encoded rows: run containers and long arrays as dense shadows built per batch on first use (default),
     the same with nearly every array shadowed (and one array item per group loaded ahead), and every container decoded in
-    every query (the round-2 behaviour)."""
+    every query (the round-2 behaviour); each on the kernel that runs a prepared program (round 5, the default) and two of
+    them on round 4's kernel, whose blocks build their work lists themselves (option matrix_fused_program = 0)."""
     gpu_ctx.set_option("matrix_shadow", request.param[0])
     gpu_ctx.set_option("matrix_shadow_array", request.param[1])
     gpu_ctx.set_option("matrix_shadow_apref", request.param[2])
+    gpu_ctx.set_option("matrix_fused_program", request.param[3])
     yield request.param
     gpu_ctx.set_option("matrix_shadow", 1)
     gpu_ctx.set_option("matrix_shadow_array", 2048)
     gpu_ctx.set_option("matrix_shadow_apref", 2)
+    gpu_ctx.set_option("matrix_fused_program", 1)
 
 
 @pytest.mark.parametrize("a_dense,b_dense,f_mode", [(False, False, "mixed"), (True, False, "none"), (False, True, "dense"), (False, False, "none")])
