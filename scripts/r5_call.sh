@@ -33,6 +33,7 @@ fused_spb) timeout 300 python scripts/fused_spb_sweep.py ${SWEEP_ARGS:-256 5} 2>
 fused) timeout 400 python scripts/fused_bench.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_bench.txt ;;
 fusedprof) timeout 300 python scripts/fused_prof.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_prof.txt ;;
 *) echo "unknown step $s" ;;
+fused_ab) timeout 500 python scripts/fused_ab.py ${FUSED_AB_ARGS:-256 1024} > $O/fused_ab.json 2> $O/fused_ab.err ;;
 esac
 done
 ls -R $O | head -40
