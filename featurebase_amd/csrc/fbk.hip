@@ -92,6 +92,7 @@ struct FbkOptions {
   int64_t matrix_shadow = 1;             // count matrix over encoded rows: dense shadows of the heavy containers, built per batch on first use (heavy_shadow); 0: decode every container in every query
   int64_t matrix_shadow_array = 2048;    //   arrays longer than this are heavy (run containers always are)
   int64_t matrix_shadow_max_mb = 16384;  //   no shadow for a batch that would need more than this (nor more than twice its arena, nor a quarter of the free device memory)
+  int64_t matrix_shadow_arena_x = 8;     //   ... nor more than this many times the batch's own arena (0: no such rule); fbk_batch_info_ex reports what a batch got
   int64_t matrix_shadow_apref = 2;       //   array items per group loaded a stage ahead when rows are shadowed (1 or 2; filtered queries: 323 vs 349 us, profiles/r03_fused_shadow_ab.txt)
   int64_t matrix_fused_program = 1;      // count matrix over encoded rows: 1 the kernel runs a prepared program (k_fused_program: row tables + resolved array items per (shard, tile, slot), built once per prepared query / per one-shot call; fbk_matrix_fusedp.hip.h), 0 every block builds its work lists itself (round 4's kernel: cross-check, A/B runs)
 #ifdef FBK_EXPERIMENTS  // (scripts/ build their own variant with -DFBK_EXPERIMENTS into build_variants/; the product library has neither the options nor the device branches)
@@ -105,6 +106,7 @@ struct FbkOptions {
   int64_t upload_chunk_mb = 64;          // size of each of the two pinned upload buffers
   int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 2;       // pair set-ops with optimize(): 2 the kernel applies Container.optimize() itself (encoded bytes into the head of the cell; no re-encode pass), 1 results of <= 1024 values leave the kernel as arrays and the re-encode pass does the rest (round 2), 0 always 8 KiB cells first (A/B runs, cross-checks)
+  int64_t setop_compact = 1;             // one-shot set-ops / folds / BSI ranges / Flip / Shift with optimize() applied inside the kernel: 1 the output batch (owned by the caller) is compacted into a right-sized arena before it is returned (payload sizes + scan + one copy per container), 0 it keeps its 8 KiB cells
   int64_t count_range_reference_quirk = 1;  // 1 (default: identical to the reference): fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227); 0: the arithmetically right count
   int64_t topn_semantics = 1;            // fbk_topn / fbk_query_topn / fbk_group_topn / fbk_topn_partials with n > 0: 1 (default) the reference's two passes — candidates = the union over the SHARDS of fragment.top(N = n) (k_topn_candidates), then their exact totals (executeTopN, executor.go:2779-2864); 0: the exact top n of all rows
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
@@ -197,6 +199,7 @@ struct fbk_batch {
   mutable int shadow_state = 0;
   std::mutex slots_mu;  // refresh_slots: h_slots / slots_stale
   uint64_t version = 0;  // bumped whenever the device descriptors are rewritten (a plan's resolved item records follow it)
+  bool borrowed = false;  // the output of a plan / prepared query: owned by it and rewritten in place (n_rows x 16 cells of 8 KiB) by its next run
 };
 
 namespace {
@@ -483,11 +486,13 @@ int32_t heavy_shadow(fbk_ctx* ctx, const fbk_batch* b, const Slot** out_slots, b
     }
     b->shadow_state = 2;
     const uint64_t bytes = uint64_t(list.size()) * 8192ull;
-    // no shadow beyond the option's cap, beyond twice the batch's own arena, or beyond a quarter of what the device has
+    // no shadow beyond the option's cap (matrix_shadow_max_mb), beyond matrix_shadow_arena_x times the batch's own arena, or beyond a quarter of what the device has
     // free right now (the shadows live outside the fragment cache's accounting until its next get / release: they must
     // never be what makes a later upload fail).  The threshold and this decision are the FIRST caller's: the shadow is
     // built once per batch content.
-    uint64_t limit = std::min<uint64_t>(uint64_t(ctx->opt.matrix_shadow_max_mb) << 20, 2 * std::max<uint64_t>(b->arena_bytes, 1 << 20));
+    uint64_t limit = uint64_t(ctx->opt.matrix_shadow_max_mb) << 20;
+    if (ctx->opt.matrix_shadow_arena_x)  // (0: no such rule — run-heavy batches, a few bytes per container and 8 KiB per shadow, are what shadows were built for)
+      limit = std::min<uint64_t>(limit, uint64_t(ctx->opt.matrix_shadow_arena_x) * std::max<uint64_t>(b->arena_bytes, 1 << 20));
     size_t mem_free = 0, mem_total = 0;
     if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) limit = std::min<uint64_t>(limit, (uint64_t(mem_free) + ctx->pool_cached_bytes) / 4);
     else (void)hipGetLastError();
@@ -686,6 +691,7 @@ const OptionDesc kOptions[] = {
     {"matrix_shadow", &FbkOptions::matrix_shadow, 0, 1},
     {"matrix_shadow_array", &FbkOptions::matrix_shadow_array, 0, 65536},
     {"matrix_shadow_max_mb", &FbkOptions::matrix_shadow_max_mb, 0, 1 << 20},
+    {"matrix_shadow_arena_x", &FbkOptions::matrix_shadow_arena_x, 0, 1 << 20},
     {"matrix_shadow_apref", &FbkOptions::matrix_shadow_apref, 1, 2},
     {"matrix_fused_program", &FbkOptions::matrix_fused_program, 0, 1},
 #ifdef FBK_EXPERIMENTS
@@ -712,6 +718,7 @@ const OptionDesc kOptions[] = {
 #endif
     {"pair_resolve", &FbkOptions::pair_resolve, 0, 1},
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
+    {"setop_compact", &FbkOptions::setop_compact, 0, 1},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
     {"topn_semantics", &FbkOptions::topn_semantics, 0, 1},
 };
@@ -899,9 +906,9 @@ hipError_t staged_h2d(fbk_ctx* ctx, uint8_t* d_dst, uint64_t total, Fill fill) {
     for (int k = 0; k < 2; ++k) {
       void* p = nullptr;
       hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+      if (e == hipSuccess) ctx->up_ring[k] = static_cast<uint8_t*>(p);  // (owned by the context from here on: freed by the next resize or by fbk_close, also when the event below fails)
       if (e == hipSuccess && !ctx->up_ev[k]) e = hipEventCreateWithFlags(&ctx->up_ev[k], hipEventDisableTiming);
       if (e != hipSuccess) return e;
-      ctx->up_ring[k] = static_cast<uint8_t*>(p);
     }
     ctx->up_cap = want;
   }
@@ -921,13 +928,25 @@ hipError_t staged_h2d(fbk_ctx* ctx, uint8_t* d_dst, uint64_t total, Fill fill) {
     if (parts <= 1) {
       fill(off, len, dst);
     } else {
+      // No exception may cross the C ABI (a cgo caller's process would terminate): a thread that cannot be started
+      // (EAGAIN at the process's thread limit -> std::system_error) or a failed reserve leaves its piece, and every later
+      // one, to the calling thread.
       std::vector<std::thread> th;
-      th.reserve(parts - 1);
-      for (unsigned t = 1; t < parts; ++t) {
-        const uint64_t a = uint64_t(t) * per, n = std::min<uint64_t>(per, len - a);
-        th.emplace_back([&fill, off, a, n, dst] { fill(off + a, n, dst + a); });
+      unsigned started = 1;
+      try {
+        th.reserve(parts - 1);
+        for (unsigned t = 1; t < parts; ++t) {
+          const uint64_t a = uint64_t(t) * per, n = std::min<uint64_t>(per, len - a);
+          th.emplace_back([&fill, off, a, n, dst] { fill(off + a, n, dst + a); });
+          started = t + 1;
+        }
+      } catch (...) {
       }
       fill(off, std::min<uint64_t>(per, len), dst);
+      for (unsigned t = started; t < parts; ++t) {
+        const uint64_t a = uint64_t(t) * per;
+        fill(off + a, std::min<uint64_t>(per, len - a), dst + a);
+      }
       for (std::thread& x : th) x.join();
     }
     hipError_t e = hipMemcpyAsync(d_dst + off, dst, len, hipMemcpyHostToDevice, ctx->stream);
@@ -968,9 +987,24 @@ static int32_t validate_container(const fbk_container_desc& d, const uint8_t* /*
   return FBK_OK;
 }
 
+static int32_t batch_upload_impl(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t n_desc, uint32_t n_rows, const void* payload, uint64_t payload_len,
+                                 fbk_batch** out_batch);
+
 int32_t fbk_batch_upload(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t n_desc, uint32_t n_rows,
                          const void* payload, uint64_t payload_len, fbk_batch** out_batch) {
   FBK_ENTER(ctx);
+  // the host-side tables of an upload are std::vectors: their allocation failures must not leave the C ABI as exceptions
+  try {
+    return batch_upload_impl(ctx, descs, n_desc, n_rows, payload, payload_len, out_batch);
+  } catch (const std::bad_alloc&) {
+    return fail(FBK_E_NOMEM, "batch_upload: host allocation failed");
+  } catch (const std::exception& e) {
+    return fail(FBK_E_INVALID, std::string("batch_upload: ") + e.what());
+  }
+}
+
+static int32_t batch_upload_impl(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t n_desc, uint32_t n_rows, const void* payload, uint64_t payload_len,
+                                 fbk_batch** out_batch) {
   if (!ctx || !out_batch || (n_desc && (!descs || !payload))) return fail(FBK_E_INVALID, "NULL argument");
   *out_batch = nullptr;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -1325,6 +1359,7 @@ struct fbk_plan {
 namespace {
 
 int32_t optimize_cells(fbk_ctx* ctx, fbk_batch* o, const uint32_t* d_runs);  // fbk_query_api.inc
+int32_t compact_cells(fbk_ctx* ctx, fbk_batch* o);                            // fbk_query_api.inc
 
 // Average encoded payload per container of a batch, in bytes.
 uint64_t batch_avg_payload(const fbk_batch* b) {
@@ -1658,6 +1693,7 @@ int32_t plan_setop_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, int32_t op, bool wa
       return fail(e == hipErrorOutOfMemory ? FBK_E_NOMEM : FBK_E_HIP, std::string("setop output: ") + hipGetErrorString(e));
     }
     p->out = o;
+    o->borrowed = true;
   }
   if (want_runs && !p->d_runs) HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_runs), std::max<uint64_t>(n_slots, 1) * 4));
   if (p->n_pairs == 0) return FBK_OK;
@@ -1833,11 +1869,13 @@ int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* 
     if (e != hipSuccess) rc = fail(FBK_E_HIP, std::string("setop: ") + hipGetErrorString(e));
   }
   if (!rc && opt && ctx->opt.setop_direct_encode != 2) rc = optimize_cells(ctx, p->out, p->d_runs);  // (mode 2: the kernel has encoded already)
+  else if (!rc && opt && ctx->opt.setop_compact) rc = compact_cells(ctx, p->out);  // ... into the head of 8 KiB cells: the caller owns this batch, it gets a right-sized arena
   if (!rc) rc = refresh_slots(p->out);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (!rc && e != hipSuccess) rc = fail(FBK_E_HIP, std::string("setop: ") + hipGetErrorString(e));
   if (!rc) {
     *out_batch = p->out;
+    p->out->borrowed = false;
     p->out = nullptr;
   }
   free_plan_storage(p);

@@ -1110,7 +1110,9 @@ __global__ void __launch_bounds__(256) k_bsi_add(const Slot* __restrict__ slotsX
 // values of the columns in exists ∩ filter are appended to a global list (sorted and
 // de-duplicated afterwards).  Operands must be DENSE rows (k_densify_rows makes them so): lane i
 // reads a whole 128-byte line of plane i per round, i.e. 16 word positions per load.
-//   rows[shard] = ordinal of the exists row; +1 sign, +2+i plane i.   One block per (shard, slot).
+//   rows[shard] = ordinal of the exists row; +1 sign, +2+i plane i.   `split` blocks per (shard, slot), 16 / split rounds of
+//   1024 columns per wave each (round 5: it was ONE block per (shard, slot) — 64 blocks for a 4-shard field on 256 CUs,
+//   0.03 of the HBM rate; the launch code splits until the grid holds ~2048 blocks).
 __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
   const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, kWave), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, kWave);
   return ((u64)hi << 32) | lo;
@@ -1119,17 +1121,19 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
 __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ rows,
                                                    uint32_t n_shards, uint32_t depth, const uint8_t* __restrict__ farena,
                                                    const uint32_t* __restrict__ frows, long long* __restrict__ out,
-                                                   u64 out_cap, u64* __restrict__ cursor) {
+                                                   u64 out_cap, u64* __restrict__ cursor, uint32_t split) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t shard = blockIdx.x >> 4, slot = blockIdx.x & 15;
+  const uint32_t part = blockIdx.x % split, cell = blockIdx.x / split;  // split: 1, 2, 4, 8 or 16
+  const uint32_t shard = cell >> 4, slot = cell & 15;
   if (shard >= n_shards) return;
+  const int rounds = 16 / (int)split;
   const uint64_t rowBytes = (uint64_t)kSlots * 8192;
   const uint8_t* ex = arena + (uint64_t)rows[shard] * rowBytes + slot * 8192ull;
   const uint8_t* sg = ex + rowBytes;
   const uint8_t* fl = farena ? farena + (uint64_t)frows[shard] * rowBytes + slot * 8192ull : nullptr;
   const uint8_t* mine = ex + (uint64_t)(2 + lane) * rowBytes;  // plane `lane` (unused when lane >= depth)
-  for (int round = 0; round < 16; ++round) {
+  for (int round = (int)part * rounds; round < (int)(part + 1) * rounds; ++round) {
     const uint32_t w0 = (uint32_t)wv * 256u + (uint32_t)round * 16u;  // first word of this round
     // the 16 exists / filter / sign words of the round: lanes 0..15 fetch one each
     u64 e = 0, sgn = 0;

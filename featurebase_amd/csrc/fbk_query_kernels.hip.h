@@ -539,6 +539,38 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan(const u64* __restrict__
   if (threadIdx.x == 0) *total = carry_s;
 }
 
+// ---- compaction of a batch whose containers are ALREADY in their final encodings (the kernels that apply optimize()
+// themselves write the encoded bytes into the head of an 8 KiB cell): the payload size of every container as it is,
+// the same two-level scan, then one wave per container copies its bytes.  No decode, no re-encode.
+__global__ void __launch_bounds__(256) k_compact_plan(const Slot* __restrict__ cells, uint64_t n_slots, u64* __restrict__ bytes) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_slots) return;
+  const Slot s = cells[i];
+  const uint32_t t = slot_n(s) ? slot_type(s) : kTypeNil;
+  const u64 b = t == kTypeArray ? (u64)s.len * 2 : t == kTypeRun ? (u64)s.len * 4 : t == kTypeBitmap ? 8192ull : 0ull;
+  bytes[i] = (b + 15) & ~15ull;
+}
+
+__global__ void __launch_bounds__(256) k_compact_write(const Slot* __restrict__ cells, const uint8_t* __restrict__ arena, const u64* __restrict__ bytes,
+                                                      const u64* __restrict__ off_local, const u64* __restrict__ off_block, uint64_t n_slots,
+                                                      uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_slots) return;
+  Slot s = cells[i];
+  const u64 nb = bytes[i];  // a multiple of 16; payloads are 16-byte aligned in both arenas
+  const u64 off = off_block[i >> 10] + off_local[i];
+  if (nb == 0) {
+    s.off = 0, s.len = 0, s.tn = 0;
+  } else {
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(arena + s.off);
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(arenaO + off);
+    for (u64 k = lane; k < nb / 16; k += kWave) dst[k] = src[k];
+    s.off = off;
+  }
+  if (lane == 0) outSlots[i] = s;
+}
+
 // Phase 3: one wave per cell re-encodes its bitmap cell into the compact arena
 // (bitmapToArray roaring.go:3687, bitmapToRun :3859) or copies it.
 __global__ void __launch_bounds__(256) k_encode_write(const Slot* __restrict__ cells, const uint8_t* __restrict__ cell_arena,

@@ -128,6 +128,8 @@ SIGNATURES = {
     "fbk_bsi_distinct": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.c_uint64, _u64p]),
     "fbk_topk": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint32, _vp]),
     "fbk_topn": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint32, _vp]),
+    "fbk_batch_compact": (C.c_int32, [_vp, _vp, _vp]),
+    "fbk_batch_memory": (C.c_int32, [_vp, _vp, _vp, _vp, _vp]),
     "fbk_topn_partials": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp]),
     "fbk_topk_bsi": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, _vpp, _u32p]),
     "fbk_flip": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _vpp, _vp]),

@@ -97,6 +97,18 @@ class Batch:
     def n_rows(self) -> int:
         return self.info()[0]
 
+    def memory(self) -> Tuple[int, int, int]:
+        """(arena bytes, heavy-row shadow bytes, shadow state 0 / 1 / 2) — fbk_batch_memory"""
+        a, sh, st = C.c_uint64(), C.c_uint64(), C.c_int32()
+        L.check(self.ctx.lib.fbk_batch_memory(self.ctx.h, self.h, C.byref(a), C.byref(sh), C.byref(st)))
+        return a.value, sh.value, st.value
+
+    def compact(self) -> int:
+        """fbk_batch_compact: the containers into a right-sized arena; returns the arena bytes afterwards"""
+        a = C.c_uint64()
+        L.check(self.ctx.lib.fbk_batch_compact(self.ctx.h, self.h, C.byref(a)))
+        return a.value
+
     def count(self, rows: Sequence[int]) -> np.ndarray:
         r = np.ascontiguousarray(rows, dtype=np.uint32)
         out = np.zeros(r.size, dtype=np.uint64)

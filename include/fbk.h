@@ -152,12 +152,13 @@ int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
  * dense_spb, fold_register, matrix_valu, matrix_spb, matrix_pass_kb, matrix_densify, matrix_fused,
  * matrix_fp4, matrix_shadow (1: the count matrix over encoded rows reads run containers and arrays of more
  * than matrix_shadow_array values through dense shadows built per batch on first use — up to
- * matrix_shadow_max_mb of device memory per batch, matrix_shadow_apref array items loaded a stage ahead; 0: every container
+ * matrix_shadow_max_mb of device memory per batch and matrix_shadow_arena_x times its own arena (0: no such rule),
+ * matrix_shadow_apref array items loaded a stage ahead; fbk_batch_memory reports what a batch got; 0: every container
  * is decoded in every query), matrix_fused_program (1: that kernel runs a prepared program — row tables and resolved array
  * items per (shard, tile, container slot), built by k_fused_program on a prepared query's first run and again when a batch
  * was rewritten, per call otherwise; 0: round 4's kernel, every block builds its work lists itself),
  * bsi_range_sum_two_pass, bsi_half_waves, bsi_planes_ahead, topk_device_sort, sparse_paths,
- * setop_direct_encode, setop_probe, fold_encode, pair_kernels, pair_wpb, pair_resolve, pair_run_probe, pair_lean,
+ * setop_direct_encode, setop_probe, setop_compact, fold_encode, pair_kernels, pair_wpb, pair_resolve, pair_run_probe, pair_lean,
  * query_resolve, upload_chunk_mb, upload_threads, count_range_reference_quirk, topn_semantics.  Every value of every
  * option gives the same results (the tests run them against each other); they select between kernels, not between
  * semantics — except count_range_reference_quirk and topn_semantics, whose DEFAULTS (1) are the reference's results and
@@ -196,6 +197,23 @@ int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_r
                                fbk_batch** out_batch);
 
 int32_t fbk_batch_free(fbk_ctx* ctx, fbk_batch* batch);
+
+/* Device memory a batch holds: its arena, its heavy-row shadows (option matrix_shadow; built on the first count matrix
+ * over encoded rows that reads the batch) and the shadow state — 0 not looked at yet, 1 shadowed, 2 nothing heavy or over a
+ * limit (matrix_shadow_max_mb of device memory; matrix_shadow_arena_x times the batch's own arena; a quarter of the free
+ * device memory): the batch's containers are then decoded in every query. */
+int32_t fbk_batch_memory(fbk_ctx* ctx, const fbk_batch* batch, uint64_t* out_arena_bytes, uint64_t* out_shadow_bytes,
+                         int32_t* out_shadow_state);
+
+/* Move the containers of a batch the caller owns into a right-sized arena.  Materialising calls with FBK_SETOP_OPTIMIZE apply
+ * Container.optimize() inside their kernel, which writes the encoded bytes into the head of an 8 KiB cell per container
+ * (arena = n_rows x 16 x 8 KiB); the one-shot calls (fbk_setop, fbk_fold_n / fbk_union_n, fbk_bsi_range*, fbk_flip,
+ * fbk_shift) compact their output before returning it (option setop_compact = 1, the default: payload sizes, one scan, one
+ * copy per container — nothing is decoded), so a caller that keeps results holds their encoded size.  Outputs of plans and
+ * prepared queries (fbk_plan_output, fbk_query_output) are BORROWED and keep the 8 KiB stride — their next run rewrites
+ * them in place — and this call refuses them; copy them out (download, or a one-shot call) to keep them.
+ * *out_arena_bytes = the arena size afterwards (also what fbk_batch_memory reports). */
+int32_t fbk_batch_compact(fbk_ctx* ctx, fbk_batch* batch, uint64_t* out_arena_bytes);
 
 /* Sizes needed to download a batch. */
 int32_t fbk_batch_info(fbk_ctx* ctx, const fbk_batch* batch, uint32_t* n_rows,
