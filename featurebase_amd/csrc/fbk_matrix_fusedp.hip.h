@@ -157,12 +157,19 @@ __global__ void __launch_bounds__(256) k_fused_program(
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------
-template <bool HAS_F, int APREF = 2, int BPREF = 2>
+template <bool HAS_F, int APREF = 2, int BPREF = 2, bool PROF = false>
 __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxProg* __restrict__ prog, const FxItem* __restrict__ items, uint32_t nA, uint32_t nBtot,
-                                                                      uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard) {
+                                                                      uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard, u64* __restrict__ prof = nullptr) {
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   constexpr int kFxPref = APREF, kFxBmPref = BPREF;
+  // PROF (experiment builds, scripts/fused_prof.py): the block in the middle of the grid writes cycle stamps, prof[(wave * 24 + stage) * 8 + k]:
+  // producers k = 0 stage start, 1 this stage's loads settled and bitmap rows stored, 2 next stage's loads issued, 3 array items
+  // done, 4 run rows done, 5 past the barrier; consumers k = 0 start, 1 arithmetic done, 5 past the barrier
+  const bool traced = PROF && blockIdx.x == (gridDim.x / 2 | 1u);
+  auto stamp = [&](uint32_t st, int k) {
+    if (PROF && traced && (threadIdx.x & 63) == 0 && st < 24u) prof[((threadIdx.x >> 6) * 24u + st) * 8u + k] = (u64)__builtin_readcyclecounter();
+  };
   __shared__ uint4 ring[2 * kFxBuf / 16];  // 135 200 bytes
   __shared__ FxProg tabs[2];               // 2 x 2384 bytes
   const int lane = threadIdx.x & 63;
@@ -197,6 +204,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
     constexpr uint32_t M4 = 0x11111111u;
     __syncthreads();  // (the producers' set-up barrier)
     for (uint32_t it = 0; it <= n_stage; ++it) {
+      stamp(it, 0);
       if (it >= 1) {
         uint4* buf = ring + ((it - 1) & 1u) * (uint32_t)(kFxBuf / 16);
         uint4* rowA = buf + r * (uint32_t)(kFxStride / 16) + 16u * (uint32_t)wv + g;
@@ -244,7 +252,9 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
         }
         if (HAS_F) rowF[lane & 15] = uint4{0, 0, 0, 0};
       }
+      stamp(it, 1);
       __syncthreads();
+      stamp(it, 5);
     }
     uint32_t* red = reinterpret_cast<uint32_t*>(ring8);
 #pragma unroll
@@ -463,12 +473,14 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
     const uint32_t si = it / kFxStages, q = it % kFxStages;
     const FxProg& T = tabs[si & 1u];
     const uint32_t bufoff = (it & 1u) * (uint32_t)kFxBuf;
+    stamp(it, 0);
     // ---- 0. this stage's loads and the next stage's items (all issued a stage ago) have landed ----
     settle(cur);
     // ---- 1. bitmap rows: registers -> LDS ----
 #pragma unroll
     for (int k = 0; k < kFxBmPref; ++k)
       if (cur.b_off[k] != ~0u) *reinterpret_cast<mm_u4*>(ring8 + (bufoff + lane16) + cur.b_off[k]) = cur.b_w[k];
+    stamp(it, 1);
     // ---- 1b. the work lists of the next slot: DMA at (si, 1) — BEFORE this stage's loads, so that they return after it —,
     //          landed by this wave's settle of (si, 2), visible to the block after that stage's barrier, read from (si, 6) on ----
     if (q == 1 && pw == 8u && si + 1 < n_act) dma_table(tabs[(si + 1) & 1u], bprog + slot_of(si + 1));
@@ -496,6 +508,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
       for (int k = 0; k < kMore; ++k)
         if (toff[k] != ~0u) *reinterpret_cast<mm_u4*>(ring8 + (bufoff + lane16) + toff[k]) = t[k];
     }
+    stamp(it, 2);
     // ---- 3a. run rows, step 1 ----
 #pragma unroll
     for (int k = 0; k < kFxRunPref; ++k)
@@ -533,6 +546,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
         }
       }
     }
+    stamp(it, 3);
     // ---- 4. run rows, step 2: the parity prefixes; then a wave's later run rows ----
     wave_lds_sync();
 #pragma unroll
@@ -552,6 +566,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
         }
       }
     }
+    stamp(it, 4);
   };
 
   // ---- set-up: the work lists of the first slot, the items of stage 0, then the stage loop ----
@@ -567,9 +582,11 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
   for (uint32_t it = 0; it <= n_stage; it += 2) {  // (n_stage is a multiple of 8)
     if (it < n_stage) stage(it, P0, P1);
     __syncthreads();
+    stamp(it, 5);
     if (it + 1 <= n_stage) {
       if (it + 1 < n_stage) stage(it + 1, P1, P0);
       __syncthreads();
+      stamp(it + 1, 5);
     }
   }
   __syncthreads();  // the consumers' reduction barrier

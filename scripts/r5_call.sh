@@ -31,7 +31,7 @@ pmc_fused) bash scripts/fused_pmc.sh $TAG/pmc_fused 256 0 fused_pmc.py count_mat
 fuzz) bash scripts/fuzz_parity.sh $O ${FUZZ_SEEDS:-0x5eed4001 0x5eed4002 0x5eed4003} > /dev/null 2>&1 ;;
 fused_spb) timeout 300 python scripts/fused_spb_sweep.py ${SWEEP_ARGS:-256 5} 2> $O/fused_spb.err | grep -v amdgpu.ids > $O/fused_spb.json ;;
 fused) timeout 400 python scripts/fused_bench.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_bench.txt ;;
-fusedprof) timeout 300 python scripts/fused_prof.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_prof.txt ;;
+fusedprof) (for pg in 1 0; do timeout 200 python scripts/fused_prof.py 256 0 $pg 2>&1 | grep -v amdgpu.ids; done) > $O/fused_prof.txt ;;
 fused_ab) timeout 500 python scripts/fused_ab.py ${FUSED_AB_ARGS:-256 1024} > $O/fused_ab.json 2> $O/fused_ab.err ;;
 *) echo "unknown step $s" ;;
 esac

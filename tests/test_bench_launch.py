@@ -84,3 +84,31 @@ def _check_compact(c, n, steps, shards4_total):
     assert c["throughput_mode_bucketed"]["steps_per_collective"] == 16 and c["per_query"]["one_cell_ms_per_step"] > 0
     g = c["group_api"]
     assert g["members"] == n and "host" in g["modes"] and g["count_matrix"]["scaling"] == "strong"
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpus_8_oversubscribed_line_on_the_gpu_box():
+    """`bench.py --gpus 8` as the driver will run it on an 8-GPU node, here with eight ranks on whatever the box has (gloo
+    collectives when there are fewer devices than ranks): rank-count-dependent code — shards_for_rank remainders (60 dense and
+    20 log-uniform shards over 8 ranks), the per-query collectives with 8 participants, the group child process with 8 members,
+    the CPU leg on rank 0 with seven ranks asleep — has then run once, and the ONE stdout line stays under the size the driver
+    parses."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    detail = "bench_detail_test_n8.json"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "10", "--warmup", "2", "--shards", "32", "--repeats", "2", "--cold-sets", "1",
+           "--shards4-total", "60", "--shards4-mixed-total", "20", "--queries4", "2", "--detail", detail]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=850)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stderr[-3000:])
+    assert len(lines[0].encode()) < 8192, len(lines[0])
+    c = json.loads(lines[0])
+    _check_compact(c, 8, 10, 60)
+    r = json.load(open(os.path.join(ROOT, detail)))
+    os.remove(os.path.join(ROOT, detail))
+    s = r["strong_scaling"]
+    assert s["rank0"]["shards_this_rank"] == 8 and s["variants"][1]["shards_this_rank"] == 3  # ranks 0..3 own 8 of the 60 / 3 of the 20
+    assert r["group_api"]["members"] == 8 and sum(r["group_api"]["count_matrix"]["shards_per_member"]) == 60
+    assert r["cpu_baseline"]["cores"] >= 1 and "the other 7 ranks" in r["cpu_baseline"]["sample"]

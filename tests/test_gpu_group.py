@@ -309,3 +309,71 @@ def test_group_topn_is_fbk_topn_over_all_shards(gpu_ctx):
     for b in keep:
         b.free()
     grp.close()
+
+
+def test_group_of_eight_members_on_one_device(gpu_ctx):
+    """The member count an 8-GPU node will have, on the one device this box has (all eight members share device 0, host and peer
+    reduce): IntersectionCount totals, the GroupBy count matrix, TopN and BSI Sum over shards dealt s mod 8 — with 11 shards, so
+    that three members hold two shards and five hold one — against the single-context results.  What depends on the NUMBER of
+    members (the reduce buffers, the member locks taken in order, the per-member argument arrays) has then run once before the
+    real node shows up; RCCL over eight distinct devices has not (test_group_rccl_over_every_visible_device)."""
+    G, n_shards, n_a = 8, 11, 6
+    w = D.dense_rows(n_shards * 2 * n_a, 0.5, 2260)
+    wf = D.dense_rows(n_shards, 0.5, 2261)
+    A1, F1 = gpu_ctx.upload_dense(w), gpu_ctx.upload_dense(wf)
+    rows = np.arange(n_shards * 2 * n_a).reshape(n_shards, 2 * n_a)
+    ra1, rb1, rf1 = rows[:, :n_a], rows[:, n_a:], np.arange(n_shards)
+    ref_m = gpu_ctx.count_matrix(A1, ra1, A1, rb1, F1, rf1)
+    ref_i = int(gpu_ctx.intersection_count(A1, ra1[:, 0], A1, rb1[:, 0]).sum())
+    ref_t = gpu_ctx.topn(A1, rows, 4, F1, rf1)
+    grp = Group([0] * G)
+    keep, plans, margs, targs = [], [], [], []
+    for m, c in enumerate(grp.members):
+        mine = list(range(m, n_shards, G))
+        a = c.upload_dense(np.ascontiguousarray(w.reshape(n_shards, 2 * n_a, 16, 1024)[mine]).reshape(-1, 16, 1024))
+        f = c.upload_dense(np.ascontiguousarray(wf[mine]))
+        keep += [a, f]
+        r = np.arange(len(mine) * 2 * n_a).reshape(len(mine), 2 * n_a)
+        plans.append(c.plan(a, r[:, 0], a, r[:, n_a]))
+        margs.append(dict(a=a, rows_a=r[:, :n_a], b=a, rows_b=r[:, n_a:], filt=f, rows_f=np.arange(len(mine))))
+        targs.append(dict(a=a, rows_a=r, filt=f, rows_f=np.arange(len(mine))))
+    for mode in (L.REDUCE_HOST, L.REDUCE_PEER):
+        grp.set_reduce(mode)
+        assert grp.plan_intersection_count_total(plans) == ref_i, mode
+        assert (grp.count_matrix(margs, n_a, n_a) == ref_m).all(), mode
+        idx, cnt = grp.topn(targs, 2 * n_a, 4)
+        assert idx.tolist() == ref_t[0].tolist() and cnt.tolist() == ref_t[1].tolist(), mode
+    for p in plans:
+        p.free()
+    for b in keep + [A1, F1]:
+        b.free()
+    grp.close()
+
+
+def test_group_rccl_over_every_visible_device():
+    """ncclCommInitAll + the all-reduce of the count partials over ALL the devices the box shows, one member each — the reduce
+    an 8-GPU node runs.  On a one-GPU box this is the one-member communicator again (the RCCL code path, not the fabric); it
+    does not skip, so that whatever the node has is exercised."""
+    import torch
+
+    n_dev = torch.cuda.device_count()
+    assert n_dev >= 1
+    grp = Group(list(range(n_dev)))
+    n_shards = 2 * n_dev + 1
+    w = D.dense_rows(n_shards * 2, 0.5, 2270)
+    exp = int(sum(np.bitwise_count(w[2 * s] & w[2 * s + 1]).sum() for s in range(n_shards)))
+    keep, plans = [], []
+    for m, c in enumerate(grp.members):
+        mine = list(range(m, n_shards, n_dev))
+        a = c.upload_dense(np.ascontiguousarray(w.reshape(n_shards, 2, 16, 1024)[mine]).reshape(-1, 16, 1024))
+        keep.append(a)
+        plans.append(c.plan(a, np.arange(len(mine)) * 2, a, np.arange(len(mine)) * 2 + 1))
+    for mode in (L.REDUCE_HOST, L.REDUCE_RCCL) + ((L.REDUCE_PEER,) if n_dev > 1 else ()):
+        grp.set_reduce(mode)
+        for _ in range(3):
+            assert grp.plan_intersection_count_total(plans) == exp, (mode, n_dev)
+    for p in plans:
+        p.free()
+    for b in keep:
+        b.free()
+    grp.close()
