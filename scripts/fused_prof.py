@@ -17,7 +17,12 @@ import datagen as D  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ab = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 prog = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # 1: the kernel that runs a prepared program (round 5), 0: round 4's
-rows, groups, filt = D.config3_flat(n, mp="fork")
+cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 3  # 3: config 3's rank-law rows; 4: config 4's log-uniform rows
+if cfg == 4:
+    rows, ga, gb, filt, _ = D.config4_flat(n, mp="fork")
+    groups = np.concatenate([ga, gb], axis=1)
+else:
+    rows, groups, filt = D.config3_flat(n, mp="fork")
 from featurebase_amd.roaring import Context  # noqa: E402
 
 ctx = Context(0)
@@ -25,7 +30,7 @@ batch = ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
 F = ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
 ctx.set_option("matrix_fused", 1)
 ctx.set_option("matrix_fused_program", prog)
-print(f"[fused prof] matrix_fused_program = {prog}", file=sys.stderr)
+print(f"[fused prof] matrix_fused_program = {prog} config {cfg}", file=sys.stderr)
 for _ in range(2):
     ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, np.arange(n))
 ctx.set_option("matrix_fused_ablate", 32 | ab)

@@ -9,7 +9,7 @@ STEPS=${STEPS:-"pytest pairs ctops"}
 for s in $STEPS; do
 case $s in
 pytest) (timeout ${PYTEST_TIMEOUT:-900} python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} 2>&1 | tail -25) > $O/pytest.log ;;
-pytest_sel) (timeout ${PYTEST_TIMEOUT:-900} python -m pytest ${PYTEST_SEL} -m gpu -x -q 2>&1 | tail -25) > $O/pytest_sel.log ;;
+pytest_sel) (timeout ${PYTEST_TIMEOUT:-900} python -m pytest ${PYTEST_SEL} -m gpu -q 2>&1 | tail -60) > $O/pytest_sel.log ;;
 pytest_full) (timeout 600 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q --durations=10 2>&1 | tail -40) > $O/pytest_full.log ;;
 pairs) timeout 300 python scripts/bench_pairs.py --out $O/pairs.json ${PAIRS_ARGS:-} > $O/pairs.txt 2> $O/pairs.err ;;
 ctops_small) timeout 400 python scripts/bench_ctops.py --rows 1024 --iters 20 --out $O/ctops_small.json --only Empty,Ary1,Ary16,Ary256,Ary512,BM4096,RunFull,Run16,Run256 2>&1 | grep -v amdgpu.ids | tail -40 > $O/ctops_small.txt ;;
@@ -31,7 +31,7 @@ pmc_fused) bash scripts/fused_pmc.sh $TAG/pmc_fused 256 0 fused_pmc.py count_mat
 fuzz) bash scripts/fuzz_parity.sh $O ${FUZZ_SEEDS:-0x5eed4001 0x5eed4002 0x5eed4003} > /dev/null 2>&1 ;;
 fused_spb) timeout 300 python scripts/fused_spb_sweep.py ${SWEEP_ARGS:-256 5} 2> $O/fused_spb.err | grep -v amdgpu.ids > $O/fused_spb.json ;;
 fused) timeout 400 python scripts/fused_bench.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_bench.txt ;;
-fusedprof) (for pg in 1 0; do timeout 200 python scripts/fused_prof.py 256 0 $pg 2>&1 | grep -v amdgpu.ids; done) > $O/fused_prof.txt ;;
+fusedprof) (for pg in 1 0; do timeout 200 python scripts/fused_prof.py 256 0 $pg ${PROF_CFG:-4} 2>&1 | grep -v amdgpu.ids; done) > $O/fused_prof.txt ;;
 fused_ab) timeout 500 python scripts/fused_ab.py ${FUSED_AB_ARGS:-256 1024} > $O/fused_ab.json 2> $O/fused_ab.err ;;
 *) echo "unknown step $s" ;;
 esac

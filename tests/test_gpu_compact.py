@@ -35,7 +35,10 @@ def test_one_shot_results_are_compacted_and_identical(gpu_ctx):
             a0, a1 = o0.memory()[0], o1.memory()[0]
             assert a0 == cells, (op, a0, cells)  # the kernel's cells
             payload = o1.info()[2]
-            assert payload <= a1 <= payload + 16 * n * 16 and (a1 < a0 // 2 or payload > a0 // 2), (op, a0, a1, payload)
+            if payload + (1 << 20) + 16 * n * 16 >= a0:  # (less than 1 MiB to gain: the cells are kept — Union of dense rows)
+                assert a1 == a0
+            else:
+                assert payload <= a1 <= payload + 16 * n * 16, (op, a0, a1, payload)
             # the explicit call on the uncompacted batch: same arena size, same content; a second call is a no-op
             assert o0.compact() == a1 and o0.compact() == a1
             w2, d2, p2 = _words(o0)
