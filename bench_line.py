@@ -37,6 +37,14 @@ def _short(s, n):
     return s if len(s) <= n else s[: n - 3] + "..."
 
 
+def _head_tail(s, head, tail):
+    """a long note cut in the middle (the CPU leg's sample says WHAT was timed first and WHERE last)"""
+    if s is None:
+        return None
+    s = str(s)
+    return s if len(s) <= head + tail + 5 else s[:head] + " ... " + s[-tail:]
+
+
 def _median(d):
     if isinstance(d, dict):
         return d.get("median")
@@ -162,7 +170,7 @@ def compact_line(full: dict, detail_name: str = "bench_detail.json") -> dict:
             "unit": cb.get("unit"),
             "cores": cb.get("cores"),
             "kind": cb.get("kind"),
-            "sample": _short(cb.get("sample"), 260),
+            "sample": _head_tail(cb.get("sample"), 170, 150),
             "single_thread": _r(cb.get("single_thread_set_ops_per_s")),
             "streaming_pass": _r((cb.get("streaming_pass") or {}).get("value")),
         }

@@ -159,7 +159,12 @@ __global__ void __launch_bounds__(256) k_fused_program(
 // ---- the kernel ------------------------------------------------------------------------------------------------
 template <bool HAS_F, int APREF = 2, int BPREF = 2, bool PROF = false>
 __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxProg* __restrict__ prog, const FxItem* __restrict__ items, uint32_t nA, uint32_t nBtot,
-                                                                      uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard, u64* __restrict__ prof = nullptr) {
+                                                                      uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard, u64* __restrict__ prof = nullptr, uint32_t ablate = 0) {
+  // `ablate` (option matrix_fused_ablate, experiment builds only — results are wrong when set): 1 no consumer arithmetic,
+  // 2 no array items, 8 no bitmap rows, 16 the producers only keep the barriers
+#ifndef FBK_EXPERIMENTS
+  ablate = 0;  // (the option does not exist in the product library: the branches on it fold away)
+#endif
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   constexpr int kFxPref = APREF, kFxBmPref = BPREF;
@@ -205,7 +210,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
     __syncthreads();  // (the producers' set-up barrier)
     for (uint32_t it = 0; it <= n_stage; ++it) {
       stamp(it, 0);
-      if (it >= 1) {
+      if (it >= 1 && !(ablate & 1u)) {
         uint4* buf = ring + ((it - 1) & 1u) * (uint32_t)(kFxBuf / 16);
         uint4* rowA = buf + r * (uint32_t)(kFxStride / 16) + 16u * (uint32_t)wv + g;
         uint4* rowB = rowA + 32 * (kFxStride / 16);
@@ -355,7 +360,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
     for (int k = 0; k < kFxPref; ++k) {
       const uint32_t idx = first_group + gq + (uint32_t)kFxGroups * k;
       E[k] = mm_u4{0, 0, 0, 0};
-      if (idx < n) E[k] = fx_ld_global16(reinterpret_cast<const uint8_t*>(items + ((u64)ib + idx)));
+      if (idx < n && !(ablate & 2u)) E[k] = fx_ld_global16(reinterpret_cast<const uint8_t*>(items + ((u64)ib + idx)));
     }
   };
   // the slot whose first stage is `it`: this wave's first bitmap rows and the slot's run-row count
@@ -384,7 +389,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
     for (int k = 0; k < kFxPref; ++k) {
       const int mine = (int)E[k][2] - (int)gl8;  // values of the item from this lane's first on
       P.a_nv[k] = 0;
-      if (mine > 0) {
+      if (mine > 0 && !(ablate & 2u)) {
         P.a_nv[k] = (uint32_t)min(mine, 8);
         P.a_off[k] = E[k][3];
         const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)E[k][1] << 32) | E[k][0]);
@@ -393,8 +398,8 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
     }
 #pragma unroll
     for (int k = 0; k < kFxBmPref; ++k) {
-      P.b_off[k] = bm_off[k];
-      if (bm_off[k] != ~0u) {
+      P.b_off[k] = (ablate & 8u) ? ~0u : bm_off[k];
+      if (bm_off[k] != ~0u && !(ablate & 8u)) {
         const uint8_t* p = reinterpret_cast<const uint8_t*>(((uintptr_t)bm_hi[k] << 32) | bm_lo[k]);
         P.b_w[k] = fx_ld_global16(p + (q * (uint32_t)kFxSB + lane16));
       }
@@ -517,7 +522,7 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
 #pragma unroll
     for (int k = 0; k < kFxPref; ++k) scatter8(cur.a_w[k], cur.a_nv[k], bufoff + cur.a_off[k]);
     {
-      const uint32_t n = fx_uniform(T.icnt[q]);
+      const uint32_t n = (ablate & 2u) ? 0u : fx_uniform(T.icnt[q]);
       if (first_group + (uint32_t)kFxGroups * kFxPref < n) {
         const uint32_t ib = fx_uniform(T.ibase[q]);
         for (uint32_t x = first_group + (uint32_t)kFxGroups * kFxPref; x < n; x += (uint32_t)kFxGroups) {
@@ -580,11 +585,11 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedp(const FxP
     prefetch(0, P0);
   }
   for (uint32_t it = 0; it <= n_stage; it += 2) {  // (n_stage is a multiple of 8)
-    if (it < n_stage) stage(it, P0, P1);
+    if (it < n_stage && !(ablate & 16u)) stage(it, P0, P1);
     __syncthreads();
     stamp(it, 5);
     if (it + 1 <= n_stage) {
-      if (it + 1 < n_stage) stage(it + 1, P1, P0);
+      if (it + 1 < n_stage && !(ablate & 16u)) stage(it + 1, P1, P0);
       __syncthreads();
       stamp(it + 1, 5);
     }

@@ -33,6 +33,7 @@ fused_spb) timeout 300 python scripts/fused_spb_sweep.py ${SWEEP_ARGS:-256 5} 2>
 fused) timeout 400 python scripts/fused_bench.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_bench.txt ;;
 fusedprof) (for pg in 1 0; do timeout 200 python scripts/fused_prof.py 256 0 $pg ${PROF_CFG:-4} 2>&1 | grep -v amdgpu.ids; done) > $O/fused_prof.txt ;;
 fused_ab) timeout 500 python scripts/fused_ab.py ${FUSED_AB_ARGS:-256 1024} > $O/fused_ab.json 2> $O/fused_ab.err ;;
+fused_ablate) (for c in ${ABL_CFGS:-4 3}; do timeout 300 python scripts/fused_ablate.py $c 2>> $O/fused_ablate.err | grep "^{" >> $O/fused_ablate.jsonl; done) ;;
 *) echo "unknown step $s" ;;
 esac
 done

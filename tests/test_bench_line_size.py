@@ -38,6 +38,11 @@ def test_compact_line_size_and_contract_keys():
     assert rf["traffic"] == full["roofline"]["traffic"]
     cb = c["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 256 and cb["unit"] == "set-ops/s" and cb["value"] > 0 and cb["sample"]
+    # the sample note keeps its head (what was timed) AND its tail (where: "... on rank 0 ..." at N > 1)
+    full2 = _full()
+    full2["cpu_baseline"]["sample"] += "; timed on rank 0 (its 1024 shards = the N = 1 workload) after the timed GPU regions, the other 7 ranks asleep in a host barrier"
+    c2 = json.loads(bench_line.dumps_line(full2))
+    assert c2["cpu_baseline"]["sample"].startswith("full workload") and "rank 0" in c2["cpu_baseline"]["sample"] and len(c2["cpu_baseline"]["sample"]) < 340
     # every secondary entry survives as {id, kernel, kernel_us, frac, parity}
     assert len(c["secondary"]) == len(full["secondary"])
     for e, f in zip(c["secondary"], full["secondary"]):
