@@ -8,7 +8,7 @@ cd $R
 STEPS=${STEPS:-"pytest pairs ctops"}
 for s in $STEPS; do
 case $s in
-pytest) (timeout ${PYTEST_TIMEOUT:-900} python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} 2>&1 | tail -25) > $O/pytest.log ;;
+pytest) (timeout ${PYTEST_TIMEOUT:-900} python -m pytest tests -m gpu -q ${PYTEST_ARGS:-} 2>&1 | tail -25) > $O/pytest.log ;;
 pytest_sel) (timeout ${PYTEST_TIMEOUT:-900} python -m pytest ${PYTEST_SEL} -m gpu -q 2>&1 | tail -60) > $O/pytest_sel.log ;;
 pytest_full) (timeout 600 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q --durations=10 2>&1 | tail -40) > $O/pytest_full.log ;;
 pairs) timeout 300 python scripts/bench_pairs.py --out $O/pairs.json ${PAIRS_ARGS:-} > $O/pairs.txt 2> $O/pairs.err ;;
