@@ -27,6 +27,7 @@
 #include "fbk_matrix_mfma.hip.h"
 #include "fbk_matrix_fused.hip.h"
 #include "fbk_matrix_fusedp.hip.h"
+#include "fbk_matrix_fusedq.hip.h"
 #include "fbk_wire_kernels.hip.h"
 
 using fbk::Slot;
@@ -94,7 +95,7 @@ struct FbkOptions {
   int64_t matrix_shadow_max_mb = 16384;  //   no shadow for a batch that would need more than this (nor more than twice its arena, nor a quarter of the free device memory)
   int64_t matrix_shadow_arena_x = 8;     //   ... nor more than this many times the batch's own arena (0: no such rule); fbk_batch_info_ex reports what a batch got
   int64_t matrix_shadow_apref = 2;       //   array items per group loaded a stage ahead when rows are shadowed (1 or 2; filtered queries: 323 vs 349 us, profiles/r03_fused_shadow_ab.txt)
-  int64_t matrix_fused_program = 1;      // count matrix over encoded rows: 1 the kernel runs a prepared program (k_fused_program: row tables + resolved array items per (shard, tile, slot), built once per prepared query / per one-shot call; fbk_matrix_fusedp.hip.h), 0 every block builds its work lists itself (round 4's kernel: cross-check, A/B runs)
+  int64_t matrix_fused_program = 2;      // count matrix over encoded rows: 2 the program-driven kernel with specialised producer waves and loads two stages ahead (fbk_matrix_fusedq.hip.h), 1 the kernel runs a prepared program (k_fused_program: row tables + resolved array items per (shard, tile, slot), built once per prepared query / per one-shot call; fbk_matrix_fusedp.hip.h), 0 every block builds its work lists itself (round 4's kernel: cross-check, A/B runs)
 #ifdef FBK_EXPERIMENTS  // (scripts/ build their own variant with -DFBK_EXPERIMENTS into build_variants/; the product library has neither the options nor the device branches)
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
 #endif
@@ -693,7 +694,7 @@ const OptionDesc kOptions[] = {
     {"matrix_shadow_max_mb", &FbkOptions::matrix_shadow_max_mb, 0, 1 << 20},
     {"matrix_shadow_arena_x", &FbkOptions::matrix_shadow_arena_x, 0, 1 << 20},
     {"matrix_shadow_apref", &FbkOptions::matrix_shadow_apref, 1, 2},
-    {"matrix_fused_program", &FbkOptions::matrix_fused_program, 0, 1},
+    {"matrix_fused_program", &FbkOptions::matrix_fused_program, 0, 2},
 #ifdef FBK_EXPERIMENTS
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
 #endif
