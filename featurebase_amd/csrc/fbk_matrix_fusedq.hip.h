@@ -24,8 +24,8 @@ namespace fbk {
 
 constexpr int kFqNA = 5;                 // array waves: producer waves 0 .. 4
 constexpr int kFqNB = kFxProducers - kFqNA;  // bitmap waves: producer waves 5 .. 11
-constexpr int kFqAP = 3;                 // array items per group and stage loaded ahead
-constexpr int kFqBP = 5;                 // bitmap rows per bitmap wave and slot loaded ahead
+constexpr int kFqAP = 4;                 // array items per group and stage loaded ahead
+constexpr int kFqBP = 6;                 // bitmap rows per bitmap wave and slot loaded ahead
 constexpr int kFqGroups = kFqNA * 4;     // 16-lane groups of the array waves: item x of a stage goes to group x mod 20
 
 template <bool HAS_F, bool PROF = false>
@@ -280,15 +280,20 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
       issue_values(S1);
       load_entries(2, nI2, ibI2);
     }
-    for (uint32_t it = 0; it <= n_stage; ++it) {
-      if (it < n_stage && !(ablate & 16u)) {
-        const uint32_t ph = it % 3u;
-        if (ph == 0) astage(it, S0, S2);
-        else if (ph == 1) astage(it, S1, S0);
-        else astage(it, S2, S1);
-      }
+    for (uint32_t it = 0; it <= n_stage; it += 3) {  // (three stages per trip: the register sets rotate by NAME, nothing is copied)
+      if (it < n_stage && !(ablate & 16u)) astage(it, S0, S2);
       __syncthreads();
       stamp(it, 5);
+      if (it + 1 <= n_stage) {
+        if (it + 1 < n_stage && !(ablate & 16u)) astage(it + 1, S1, S0);
+        __syncthreads();
+        stamp(it + 1, 5);
+      }
+      if (it + 2 <= n_stage) {
+        if (it + 2 < n_stage && !(ablate & 16u)) astage(it + 2, S2, S1);
+        __syncthreads();
+        stamp(it + 2, 5);
+      }
     }
     __syncthreads();  // the consumers' reduction barrier
     return;
@@ -437,26 +442,19 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
     if (it + 2 < n_stage) issue(it + 2, fill);
     else clear_set(fill);
     stamp(it, 2);
-    // more than 42 bitmap rows among the 65: the rest is loaded in place, all of them before the first is stored
+    // more than kFqNB x kFqBP bitmap rows among the 65: the rest is loaded in place, two rows at a time
     if (c_nbm > (uint32_t)(kFqNB * kFqBP) && !(ablate & 8u)) {
-      constexpr int kMore = (kFxNR + kFqNB - 1) / kFqNB - kFqBP;  // 4
-      mm_u4 t[kMore];
-      uint32_t toff[kMore];
-#pragma unroll
-      for (int k = 0; k < kMore; ++k) {
-        const uint32_t e = bw + (uint32_t)kFqNB * (kFqBP + k);
-        toff[k] = ~0u;
-        if (e < c_nbm) {
-          const uint32_t row = T.bml[e];
-          uint32_t len;
-          const uint8_t* p = row_ptr(T, row, len);
-          t[k] = fx_ld_global16(p + (q * (uint32_t)kFxSB + lane16));
-          toff[k] = row * (uint32_t)kFxStride;
-        }
+      for (uint32_t e = bw + (uint32_t)(kFqNB * kFqBP); e < c_nbm; e += 2u * (uint32_t)kFqNB) {
+        const uint32_t e2 = e + (uint32_t)kFqNB;
+        const uint32_t row = fx_uniform(T.bml[e]), row2 = e2 < c_nbm ? fx_uniform(T.bml[e2]) : row;
+        uint32_t len;
+        const uint8_t* p = row_ptr(T, row, len);
+        const uint8_t* p2 = row_ptr(T, row2, len);
+        const mm_u4 t = fx_ld_global16(p + (q * (uint32_t)kFxSB + lane16));
+        const mm_u4 t2 = fx_ld_global16(p2 + (q * (uint32_t)kFxSB + lane16));
+        *reinterpret_cast<mm_u4*>(ring8 + (bufoff + lane16) + row * (uint32_t)kFxStride) = t;
+        if (e2 < c_nbm) *reinterpret_cast<mm_u4*>(ring8 + (bufoff + lane16) + row2 * (uint32_t)kFxStride) = t2;
       }
-#pragma unroll
-      for (int k = 0; k < kMore; ++k)
-        if (toff[k] != ~0u) *reinterpret_cast<mm_u4*>(ring8 + (bufoff + lane16) + toff[k]) = t[k];
     }
     stamp(it, 3);
     // run rows (each owned by one wave: its parity prefix follows its own toggles): the one loaded ahead, then the rest in place
@@ -490,15 +488,20 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
     issue(0, B0);
     issue(1, B1);
   }
-  for (uint32_t it = 0; it <= n_stage; ++it) {
-    if (it < n_stage && !(ablate & 16u)) {
-      const uint32_t ph = it % 3u;
-      if (ph == 0) bstage(it, B0, B2);
-      else if (ph == 1) bstage(it, B1, B0);
-      else bstage(it, B2, B1);
-    }
+  for (uint32_t it = 0; it <= n_stage; it += 3) {
+    if (it < n_stage && !(ablate & 16u)) bstage(it, B0, B2);
     __syncthreads();
     stamp(it, 5);
+    if (it + 1 <= n_stage) {
+      if (it + 1 < n_stage && !(ablate & 16u)) bstage(it + 1, B1, B0);
+      __syncthreads();
+      stamp(it + 1, 5);
+    }
+    if (it + 2 <= n_stage) {
+      if (it + 2 < n_stage && !(ablate & 16u)) bstage(it + 2, B2, B1);
+      __syncthreads();
+      stamp(it + 2, 5);
+    }
   }
   __syncthreads();  // the consumers' reduction barrier
 }

@@ -16,7 +16,7 @@ import datagen as D  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ab = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-prog = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # 1: the kernel that runs a prepared program (round 5), 0: round 4's
+prog = int(sys.argv[3]) if len(sys.argv) > 3 else 2  # 1: the kernel that runs a prepared program (round 5), 0: round 4's
 cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 3  # 3: config 3's rank-law rows; 4: config 4's log-uniform rows
 if cfg == 4:
     rows, ga, gb, filt, _ = D.config4_flat(n, mp="fork")

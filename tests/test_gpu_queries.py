@@ -664,13 +664,15 @@ def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
     batch.free()
 
 
-@pytest.fixture(params=[(1, 2048, 2, 1), (1, 64, 1, 1), (0, 2048, 2, 1), (1, 2048, 2, 0), (0, 2048, 2, 0)],
-                ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows", "heavy-shadows-round4-kernel", "no-shadows-round4-kernel"])
+@pytest.fixture(params=[(1, 2048, 2, 2), (1, 64, 1, 2), (0, 2048, 2, 2), (1, 2048, 2, 1), (0, 2048, 2, 1), (1, 2048, 2, 0), (0, 2048, 2, 0)],
+                ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows", "heavy-shadows-program-first-form", "no-shadows-program-first-form",
+                     "heavy-shadows-round4-kernel", "no-shadows-round4-kernel"])
 def shadow_mode(request, gpu_ctx):
     """Count matrix over encoded rows: run containers and long arrays as dense shadows built per batch on first use (default),
     the same with nearly every array shadowed (and one array item per group loaded ahead), and every container decoded in
-    every query (the round-2 behaviour); each on the kernel that runs a prepared program (round 5, the default) and two of
-    them on round 4's kernel, whose blocks build their work lists themselves (option matrix_fused_program = 0)."""
+    every query (the round-2 behaviour); each on the kernel that runs a prepared program with specialised producer waves (round
+    5, the default: option matrix_fused_program = 2), two of them on the first program-driven form (= 1) and on round 4's kernel,
+    whose blocks build their work lists themselves (= 0)."""
     gpu_ctx.set_option("matrix_shadow", request.param[0])
     gpu_ctx.set_option("matrix_shadow_array", request.param[1])
     gpu_ctx.set_option("matrix_shadow_apref", request.param[2])
@@ -679,7 +681,7 @@ def shadow_mode(request, gpu_ctx):
     gpu_ctx.set_option("matrix_shadow", 1)
     gpu_ctx.set_option("matrix_shadow_array", 2048)
     gpu_ctx.set_option("matrix_shadow_apref", 2)
-    gpu_ctx.set_option("matrix_fused_program", 1)
+    gpu_ctx.set_option("matrix_fused_program", 2)
 
 
 @pytest.mark.parametrize("a_dense,b_dense,f_mode", [(False, False, "mixed"), (True, False, "none"), (False, True, "dense"), (False, False, "none")])
