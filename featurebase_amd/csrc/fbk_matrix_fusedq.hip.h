@@ -68,59 +68,80 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
 
   if (wv < kFxConsumers) {
     // ============================== consumers ==============================
+    // The LDS reads of an octet are issued a whole octet ahead by hand (asm volatile, hand-counted s_waitcnt, the idiom of
+    // fbk_matrix_mfma.hip.h): written as plain C++ the scheduler moved every read down to its first use, and each of the eight
+    // octets of a stage then waited out a full LDS round trip — the consumers alone took 1.4 us per stage, more than twice
+    // what their 290 vector and 32 matrix instructions need (scripts/fused_ablate.py, profiles/r05_fused_ablate*.jsonl).
     const uint32_t r = lane & 31, g = lane >> 5;
     mm_v16f acc0{}, acc1{}, acc2{}, acc3{};
     constexpr uint32_t M4 = 0x11111111u;
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)&ring[0];
+    // rows as 16-byte pieces: this wave's K range is pieces 16 wv .. 16 wv + 15 of every row; octet o = pieces 16 wv + 2 o + g
+    const uint32_t addrA = lds0 + r * (uint32_t)kFxStride + (16u * (uint32_t)wv + g) * 16u;  // row r of A; row 32 + r of B is 32 strides on
+    const uint32_t addrF = lds0 + 64u * (uint32_t)kFxStride + (16u * (uint32_t)wv + g) * 16u;
+    const uint32_t addrFz = lds0 + 64u * (uint32_t)kFxStride + (16u * (uint32_t)wv + ((uint32_t)lane & 15u)) * 16u;
+    mm_u4 zero4 = mm_u4{0, 0, 0, 0};
+    asm volatile("" : "+v"(zero4));
+    struct Oct {
+      mm_u4 a, b, f;
+    };
+    constexpr int kLdOps = (HAS_F ? 3 : 2) + 2;  // LDS instructions of one octet's loads: the reads and the two clean-up writes behind them
+    constexpr int kBOff = 32 * kFxStride;        // (33 280: the offset field of a DS instruction is 16 bits)
+    auto issue = [&](Oct& o, uint32_t bufoff, int t) {
+      const uint32_t aa = addrA + bufoff, ff = addrF + bufoff;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o.a) : "v"(aa), "n"(32 * t));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o.b) : "v"(aa), "n"(kBOff + 32 * t));
+      if (HAS_F) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o.f) : "v"(ff), "n"(32 * t));
+      // clean behind the read (LDS operations of one wave execute in order): the producers get the buffer back zeroed
+      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aa), "v"(zero4), "n"(32 * t) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aa), "v"(zero4), "n"(kBOff + 32 * t) : "memory");
+    };
+    auto landed = [&](Oct& o, bool more_behind) {  // o's reads are complete (LDS returns in order)
+      if (more_behind) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(kLdOps) : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(o.a));
+      asm volatile("" : "+v"(o.b));
+      if (HAS_F) asm volatile("" : "+v"(o.f));
+    };
+    auto octet = [&](const Oct& o) {
+      uint32_t a[4] = {o.a[0], o.a[1], o.a[2], o.a[3]};
+      const uint32_t bb[4] = {o.b[0], o.b[1], o.b[2], o.b[3]};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) a[d] = HAS_F ? (a[d] & o.f[d]) : a[d];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mm_v8i oa, ob;  // the instruction reads the first four registers of an FP4 operand
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          oa[d] = (int)(k < 3 ? (a[d] & (M4 << k)) : ((a[d] >> 3) & M4));
+          ob[d] = (int)(k < 3 ? (bb[d] & (M4 << k)) : ((bb[d] >> 3) & M4));
+        }
+        if (k == 0) acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        else if (k == 1) acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        else if (k == 2) acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc2, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        else acc3 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc3, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+    };
     __syncthreads();  // (the producers' set-up barrier)
     for (uint32_t it = 0; it <= n_stage; ++it) {
       stamp(it, 0);
       if (it >= 1 && !(ablate & 1u)) {
-        uint4* buf = ring + ((it - 1) & 1u) * (uint32_t)(kFxBuf / 16);
-        uint4* rowA = buf + r * (uint32_t)(kFxStride / 16) + 16u * (uint32_t)wv + g;
-        uint4* rowB = rowA + 32 * (kFxStride / 16);
-        uint4* rowF = buf + 64 * (kFxStride / 16) + 16u * (uint32_t)wv;
-        auto ld = [&](int o, uint4& va, uint4& vb, uint4& vf) {
-          va = rowA[2 * o];
-          vb = rowB[2 * o];
-          if (HAS_F) vf = rowF[2 * o + g];
-          rowA[2 * o] = uint4{0, 0, 0, 0};  // clean behind the read (LDS operations of one wave execute in order)
-          rowB[2 * o] = uint4{0, 0, 0, 0};
-        };
-        auto octet = [&](const uint4& va, const uint4& vb, const uint4& vf) {
-          uint32_t a[4] = {va.x, va.y, va.z, va.w};
-          const uint32_t bb[4] = {vb.x, vb.y, vb.z, vb.w};
-          const uint32_t f[4] = {vf.x, vf.y, vf.z, vf.w};
-#pragma unroll
-          for (int d = 0; d < 4; ++d) a[d] = HAS_F ? (a[d] & f[d]) : a[d];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            mm_v8i oa, ob;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-              oa[d] = (int)(k < 3 ? (a[d] & (M4 << k)) : ((a[d] >> 3) & M4));
-              ob[d] = (int)(k < 3 ? (bb[d] & (M4 << k)) : ((bb[d] >> 3) & M4));
-            }
-            if (k == 0) acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-            else if (k == 1) acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-            else if (k == 2) acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc2, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-            else acc3 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, ob, acc3, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-          }
-        };
-        uint4 xa, xb, xf = uint4{0, 0, 0, 0}, ya, yb, yf = uint4{0, 0, 0, 0};
-        ld(0, xa, xb, xf);
-        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t bufoff = ((it - 1) & 1u) * (uint32_t)kFxBuf;
+        Oct X, Y;
+        X.f = Y.f = mm_u4{0, 0, 0, 0};
+        issue(X, bufoff, 0);
 #pragma unroll
         for (int o = 0; o < 8; o += 2) {
-          ld(o + 1, ya, yb, yf);
-          __builtin_amdgcn_sched_barrier(0);
-          octet(xa, xb, xf);
-          __builtin_amdgcn_sched_barrier(0);
-          if (o + 2 < 8) ld(o + 2, xa, xb, xf);
-          __builtin_amdgcn_sched_barrier(0);
-          octet(ya, yb, yf);
-          __builtin_amdgcn_sched_barrier(0);
+          issue(Y, bufoff, o + 1);
+          landed(X, true);
+          octet(X);
+          if (o + 2 < 8) issue(X, bufoff, o + 2);
+          landed(Y, o + 2 < 8);
+          octet(Y);
         }
-        if (HAS_F) rowF[lane & 15] = uint4{0, 0, 0, 0};
+        // the filter row's 16 pieces of this wave's K range (all lanes, four per piece, the same zeros)
+        if (HAS_F) asm volatile("ds_write_b128 %0, %1" ::"v"(addrFz + bufoff), "v"(zero4) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the compiler does not know of the hand-issued writes: they are done before the barrier)
       }
       stamp(it, 1);
       __syncthreads();

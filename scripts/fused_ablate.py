@@ -37,7 +37,7 @@ batch = ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
 F = ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
 fidx = np.arange(n)
 out = {"config": cfg, "shards": n, "encoded_bytes": int(rows.bytes + filt.bytes), "variants": []}
-for prog in (2, 1):
+for prog in (2,):
     ctx.set_option("matrix_fused_program", prog)
     for ab, what in ((0, "everything"), (1, "no consumer arithmetic"), (2, "no array items"), (8, "no bitmap rows"), (10, "no array items, no bitmap rows"),
                      (16, "producers: barriers only"), (17, "barriers only (consumers and producers)"), (3, "no consumer arithmetic, no array items")):
