@@ -94,8 +94,10 @@ struct FbkOptions {
   int64_t matrix_shadow_array = 2048;    //   arrays longer than this are heavy (run containers always are)
   int64_t matrix_shadow_max_mb = 16384;  //   no shadow for a batch that would need more than this (nor more than twice its arena, nor a quarter of the free device memory)
   int64_t matrix_shadow_arena_x = 8;     //   ... nor more than this many times the batch's own arena (0: no such rule); fbk_batch_info_ex reports what a batch got
-  int64_t matrix_shadow_apref = 2;       //   array items per group loaded a stage ahead when rows are shadowed (1 or 2; filtered queries: 323 vs 349 us, profiles/r03_fused_shadow_ab.txt)
-  int64_t matrix_fused_program = 2;      // count matrix over encoded rows: 2 the program-driven kernel with specialised producer waves and loads two stages ahead (fbk_matrix_fusedq.hip.h), 1 the kernel runs a prepared program (k_fused_program: row tables + resolved array items per (shard, tile, slot), built once per prepared query / per one-shot call; fbk_matrix_fusedp.hip.h), 0 every block builds its work lists itself (round 4's kernel: cross-check, A/B runs)
+#ifdef FBK_EXPERIMENTS
+  int64_t matrix_shadow_apref = 2;       //   (round 4's kernel only) array items per group loaded a stage ahead when rows are shadowed
+#endif
+  int64_t matrix_fused_program = 2;      // count matrix over encoded rows: 2 the program-driven kernel with specialised producer waves and loads two stages ahead (fbk_matrix_fusedq.hip.h), 1 its first form (fbk_matrix_fusedp.hip.h: the cross-check); both run a prepared program (k_fused_program: row tables + resolved array items per (shard, tile, slot), built once per prepared query / per one-shot call).  (0, experiments build only: round 4's kernel, every block builds its work lists itself)
 #ifdef FBK_EXPERIMENTS  // (scripts/ build their own variant with -DFBK_EXPERIMENTS into build_variants/; the product library has neither the options nor the device branches)
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
 #endif
@@ -693,8 +695,12 @@ const OptionDesc kOptions[] = {
     {"matrix_shadow_array", &FbkOptions::matrix_shadow_array, 0, 65536},
     {"matrix_shadow_max_mb", &FbkOptions::matrix_shadow_max_mb, 0, 1 << 20},
     {"matrix_shadow_arena_x", &FbkOptions::matrix_shadow_arena_x, 0, 1 << 20},
+#ifdef FBK_EXPERIMENTS
     {"matrix_shadow_apref", &FbkOptions::matrix_shadow_apref, 1, 2},
     {"matrix_fused_program", &FbkOptions::matrix_fused_program, 0, 2},
+#else
+    {"matrix_fused_program", &FbkOptions::matrix_fused_program, 1, 2},
+#endif
 #ifdef FBK_EXPERIMENTS
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
 #endif

@@ -153,11 +153,11 @@ int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
  * matrix_fp4, matrix_shadow (1: the count matrix over encoded rows reads run containers and arrays of more
  * than matrix_shadow_array values through dense shadows built per batch on first use — up to
  * matrix_shadow_max_mb of device memory per batch and matrix_shadow_arena_x times its own arena (0: no such rule),
- * matrix_shadow_apref array items loaded a stage ahead; fbk_batch_memory reports what a batch got; 0: every container
- * is decoded in every query), matrix_fused_program (2, the default, and 1: that kernel runs a prepared program — row tables and
- * resolved array items per (shard, tile, container slot), built by k_fused_program on a prepared query's first run and again
- * when a batch was rewritten, per call otherwise; 2 with producer waves specialised on array / bitmap rows and their loads two
- * stages ahead, 1 the first form; 0: round 4's kernel, every block builds its work lists itself),
+ * fbk_batch_memory reports what a batch got; 0: every container
+ * is decoded in every query), matrix_fused_program (that kernel runs a prepared program — row tables and resolved array items
+ * per (shard, tile, container slot), built by k_fused_program on a prepared query's first run and again when a batch was
+ * rewritten, per call otherwise: 2, the default, with producer waves specialised on array / bitmap rows and their loads two
+ * stages ahead; 1 the first form, kept as the cross-check),
  * bsi_range_sum_two_pass, bsi_half_waves, bsi_planes_ahead, topk_device_sort, sparse_paths,
  * setop_direct_encode, setop_probe, setop_compact, fold_encode, pair_kernels, pair_wpb, pair_resolve, pair_run_probe, pair_lean,
  * query_resolve, upload_chunk_mb, upload_threads, count_range_reference_quirk, topn_semantics.  Every value of every

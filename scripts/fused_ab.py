@@ -42,7 +42,6 @@ for name, d, p, nr, g, fd, fp, n, nbytes in sets:
     for shadow, thr, apref in ((1, 2048, 2), (0, 2048, 2)):
         ctx.set_option("matrix_shadow", shadow)
         ctx.set_option("matrix_shadow_array", thr)
-        ctx.set_option("matrix_shadow_apref", apref)
         batch = ctx.upload_flat(d, p, nr)  # (a shadow is built once per batch, with the options in force then)
         F = ctx.upload_flat(fd, fp, n)
         for prog in (2, 1, 2):

@@ -664,23 +664,21 @@ def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
     batch.free()
 
 
-@pytest.fixture(params=[(1, 2048, 2, 2), (1, 64, 1, 2), (0, 2048, 2, 2), (1, 2048, 2, 1), (0, 2048, 2, 1), (1, 2048, 2, 0), (0, 2048, 2, 0)],
-                ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows", "heavy-shadows-program-first-form", "no-shadows-program-first-form",
-                     "heavy-shadows-round4-kernel", "no-shadows-round4-kernel"])
+@pytest.fixture(params=[(1, 2048, 2), (1, 64, 2), (0, 2048, 2), (1, 2048, 1), (1, 64, 1), (0, 2048, 1)],
+                ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows", "heavy-shadows-first-form", "shadows-of-arrays-over-64-values-first-form",
+                     "no-shadows-first-form"])
 def shadow_mode(request, gpu_ctx):
-    """Count matrix over encoded rows: run containers and long arrays as dense shadows built per batch on first use (default),
-    the same with nearly every array shadowed (and one array item per group loaded ahead), and every container decoded in
-    every query (the round-2 behaviour); each on the kernel that runs a prepared program with specialised producer waves (round
-    5, the default: option matrix_fused_program = 2), two of them on the first program-driven form (= 1) and on round 4's kernel,
-    whose blocks build their work lists themselves (= 0)."""
+    """Count matrix over encoded rows: run containers and long arrays as dense shadows built per batch on first use (default), the
+    same with nearly every array shadowed (more than 42 bitmap rows per slot: the in-place path of the bitmap waves), and every
+    container decoded in every query (run rows, long arrays); each on the program-driven kernel with specialised producer waves
+    (round 5's default: option matrix_fused_program = 2) and on its first form (= 1), which runs the same program with twelve
+    general producer waves — two kernels that share nothing but the program and the consumers' arithmetic."""
     gpu_ctx.set_option("matrix_shadow", request.param[0])
     gpu_ctx.set_option("matrix_shadow_array", request.param[1])
-    gpu_ctx.set_option("matrix_shadow_apref", request.param[2])
-    gpu_ctx.set_option("matrix_fused_program", request.param[3])
+    gpu_ctx.set_option("matrix_fused_program", request.param[2])
     yield request.param
     gpu_ctx.set_option("matrix_shadow", 1)
     gpu_ctx.set_option("matrix_shadow_array", 2048)
-    gpu_ctx.set_option("matrix_shadow_apref", 2)
     gpu_ctx.set_option("matrix_fused_program", 2)
 
 
