@@ -76,6 +76,27 @@ for name, d, p, nr, g, fd, fp, n, nbytes in sets:
             print(name, res[-1], file=sys.stderr, flush=True)
             q.free()
             qn.free()
+        if shadow == 1:  # slots per block of the default kernel (16: one block per shard; fewer: more, shorter blocks)
+            sweep = []
+            ctx.set_option("matrix_fused_program", 2)
+            for spb in (16, 8, 4):
+                ctx.set_option("matrix_spb", spb)
+                q = ctx.prepare_count_matrix(batch, g[:, :32], batch, g[:, 32:], F, fidx)
+                q.run()
+                ok = bool((q.read() == ref).all())
+                ctx.set_option("time_kernels", 1)
+                ts = []
+                for _ in range(10):
+                    q.run()
+                    torch.cuda.synchronize()
+                    ts.append(ctx.get_option("last_kernel_ns") / 1e3)
+                ctx.set_option("time_kernels", 0)
+                ts.sort()
+                sweep.append({"spb": spb, "kernel_us": ts[len(ts) // 2], "kernel_us_min": ts[0], "same_counts": ok})
+                print(name, "spb", sweep[-1], file=sys.stderr, flush=True)
+                q.free()
+            ctx.set_option("matrix_spb", 0)
+            out.setdefault("spb_sweep", {})[name] = sweep
         batch.free()
         F.free()
     out["sets"][name] = {"shards": n, "encoded_bytes": int(nbytes), "variants": res}
