@@ -361,13 +361,13 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         dd = d3
         heavy = int((((dd["type"] == 3) & (dd["n"] != 0)) | ((dd["type"] == 1) & (dd["len"] > 2048))).sum())
         heavy_payload = int((dd["len"][(dd["type"] == 3) & (dd["n"] != 0)].astype(np.int64) * 4).sum() + (dd["len"][(dd["type"] == 1) & (dd["len"] > 2048)].astype(np.int64) * 2).sum())
-        out.append(_entry("c3.groupby32x32|config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel, heavy containers through dense shadows (default)", "k_count_matrix_fused",
+        out.append(_entry("c3.groupby32x32|config3 rows, GroupBy 32 x 32 (+ filter) on mixed rows: decode inside the matrix-core kernel, heavy containers through dense shadows (default)", "k_count_matrix_fusedq",
                           nbytes + 8 * 1024 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 1024 / (g["median"] * 1e-6),
                           call_us=call_us(lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx)),
                           heavy_row_shadows={"containers": heavy, "resident_bytes": heavy * 8192 + 16 * 16 * rows.n_rows, "built": "once per batch, on the first count matrix that reads it",
                                              "bytes_read_per_query": nbytes - heavy_payload + heavy * 8192,
                                              "note": "frac / kernel_frac are quoted on the ENCODED bytes (the algorithmic bytes of the query); the kernel itself reads bytes_read_per_query"},
-                          hbm_note="the kernel is bound by vector instruction issue, not by HBM: reading the run containers and long arrays as 8 KiB bitmaps instead of decoding them in every query trades bytes for issue slots (DESIGN.md section 9; option matrix_shadow=0: 397 us)", **common))
+                          hbm_note="round 5: the kernel runs a prepared program (k_fused_program) with producer waves specialised on array / bitmap rows and loads two stages ahead; with the heavy rows shadowed the bytes it reads (bytes_read_per_query) take ~180 us at the achievable HBM rate, the consumers alone ~180 us (scripts/fused_ablate.py; DESIGN.md section 9)", **common))
         # row pairs of the same rows (RowSegment.IntersectionCount / Intersect on non-dense rows): rows 0..31 against rows 32..63 of every shard
         pa, pb = groups[:, :32].reshape(-1), groups[:, 32:].reshape(-1)
         plan = ctx.plan(batch, pa, batch, pb)
@@ -518,7 +518,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         types = np.bincount(d4["type"], minlength=4)
         g, w, kq = _timed_query(torch, stream, q4m, max(5, iters // 2), ctx)
         out.append(_entry(f"c4.loguniform_slice|config4 slice as SURVEY 8d writes it: {n4m} shards x (32 x 32 rows, densities log-uniform [0.001, 0.5] + filter p = 0.5), IntersectionCount matrix on ENCODED rows",
-                          "k_count_matrix_fused", nbytes + 8 * n_a * n_b * n4m, g, w, kq, shards=n4m, host_gen_s=gen_s, upload_s=up_s, set_ops_per_s=n4m * 16 * n_a * n_b / (g["median"] * 1e-6),
+                          "k_count_matrix_fusedq", nbytes + 8 * n_a * n_b * n4m, g, w, kq, shards=n4m, host_gen_s=gen_s, upload_s=up_s, set_ops_per_s=n4m * 16 * n_a * n_b / (g["median"] * 1e-6),
                           containers={"array": int(types[1]), "bitmap": int(types[2]), "run": int(types[3])}, cpu_baseline=cpu4m, timing=timing_note,
                           note="frac is quoted on the ENCODED bytes (arrays 2 n, bitmaps 8192: the algorithmic bytes of SURVEY 8d); the dense-only slice above reads 2.1 x these bytes per shard",
                           parity=f"every one of the {n4m} per-shard matrices bit-exact against the oracle" if want_cpu else "unchecked (--no-cpu-baseline)"))
@@ -731,7 +731,7 @@ def config4_strong_mixed(torch, dist, fdist, dev, ctx, stream, rank, world, args
         b.free()
     return {"id": "loguniform", "rows": f"{n_a} x {n_b} + filter row per shard, densities log-uniform [0.001, 0.5] (SURVEY 8d), encoded: {int(types[1])} array / {int(types[2])} bitmap / {int(types[3])} run containers on this rank",
             "shards_total": total, "shards_this_rank": ns, "slices": len(qs), "resident_bytes_this_rank": int(nbytes), "make_resident_s": resident_s,
-            "ms_per_query_pipelined": tv[0] * 1e3, "set_ops_per_s": total * 16 * n_a * n_b / tv[0] if tv[0] else None, "kernel": "k_count_matrix_fused", "kernel_us": k_med,
+            "ms_per_query_pipelined": tv[0] * 1e3, "set_ops_per_s": total * 16 * n_a * n_b / tv[0] if tv[0] else None, "kernel": "k_count_matrix_fusedq", "kernel_us": k_med,
             "kernel_us_max_over_ranks": tv[1], "kernel_frac": (nbytes / (k_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) if k_med else None, "parity": parity,
             "collectives": res["collectives"], "latency_s": res["latency_s"]}
 
