@@ -1118,10 +1118,12 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
   return ((u64)hi << 32) | lo;
 }
 
+constexpr int kBsiValStride = 144;  // bytes per plane row of the staging tile (128 + 16)
 __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ rows,
                                                    uint32_t n_shards, uint32_t depth, const uint8_t* __restrict__ farena,
                                                    const uint32_t* __restrict__ frows, long long* __restrict__ out,
                                                    u64 out_cap, u64* __restrict__ cursor, uint32_t split) {
+  __shared__ ulonglong2 stage[4][64 * kBsiValStride / 16];  // 4 x 9216 bytes: one 64-plane x 128-byte tile per wave
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t part = blockIdx.x % split, cell = blockIdx.x / split;  // split: 1, 2, 4, 8 or 16
@@ -1132,7 +1134,6 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
   const uint8_t* ex = arena + (uint64_t)rows[shard] * rowBytes + slot * 8192ull;
   const uint8_t* sg = ex + rowBytes;
   const uint8_t* fl = farena ? farena + (uint64_t)frows[shard] * rowBytes + slot * 8192ull : nullptr;
-  const uint8_t* mine = ex + (uint64_t)(2 + lane) * rowBytes;  // plane `lane` (unused when lane >= depth)
   for (int round = (int)part * rounds; round < (int)(part + 1) * rounds; ++round) {
     const uint32_t w0 = (uint32_t)wv * 256u + (uint32_t)round * 16u;  // first word of this round
     // the 16 exists / filter / sign words of the round: lanes 0..15 fetch one each
@@ -1154,19 +1155,29 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
     u64 basepos = 0;
     if (lane == 0) basepos = atomicAdd(cursor, (u64)total);
     basepos = ((u64)__shfl((int)(uint32_t)(basepos >> 32), 0, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)basepos, 0, kWave);
-    // this lane's plane: 16 words = one 128-byte line
+    // this lane's plane: 16 words = one 128-byte line.  Loaded COALESCED — instruction j brings the lines of planes 8 j .. 8 j + 7,
+    // eight lanes per line — and handed to lane `plane` through the wave's LDS staging (row stride 144 B: the eight lanes of a
+    // 16-byte-per-lane access fall into eight different bank groups both ways).  Round 4's form had every lane read its own
+    // plane's line directly: 64 different lines per load instruction, 0.03 of the HBM rate.
     u64 pw[16];
-    if (lane < (int)depth) {
-      const ulonglong2* q = reinterpret_cast<const ulonglong2*>(mine + (uint64_t)w0 * 8);
+    {
+      uint8_t* stg = reinterpret_cast<uint8_t*>(&stage[wv][0]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int plane = 8 * j + (lane >> 3), piece = lane & 7;
+        ulonglong2 v;
+        v.x = v.y = 0;
+        if (plane < (int)depth) v = ld_stream(reinterpret_cast<const ulonglong2*>(ex + (uint64_t)(2 + plane) * rowBytes + (uint64_t)w0 * 8) + piece);
+        *reinterpret_cast<ulonglong2*>(stg + plane * kBsiValStride + piece * 16) = v;
+      }
+      wave_lds_sync();
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const ulonglong2 v = ld_stream(&q[k]);
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(stg + lane * kBsiValStride + k * 16);
         pw[2 * k] = v.x;
         pw[2 * k + 1] = v.y;
       }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) pw[k] = 0;
+      wave_lds_sync();  // (the next round writes the staging again)
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
