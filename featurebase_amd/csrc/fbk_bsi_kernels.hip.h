@@ -1134,6 +1134,34 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
   const uint8_t* ex = arena + (uint64_t)rows[shard] * rowBytes + slot * 8192ull;
   const uint8_t* sg = ex + rowBytes;
   const uint8_t* fl = farena ? farena + (uint64_t)frows[shard] * rowBytes + slot * 8192ull : nullptr;
+  // Where this block's values go: ONE atomic on the global cursor per block (round 4 and the first cut of round 5 took one per wave and
+  // round: 4096 atomics on one address for a 4-shard field — ~50 us of serialised L2 round trips, which is what the kernel's 70 us were
+  // once it had enough blocks).  Each wave adds up the columns of its rounds (exists ∩ filter, 16 words per round), the block reserves
+  // the sum, a wave starts behind the waves before it.
+  __shared__ uint32_t wtot[4];
+  __shared__ u64 block_base;
+  {
+    uint32_t mine_tot = 0;
+    for (int round = (int)part * rounds; round < (int)(part + 1) * rounds; ++round) {
+      const uint32_t w0 = (uint32_t)wv * 256u + (uint32_t)round * 16u;
+      u64 e = 0;
+      if (lane < 16) {
+        e = reinterpret_cast<const u64*>(ex)[w0 + lane];
+        if (fl) e &= reinterpret_cast<const u64*>(fl)[w0 + lane];
+      }
+      mine_tot += (uint32_t)__popcll(e);
+    }
+    mine_tot = wave_reduce_add(mine_tot);
+    if (lane == 0) wtot[wv] = mine_tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t t = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+      block_base = t ? atomicAdd(cursor, (u64)t) : 0ull;
+    }
+    __syncthreads();
+  }
+  u64 wave_pos = block_base;
+  for (int w = 0; w < wv; ++w) wave_pos += wtot[w];
   for (int round = (int)part * rounds; round < (int)(part + 1) * rounds; ++round) {
     const uint32_t w0 = (uint32_t)wv * 256u + (uint32_t)round * 16u;  // first word of this round
     // the 16 exists / filter / sign words of the round: lanes 0..15 fetch one each
@@ -1152,9 +1180,8 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
     }
     const uint32_t total = __shfl(incl, 15, kWave);
     if (total == 0) continue;  // wave-uniform: no column of these 1024 has a value
-    u64 basepos = 0;
-    if (lane == 0) basepos = atomicAdd(cursor, (u64)total);
-    basepos = ((u64)__shfl((int)(uint32_t)(basepos >> 32), 0, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)basepos, 0, kWave);
+    const u64 basepos = wave_pos;
+    wave_pos += total;
     // this lane's plane: 16 words = one 128-byte line.  Loaded COALESCED — instruction j brings the lines of planes 8 j .. 8 j + 7,
     // eight lanes per line — and handed to lane `plane` through the wave's LDS staging (row stride 144 B: the eight lanes of a
     // 16-byte-per-lane access fall into eight different bank groups both ways).  Round 4's form had every lane read its own
