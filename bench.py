@@ -338,23 +338,13 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         def call_us(fn, n=max(5, iters // 2)):
             return _timed_call(torch, stream, fn, n)[0]
 
-        # (A/B in the same process: option query_resolve = 0 — the kernel gathers its 64 descriptors through the row list, as the one-shot
-        # call does — against the prepared query's resolved row records, k_resolve_rows)
-        def without_records(q):
-            ctx.set_option("query_resolve", 0)
-            r = _timed_query(torch, stream, q, iters, ctx)[2]
-            ctx.set_option("query_resolve", 1)
-            q.run()
-            return r
-
         g, w, kq = _timed_query(torch, stream, q_fold, iters, ctx)
         out.append(_entry("c3.union64_icount|config3: Union-of-64 rows then IntersectionCount(filter), fused, mixed array/run/bitmap rows (rank-law density 0.001-0.5)",
                           "k_fold_scatter<OR>", nbytes + 8 * n3, g, w, kq, set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), cpu_baseline=cpu3,
-                          call_us=call_us(lambda: ctx.union_n_intersection_count(batch, groups, F, fidx)), kernel_us_without_row_records=without_records(q_fold), **common))
+                          call_us=call_us(lambda: ctx.union_n_intersection_count(batch, groups, F, fidx)), **common))
         g, w, kq = _timed_query(torch, stream, q_top, iters, ctx)
         out.append(_entry("c3.rows_vs_filter|config3 rows, TopN/TopK shape: 64 rows x 1 filter row per shard", "k_rows_vs_filter", nbytes + 8 * 64 * n3, g, w, kq,
-                          set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), call_us=call_us(lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1))),
-                          kernel_us_without_row_records=without_records(q_top), **common))
+                          set_ops_per_s=n3 * 16 * 64 / (g["median"] * 1e-6), call_us=call_us(lambda: ctx.count_matrix(batch, groups, F, fidx.reshape(-1, 1))), **common))
         g, w, kq = _timed_query(torch, stream, q_gb, max(5, iters // 2), ctx)
         # heavy containers (run containers, arrays of more than 2048 values) are read through dense shadows the library builds per
         # batch on the first count matrix (option matrix_shadow, fbk.hip heavy_shadow): what that costs in memory and traffic
@@ -376,16 +366,8 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         if want_cpu:
             assert (pc == PB.intersection_count(OA, pa, OA, pb)).all(), "config 3 row pairs: GPU and oracle disagree"
         g, w = _timed_call(torch, stream, plan.intersection_count, iters)
-        # A/B in the same process: option pair_lean = 4 — the plan sorts its items by class on the host (once) and the array x array
-        # items of <= 1024 / 2048 values go to the lean kernel k_icount_aa (4 KiB table, 32 waves per CU), the rest to k_icount2.
-        # Off by default: ~1 ms of host work per plan to save a few microseconds per run
-        ctx.set_option("pair_lean", 4)
-        g_lean, _ = _timed_call(torch, stream, plan.intersection_count, iters)
-        assert (plan.read() == pc).all(), "config 3 row pairs: the class-sorted launch pair and the single kernel disagree"
-        ctx.set_option("pair_lean", 0)
-        plan.intersection_count()
         out.append(_entry(f"c3.pairs_icount|config3 rows, {pa.size} row pairs (rows 0..31 x rows 32..63 of every shard): IntersectionCount, launch-only plan", "k_icount2", rows.bytes, g, w,
-                          set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), launch_us_with_the_items_sorted_by_class=g_lean, **common))
+                          set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), **common))
         g, w = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND), iters)
         out.append(_entry(f"c3.pairs_intersect_cells|config3 rows, {pa.size} row pairs: Intersect materialised (8 KiB cells), launch-only plan", "k_setop2<AND>", rows.bytes + pa.size * 16 * 8192, g, w,
                           set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), **common))
@@ -400,12 +382,6 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             assert (PB.RowSet.from_flat(ds, ps_, nrs).words() == eo.words()).all(), "config 3 row pairs, Intersect + optimize: bit content differs from the oracle"
             eo.free()
         g, w = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND, L.SETOP_OPTIMIZE), iters)
-        # A/B in the same process: option setop_probe = 0 decodes both operands of every item into 8 KiB fragments (the form every
-        # other type pair takes); 1 (shipped) lets an array operand probe the other's table and writes the survivors as they come
-        ctx.set_option("setop_probe", 0)
-        g_frag, _ = _timed_call(torch, stream, lambda: plan.setop(L.OP_AND, L.SETOP_OPTIMIZE), iters)
-        ctx.set_option("setop_probe", 1)
-        plan.setop(L.OP_AND, L.SETOP_OPTIMIZE)
         # for scale: the one-shot call with optimize() inside the kernel, and with the round-2/3 pipeline (bitmap / small-array cells,
         # then the separate re-encode pass: plan, two scans, a host round trip for the arena size, write)
         c_in = call_us(lambda: ctx.setop(L.OP_AND, batch, pa, batch, pb, L.SETOP_OPTIMIZE)[0].free())
@@ -414,7 +390,7 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
         ctx.set_option("setop_direct_encode", 2)
         out.append(_entry(f"c3.pairs_intersect_optimize|config3 rows, {pa.size} row pairs: Intersect materialised + optimize() inside the kernel (only the encoded containers are written), launch-only plan", "k_setop2<AND> (optimize)",
                           rows.bytes + so_bytes, g, w, set_ops_per_s=pa.size * 16 / (g["median"] * 1e-6), output_payload_bytes=so_bytes, call_us=c_in,
-                          call_us_with_the_separate_reencode_pass=c_sep, launch_us_with_both_operands_decoded_into_fragments=g_frag, **common))
+                          call_us_with_the_separate_reencode_pass=c_sep, **common))
         plan.free()
         # Union-of-64 MATERIALISED + optimize(): the prepared query (group lists and the output batch resident: memset + one launch of the
         # fold kernel, which encodes in its epilogue) beside the one-shot call; every result container compared with the oracle's
@@ -479,10 +455,15 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             for o in (OA, OB, OF):
                 o.free()
         nbytes = n4 * (n_a + n_b + 1) * 16 * 8192
-        g, w, kq = _timed_query(torch, stream, q4, max(5, iters // 2), ctx)
+        # (as for the log-uniform slice below: the first launches after the rows were written run 4-15 % slower than the sustained
+        # rate; the entry's kernel_us is the SUSTAINED one — SURVEY 8d's protocol is "warm-up, then >= 20 timed" — the first five
+        # launches are reported beside it)
+        _, _, kq4_first = _timed_query(torch, stream, q4, 5, ctx, warm=0)
+        g, w, kq = _timed_query(torch, stream, q4, 20, ctx, warm=10)
         out.append(_entry(f"c4.dense_slice|config4 slice: {n4} shards x (32 x 32 rows + filter), dense bitmaps, IntersectionCount matrix", "k_count_matrix_mfma",
                           nbytes + 8 * n_a * n_b * n4, g, w, kq, shards=n4, host_gen_s=gen_s, set_ops_per_s=n4 * 16 * n_a * n_b / (g["median"] * 1e-6),
                           pair_bits_scanned_GBps=n4 * n_a * n_b * 2 * 16 * 8192 / (g["median"] * 1e-6) / 1e9, cpu_baseline=cpu4, timing=timing_note,
+                          kernel_us_first_launches=kq4_first,
                           call_us=_timed_call(torch, stream, lambda: ctx.count_matrix(A, ra, B, rb, F, rf), 5)[0],
                           parity=f"every one of the {n4} per-shard matrices bit-exact against the oracle" if want_cpu else "cell (3,5) vs numpy over all shards"))
         q4.free()

@@ -26,7 +26,7 @@
 #include "fbk_matrix_kernels.hip.h"
 #include "fbk_matrix_mfma.hip.h"
 #include "fbk_matrix_fused.hip.h"
-#include "fbk_matrix_fusedp.hip.h"
+#include "fbk_matrix_fused.hip.h"
 #include "fbk_matrix_fusedq.hip.h"
 #include "fbk_wire_kernels.hip.h"
 
@@ -80,13 +80,9 @@ inline uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
 // afterwards only through fbk_set_option: no entry point calls getenv.
 struct FbkOptions {
   int64_t dense_spb = 16;                // slots per block of k_icount_dense: 1|2|4|8|16
-  int64_t fold_register = 0;             // 1: register-accumulating fold kernel for every op (A/B runs)
-  int64_t fold_encode = 1;               // n-way Union / Xor / Difference + optimize(): 1 encode in the fold kernel's epilogue, 0 the separate re-encode pass (cross-check)
-  int64_t matrix_valu = 0;               // 1: vector-ALU count-matrix kernel instead of the matrix cores (A/B runs)
   int64_t matrix_spb = 0;                // slots per block of the dense count matrix; 0 = chosen per launch
   int64_t matrix_pass_kb = 1 << 20;      // per-shard matrices are produced in passes of at most this many KiB
-  int64_t matrix_densify = -1;           // encoded rows: 1 densify + dense kernel, 0 generic pair kernel, -1 cost model
-  int64_t matrix_fused = -1;             // encoded rows: 1 decode inside the matrix-core kernel, 0 never, -1 cost model
+  int64_t matrix_fused = -1;             // count matrix over encoded rows: 1 decode inside the matrix-core kernel, 0 the generic pair kernel, -1 by the matrix size
   int64_t matrix_fp4 = -1;               // dense count matrix on the FP4 matrix instruction: 1 always, 0 never, -1 when it has several tiles
   int64_t time_kernels = 0;              // 1: HIP events around the dominant kernel of a query-level call (count matrix, fold, BSI range / sum)
   int64_t last_kernel_ns = 0;            //    ... read its duration back here (fbk_get_option) after the call
@@ -94,34 +90,21 @@ struct FbkOptions {
   int64_t matrix_shadow_array = 2048;    //   arrays longer than this are heavy (run containers always are)
   int64_t matrix_shadow_max_mb = 16384;  //   no shadow for a batch that would need more than this (nor more than twice its arena, nor a quarter of the free device memory)
   int64_t matrix_shadow_arena_x = 8;     //   ... nor more than this many times the batch's own arena (0: no such rule); fbk_batch_info_ex reports what a batch got
-#ifdef FBK_EXPERIMENTS
-  int64_t matrix_shadow_apref = 2;       //   (round 4's kernel only) array items per group loaded a stage ahead when rows are shadowed
-#endif
-  int64_t matrix_fused_program = 2;      // count matrix over encoded rows: 2 the program-driven kernel with specialised producer waves and loads two stages ahead (fbk_matrix_fusedq.hip.h), 1 its first form (fbk_matrix_fusedp.hip.h: the cross-check); both run a prepared program (k_fused_program: row tables + resolved array items per (shard, tile, slot), built once per prepared query / per one-shot call).  (0, experiments build only: round 4's kernel, every block builds its work lists itself)
 #ifdef FBK_EXPERIMENTS  // (scripts/ build their own variant with -DFBK_EXPERIMENTS into build_variants/; the product library has neither the options nor the device branches)
   int64_t matrix_fused_ablate = 0;       // timing experiments on the fused kernel (skips parts of it: WRONG results)
 #endif
   int64_t topk_device_sort = -1;         // 1 / 0 pins the ordering path of fbk_topk, -1: by field size
-  int64_t bsi_range_sum_two_pass = 0;    // 1: fbk_bsi_range_sum always runs the range and the sum as two passes (A/B runs)
-  int64_t bsi_half_waves = 1;            // dense BSI batches: the one-pass Range + Sum runs half a container per wavefront; 0: one wavefront per container (A/B runs)
-  int64_t bsi_planes_ahead = 3;          // one-pass BSI kernels on dense batches: planes in flight per wavefront (3 or 4)
   int64_t upload_threads = 0;            // host threads that fill the pinned upload buffers (0: min(8, cores / 2))
   int64_t upload_chunk_mb = 64;          // size of each of the two pinned upload buffers
-  int64_t sparse_paths = 1;              // 0: every container pair goes through the 8 KiB LDS decode (A/B runs)
   int64_t setop_direct_encode = 2;       // pair set-ops with optimize(): 2 the kernel applies Container.optimize() itself (encoded bytes into the head of the cell; no re-encode pass), 1 results of <= 1024 values leave the kernel as arrays and the re-encode pass does the rest (round 2), 0 always 8 KiB cells first (A/B runs, cross-checks)
   int64_t setop_compact = 1;             // one-shot set-ops / folds / BSI ranges / Flip / Shift with optimize() applied inside the kernel: 1 the output batch (owned by the caller) is compacted into a right-sized arena before it is returned (payload sizes + scan + one copy per container), 0 it keeps its 8 KiB cells
   int64_t count_range_reference_quirk = 1;  // 1 (default: identical to the reference): fbk_count_range reproduces RunCountRange's double count of a run ending at `end` (roaring.go:3216-3227); 0: the arithmetically right count
   int64_t topn_semantics = 1;            // fbk_topn / fbk_query_topn / fbk_group_topn / fbk_topn_partials with n > 0: 1 (default) the reference's two passes — candidates = the union over the SHARDS of fragment.top(N = n) (k_topn_candidates), then their exact totals (executeTopN, executor.go:2779-2864); 0: the exact top n of all rows
   int64_t pair_wpb = 0;                  // wavefronts per block of k_icount2 / k_setop2: 1 (a wave's LDS table is released when IT ends) or 4; 0 = by the rows' payload size
-  int64_t pair_resolve = 1;              // k_icount2 reads the plan's resolved item records and stores one count per wave (0: row index -> descriptor per wave, atomics; A/B runs)
 #ifdef FBK_EXPERIMENTS
   int64_t pair_stamp = 0;                // timing experiment on k_icount2: waves report shader cycles of a phase instead of counts (WRONG results)
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
 #endif
-  int64_t setop_probe = 1;               // k_setop2 with in-kernel optimize(): Intersect / Difference whose result is a subset of an array operand by table + probe, survivors written as the array (0: both operands decoded into fragments, as for every other type pair; same bytes)
-  int64_t pair_lean = 0;                 // 1 / 4: a count plan that runs again sorts its items by class on the host and gives the array x array items of <= 1024 / 2048 values to k_icount_aa (4 KiB table, 32 waves per CU; 1 or 4 waves per block); 0: k_icount2 for every item
-  int64_t pair_run_probe = 1;            // k_icount2: array x run items by probing the run container's table (boundary masks + map of full dwords) instead of decoding both operands (0: pair_stream, as for run x run / run x bitmap)
-  int64_t query_resolve = 1;             // prepared folds / TopN: the row descriptors of every (group / shard, slot) resolved into contiguous records once per version of the batch (0: the kernels gather them through the row lists, as the one-shot calls do)
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
 
@@ -466,8 +449,8 @@ int32_t window_index(fbk_ctx* ctx, const fbk_batch* b, const uint4** out) {
 
 // The descriptor table the in-kernel-decode count matrix should read for `b`: the batch's own, or — option matrix_shadow — a copy
 // in which every HEAVY container (a run container, an array of more than matrix_shadow_array values) is a bitmap in a shadow
-// arena built here on first use.  k_count_matrix_fused is bound by vector instruction issue, and what it issues them for is
-// decoding exactly those containers again in every query (397 us for 581 MB of config 3's rows); as bitmap
+// arena built here on first use.  The kernel that decodes rows in place is bound by vector instruction issue, and what it issued them for
+// was decoding exactly those containers again in every query (397 us for 581 MB of config 3's rows); as bitmap
 // rows they cost one 16-byte load per lane and stage.  The trade is the review's option (a): more bytes per query (8 KiB per
 // heavy container instead of its payload) and resident memory for the shadows (capped: matrix_shadow_max_mb), paid once per
 // batch like the window index and amortised over every query on a cached fragment.  Shadow descriptors address the shadow arena
@@ -683,12 +666,8 @@ struct OptionDesc {
 };
 const OptionDesc kOptions[] = {
     {"dense_spb", &FbkOptions::dense_spb, 1, 16},
-    {"fold_register", &FbkOptions::fold_register, 0, 1},
-    {"fold_encode", &FbkOptions::fold_encode, 0, 1},
-    {"matrix_valu", &FbkOptions::matrix_valu, 0, 1},
     {"matrix_spb", &FbkOptions::matrix_spb, 0, 16},
     {"matrix_pass_kb", &FbkOptions::matrix_pass_kb, 1, int64_t(1) << 40},
-    {"matrix_densify", &FbkOptions::matrix_densify, -1, 1},
     {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
     {"matrix_fp4", &FbkOptions::matrix_fp4, -1, 1},
     {"matrix_shadow", &FbkOptions::matrix_shadow, 0, 1},
@@ -696,34 +675,19 @@ const OptionDesc kOptions[] = {
     {"matrix_shadow_max_mb", &FbkOptions::matrix_shadow_max_mb, 0, 1 << 20},
     {"matrix_shadow_arena_x", &FbkOptions::matrix_shadow_arena_x, 0, 1 << 20},
 #ifdef FBK_EXPERIMENTS
-    {"matrix_shadow_apref", &FbkOptions::matrix_shadow_apref, 1, 2},
-    {"matrix_fused_program", &FbkOptions::matrix_fused_program, 0, 2},
-#else
-    {"matrix_fused_program", &FbkOptions::matrix_fused_program, 1, 2},
-#endif
-#ifdef FBK_EXPERIMENTS
     {"matrix_fused_ablate", &FbkOptions::matrix_fused_ablate, 0, 63},
 #endif
     {"time_kernels", &FbkOptions::time_kernels, 0, 1},
     {"last_kernel_ns", &FbkOptions::last_kernel_ns, 0, INT64_MAX},
     {"topk_device_sort", &FbkOptions::topk_device_sort, -1, 1},
-    {"bsi_range_sum_two_pass", &FbkOptions::bsi_range_sum_two_pass, 0, 1},
-    {"bsi_half_waves", &FbkOptions::bsi_half_waves, 0, 1},
-    {"bsi_planes_ahead", &FbkOptions::bsi_planes_ahead, 3, 4},
     {"upload_threads", &FbkOptions::upload_threads, 0, 64},
     {"upload_chunk_mb", &FbkOptions::upload_chunk_mb, 1, 1024},
-    {"sparse_paths", &FbkOptions::sparse_paths, 0, 1},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
-    {"setop_probe", &FbkOptions::setop_probe, 0, 1},
-    {"query_resolve", &FbkOptions::query_resolve, 0, 1},
-    {"pair_run_probe", &FbkOptions::pair_run_probe, 0, 1},
-    {"pair_lean", &FbkOptions::pair_lean, 0, 4},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
 #ifdef FBK_EXPERIMENTS
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
 #endif
-    {"pair_resolve", &FbkOptions::pair_resolve, 0, 1},
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
     {"setop_compact", &FbkOptions::setop_compact, 0, 1},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
@@ -1355,12 +1319,6 @@ struct fbk_plan {
   Slot* d_items = nullptr;
   uint32_t* d_wave_counts = nullptr;
   uint64_t items_va = ~0ull, items_vb = ~0ull;
-  // round 4 (option pair_lean): from its second run on a plan sorts its items by class on the host — the lean array x array
-  // items first (k_icount_aa), then the rest (k_icount2) — records in that order + the item each record stands for
-  Slot* d_items_sorted = nullptr;
-  uint32_t* d_item_ids = nullptr;
-  uint64_t n_lean = 0, sorted_va = ~0ull, sorted_vb = ~0ull;
-  uint64_t count_runs = 0;
 };
 
 namespace {
@@ -1433,79 +1391,12 @@ int32_t plan_resolve_items(fbk_ctx* ctx, fbk_plan* p) {
   return FBK_OK;
 }
 
-// The plan's items sorted by class (see k_icount_aa): false = not available for this run (a batch whose descriptors were
-// rewritten on the device and not read back yet, or no memory) — the caller launches the one kernel over all items.
-bool plan_sort_items(fbk_ctx* ctx, fbk_plan* p) {
-  const fbk_batch *a = p->a, *b = p->b;
-  const uint64_t n_items = p->n_pairs * fbk::kSlots;
-  if (n_items == 0 || n_items > (1ull << 31)) return false;
-  if (p->d_items_sorted && p->sorted_va == a->version && p->sorted_vb == b->version) return true;
-  // the host descriptors are read under the batches' own locks (another context of the device may be refreshing them:
-  // refresh_slots); both at once through std::lock — a plan over (b, a) on another context takes them in the other order
-  std::unique_lock<std::mutex> la(const_cast<fbk_batch*>(a)->slots_mu, std::defer_lock), lb;
-  if (b != a) {
-    lb = std::unique_lock<std::mutex>(const_cast<fbk_batch*>(b)->slots_mu, std::defer_lock);
-    std::lock(la, lb);
-  } else {
-    la.lock();
-  }
-  if (a->slots_stale || b->slots_stale) return false;
-  std::vector<uint8_t> lean(n_items);
-  uint64_t n_lean = 0;
-  for (uint64_t i = 0; i < p->n_pairs; ++i)
-    for (int s = 0; s < fbk::kSlots; ++s) {
-      const Slot& sa = a->h_slots[uint64_t(p->h_rows_a[i]) * fbk::kSlots + s];
-      const Slot& sb = b->h_slots[uint64_t(p->h_rows_b[i]) * fbk::kSlots + s];
-      const bool l = fbk::slot_n(sa) != 0 && fbk::slot_n(sb) != 0 && fbk::slot_type(sa) == fbk::kTypeArray && fbk::slot_type(sb) == fbk::kTypeArray &&
-                     std::min(sa.len, sb.len) <= fbk::kLeanShortMax && std::max(sa.len, sb.len) <= fbk::kLeanLongMax;
-      lean[i * fbk::kSlots + s] = l;
-      n_lean += l;
-    }
-  std::vector<Slot> recs(2 * n_items);
-  std::vector<uint32_t> ids(n_items);
-  uint64_t pl = 0, pg = n_lean;
-  for (uint64_t i = 0; i < p->n_pairs; ++i)
-    for (int s = 0; s < fbk::kSlots; ++s) {
-      const uint64_t it = i * fbk::kSlots + s, at = lean[it] ? pl++ : pg++;
-      recs[2 * at] = a->h_slots[uint64_t(p->h_rows_a[i]) * fbk::kSlots + s];
-      recs[2 * at + 1] = b->h_slots[uint64_t(p->h_rows_b[i]) * fbk::kSlots + s];
-      ids[at] = uint32_t(it);
-    }
-  if (!p->d_items_sorted) {
-    Slot* di = nullptr;
-    uint32_t* dd = nullptr;
-    if (ctx_malloc(ctx, reinterpret_cast<void**>(&di), n_items * 2 * sizeof(Slot)) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    if (ctx_malloc(ctx, reinterpret_cast<void**>(&dd), n_items * sizeof(uint32_t)) != hipSuccess) {
-      (void)hipGetLastError();
-      ctx_free(ctx, di);
-      return false;
-    }
-    p->d_items_sorted = di;
-    p->d_item_ids = dd;
-  }
-  // (synchronous copies out of pageable vectors, once per version of the two batches; earlier launches of this plan that
-  // read the previous records are drained first)
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(p->d_items_sorted, recs.data(), recs.size() * sizeof(Slot), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(p->d_item_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
-    (void)hipGetLastError();
-    p->sorted_va = p->sorted_vb = ~0ull;
-    return false;
-  }
-  p->n_lean = n_lean;
-  p->sorted_va = a->version;
-  p->sorted_vb = b->version;
-  return true;
-}
-
 template <int OP>
 void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs, const Slot* items) {
   const uint32_t blocks = uint32_t(p->n_pairs * fbk::kSlots / 4);
   // (the in-kernel optimize() — mode 2 — only when the caller asked for optimize(): plain set-ops keep their bitmap cells)
   const uint32_t direct = want_runs ? uint32_t(p->ctx->opt.setop_direct_encode) : 0u;
-  const uint32_t direct2 = direct | (p->ctx->opt.setop_probe ? 0x100u : 0u);  // k_setop2 only
+  const uint32_t direct2 = direct | 0x100u;  // k_setop2 only: Intersect / Difference whose result is a subset of an array operand by table + probe (an A/B option until round 5)
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
                        p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots);
@@ -1543,8 +1434,6 @@ void free_plan_storage(fbk_plan* p) {
   if (p->d_runs) (void)ctx_free(p->ctx, p->d_runs);
   if (p->d_items) (void)ctx_free(p->ctx, p->d_items);
   if (p->d_wave_counts) (void)ctx_free(p->ctx, p->d_wave_counts);
-  if (p->d_items_sorted) (void)ctx_free(p->ctx, p->d_items_sorted);
-  if (p->d_item_ids) (void)ctx_free(p->ctx, p->d_item_ids);
   free_batch_storage(p->out);
   delete p;
 }
@@ -1615,44 +1504,26 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
   } else {
     const bool pk2 = use_pair_kernels2(ctx, p->a, p->b, -1);
     // (resolved item records + a count per wave pay for their second launch only where the items are heavy: one-wave blocks)
-    const bool resolved = pk2 && ctx->opt.pair_resolve && pair_wpb_for(ctx, p->a, p->b) == 1;
+    const bool resolved = pk2 && pair_wpb_for(ctx, p->a, p->b) == 1;
     if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     if (resolved)
       if (int32_t rc = plan_resolve_items(ctx, p)) return rc;
-    // a plan that runs again is worth sorting: the lean items to k_icount_aa, the others to k_icount2, both adding into the
-    // per-item counts that k_sum_wave_counts folds per pair
-    const bool sorted = resolved && ctx->opt.pair_lean && p->count_runs >= 1 && plan_sort_items(ctx, p);
-    ++p->count_runs;
     if (pk2) {
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
                      p->d_counts, pair_flags, resolved ? p->d_items : (const Slot*)nullptr,  \
-                     resolved ? p->d_wave_counts : (uint32_t*)nullptr, (const uint32_t*)nullptr)
+                     resolved ? p->d_wave_counts : (uint32_t*)nullptr)
       // One container slot per wave.  (The kernel is written for SPW slots per wave with the next slot's payload in flight while the
       // current one is decoded; SPW = 2 / 4 measured 49.6 / 56 us against 46 in round 3 — fewer waves lose more than the prefetch
       // gains — and are no longer instantiated.)
       const int wpb = pair_wpb_for(ctx, p->a, p->b);
 #ifdef FBK_EXPERIMENTS
-      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (ctx->opt.pair_run_probe ? 2u : 0u) | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16);
+      const uint32_t pair_flags = 3u | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16);
 #else
-      const uint32_t pair_flags = uint32_t(ctx->opt.sparse_paths) | (ctx->opt.pair_run_probe ? 2u : 0u);
+      constexpr uint32_t pair_flags = 3u;  // bit 0: the small-array / probe paths, bit 1: array x run items probe the run container's table (both were A/B options until round 5)
 #endif
-      if (sorted) {
-        const uint64_t n_items = p->n_pairs * fbk::kSlots, n_gen = n_items - p->n_lean;
-        if (p->n_lean) {
-          if (ctx->opt.pair_lean == 4)
-            hipLaunchKernelGGL((fbk::k_icount_aa<4>), dim3(uint32_t((p->n_lean + 3) / 4)), dim3(256), 0, ctx->stream, p->d_items_sorted, uint32_t(p->n_lean), p->a->d_arena,
-                               p->b->d_arena, p->d_item_ids, p->d_wave_counts);
-          else
-            hipLaunchKernelGGL((fbk::k_icount_aa<1>), dim3(uint32_t(p->n_lean)), dim3(64), 0, ctx->stream, p->d_items_sorted, uint32_t(p->n_lean), p->a->d_arena,
-                               p->b->d_arena, p->d_item_ids, p->d_wave_counts);
-        }
-        if (n_gen)  // (one record per block; "pairs" = sixteenths of the record list, only a bound here)
-          hipLaunchKernelGGL((fbk::k_icount2<1, 1>), dim3(uint32_t(n_gen)), dim3(64), 0, ctx->stream, p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots,
-                             p->b->d_arena, p->d_rows_b, (n_gen + fbk::kSlots - 1) / fbk::kSlots, p->d_counts, pair_flags, p->d_items_sorted + 2 * p->n_lean, p->d_wave_counts,
-                             p->d_item_ids + p->n_lean);
-      } else if (wpb == 4) FBK_LAUNCH_ICOUNT2(1, 4);
+      if (wpb == 4) FBK_LAUNCH_ICOUNT2(1, 4);
       else FBK_LAUNCH_ICOUNT2(1, 1);
 #undef FBK_LAUNCH_ICOUNT2
       if (resolved)
@@ -1662,7 +1533,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
     else
       hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,
                          p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->d_counts,
-                         uint32_t(ctx->opt.sparse_paths));
+                         1u);
     if (fused_total)
       hipLaunchKernelGGL(fbk::k_sum_u64, dim3(1), dim3(256), 0, ctx->stream, p->d_counts, p->n_pairs, fused_total);
     if (accum) hipLaunchKernelGGL(fbk::k_sum_u64_add, dim3(1), dim3(256), 0, ctx->stream, p->d_counts, p->n_pairs, accum);
@@ -1707,7 +1578,7 @@ int32_t plan_setop_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, int32_t op, bool wa
   const bool dense = p->a->dense && p->b->dense && !want_runs;
   // the one-wave-block pair kernels start from the plan's resolved item records (as the count does)
   const Slot* items = nullptr;
-  if (!dense && ctx->opt.pair_resolve && use_pair_kernels2(ctx, p->a, p->b, op) && pair_wpb_for(ctx, p->a, p->b) == 1) {
+  if (!dense && use_pair_kernels2(ctx, p->a, p->b, op) && pair_wpb_for(ctx, p->a, p->b) == 1) {
     if (int32_t rc = plan_resolve_items(ctx, p)) return rc;
     items = p->d_items;
   }

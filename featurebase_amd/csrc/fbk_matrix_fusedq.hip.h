@@ -1,7 +1,8 @@
-// fbk_matrix_fusedq.hip.h — the program-driven count matrix over encoded rows (fbk_matrix_fusedp.hip.h) with its producer
-// waves SPECIALISED and their loads issued TWO stages ahead (round 5, second step).
+// fbk_matrix_fusedq.hip.h — the count matrix over encoded rows: the kernel that runs the prepared program of
+// fbk_matrix_fused.hip.h, with its producer waves SPECIALISED and their loads issued TWO stages ahead (round 5).
 //
-// What the ablations of the first step said (scripts/fused_ablate.py, profiles/r05_fused_ablate.jsonl; config 4 as SURVEY 8d
+// What the ablations of the first program-driven form said (twelve identical producer waves; scripts/fused_ablate.py,
+// profiles/r05_fused_ablate.jsonl; config 4 as SURVEY 8d
 // writes it, 1024 shards): the whole kernel 1135-1200 us; the consumers ALONE (producers reduced to their barriers) 717 us;
 // the producers alone 1056 us, 734 without the array items; the bytes at the achievable HBM rate ~700 us.  Every part fits
 // the budget, their sum does not overlap: a stage's loads go out at its start and are waited for at the start of the next one,
@@ -15,10 +16,10 @@
 //   * 7 BITMAP waves: kFqBP = 6 bitmap rows each (42 per slot) global -> registers -> LDS, the run rows (one per wave loaded
 //     ahead, the rest in place), the table DMA of the next slot;
 // and with half the state per wave each role keeps THREE register sets: the loads of stage t + 2 go out during stage t (the
-// items' entries during stage t - 1), two stages of loads are in flight per CU.  Consumers as in fbk_matrix_fusedp.hip.h, with a
+// items' entries during stage t - 1), two stages of loads are in flight per CU.  The consumers: FP4 operands by one v_and per dword, hand-counted LDS waits, a
 // fourth accumulator (the k = 3 product no longer waits for the k = 0 one of the same octet).
 #pragma once
-#include "fbk_matrix_fusedp.hip.h"
+#include "fbk_matrix_fused.hip.h"
 
 namespace fbk {
 

@@ -5,7 +5,7 @@
 //
 // is C = A' · Bᵀ over {0,1} with K = 65536 bit positions per container: nA x nB pairs reuse
 // nA + nB containers, so unlike every other kernel of this library the shape is arithmetic-bound
-// on the vector ALU (k_count_matrix_dense: 2.1 M container pairs x 64 v_and / v_bcnt per lane,
+// on the vector ALU (round 1's vector-ALU kernel: 2.1 M container pairs x 64 v_and / v_bcnt per lane,
 // 350 us for 128 shards x 32 x 32 rows, twice the time it takes to read the rows once).  The
 // matrix cores do the pair work instead: v_mfma_i32_32x32x32_i8 multiplies a 32-row x 32-byte A
 // operand with a 32-column x 32-byte B operand, and a bit becomes a byte with ONE v_and:

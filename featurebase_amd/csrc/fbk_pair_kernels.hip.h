@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
                                                      const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
                                                      const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
                                                      u64* __restrict__ out, uint32_t sparse_paths, const Slot* __restrict__ items,
-                                                     uint32_t* __restrict__ wave_out, const uint32_t* __restrict__ out_ids) {
+                                                     uint32_t* __restrict__ wave_out) {
   __shared__ u64 lds[WPB][kWords];
   __shared__ uint32_t mini[WPB][2 * kMiniDwords];
 #ifndef FBK_EXPERIMENTS
@@ -767,112 +767,16 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
     // one plain store per wave; k_sum_wave_counts adds a pair's waves up.  (The uint64 atomics of the 16 waves of a
     // pair onto out[pair] — from up to 8 XCDs, so executed at the memory side — and the memset they need in front cost
     // ~8 us of a 46 us launch.)
-    // (out_ids: the items were sorted by class, fbk.hip plan_sort_items — record wid is item out_ids[wid] of the plan)
-    if (lane == 0) wave_out[out_ids ? out_ids[wid] : wid] = c;
+    if (lane == 0) wave_out[wid] = c;
   } else if (lane == 0 && c) {
     atomicAdd(&out[pair], (u64)c);
   }
 }
 
-// ---- the LEAN array x array count (round 4, option pair_lean) ------------------------------------------------------
-//
-// k_icount2 above is bound by waves in flight x wave lifetime: every wave reserves the worst case of any type pair — an
-// 8 KiB table, the interior maps, 93 registers — so a CU holds 18 of them, although half of config 3's items are two arrays
-// of a few hundred values.  A plan that runs again sorts its items by class on the host (fbk.hip plan_sort_items; the
-// descriptors of both batches must be current there) and hands the array x array items with <= kLeanShortMax /
-// kLeanLongMax values to this kernel: a 4 KiB table for HALF the value range, used twice — the arrays are sorted, so
-// the values below 32768 are a prefix of each; a dword row of 128 values belongs to one half (or, once per array, to
-// both), which two v_readlane per row decide, and every row is scattered / probed ONCE — both arrays entirely in
-// registers (8 + 16 dwords per lane, requested before anything else), no tail batches, no maps: 4 KiB of LDS and <= 64
-// registers = 32 waves per CU.  (intersectionCountArrayArray, roaring.go:4514-4536.)
-constexpr uint32_t kLeanShortMax = 1024, kLeanLongMax = 2048;
-
-// bit k of rows[h]: dword row k of a sorted array of n values (v[k] = dword k * 64 + lane, zero past the end) holds
-// values of half h of the range
-template <int N>
-__device__ __forceinline__ void lean_rows(const uint32_t (&v)[N], uint32_t n, uint32_t (&rows)[2]) {
-  rows[0] = rows[1] = 0;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if ((uint32_t)k * 128u < n) {  // (wave-uniform)
-      const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)v[k], 0) & 0xFFFFu;
-      const uint32_t il = min(n, (uint32_t)(k + 1) * 128u) - 1u;  // the row's last value
-      const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)v[k], (int)((il >> 1) & 63u));
-      const uint32_t last = (il & 1u) ? dl >> 16 : dl & 0xFFFFu;
-      if (first < 32768u) rows[0] |= 1u << k;
-      if (last >= 32768u) rows[1] |= 1u << k;
-    }
-  }
-}
-
-template <int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_icount_aa(const Slot* __restrict__ items, uint32_t n_items, const uint8_t* __restrict__ arenaA,
-                                                       const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ out_ids,
-                                                       uint32_t* __restrict__ wave_out) {
-  __shared__ uint32_t tab[WPB][1024];  // one bit per value of half the range
-  const int lane = threadIdx.x & 63;
-  const int wv = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t wid = blockIdx.x * WPB + (uint32_t)wv;
-  if (wid >= n_items) return;
-  const Slot sa = items[2 * (uint64_t)wid], sb = items[2 * (uint64_t)wid + 1];  // (scalar loads: wid is wave-uniform)
-  const uint32_t oid = out_ids[wid];
-  const bool a_short = sa.len <= sb.len;
-  const uint8_t* ps = a_short ? arenaA + sa.off : arenaB + sb.off;
-  const uint8_t* pl = a_short ? arenaB + sb.off : arenaA + sa.off;
-  const uint32_t ls = a_short ? sa.len : sb.len, ll = a_short ? sb.len : sa.len;  // <= 1024, <= 2048 (the host's classification)
-  const uint32_t nus = (ls + 1u) >> 1, nul = (ll + 1u) >> 1;
-  const uint32_t* qs = reinterpret_cast<const uint32_t*>(ps) + lane;
-  const uint32_t* ql = reinterpret_cast<const uint32_t*>(pl) + lane;
-  uint32_t vs[8], vl[16];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    vs[k] = 0;
-    if ((uint32_t)k * kWave < nus) vs[k] = ((uint32_t)k * kWave + (uint32_t)lane < nus) ? qs[k * kWave] : 0u;
-  }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    vl[k] = 0;
-    if ((uint32_t)k * kWave < nul) vl[k] = ((uint32_t)k * kWave + (uint32_t)lane < nul) ? ql[k * kWave] : 0u;
-  }
-  uint32_t rs[2], rl[2];
-  lean_rows<8>(vs, ls, rs);
-  lean_rows<16>(vl, ll, rl);
-  uint32_t* t = tab[wv];
-  uint32_t hits = 0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    if (rs[h] == 0 || rl[h] == 0) continue;  // (wave-uniform: one of the arrays has nothing in this half)
-    {
-      uint4 z;
-      z.x = z.y = z.z = z.w = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) reinterpret_cast<uint4*>(t)[j * kWave + lane] = z;
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if ((rs[h] >> k) & 1u) {
-        const uint32_t i2 = ((uint32_t)k * kWave + (uint32_t)lane) * 2u;
-        const uint32_t lo = vs[k] & 0xFFFFu, hi = vs[k] >> 16;
-        if (i2 < ls && (lo >> 15) == (uint32_t)h) atomicOr(&t[(lo >> 5) & 1023u], 1u << (lo & 31u));
-        if (i2 + 1u < ls && (hi >> 15) == (uint32_t)h) atomicOr(&t[(hi >> 5) & 1023u], 1u << (hi & 31u));
-      }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if ((rl[h] >> k) & 1u) {
-        const uint32_t i2 = ((uint32_t)k * kWave + (uint32_t)lane) * 2u;
-        const uint32_t lo = vl[k] & 0xFFFFu, hi = vl[k] >> 16;
-        const uint32_t b0 = (t[(lo >> 5) & 1023u] >> (lo & 31u)) & 1u, b1 = (t[(hi >> 5) & 1023u] >> (hi & 31u)) & 1u;
-        hits += ((i2 < ll && (lo >> 15) == (uint32_t)h) ? b0 : 0u) + ((i2 + 1u < ll && (hi >> 15) == (uint32_t)h) ? b1 : 0u);
-      }
-    }
-    wave_lds_sync();
-  }
-  const uint32_t c = wave_reduce_add(hits);
-  if (lane == 0) wave_out[oid] = c;
-}
+// (Round 4 built a LEAN array x array count here — k_icount_aa: a 4 KiB table for half the value range used twice, both
+// arrays in registers, 32 registers, 32 waves per CU, fed by a host pass that sorted a plan's items by class.  Parity-green and
+// worth 0-3 % on config 3's row pairs (those items are half of the waves and a seventh of the time; profiles/r04_pairs_lean_ab.json):
+// removed in round 5 with its option.)
 
 // out[pair] = the sum of the pair's waves' counts (per = 16 / SPW of them, consecutive)
 __global__ void __launch_bounds__(256) k_sum_wave_counts(const uint32_t* __restrict__ wave_counts, uint32_t per, uint64_t n_pairs, u64* __restrict__ out) {

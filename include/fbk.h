@@ -147,26 +147,30 @@ int32_t fbk_last_error_r(fbk_ctx* ctx, char* buf, uint64_t cap, int32_t* out_cod
  * closed with fbk_close, before its root. */
 int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
 
-/* Tuning / test knobs (A/B measurements, forcing code paths in tests).  The environment variables
- * FBK_<NAME> are read ONCE, by fbk_open; afterwards only these calls change an option.  Names:
- * dense_spb, fold_register, matrix_valu, matrix_spb, matrix_pass_kb, matrix_densify, matrix_fused,
- * matrix_fp4, matrix_shadow (1: the count matrix over encoded rows reads run containers and arrays of more
- * than matrix_shadow_array values through dense shadows built per batch on first use — up to
- * matrix_shadow_max_mb of device memory per batch and matrix_shadow_arena_x times its own arena (0: no such rule),
- * fbk_batch_memory reports what a batch got; 0: every container
- * is decoded in every query), matrix_fused_program (that kernel runs a prepared program — row tables and resolved array items
- * per (shard, tile, container slot), built by k_fused_program on a prepared query's first run and again when a batch was
- * rewritten, per call otherwise: 2, the default, with producer waves specialised on array / bitmap rows and their loads two
- * stages ahead; 1 the first form, kept as the cross-check),
- * bsi_range_sum_two_pass, bsi_half_waves, bsi_planes_ahead, topk_device_sort, sparse_paths,
- * setop_direct_encode, setop_probe, setop_compact, fold_encode, pair_kernels, pair_wpb, pair_resolve, pair_run_probe, pair_lean,
- * query_resolve, upload_chunk_mb, upload_threads, count_range_reference_quirk, topn_semantics.  Every value of every
- * option gives the same results (the tests run them against each other); they select between kernels, not between
- * semantics — except count_range_reference_quirk and topn_semantics, whose DEFAULTS (1) are the reference's results and
- * whose other value (0) is the arithmetically exact one (see fbk_count_range, fbk_topn).
- * Measurement: time_kernels = 1 makes the query-level calls (count matrix, n-way fold, BSI range /
- * sum / min / max) record HIP events on the context's stream right before and after their dominant kernel;
- * fbk_get_option("last_kernel_ns") then returns that kernel's duration for the last such call. */
+/* Options (20; round 5 removed fifteen A/B switches together with the kernels and paths that had lost their comparison —
+ * DESIGN.md section 4 lists them).  The environment variables FBK_<NAME> are read ONCE, by fbk_open; afterwards only these
+ * calls change an option.
+ *   semantics (DEFAULT 1 = the reference's result, 0 = the arithmetically exact one; see fbk_count_range, fbk_topn):
+ *     count_range_reference_quirk, topn_semantics;
+ *   memory: matrix_shadow (1: the count matrix over encoded rows reads run containers and arrays of more than
+ *     matrix_shadow_array values through dense shadows built per batch on first use — up to matrix_shadow_max_mb of device
+ *     memory per batch and matrix_shadow_arena_x times its own arena (0: no such rule), fbk_batch_memory reports what a batch
+ *     got; 0: every container is decoded in every query), setop_compact (fbk_batch_compact applied to the outputs of one-shot
+ *     calls with FBK_SETOP_OPTIMIZE), matrix_pass_kb (per-shard matrices are produced in passes of at most this size),
+ *     upload_chunk_mb, upload_threads (the pinned staging buffers of the uploads and the host threads that fill them);
+ *   measurement: time_kernels = 1 makes the query-level calls (count matrix, n-way fold, BSI range / sum / min / max) record
+ *     HIP events on the context's stream right before and after their dominant kernel; fbk_get_option("last_kernel_ns")
+ *     then returns that kernel's duration for the last such call;
+ *   kernel selection, each a choice the library makes by itself (the default) that a test or a measurement can pin — BOTH
+ *     sides are product paths, chosen by the shape of the call or of the rows: dense_spb and matrix_spb (container slots per
+ *     block of the dense count / the count matrices), matrix_fused (encoded rows: -1 by the matrix size, 1 the matrix-core
+ *     kernel that decodes the rows in place, 0 the generic pair kernel), matrix_fp4 (dense count matrix on the FP4 matrix
+ *     instruction: -1 for matrices of several tiles), topk_device_sort (-1 by the field size), pair_kernels (0 by the rows'
+ *     payload: the round-2 kernels for tiny containers, the table + probe kernels otherwise), pair_wpb (their waves per
+ *     block: 0 by the rows' payload), setop_direct_encode (pair set-ops with FBK_SETOP_OPTIMIZE: 2 Container.optimize() inside
+ *     the kernel; 1 / 0 bitmap or small-array cells and a separate re-encode pass — the byte-for-byte cross-check of the
+ *     in-kernel encoders, and what a plan's launch-only form refuses).
+ * Every value of every kernel-selection option gives the same results (the tests run them against each other). */
 int32_t fbk_set_option(fbk_ctx* ctx, const char* name, int64_t value);
 int32_t fbk_get_option(fbk_ctx* ctx, const char* name, int64_t* out_value);
 

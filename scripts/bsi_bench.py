@@ -51,29 +51,27 @@ line("Sum(filter)  k_bsi_sum_slot (wavefront per (shard, slot))", plane_bytes * 
 line("Sum()        k_bsi_sum_slot (wavefront per (shard, slot))", plane_bytes * (depth + 2), lambda: ctx.bsi_sum(batch, base, depth))
 for op, pred, what in ((L.BSI_GT, 1 << 62, "Range(> 2^62)"), (L.BSI_LT, -5, "Range(< -5)"), (L.BSI_EQ, 12345, "Range(== 12345)")):
     line(f"{what:16s} k_bsi_range_slot (wavefront)", plane_bytes * (depth + 3), lambda: ctx.bsi_range(batch, base, op, depth, pred)[0].free())
-for two_pass in (1, 0):
-    ctx.set_option("bsi_range_sum_two_pass", two_pass)
-    r = ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, 1 << 62)
-    if two_pass:
-        ref_rs = r
-        continue
-    for hw in (0, 1):
-        ctx.set_option("bsi_half_waves", hw)
-        r = ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, 1 << 62)
-        assert (ref_rs[0] == r[0]).all() and (ref_rs[1] == r[1]).all(), "Range+Sum: one pass and two passes disagree"
-        print("  bsi_half_waves =", hw)
-        line("Sum(Range(> 2^62)) one pass  k_bsi_range_sum_slot / _half", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, 1 << 62))
-        line("Sum(Range(< -5)) one pass    k_bsi_range_sum_slot / _half", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_LT, depth, -5))
-        line("Sum(Range(> -5)) one pass    ..<other class>", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, -5))
+def range_then_sum(op, pred):
+    rows, _ = ctx.bsi_range(batch, base, op, depth, pred)
+    r = ctx.bsi_sum(batch, base, depth, rows, fidx)
+    rows.free()
+    return r
+
+
+ref_rs = range_then_sum(L.BSI_GT, 1 << 62)
+r = ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, 1 << 62)
+assert (ref_rs[0] == r[0]).all() and (ref_rs[1] == r[1]).all(), "Range+Sum: one pass and two calls disagree"
+line("Sum(Range(> 2^62)) one pass  k_bsi_range_sum_slot / _half", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, 1 << 62))
+line("Sum(Range(< -5)) one pass    k_bsi_range_sum_slot / _half", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_LT, depth, -5))
+line("Sum(Range(> -5)) one pass    ..<other class>", plane_bytes * (depth + 2), lambda: ctx.bsi_range_sum(batch, base, L.BSI_GT, depth, -5))
 print("  (two passes: the Range and the Sum(filter) lines above, one after the other)")
-ctx.set_option("bsi_range_sum_two_pass", 1)
-ref_b = ctx.bsi_range_between_sum(batch, base, depth, -(1 << 61), 1 << 62)
-ref_c = ctx.bsi_range_between_sum(batch, base, depth, 1 << 60, 1 << 62)
-ctx.set_option("bsi_range_sum_two_pass", 0)
-for (lo, hi), ref_x, what in (((-(1 << 61), 1 << 62), ref_b, "both signs"), ((1 << 60, 1 << 62), ref_c, "one sign, split lanes")):
+for (lo, hi), what in (((-(1 << 61), 1 << 62), "both signs"), ((1 << 60, 1 << 62), "one sign, split lanes")):
+    rows, _ = ctx.bsi_range_between(batch, base, depth, lo, hi)
+    ref_x = ctx.bsi_sum(batch, base, depth, rows, fidx)
+    rows.free()
     r = ctx.bsi_range_between_sum(batch, base, depth, lo, hi)
-    assert (ref_x[0] == r[0]).all() and (ref_x[1] == r[1]).all(), "Between+Sum: one pass and two passes disagree"
-    line(f"Sum(Between) one pass, {what:22s} k_bsi_between_sum_half", plane_bytes * (depth + 2), lambda: ctx.bsi_range_between_sum(batch, base, depth, lo, hi))
+    assert (ref_x[0] == r[0]).all() and (ref_x[1] == r[1]).all(), "Between+Sum: one pass and two calls disagree"
+    line(f"Sum(Between) one pass, {what:22s} k_bsi_between_sum_part", plane_bytes * (depth + 2), lambda: ctx.bsi_range_between_sum(batch, base, depth, lo, hi))
 line("Between (row output)                     k_bsi_range_slot", plane_bytes * (depth + 2), lambda: ctx.bsi_range_between(batch, base, depth, 1 << 60, 1 << 62)[0].free())
 line("Min          k_bsi_minmax_slot (wavefront per (shard, slot))", plane_bytes * (depth + 2), lambda: ctx.bsi_min(batch, base, depth))
 line("Max(filter)  k_bsi_minmax_slot (wavefront per (shard, slot))", plane_bytes * (depth + 3), lambda: ctx.bsi_max(batch, base, depth, filt, fidx))

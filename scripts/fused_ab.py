@@ -1,8 +1,10 @@
-"""Round 5 A/B of the count matrix over encoded rows, in ONE process on ONE box: the kernel that runs a prepared program
-(option matrix_fused_program = 1, fbk_matrix_fusedp.hip.h) against round 4's kernel (= 0), on config 3's rows (GroupBy 32 x 32 +
-filter, rank-law densities with runs) and on config 4 as SURVEY 8d writes it (log-uniform densities), each under several
-heavy-row shadow thresholds (option matrix_shadow_array: arrays longer than this are read through dense shadows).
-Prepared queries, kernel time from the library's events (option time_kernels), every variant checked against the first.
+"""The count matrix over encoded rows (k_fused_program + k_count_matrix_fusedq) in ONE process on ONE box: config 3's rows
+(GroupBy 32 x 32 + filter, rank-law densities with runs) and config 4 as SURVEY 8d writes it (log-uniform densities), with and
+without the heavy-row shadows (option matrix_shadow), with and without the filter, and by container slots per block (option
+matrix_spb).  Prepared queries, kernel time from the library's events (option time_kernels), every variant checked against
+the first.  (Round 5 used this script for the A/B of the program-driven kernels against round 4's kernel — option
+matrix_fused_program, since removed with the kernels that lost: profiles/r05_fused_program_ab.json,
+r05_fused_ab_specialised_producers.json, r05_fused_ab_final_kernel.json.)
 
     python scripts/fused_ab.py [shards3=256] [shards4=1024] > gpurun_out/.../fused_ab.json
 """
@@ -44,8 +46,7 @@ for name, d, p, nr, g, fd, fp, n, nbytes in sets:
         ctx.set_option("matrix_shadow_array", thr)
         batch = ctx.upload_flat(d, p, nr)  # (a shadow is built once per batch, with the options in force then)
         F = ctx.upload_flat(fd, fp, n)
-        for prog in (2, 1, 2):
-            ctx.set_option("matrix_fused_program", prog)
+        for rep in (0, 1):  # (two rounds of the same measurement: the first launches after an upload run slower)
             q = ctx.prepare_count_matrix(batch, g[:, :32], batch, g[:, 32:], F, fidx)
             q.run()
             got = q.read()
@@ -71,14 +72,13 @@ for name, d, p, nr, g, fd, fp, n, nbytes in sets:
                 tn.append(ctx.get_option("last_kernel_ns") / 1e3)
             ctx.set_option("time_kernels", 0)
             tn.sort()
-            res.append({"shadow": shadow, "shadow_array": thr, "apref": apref, "program": prog, "kernel_us": ts[len(ts) // 2], "kernel_us_min": ts[0], "same_counts": ok,
+            res.append({"shadow": shadow, "shadow_array": thr, "round": rep, "kernel_us": ts[len(ts) // 2], "kernel_us_min": ts[0], "same_counts": ok,
                         "frac": nbytes / (ts[len(ts) // 2] * 1e-6) / 8e12, "no_filter_kernel_us": tn[len(tn) // 2]})
             print(name, res[-1], file=sys.stderr, flush=True)
             q.free()
             qn.free()
         if shadow == 1:  # slots per block of the default kernel (16: one block per shard; fewer: more, shorter blocks)
             sweep = []
-            ctx.set_option("matrix_fused_program", 2)
             for spb in (16, 8, 4):
                 ctx.set_option("matrix_spb", spb)
                 q = ctx.prepare_count_matrix(batch, g[:, :32], batch, g[:, 32:], F, fidx)
@@ -100,5 +100,4 @@ for name, d, p, nr, g, fd, fp, n, nbytes in sets:
         batch.free()
         F.free()
     out["sets"][name] = {"shards": n, "encoded_bytes": int(nbytes), "variants": res}
-ctx.set_option("matrix_fused_program", 2)
 print(json.dumps(out))

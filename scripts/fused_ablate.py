@@ -1,4 +1,4 @@
-"""What the program-driven count-matrix kernel (fbk_matrix_fusedp.hip.h) spends its stage on, by switching parts of it OFF in the
+"""What the program-driven count-matrix kernel (fbk_matrix_fusedq.hip.h) spends its stage on, by switching parts of it OFF in the
 experiments build (option matrix_fused_ablate; the counts are WRONG then): 1 no consumer arithmetic, 2 no array items, 8 no bitmap
 rows, 16 the producers only keep the barriers.  Kernel time from the library's events, prepared query.
 
@@ -37,12 +37,9 @@ batch = ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
 F = ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
 fidx = np.arange(n)
 out = {"config": cfg, "shards": n, "encoded_bytes": int(rows.bytes + filt.bytes), "variants": []}
-for prog in (2,):
-    ctx.set_option("matrix_fused_program", prog)
+for prog in (2,):  # (2 = the shipped kernel; rounds' earlier kernels were removed)
     for ab, what in ((0, "everything"), (1, "no consumer arithmetic"), (2, "no array items"), (8, "no bitmap rows"), (10, "no array items, no bitmap rows"),
                      (16, "producers: barriers only"), (17, "barriers only (consumers and producers)"), (3, "no consumer arithmetic, no array items")):
-        if prog == 0 and ab >= 16:
-            continue
         ctx.set_option("matrix_fused_ablate", ab)
         q = ctx.prepare_count_matrix(batch, g[:, :32], batch, g[:, 32:], F, fidx)
         q.run()

@@ -1,5 +1,6 @@
-"""Cycle stamps of one block of k_count_matrix_fused (option matrix_fused_ablate = 32: the instrumented
-build prints them to stderr).   python scripts/fused_prof.py [shards=256] [ablate bits=0]"""
+"""Cycle stamps of one block of k_count_matrix_fusedq (option matrix_fused_ablate = 32: the instrumented
+build prints them to stderr; that build SPILLS, so the stamps over-state the consumers' start — see
+profiles/r05_fused_cycle_stamps_config4_prof_build_spills.txt).   python scripts/fused_prof.py [shards=256] [ablate bits=0] [unused] [config=3]"""
 import os
 import sys
 
@@ -16,7 +17,6 @@ import datagen as D  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ab = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-prog = int(sys.argv[3]) if len(sys.argv) > 3 else 2  # 1: the kernel that runs a prepared program (round 5), 0: round 4's
 cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 3  # 3: config 3's rank-law rows; 4: config 4's log-uniform rows
 if cfg == 4:
     rows, ga, gb, filt, _ = D.config4_flat(n, mp="fork")
@@ -29,8 +29,7 @@ ctx = Context(0)
 batch = ctx.upload_flat(rows.descs(), rows.payload(), rows.n_rows)
 F = ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
 ctx.set_option("matrix_fused", 1)
-ctx.set_option("matrix_fused_program", prog)
-print(f"[fused prof] matrix_fused_program = {prog} config {cfg}", file=sys.stderr)
+print(f"[fused prof] config {cfg}", file=sys.stderr)
 for _ in range(2):
     ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, np.arange(n))
 ctx.set_option("matrix_fused_ablate", 32 | ab)

@@ -8,7 +8,7 @@ Kernels reached: k_setop<OP> (generic pairs), k_encode_plan / k_scan_blocks / k_
 k_encode_write (optimize), k_count_range, k_fold_n<AND>, k_fold_scatter<XOR/ANDNOT>, k_shift, k_flip,
 k_bsi_add, k_bsi_values (+ hipcub sort), k_bsi_minmax_slot, k_bsi_range_slot / k_bsi_sum_slot, k_rows_flags, k_wire_copy (roaring
 upload + download), k_validate_recount, k_recount, k_rows_vs_filter + k_topn_filter,
-k_counts_to_bsi / k_cell_stats, k_count_matrix_fused, k_count_matrix<4>."""
+k_counts_to_bsi / k_cell_stats, k_count_matrix_fusedq, k_count_matrix<4>."""
 import json
 import os
 import sys
@@ -65,13 +65,10 @@ rec(f"fbk_flip [123, 900000] (k_flip), {allrows.size} rows", nbytes + allrows.si
 rec(f"fbk_rows column filter (k_rows_flags + scan / select), {allrows.size} rows", allrows.size * 16 * 16, lambda: ctx.rows(batch, allrows, (3 << 16) + 77))
 rec("fbk_topn MinThreshold + Tanimoto (k_rows_vs_filter, k_row_cardinality, k_topn_filter)", nbytes, lambda: ctx.topn(batch, groups, 10, F, fidx, tanimoto_threshold=2))
 rec("fbk_topk_bsi (k_rows_vs_filter, k_counts_to_bsi, k_cell_stats)", nbytes, lambda: ctx.topk_bsi(batch, groups, F, fidx))
-rec("fbk_count_matrix 32 x 32 + filter, densify + dense kernel (k_densify_rows, k_count_matrix_mfma)", nbytes, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx))
-ctx.set_option("matrix_fused", 1)
-rec("fbk_count_matrix 32 x 32 + filter, in-kernel decode (k_count_matrix_fused)", nbytes, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx))
-ctx.set_option("matrix_fused", -1)
-ctx.set_option("matrix_densify", 0)
+rec("fbk_count_matrix 32 x 32 + filter, in-kernel decode (k_fused_program + k_count_matrix_fusedq)", nbytes, lambda: ctx.count_matrix(batch, groups[:, :32], batch, groups[:, 32:], F, fidx))
+ctx.set_option("matrix_fused", 0)
 rec("fbk_count_matrix 8 x 8 + filter, generic pair kernel (k_count_matrix<4>)", nbytes * 17 / 65, lambda: ctx.count_matrix(batch, groups[:, :8], batch, groups[:, 32:40], F, fidx))
-ctx.set_option("matrix_densify", -1)
+ctx.set_option("matrix_fused", -1)
 # serialised roaring: download the union result and upload it again
 u, _ = ctx.union_n(batch, groups, L.SETOP_OPTIMIZE)
 blob = u.to_roaring()

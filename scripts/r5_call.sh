@@ -19,7 +19,6 @@ bench2) timeout 400 python bench.py --gpus 2 --steps 100 > $O/bench_n2.json 2> $
 misc) (cd /tmp; export TMPDIR=/tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/misc -o misc -- python $R/scripts/profile_misc.py 64 > $O/misc.json 2> /dev/null; python3 $R/scripts/kernel_trace_by_grid.py $O/misc/misc_kernel_trace.csv 1 > $O/misc_kernel_trace_by_grid.csv) ;;
 benchprof) (cd /tmp; export TMPDIR=/tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --repeats 5 --no-cpu-baseline --shards4-total 1024 --shards4-mixed-total 1024 > $O/bench_prof.json 2> /dev/null; python3 $R/scripts/kernel_trace_by_grid.py $O/kt/bench_kernel_trace.csv 3 > $O/kernel_trace_by_grid.csv) ;;
 pmc_pairs) KF=${KF:-icount}; bash scripts/fused_pmc.sh $TAG/pmc_v1 64 pair_kernels=1 pairs_pmc.py $KF > $O/pmc_pairs_v1.txt 2>&1; bash scripts/fused_pmc.sh $TAG/pmc_v2 64 pair_kernels=2 pairs_pmc.py $KF > $O/pmc_pairs_v2.txt 2>&1 ;;
-bsi_ahead) (for a in 3 4; do FBK_BSI_PLANES_AHEAD=$a timeout 200 python scripts/bsi_bench.py 2>&1 | grep -i "one pass\|half_waves\|Sum()" > $O/bsi_ahead$a.txt; done) ;;
 bsi) (timeout 200 python scripts/bsi_bench.py 2>&1 | grep -v amdgpu.ids > $O/bsi_bench.txt) ;;
 pmc_hbm) (cd /tmp; export TMPDIR=/tmp; BA="--steps 20 --warmup 2 --repeats 2 --no-cpu-baseline --cold-sets 1 --shards4 128 --shards4-mixed 128 --shards4-total 0 --shards4-mixed-total 0"; timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o b -- python $R/bench.py $BA > /dev/null 2>&1; timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o b -- python $R/bench.py $BA > /dev/null 2>&1; python3 $R/scripts/pmc_hbm_summary.py $O "bench.py $BA (round 5)" > $O/pmc_hbm_bytes.txt 2>&1) ;;
 pmc_pairs4) bash scripts/fused_pmc.sh $TAG/pmc_pairs ${PMC_SHARDS:-256} pair_kernels=2 pairs_pmc.py icount2 > $O/pmc_pairs_shipped.txt 2>&1 ;;
@@ -29,9 +28,7 @@ small) timeout 300 python scripts/small_shapes_ab.py ${SMALL_ARGS:-64 7} 2> $O/s
 scatter_ab) (for i in 1 2; do for lib in "" build_variants/${AB_VARIANT:-r4_container_dealing}/libfbk.so; do FBK_LIB_PATH=${lib:+$R/$lib} timeout 200 python scripts/scatter_ab.py 2>> $O/scatter_ab.err | grep "^{" >> $O/scatter_ab.jsonl; done; done) ;;
 pmc_fused) bash scripts/fused_pmc.sh $TAG/pmc_fused 256 0 fused_pmc.py count_matrix_fused > $O/pmc_fused_shipped.txt 2>&1 ;;
 fuzz) bash scripts/fuzz_parity.sh $O ${FUZZ_SEEDS:-0x5eed4001 0x5eed4002 0x5eed4003} > /dev/null 2>&1 ;;
-fused_spb) timeout 300 python scripts/fused_spb_sweep.py ${SWEEP_ARGS:-256 5} 2> $O/fused_spb.err | grep -v amdgpu.ids > $O/fused_spb.json ;;
-fused) timeout 400 python scripts/fused_bench.py 256 2>&1 | grep -v amdgpu.ids > $O/fused_bench.txt ;;
-fusedprof) (for pg in 1 0; do timeout 200 python scripts/fused_prof.py 256 0 $pg ${PROF_CFG:-4} 2>&1 | grep -v amdgpu.ids; done) > $O/fused_prof.txt ;;
+fusedprof) (timeout 200 python scripts/fused_prof.py 256 0 2 ${PROF_CFG:-4} 2>&1 | grep -v amdgpu.ids) > $O/fused_prof.txt ;;
 fused_ab) timeout 500 python scripts/fused_ab.py ${FUSED_AB_ARGS:-256 1024} > $O/fused_ab.json 2> $O/fused_ab.err ;;
 fused_ablate) (for c in ${ABL_CFGS:-4 3}; do timeout 300 python scripts/fused_ablate.py $c 2>> $O/fused_ablate.err | grep "^{" >> $O/fused_ablate.jsonl; done) ;;
 *) echo "unknown step $s" ;;

@@ -1,6 +1,6 @@
 """Small GroupBy shapes on config 3's mixed rows: which count-matrix path serves an n_a x n_b (+ filter) query of a few
 rows per side best — the generic pair kernel (k_count_matrix<4>), the in-kernel-decode matrix-core kernel
-(k_count_matrix_fused) or densify + the dense kernel — and fbk_count_range.  Interleaved A/B inside one process, kernel
+(k_count_matrix_fusedq) — and fbk_count_range.  Interleaved A/B inside one process, kernel
 time by the library's own HIP events (option time_kernels) and the prepared query's GPU time.
 
     python scripts/small_shapes_ab.py [shards=64] [rounds=7]
@@ -32,8 +32,9 @@ fidx = np.arange(n)
 ctx.set_option("time_kernels", 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 out = {"shards": n, "shapes": {}}
-VARIANTS = {"generic (k_count_matrix<4>)": {"matrix_fused": 0, "matrix_densify": 0}, "fused (k_count_matrix_fused)": {"matrix_fused": 1, "matrix_densify": -1},
-            "densify + dense": {"matrix_fused": 0, "matrix_densify": 1}, "library default": {"matrix_fused": -1, "matrix_densify": -1}}
+# (round 4 also ran "densify + dense" — k_densify_rows into temporary rows, then the dense kernel; that path was removed in round 5,
+# its numbers are in profiles/r04_small_shapes_ab.json)
+VARIANTS = {"generic (k_count_matrix<4>)": {"matrix_fused": 0}, "fused (k_count_matrix_fusedq)": {"matrix_fused": 1}, "library default": {"matrix_fused": -1}}
 for (na, nb, use_f) in ((8, 8, True), (8, 8, False), (4, 16, True), (16, 16, True), (2, 2, True), (3, 30, False)):
     ra, rb = groups[:, :na], groups[:, 32:32 + nb]
     q = ctx.prepare_count_matrix(batch, ra, batch, rb, F if use_f else None, fidx if use_f else None)
@@ -54,7 +55,6 @@ for (na, nb, use_f) in ((8, 8, True), (8, 8, False), (4, 16, True), (16, 16, Tru
             else:
                 res.setdefault(name, []).append((e0.elapsed_time(e1) * 1e3, ctx.get_option("last_kernel_ns") / 1e3))
     ctx.set_option("matrix_fused", -1)
-    ctx.set_option("matrix_densify", -1)
     q.free()
     out["shapes"][f"{na} x {nb}" + (" + filter" if use_f else "")] = {
         k: {"gpu_us": sorted(x[0] for x in v)[len(v) // 2], "kernel_us": sorted(x[1] for x in v)[len(v) // 2]} for k, v in res.items()}

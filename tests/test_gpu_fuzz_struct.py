@@ -81,7 +81,7 @@ def _fuzz_pairwise_and_folds(gpu_ctx, oracle, it):
     Y, WY = (X, WX) if rng.random() < 0.3 else make_batch(gpu_ctx, rng, int(rng.integers(1, 50)))
     n = int(rng.integers(1, 120))
     ia, ib = rng.integers(0, len(WX), n), rng.integers(0, len(WY), n)
-    for name, val in (("sparse_paths", int(rng.integers(0, 2))), ("setop_direct_encode", int(rng.integers(0, 3))), ("setop_probe", int(rng.integers(0, 2))), ("pair_run_probe", int(rng.integers(0, 2))), ("pair_wpb", int(rng.choice([0, 1, 4]))), ("pair_resolve", int(rng.integers(0, 2))), ("dense_spb", int(rng.choice([1, 2, 4, 8, 16])))):
+    for name, val in (("setop_direct_encode", int(rng.integers(0, 3))), ("pair_wpb", int(rng.choice([0, 1, 4]))), ("dense_spb", int(rng.choice([1, 2, 4, 8, 16])))):
         gpu_ctx.set_option(name, val)
     try:
         got = gpu_ctx.intersection_count(X, ia, Y, ib)
@@ -113,7 +113,6 @@ def _fuzz_pairwise_and_folds(gpu_ctx, oracle, it):
         F, WF = make_batch(gpu_ctx, rng, g)
         for op in NP_OPS:
             flags = L.SETOP_OPTIMIZE if rng.random() < 0.5 else 0
-            gpu_ctx.set_option("fold_register", int(rng.integers(0, 2)))
             out, cnt = gpu_ctx.fold_n(op, X, groups, flags)
             W, res = out_words(out, g)
             exp = np.stack([fold(op, WX, ids) for ids in groups])
@@ -130,7 +129,7 @@ def _fuzz_pairwise_and_folds(gpu_ctx, oracle, it):
         out.free()
         F.free()
     finally:
-        for name, val in (("sparse_paths", 1), ("setop_direct_encode", 2), ("setop_probe", 1), ("pair_run_probe", 1), ("pair_wpb", 0), ("pair_resolve", 1), ("dense_spb", 16), ("fold_register", 0)):
+        for name, val in (("setop_direct_encode", 2), ("pair_wpb", 0), ("dense_spb", 16)):
             gpu_ctx.set_option(name, val)
         if Y is not X:
             Y.free()
@@ -153,8 +152,7 @@ def test_fuzz_count_matrix_and_topk(gpu_ctx, it):
     use_f = rng.random() < 0.7
     F, WF = make_batch(gpu_ctx, rng, n_shards) if use_f else (None, None)
     rf = rng.permutation(n_shards) if use_f else None
-    opts = {"matrix_fused": int(rng.integers(-1, 2)), "matrix_densify": int(rng.integers(-1, 2)), "matrix_fp4": int(rng.integers(-1, 2)),
-            "matrix_spb": int(rng.choice([0, 1, 2, 4, 8, 16])), "matrix_valu": int(rng.random() < 0.15),
+    opts = {"matrix_fused": int(rng.integers(-1, 2)), "matrix_fp4": int(rng.integers(-1, 2)), "matrix_spb": int(rng.choice([0, 1, 2, 4, 8, 16])),
             "matrix_pass_kb": int(rng.choice([1 << 20, 64, 4]))}
     for name, val in opts.items():
         gpu_ctx.set_option(name, val)
@@ -183,7 +181,7 @@ def test_fuzz_count_matrix_and_topk(gpu_ctx, it):
             e = order[:k] if k else order
             assert idx.tolist() == e and cnt.tolist() == [int(per_row[i]) for i in e], (k, opts)
     finally:
-        for name, val in (("matrix_fused", -1), ("matrix_densify", -1), ("matrix_fp4", -1), ("matrix_spb", 0), ("matrix_valu", 0), ("matrix_pass_kb", 1 << 20), ("topk_device_sort", -1)):
+        for name, val in (("matrix_fused", -1), ("matrix_fp4", -1), ("matrix_spb", 0), ("matrix_pass_kb", 1 << 20), ("topk_device_sort", -1)):
             gpu_ctx.set_option(name, val)
         if F is not None:
             F.free()
@@ -288,8 +286,6 @@ def test_fuzz_bsi(gpu_ctx, oracle, it):
         batch, base = gpu_ctx.upload(rows), np.array(base, dtype=np.uint32)
     F = gpu_ctx.upload([{k & 15: D.to_fbk(c) for k, c in f.items() if c.n} for f in filts])
     rf = np.arange(n_sh)
-    gpu_ctx.set_option("bsi_planes_ahead", int(rng.choice([3, 4])))
-    gpu_ctx.set_option("bsi_half_waves", int(rng.integers(0, 2)))
     try:
         for use_f in (False, True):
             fa = (F, rf) if use_f else (None, None)
@@ -334,7 +330,5 @@ def test_fuzz_bsi(gpu_ctx, oracle, it):
             assert all((got[k & 15].words() == c.words()).all() for k, c in e.items() if c.n)
         out.free()
     finally:
-        gpu_ctx.set_option("bsi_planes_ahead", 3)
-        gpu_ctx.set_option("bsi_half_waves", 1)
         batch.free()
         F.free()

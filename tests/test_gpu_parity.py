@@ -13,17 +13,15 @@ from featurebase_amd import lib as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(1, 1), (2, 1), (2, 0), (0, 1)], ids=["pair-kernels-r2", "pair-kernels-r3", "pair-kernels-r3-runs-decoded", "pair-kernels-auto"], autouse=True)
+@pytest.fixture(params=[1, 2, 0], ids=["pair-kernels-r2", "pair-kernels-r3", "pair-kernels-auto"], autouse=True)
 def pair_kernel_generation(request, gpu_ctx):
     """Every test of this file runs with the round-2 pair kernels (k_icount / k_setop), with the round-3 ones (k_icount2 /
-    k_setop2: table + probe, interior-map run decode, one-wave blocks; round 4: array x run by probing the run table, and with
-    option pair_run_probe = 0 by decoding both) and with the library's own choice by payload size: each generation is checked
-    against the oracle on every input of the file, not only on the rows the dispatch would hand it."""
-    gpu_ctx.set_option("pair_kernels", request.param[0])
-    gpu_ctx.set_option("pair_run_probe", request.param[1])
-    yield request.param[0]
+    k_setop2: table + probe, interior-map run decode, one-wave blocks; array x run by probing the run table) and with the
+    library's own choice by payload size: each generation is checked against the oracle on every input of the file, not
+    only on the rows the dispatch would hand it."""
+    gpu_ctx.set_option("pair_kernels", request.param)
+    yield request.param
     gpu_ctx.set_option("pair_kernels", 0)
-    gpu_ctx.set_option("pair_run_probe", 1)
 
 OPS = [(L.OP_AND, "intersect"), (L.OP_OR, "union"), (L.OP_XOR, "xor"), (L.OP_ANDNOT, "difference")]
 ZERO = np.zeros(1024, dtype=np.uint64)

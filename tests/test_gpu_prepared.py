@@ -265,7 +265,7 @@ def test_prepared_topn_orders_on_the_device(gpu_ctx, mixed):
 
 def test_prepared_row_records_follow_a_rewritten_batch(gpu_ctx, mixed):
     """Prepared folds / TopN resolve the descriptors of every (group / shard, slot) into contiguous records on their first run
-    (k_resolve_rows, option query_resolve).  Same results with and without them; and when the batch the query reads is REWRITTEN
+    (k_resolve_rows).  Same results as the one-shot calls, which do not use them; and when the batch the query reads is REWRITTEN
     on the device (here: the output of a plan, re-run with another operation) the next run resolves again instead of chasing the
     old descriptors."""
     rows, g, filt, OA, OF = mixed
@@ -274,24 +274,28 @@ def test_prepared_row_records_follow_a_rewritten_batch(gpu_ctx, mixed):
     F = gpu_ctx.upload_flat(filt.descs(), filt.payload(), filt.n_rows)
     fidx = np.arange(n)
     try:
-        res = {}
-        for mode in (1, 0):
-            gpu_ctx.set_option("query_resolve", mode)
-            q1 = gpu_ctx.prepare_fold_intersection_count(L.OP_OR, batch, g, F, fidx)
-            q2 = gpu_ctx.prepare_fold(L.OP_XOR, batch, g[:, :7], L.SETOP_OPTIMIZE)
-            q3 = gpu_ctx.prepare_topn(batch, g, 0, F, fidx)
-            q4 = gpu_ctx.prepare_count_matrix(batch, g, F, fidx.reshape(-1, 1))
-            for q in (q1, q2, q3, q4):
-                q.run()
-                q.run()
-            d2, p2, _ = q2.output().download_flat()
-            res[mode] = (q1.read().tolist(), q2.read().tolist(), d2.tobytes(), p2.tobytes(), [x.tolist() for x in q3.read()], q4.read().tolist())
-            for q in (q1, q2, q3, q4):
-                q.free()
-        assert res[0] == res[1]
-        assert res[1][0] == PB.union_n_intersection_count(OA, g, OF, fidx)[0].tolist()
+        # prepared (resolved records) against the one-shot calls, whose kernels gather the descriptors through the row lists
+        q1 = gpu_ctx.prepare_fold_intersection_count(L.OP_OR, batch, g, F, fidx)
+        q2 = gpu_ctx.prepare_fold(L.OP_XOR, batch, g[:, :7], L.SETOP_OPTIMIZE)
+        q3 = gpu_ctx.prepare_topn(batch, g, 0, F, fidx)
+        q4 = gpu_ctx.prepare_count_matrix(batch, g, F, fidx.reshape(-1, 1))
+        for q in (q1, q2, q3, q4):
+            q.run()
+            q.run()
+        d2, p2, _ = q2.output().download_flat()
+        o2, c2 = gpu_ctx.fold_n(L.OP_XOR, batch, g[:, :7], L.SETOP_OPTIMIZE)
+        e_d2, e_p2, _ = o2.download_flat()
+        assert q1.read().tolist() == gpu_ctx.fold_n_intersection_count(L.OP_OR, batch, g, F, fidx).tolist()
+        assert q1.read().tolist() == PB.union_n_intersection_count(OA, g, OF, fidx)[0].tolist()
+        assert q2.read().tolist() == c2.tolist() and d2.tobytes() == e_d2.tobytes() and p2.tobytes() == e_p2.tobytes()
+        e_idx, e_cnt = gpu_ctx.topn(batch, g, 0, F, fidx)
+        idx, cnt = q3.read()
+        assert idx.tolist() == e_idx.tolist() and cnt.tolist() == e_cnt.tolist()
+        assert (q4.read() == gpu_ctx.count_matrix(batch, g, F, fidx.reshape(-1, 1))).all()
+        o2.free()
+        for q in (q1, q2, q3, q4):
+            q.free()
         # a query over a batch that changes under it
-        gpu_ctx.set_option("query_resolve", 1)
         ia, ib = g[:, :6].reshape(-1), g[:, 6:12].reshape(-1)  # 6 output rows per shard
         plan = gpu_ctx.plan(batch, ia, batch, ib)
         plan.setop(L.OP_OR)
@@ -322,6 +326,6 @@ def test_prepared_row_records_follow_a_rewritten_batch(gpu_ctx, mixed):
         qm.free()
         plan.free()
     finally:
-        gpu_ctx.set_option("query_resolve", 1)
+        gpu_ctx.set_option("matrix_fused", -1)
     batch.free()
     F.free()

@@ -205,7 +205,7 @@ def check_range(gpu_ctx, B, frags, depth, batch, base, op, pred, flags=0):
 
 
 @pytest.mark.parametrize("case", CASES["range_cases"], ids=lambda c: c["test"])
-def test_bsi_range_reference_cases_on_gpu(gpu_ctx, B, case, bsi_kernel_form):
+def test_bsi_range_reference_cases_on_gpu(gpu_ctx, B, case):
     """The reference's TestFragment_Range literals evaluated by the HIP plane-program kernel."""
     depth = max(v[1] for v in case["values"])
     fr = B.bsi_fragment_from_values({v[0]: v[2] for v in case["values"]}, depth)
@@ -227,7 +227,7 @@ def test_bsi_range_reference_cases_on_gpu(gpu_ctx, B, case, bsi_kernel_form):
     batch.free()
 
 
-def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B, bsi_kernel_form):
+def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B):
     """TestFragmentBSIUnsigned / Signed (fragment_internal_test.go:3768-4275) on the GPU."""
     k = 6
     fu = B.bsi_fragment_from_values({i: i for i in range(1 << k)}, k)
@@ -248,17 +248,7 @@ def test_bsi_diagonal_sweeps_on_gpu(gpu_ctx, B, bsi_kernel_form):
     batch.free()
 
 
-@pytest.fixture(params=[3, 4], ids=["3-planes-ahead", "4-planes-ahead"])
-def bsi_kernel_form(request, gpu_ctx):
-    """The one-pass kernels on dense batches keep 3 (default) or 4 planes in flight, counted by hand: every depth is its
-    own instantiation (scripts/check_inflight.py verifies the binary of each).  The other BSI kernels have one form since
-    round 3 (the round-1 block kernels and the quarter-container Sum(Between) are gone)."""
-    gpu_ctx.set_option("bsi_planes_ahead", request.param)
-    yield request.param
-    gpu_ctx.set_option("bsi_planes_ahead", 3)
-
-
-def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle, bsi_kernel_form):
+def test_bsi_random_multi_shard_sum_and_range(gpu_ctx, B, oracle):
     O = oracle
     rng = D.rng_for(61)
     depth = 64
@@ -318,19 +308,19 @@ def test_bsi_range_sum_one_pass_equals_range_then_sum(gpu_ctx, B, oracle):
     rf = np.arange(len(frags))
     svals = sorted(vals_all[0].values())
     preds = [svals[len(svals) // 2], svals[len(svals) // 4], svals[0], svals[-1], 0, 1, -1, 2, -2, 500, -500, (1 << 63) - 1, -(1 << 63), 1 << 62, -(1 << 62)]
-    try:
-        for two_pass in (0, 1):
-            gpu_ctx.set_option("bsi_range_sum_two_pass", two_pass)
-            for name, op in B.OPS.items():
-                for p in preds if not two_pass else preds[:3]:
-                    sums, cnts = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p)
-                    fs, fc = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p, F, rf)
-                    for s, fr in enumerate(frags):
-                        e = B.bsi_range(fr, op, depth, p)
-                        assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(fr, e, True), (name, p, s, two_pass)
-                        assert (int(fs[s]), int(fc[s])) == B.bsi_sum(fr, e.intersect(filts[s]), True), (name, p, s, "filter", two_pass)
-    finally:
-        gpu_ctx.set_option("bsi_range_sum_two_pass", 0)
+    for name, op in B.OPS.items():
+        for p in preds:
+            sums, cnts = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p)
+            fs, fc = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p, F, rf)
+            # ... and the two calls it replaces: fbk_bsi_range, then fbk_bsi_sum over the result rows
+            rows2, _ = gpu_ctx.bsi_range(batch, base, L.BSI_OPS[name], depth, p)
+            s2, c2 = gpu_ctx.bsi_sum(batch, base, depth, rows2, rf)
+            rows2.free()
+            for s, fr in enumerate(frags):
+                e = B.bsi_range(fr, op, depth, p)
+                assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(fr, e, True), (name, p, s)
+                assert (int(s2[s]), int(c2[s])) == (int(sums[s]), int(cnts[s])), (name, p, s, "range then sum")
+                assert (int(fs[s]), int(fc[s])) == B.bsi_sum(fr, e.intersect(filts[s]), True), (name, p, s, "filter")
     # a shallower field, whose predicates saturate
     d2 = 10
     v2 = {int(c): int(v) for c, v in zip(rng.choice(1 << 20, size=4000, replace=False), rng.integers(-1023, 1024, size=4000))}
@@ -346,7 +336,7 @@ def test_bsi_range_sum_one_pass_equals_range_then_sum(gpu_ctx, B, oracle):
 
 def test_bsi_dense_batches_half_container_kernels(gpu_ctx, B, oracle):
     """A BSI batch in the dense layout (fbk_batch_upload_dense) takes the half-container-per-wavefront kernel for the
-    one-pass Range + Sum: same totals as one wavefront per container (option bsi_half_waves=0) and as the oracle, with
+    one-pass Range + Sum: same totals as the oracle, with
     filters of every encoding, empty halves, a shard whose exists row is empty (Sum on the dense batch alongside)."""
     O = oracle
     rng = D.rng_for(64)
@@ -365,33 +355,29 @@ def test_bsi_dense_batches_half_container_kernels(gpu_ctx, B, oracle):
     F = gpu_ctx.upload([D.to_fbk_row(r) for r in filt_rows])
     fbms = [O.OBitmap.from_containers(list(r.items())) for r in filt_rows]
     rf = np.arange(n_sh)
-    try:
-        for hw in (1, 0):
-            gpu_ctx.set_option("bsi_half_waves", hw)
-            sums, cnts = gpu_ctx.bsi_sum(batch, base, depth)
-            fs, fc = gpu_ctx.bsi_sum(batch, base, depth, F, rf)
+    hw = "dense"
+    sums, cnts = gpu_ctx.bsi_sum(batch, base, depth)
+    fs, fc = gpu_ctx.bsi_sum(batch, base, depth, F, rf)
+    for s in range(n_sh):
+        assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(frags[s], None, False), (s, hw)
+        assert (int(fs[s]), int(fc[s])) == B.bsi_sum(frags[s], fbms[s], True), (s, hw)
+    for name, op in B.OPS.items():
+        for p in (100, -100, 4000, -4000, 8191, -8191, 1, -1, 0):
+            sums, cnts = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p)
+            fs, fc = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p, F, rf)
             for s in range(n_sh):
-                assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(frags[s], None, False), (s, hw)
-                assert (int(fs[s]), int(fc[s])) == B.bsi_sum(frags[s], fbms[s], True), (s, hw)
-            for name, op in B.OPS.items():
-                for p in (100, -100, 4000, -4000, 8191, -8191, 1, -1, 0):
-                    sums, cnts = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p)
-                    fs, fc = gpu_ctx.bsi_range_sum(batch, base, L.BSI_OPS[name], depth, p, F, rf)
-                    for s in range(n_sh):
-                        e = B.bsi_range(frags[s], op, depth, p)
-                        assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(frags[s], e, True), (name, p, s, hw)
-                        assert (int(fs[s]), int(fc[s])) == B.bsi_sum(frags[s], e.intersect(fbms[s]), True), (name, p, s, hw, "filter")
-            # lo <= v <= hi: two lanes of one sign class (split at the highest differing bit), two sign classes, bounds beyond
-            # the field; lo >= hi and hw = 0 take the two-pass path
-            for lo, hi in ((100, 4000), (-4000, -100), (-300, 500), (0, 8191), (-8191, 0), (-9000, 9000), (1, 2), (4095, 4096), (-1, 0), (7, 7), (9, 3), (5000, 20000)):
-                bs, bc = gpu_ctx.bsi_range_between_sum(batch, base, depth, lo, hi)
-                fs, fc = gpu_ctx.bsi_range_between_sum(batch, base, depth, lo, hi, F, rf)
-                for s in range(n_sh):
-                    e = B.bsi_range_between(frags[s], depth, lo, hi)
-                    assert (int(bs[s]), int(bc[s])) == B.bsi_sum(frags[s], e, True), ("between", lo, hi, s, hw)
-                    assert (int(fs[s]), int(fc[s])) == B.bsi_sum(frags[s], e.intersect(fbms[s]), True), ("between", lo, hi, s, hw, "filter")
-    finally:
-        gpu_ctx.set_option("bsi_half_waves", 1)
+                e = B.bsi_range(frags[s], op, depth, p)
+                assert (int(sums[s]), int(cnts[s])) == B.bsi_sum(frags[s], e, True), (name, p, s, hw)
+                assert (int(fs[s]), int(fc[s])) == B.bsi_sum(frags[s], e.intersect(fbms[s]), True), (name, p, s, hw, "filter")
+    # lo <= v <= hi: two lanes of one sign class (split at the highest differing bit), two sign classes, bounds beyond
+    # the field; lo >= hi takes the two-pass path
+    for lo, hi in ((100, 4000), (-4000, -100), (-300, 500), (0, 8191), (-8191, 0), (-9000, 9000), (1, 2), (4095, 4096), (-1, 0), (7, 7), (9, 3), (5000, 20000)):
+        bs, bc = gpu_ctx.bsi_range_between_sum(batch, base, depth, lo, hi)
+        fs, fc = gpu_ctx.bsi_range_between_sum(batch, base, depth, lo, hi, F, rf)
+        for s in range(n_sh):
+            e = B.bsi_range_between(frags[s], depth, lo, hi)
+            assert (int(bs[s]), int(bc[s])) == B.bsi_sum(frags[s], e, True), ("between", lo, hi, s, hw)
+            assert (int(fs[s]), int(fc[s])) == B.bsi_sum(frags[s], e.intersect(fbms[s]), True), ("between", lo, hi, s, hw, "filter")
     batch.free()
     F.free()
 
@@ -664,30 +650,24 @@ def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
     batch.free()
 
 
-@pytest.fixture(params=[(1, 2048, 2), (1, 64, 2), (0, 2048, 2), (1, 2048, 1), (1, 64, 1), (0, 2048, 1)],
-                ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows", "heavy-shadows-first-form", "shadows-of-arrays-over-64-values-first-form",
-                     "no-shadows-first-form"])
+@pytest.fixture(params=[(1, 2048), (1, 64), (0, 2048)], ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows"])
 def shadow_mode(request, gpu_ctx):
     """Count matrix over encoded rows: run containers and long arrays as dense shadows built per batch on first use (default), the
     same with nearly every array shadowed (more than 42 bitmap rows per slot: the in-place path of the bitmap waves), and every
-    container decoded in every query (run rows, long arrays); each on the program-driven kernel with specialised producer waves
-    (round 5's default: option matrix_fused_program = 2) and on its first form (= 1), which runs the same program with twelve
-    general producer waves — two kernels that share nothing but the program and the consumers' arithmetic."""
+    container decoded in every query (run rows, long arrays).  Each result is compared with the oracle's groupByIterator counts
+    per shard, and with the generic pair kernel on the same call (two kernels that share no code)."""
     gpu_ctx.set_option("matrix_shadow", request.param[0])
     gpu_ctx.set_option("matrix_shadow_array", request.param[1])
-    gpu_ctx.set_option("matrix_fused_program", request.param[2])
     yield request.param
     gpu_ctx.set_option("matrix_shadow", 1)
     gpu_ctx.set_option("matrix_shadow_array", 2048)
-    gpu_ctx.set_option("matrix_fused_program", 2)
 
 
 @pytest.mark.parametrize("a_dense,b_dense,f_mode", [(False, False, "mixed"), (True, False, "none"), (False, True, "dense"), (False, False, "none")])
-def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle, B, a_dense, b_dense, f_mode, shadow_mode):
-    """nA x nB >= 100 with array / run containers among the rows: fbk_count_matrix densifies the
-    referenced rows into temporary bitmap rows and runs the dense matrix kernel; every mix of
-    dense and encoded operands, checked against the oracle's groupByIterator counts — and against
-    the generic pair kernel (FBK_MATRIX_DENSIFY=0) on the same call."""
+def test_count_matrix_mixed_rows_fused_and_generic_paths(gpu_ctx, oracle, B, a_dense, b_dense, f_mode, shadow_mode):
+    """nA x nB >= 16 with array / run containers among the rows: fbk_count_matrix decodes the rows inside the
+    matrix-core kernel; every mix of dense and encoded operands, checked against the oracle's groupByIterator
+    counts — and against the generic pair kernel (matrix_fused=0) on the same call."""
     O = oracle
     rng = D.rng_for(57)
     n_shards, n_a, n_b = 5, 48, 43
@@ -725,10 +705,8 @@ def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle
         assert (ps[k] == e).all(), (k, s)
         exp_tot += e
     assert (tot == exp_tot).all()
-    # the default above decodes inside the matrix-core kernel (fbk_matrix_fused.hip.h): every
-    # slots-per-block split of that launch; then the same call on the other two paths for encoded rows:
-    # densify + dense matrix-core kernel (round 1's path, matrix_fused=0) and the generic pair kernel
-    # (matrix_fused=0, matrix_densify=0)
+    # the default above decodes inside the matrix-core kernel (fbk_matrix_fusedq.hip.h): every
+    # slots-per-block split of that launch; then the same call on the generic pair kernel (matrix_fused=0)
     try:
         for spb in (16, 8, 4, 2, 1):
             gpu_ctx.set_option("matrix_spb", spb)
@@ -736,14 +714,10 @@ def test_count_matrix_mixed_rows_fused_densify_and_generic_paths(gpu_ctx, oracle
             assert (tot_s == tot).all() and (ps_s == ps).all(), spb
         gpu_ctx.set_option("matrix_spb", 0)
         gpu_ctx.set_option("matrix_fused", 0)
-        tot_d, ps_d = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
-        assert (tot_d == tot).all() and (ps_d == ps).all()
-        gpu_ctx.set_option("matrix_densify", 0)
         tot_g, ps_g = gpu_ctx.count_matrix(A, ra, Bt, rb, F, perm if F is not None else None, per_shard=True)
     finally:
         gpu_ctx.set_option("matrix_spb", 0)
         gpu_ctx.set_option("matrix_fused", -1)
-        gpu_ctx.set_option("matrix_densify", -1)
     assert (tot_g == tot).all() and (ps_g == ps).all()
     for b in (A, Bt, F):
         if b is not None:
@@ -817,11 +791,9 @@ def test_count_matrix_fused_window_edges(gpu_ctx, oracle, B, f_kind, shadow_mode
         gpu_ctx.set_option("matrix_fused", 1)
         tot, ps = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf, per_shard=True)
         gpu_ctx.set_option("matrix_fused", 0)
-        gpu_ctx.set_option("matrix_densify", 0)
         tot_g, ps_g = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf, per_shard=True)
     finally:
         gpu_ctx.set_option("matrix_fused", -1)
-        gpu_ctx.set_option("matrix_densify", -1)
     for s in range(n_shards):
         e = B.groupby_counts(B.Fragment([obm(r) for r in a_rows[s]]), B.Fragment([obm(r) for r in b_rows[s]]), obm(f_rows[s]) if f_rows else None)
         assert (ps[s] == e).all(), (s, np.argwhere(ps[s] != e)[:5])
@@ -1293,11 +1265,11 @@ def test_bsi_add_reference_cases(gpu_ctx, oracle):
         bt.free()
 
 
-def test_fold_optimize_in_the_epilogue_equals_the_separate_pass(gpu_ctx, oracle):
-    """Union / Xor / Difference of k rows + optimize(): the fold kernel's own epilogue (option fold_encode=1, the default) and
-    the separate re-encode pass over 8 KiB cells (fold_encode=0) produce the same descriptors and payload bytes — and the
-    same Pilosa-roaring image (Bitmap.WriteTo, roaring.go:1730-1817) — and every container has optimize()'s encoding of the
-    oracle's result.  Rows are chosen to land on every outcome: nil, short / long arrays (incl. 4095 values), run lists of
+def test_fold_optimize_in_the_epilogue(gpu_ctx, oracle):
+    """Union / Xor / Difference / Intersect of k rows + optimize() in the fold kernel's own epilogue: the bits and counts of the
+    oracle's fold, every container in optimize()'s encoding of the oracle's result (roaring.go:3412-3461), the call repeatable
+    byte for byte (descriptors, payload, Pilosa-roaring image).  (Until round 5 a separate re-encode pass over 8 KiB cells was
+    kept behind option fold_encode = 0 and compared byte for byte; the pair set-ops still run it: setop_direct_encode < 2.)  Rows are chosen to land on every outcome: nil, short / long arrays (incl. 4095 values), run lists of
     1 .. 2048 intervals (incl. runs spanning the two halves of a cell and runs ending at 65535), bitmaps, full containers."""
     O = oracle
     rng = D.rng_for(4242)
@@ -1347,28 +1319,24 @@ def test_fold_optimize_in_the_epilogue_equals_the_separate_pass(gpu_ctx, oracle)
             acc = acc.xor(b) if op == L.OP_XOR else acc.intersect(b)
         return acc
 
-    try:
-        for op in (L.OP_OR, L.OP_XOR, L.OP_ANDNOT, L.OP_AND):
-            got = {}
-            for mode in (1, 0):
-                gpu_ctx.set_option("fold_encode", mode)
-                out, cnt = gpu_ctx.fold_n(op, batch, groups, L.SETOP_OPTIMIZE)
-                d, p, n_rows = out.download_flat()
-                got[mode] = (d.copy(), p.copy(), cnt.copy(), out.to_roaring(), out.download())
-                out.free()
-            (d1, p1, c1, img1, res1), (d0, p0, c0, img0, _) = got[1], got[0]
-            assert (c1 == c0).all() and d1.tobytes() == d0.tobytes() and p1.tobytes() == p0.tobytes() and img1 == img0, op
-            types = set()
-            for g, ids in enumerate(groups):
-                exp = fold(op, [O.OBitmap.from_containers(list(rows[i].items())) for i in ids])
-                assert int(c1[g]) == exp.count(), (op, g)
-                assert (row_words(res1[g]) == bitmap_words(exp)).all(), (op, g)
-                assert_optimized_like_oracle(O, res1[g], exp)
-                types |= {c.typ for c in res1[g].values()}
-            if op != L.OP_AND:  # (the intersection of five rows is sparse)
-                assert types >= {L.TYPE_ARRAY, L.TYPE_BITMAP, L.TYPE_RUN}, (op, types)  # every encoding was produced
-    finally:
-        gpu_ctx.set_option("fold_encode", 1)
+    for op in (L.OP_OR, L.OP_XOR, L.OP_ANDNOT, L.OP_AND):
+        got = {}
+        for rep in (1, 0):
+            out, cnt = gpu_ctx.fold_n(op, batch, groups, L.SETOP_OPTIMIZE)
+            d, p, n_rows = out.download_flat()
+            got[rep] = (d.copy(), p.copy(), cnt.copy(), out.to_roaring(), out.download())
+            out.free()
+        (d1, p1, c1, img1, res1), (d0, p0, c0, img0, _) = got[1], got[0]
+        assert (c1 == c0).all() and d1.tobytes() == d0.tobytes() and p1.tobytes() == p0.tobytes() and img1 == img0, op
+        types = set()
+        for g, ids in enumerate(groups):
+            exp = fold(op, [O.OBitmap.from_containers(list(rows[i].items())) for i in ids])
+            assert int(c1[g]) == exp.count(), (op, g)
+            assert (row_words(res1[g]) == bitmap_words(exp)).all(), (op, g)
+            assert_optimized_like_oracle(O, res1[g], exp)
+            types |= {c.typ for c in res1[g].values()}
+        if op != L.OP_AND:  # (the intersection of five rows is sparse)
+            assert types >= {L.TYPE_ARRAY, L.TYPE_BITMAP, L.TYPE_RUN}, (op, types)  # every encoding was produced
     batch.free()
 
 
@@ -1410,16 +1378,15 @@ def test_setop_optimize_inside_the_kernel_equals_the_separate_pass(gpu_ctx, orac
             gpu_ctx.set_option("pair_kernels", pk)
             for op, name in [(L.OP_AND, "intersect"), (L.OP_OR, "union"), (L.OP_XOR, "xor"), (L.OP_ANDNOT, "difference")]:
                 got = {}
-                # (mode 2 with and without option setop_probe: Intersect / Difference of an array operand by table + probe, survivors
-                # written as the array they are, against both operands decoded into fragments — "2f")
-                for mode in (2, "2f", 1, 0):
-                    gpu_ctx.set_option("setop_direct_encode", 2 if mode == "2f" else mode)
-                    gpu_ctx.set_option("setop_probe", 0 if mode == "2f" else 1)
+                # (mode 2: Intersect / Difference of an array operand go by table + probe, survivors written as the array they are;
+                # modes 1 and 0 decode both operands into fragments and re-encode in a separate pass)
+                for mode in (2, 1, 0):
+                    gpu_ctx.set_option("setop_direct_encode", mode)
                     out, cnt = gpu_ctx.setop(op, A, idx, Bt, idx, flags=L.SETOP_OPTIMIZE)
                     d, p, _ = out.download_flat()
                     got[mode] = (d.tobytes(), p.tobytes(), cnt.copy(), out.to_roaring(), out.download())
                     out.free()
-                for mode in ("2f", 1, 0):
+                for mode in (1, 0):
                     assert got[2][0] == got[mode][0] and got[2][1] == got[mode][1] and (got[2][2] == got[mode][2]).all() and got[2][3] == got[mode][3], (pk, name, mode)
                 types = set()
                 for r in range(n):
@@ -1446,17 +1413,16 @@ def test_setop_optimize_inside_the_kernel_equals_the_separate_pass(gpu_ctx, orac
     finally:
         gpu_ctx.set_option("pair_kernels", 0)
         gpu_ctx.set_option("setop_direct_encode", 2)
-        gpu_ctx.set_option("setop_probe", 1)
     A.free()
     Bt.free()
 
 
-def test_pair_count_with_the_items_sorted_by_class(gpu_ctx, oracle):
-    """Option pair_lean: a count plan that runs again sorts its items by class on the host — array x array items of <= 1024 /
-    <= 2048 values go to k_icount_aa (a 4 KiB table for half the value range, used twice), the rest to k_icount2 — and the two
-    launches add into the same per-item counts.  Same results as the single kernel and as the oracle, for arrays on both
-    sides of every limit (row boundaries of 128 values, the 32768 split inside a row, the class limits), with 1 and 4 waves
-    per block, on the first (unsorted) and the later runs; a plan over a batch that was written on the device falls back."""
+def test_pair_count_arrays_on_every_row_and_half_boundary(gpu_ctx, oracle):
+    """Row-pair counts whose arrays sit on both sides of every boundary the table + probe kernels know: dword rows of 128 values,
+    the 32768 split of the value range, 1024 / 2048 / 4095 values, values confined to one half, consecutive values; bitmaps and
+    runs mixed in.  Both generations of the pair kernels, a plan run three times, and a plan over a batch that was written on
+    the device (the resolved item records follow the batch's version).  (The data set of round 4's lean array x array kernel,
+    which was removed in round 5.)"""
     O = oracle
     rng = D.rng_for(4545)
 
@@ -1500,34 +1466,33 @@ def test_pair_count_with_the_items_sorted_by_class(gpu_ctx, oracle):
     ib = np.concatenate([ib, np.arange(n)])
     exp = [sum(O.intersection_count(rows_a[a][ka], rows_b[b][b * 16 + (ka & 15)]) for ka in rows_a[a] if b * 16 + (ka & 15) in rows_b[b]) for a, b in zip(ia, ib)]
     try:
-        gpu_ctx.set_option("pair_kernels", 2)
-        for lean in (0, 1, 4):
-            gpu_ctx.set_option("pair_lean", lean)
+        for pk in (2, 1, 0):
+            gpu_ctx.set_option("pair_kernels", pk)
             plan = gpu_ctx.plan(A, ia, Bt, ib)
             for run in range(3):
                 plan.intersection_count()
-                assert plan.read().tolist() == exp, (lean, run)
+                assert plan.read().tolist() == exp, (pk, run)
             plan.free()
-        # a batch written on the device (a plan's output): its host descriptors are stale, the plan keeps the one kernel
+        # a batch written on the device (a plan's output): the plan over it resolves its items from the device descriptors
+        gpu_ctx.set_option("pair_kernels", 2)
         p0 = gpu_ctx.plan(A, ia, Bt, ib)
         p0.setop(L.OP_OR)
         out = p0.output()
         m = len(ia)
-        gpu_ctx.set_option("pair_lean", 0)
         ref = gpu_ctx.intersection_count(out, np.arange(m), Bt, ib)
-        gpu_ctx.set_option("pair_lean", 1)
+        # |(A ∪ B) ∩ B| = |B|
+        assert ref.tolist() == [O.OBitmap.from_containers(list(rows_b[b].items())).count() for b in ib]
         plan = gpu_ctx.plan(out, np.arange(m), Bt, ib)
         for run in range(3):
             plan.intersection_count()
             assert plan.read().tolist() == ref.tolist(), run
-        out.download()  # (reads the descriptors back: from now on the plan may sort)
+        out.download()  # (reads the descriptors back)
         for run in range(2):
             plan.intersection_count()
             assert plan.read().tolist() == ref.tolist(), run
         plan.free()
         p0.free()
     finally:
-        gpu_ctx.set_option("pair_lean", 0)
         gpu_ctx.set_option("pair_kernels", 0)
     A.free()
     Bt.free()

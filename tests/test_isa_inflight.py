@@ -43,7 +43,7 @@ def test_the_hand_counted_kernels_are_in_the_binary(kernels):
     """(the check above must not pass because the kernels it is there for were renamed away)"""
     _, funcs = kernels
     names = "\n".join(funcs)
-    for k in ("k_bsi_range_sum_halfILb0ELi3", "k_bsi_range_sum_halfILb1ELi4", "k_bsi_between_sum_partILi8ELi3", "k_bsi_between_sum_partILi8ELi4", "k_fold_scatterILi1", "k_rows_vs_filter"):
+    for k in ("k_bsi_range_sum_halfILb0ELi3", "k_bsi_range_sum_halfILb1ELi3", "k_bsi_between_sum_partILi8ELi3", "k_fold_scatterILi1", "k_rows_vs_filter", "k_count_matrix_fusedqILb1ELb0", "k_count_matrix_mfma"):
         assert k in names, k
     # and they do contain hand-written waits with loads in flight behind them
     for k in ("k_bsi_range_sum_halfILb0ELi3", "k_fold_scatterILi1ELi0"):
