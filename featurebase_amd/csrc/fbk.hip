@@ -1396,7 +1396,11 @@ void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs, const
   const uint32_t blocks = uint32_t(p->n_pairs * fbk::kSlots / 4);
   // (the in-kernel optimize() — mode 2 — only when the caller asked for optimize(): plain set-ops keep their bitmap cells)
   const uint32_t direct = want_runs ? uint32_t(p->ctx->opt.setop_direct_encode) : 0u;
+#ifdef FBK_EXPERIMENTS  // (option pair_ablate, timing experiments on k_setop2: item classes skipped, emission without its stores — WRONG results)
+  const uint32_t direct2 = direct | 0x100u | (uint32_t(p->ctx->opt.pair_ablate) << 16);
+#else
   const uint32_t direct2 = direct | 0x100u;  // k_setop2 only: Intersect / Difference whose result is a subset of an array operand by table + probe (an A/B option until round 5)
+#endif
   if (dense)
     hipLaunchKernelGGL(fbk::k_setop_dense<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_arena, p->d_rows_a,
                        p->b->d_arena, p->d_rows_b, p->out->d_arena, p->out->d_slots);

@@ -831,6 +831,7 @@ struct ProbeEmit {
   uint32_t runs = 0;               // this lane's survivors that start a run
   uint32_t last_val = 0x7FFFFFFFu; // the array element in front of lane 0's of the coming dword row, and whether it
   uint32_t last_kept = 0;          // survived (wave-uniform)
+  bool nostore = false;            // (timing experiments only)
 };
 
 // one batch of the probing array: KEEP = 1 keeps the values set in the table, 0 those that are not; MAP: the table holds a
@@ -857,8 +858,8 @@ __device__ __forceinline__ void array_probe_emit_batch(uint32_t tb, uint32_t mb,
     if (lane == 0) pv = e.last_val;
     const bool pk = (((m_hi << 1) | (u64)e.last_kept) >> lane) & 1ull;
     const uint32_t pos = e.before + (uint32_t)__popcll(m_lo & lane_lt) + (uint32_t)__popcll(m_hi & lane_lt);
-    if (k_lo) o16[pos] = (uint16_t)lo;
-    if (k_hi) o16[pos + (k_lo ? 1u : 0u)] = (uint16_t)hi;
+    if (k_lo && !e.nostore) o16[pos] = (uint16_t)lo;
+    if (k_hi && !e.nostore) o16[pos + (k_lo ? 1u : 0u)] = (uint16_t)hi;
     e.runs += ((k_lo && !(pk && pv + 1u == lo)) ? 1u : 0u) + ((k_hi && !(k_lo && lo + 1u == hi)) ? 1u : 0u);
     e.before += (uint32_t)__popcll(m_lo) + (uint32_t)__popcll(m_hi);
     e.last_val = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
@@ -869,10 +870,11 @@ __device__ __forceinline__ void array_probe_emit_batch(uint32_t tb, uint32_t mb,
 // the whole probing array of <= 4095 values (batch 0 in v0, batches 1..3 in the tail requested before the table was built)
 template <int KEEP, bool MAP = false>
 __device__ __forceinline__ void array_probe_emit_all(const uint8_t* __restrict__ /*p*/, uint32_t len, int lane, uint32_t tb, const uint32_t (&v0)[kPairBatch],
-                                                     const ProbeTail& t, uint16_t* __restrict__ o16, uint32_t& n_out, uint32_t& runs_out, uint32_t mb = 0) {
+                                                     const ProbeTail& t, uint16_t* __restrict__ o16, uint32_t& n_out, uint32_t& runs_out, uint32_t mb = 0, bool nostore = false) {
   const uint32_t n_units = (len + 1u) >> 1;
   constexpr uint32_t B = kPairBatch * kWave;
   ProbeEmit e;
+  e.nostore = nostore;
   array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 0, lane, v0, o16, e);
   if (n_units > B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, B, lane, t.v1, o16, e);
   if (n_units > 2 * B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 2 * B, lane, t.v2, o16, e);
@@ -886,7 +888,7 @@ __device__ __forceinline__ void array_probe_emit_all(const uint8_t* __restrict__
 template <int KEEP>
 __device__ __forceinline__ void array_vs_array_emit(const uint8_t* __restrict__ pt, uint32_t lt, uint32_t (&vt)[kPairBatch], const uint8_t* __restrict__ pp,
                                                     uint32_t lp, const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint16_t* __restrict__ o16,
-                                                    uint32_t& n_out, uint32_t& runs_out) {
+                                                    uint32_t& n_out, uint32_t& runs_out, bool nostore = false) {
   ProbeTail tail;
   probe_tail_load(pp, lp, lane, tail);
   const uint32_t tbase = lds_table_base(table);
@@ -894,7 +896,7 @@ __device__ __forceinline__ void array_vs_array_emit(const uint8_t* __restrict__ 
   wave_lds_sync();
   sparse_xor_all(kTypeArray, pt, lt, lane, tbase, vt);
   wave_lds_sync();
-  array_probe_emit_all<KEEP>(pp, lp, lane, tbase, vp, tail, o16, n_out, runs_out);
+  array_probe_emit_all<KEEP>(pp, lp, lane, tbase, vp, tail, o16, n_out, runs_out, 0, nostore);
   wave_lds_sync();
 }
 
@@ -902,7 +904,7 @@ __device__ __forceinline__ void array_vs_array_emit(const uint8_t* __restrict__ 
 template <int KEEP>
 __device__ __forceinline__ void array_vs_bitmap_emit(const uint8_t* __restrict__ pbm, const uint8_t* __restrict__ pp, uint32_t lp,
                                                      const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint16_t* __restrict__ o16, uint32_t& n_out,
-                                                     uint32_t& runs_out) {
+                                                     uint32_t& runs_out, bool nostore = false) {
   u64 wb[kWordsPerLane];
   frag_load_bitmap(pbm, lane, wb);
   ProbeTail tail;
@@ -916,7 +918,7 @@ __device__ __forceinline__ void array_vs_bitmap_emit(const uint8_t* __restrict__
     q[j * kWave + lane] = x;  // fragment layout -> natural word order in the table
   }
   wave_lds_sync();
-  array_probe_emit_all<KEEP>(pp, lp, lane, lds_table_base(table), vp, tail, o16, n_out, runs_out);
+  array_probe_emit_all<KEEP>(pp, lp, lane, lds_table_base(table), vp, tail, o16, n_out, runs_out, 0, nostore);
   wave_lds_sync();
 }
 
@@ -926,12 +928,12 @@ __device__ __forceinline__ void array_vs_bitmap_emit(const uint8_t* __restrict__
 template <int KEEP>
 __device__ __forceinline__ void array_vs_run_emit(const uint8_t* __restrict__ pr, uint32_t lr, uint32_t (&vr)[kPairBatch], const uint8_t* __restrict__ pp,
                                                   uint32_t lp, const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint32_t* mini,
-                                                  uint16_t* __restrict__ o16, uint32_t& n_out, uint32_t& runs_out) {
+                                                  uint16_t* __restrict__ o16, uint32_t& n_out, uint32_t& runs_out, bool nostore = false) {
   ProbeTail tail;
   probe_tail_load(pp, lp, lane, tail);
   uint32_t tbase, mbase;
   run_table_build(pr, lr, vr, lane, table, mini, tbase, mbase);
-  array_probe_emit_all<KEEP, true>(pp, lp, lane, tbase, vp, tail, o16, n_out, runs_out, mbase);
+  array_probe_emit_all<KEEP, true>(pp, lp, lane, tbase, vp, tail, o16, n_out, runs_out, mbase, nostore);
   wave_lds_sync();
 }
 
@@ -947,7 +949,15 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
   __shared__ uint32_t mini[WPB][2 * kMiniDwords];
   const int lane = threadIdx.x & 63;
   const int wv = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: descriptors become scalar loads (see k_icount2)
-  const bool probe = (direct & 0x100u) != 0;  // option setop_probe: Intersect / Difference of an array by table + probe (A/B: both forms give the same bytes)
+  const bool probe = (direct & 0x100u) != 0;  // Intersect / Difference of an array by table + probe
+  // timing experiments (option pair_ablate in the experiments build, WRONG results): 8 items with a run are skipped, 16 array x array
+  // items, 32 bitmap x array items, 64 the probe paths keep their arithmetic but store no survivor, 128 the general path (both
+  // operands decoded into fragments) is skipped
+#ifdef FBK_EXPERIMENTS
+  const uint32_t abl = direct >> 16;
+#else
+  constexpr uint32_t abl = 0;
+#endif
   direct &= 0xFFu;
   const uint64_t wslot = (uint64_t)blockIdx.x * WPB + (uint64_t)wv;
   const uint64_t pair = wslot >> 4;
@@ -977,6 +987,18 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
       if (outRuns) outRuns[wslot] = 0;
     }
     return;
+  }
+  if (abl) {
+    const uint32_t xa = slot_type(sa), xb = slot_type(sb);
+    const bool skip = ((abl & 8u) && (xa == kTypeRun || xb == kTypeRun)) || ((abl & 16u) && xa == kTypeArray && xb == kTypeArray) ||
+                      ((abl & 32u) && ((xa == kTypeArray && xb == kTypeBitmap) || (xa == kTypeBitmap && xb == kTypeArray)));
+    if (skip) {  // (wave-uniform)
+      if (lane == 0) {
+        outSlots[wslot] = so;
+        if (outRuns) outRuns[wslot] = 0;
+      }
+      return;
+    }
   }
   if (OP == 0 && direct && (outRuns || direct == 2u)) {
     // intersection with a small array, written as an array (see k_setop)
@@ -1018,6 +1040,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
     const uint8_t* pa = arenaA + sa.off;
     const uint8_t* pb = arenaB + sb.off;
     uint16_t* o16 = reinterpret_cast<uint16_t*>(arenaO + so.off);
+    const bool nostore = (abl & 64u) != 0;  // (experiment: the probe paths keep their arithmetic and store no survivor)
     uint32_t c = 0, r = 0;
     bool done = false;
     // who probes: the array the result is a subset of (Difference: A; Intersect: the LONGER array, so that the shorter one is
@@ -1036,16 +1059,16 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
         if (tt == kTypeArray) {
           sparse_load(pp, (lp + 1u) >> 1, 0, lane, vp);
           sparse_load(pt, (lt + 1u) >> 1, 0, lane, vt);
-          array_vs_array_emit<OP == 0>(pt, lt, vt, pp, lp, vp, lane, lds[wv], o16, c, r);
+          array_vs_array_emit<OP == 0>(pt, lt, vt, pp, lp, vp, lane, lds[wv], o16, c, r, nostore);
           done = true;
         } else if (tt == kTypeBitmap) {
           sparse_load(pp, (lp + 1u) >> 1, 0, lane, vp);
-          array_vs_bitmap_emit<OP == 0>(pt, pp, lp, vp, lane, lds[wv], o16, c, r);
+          array_vs_bitmap_emit<OP == 0>(pt, pp, lp, vp, lane, lds[wv], o16, c, r, nostore);
           done = true;
         } else if (tt == kTypeRun && lt <= kRunFillMax) {
           sparse_load(pp, (lp + 1u) >> 1, 0, lane, vp);
           sparse_load(pt, lt, 0, lane, vt);
-          array_vs_run_emit<OP == 0>(pt, lt, vt, pp, lp, vp, lane, lds[wv], mini[wv], o16, c, r);
+          array_vs_run_emit<OP == 0>(pt, lt, vt, pp, lp, vp, lane, lds[wv], mini[wv], o16, c, r, nostore);
           done = true;
         }
       }
@@ -1059,6 +1082,13 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
       }
       return;
     }
+  }
+  if (abl & 128u) {  // (experiment: no item takes the general path)
+    if (lane == 0) {
+      outSlots[wslot] = so;
+      if (outRuns) outRuns[wslot] = 0;
+    }
+    return;
   }
   u64 wa[kWordsPerLane], wb[kWordsPerLane];
   frag_load_pair(sa, arenaA, sb, arenaB, lane, lds[wv], mini[wv], wa, wb);

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--variants", default="pair_kernels=1;pair_kernels=2", help="';'-separated option sets, each a ','-separated list of name=value")
     ap.add_argument("--out", default="")
     ap.add_argument("--only-count", action="store_true")
+    ap.add_argument("--ops", default="", help="comma-separated subset of the operation names (e.g. 'intersectionCount,intersect + optimize()')")
     ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
     if "pair_ablate" in args.variants or "pair_stamp" in args.variants or any("ablate" in o or "stamp" in o for o in args.opt):
@@ -64,6 +65,8 @@ def main():
            ("intersect + optimize()", (L.OP_AND, L.SETOP_OPTIMIZE)), ("difference + optimize()", (L.OP_ANDNOT, L.SETOP_OPTIMIZE))]
     if args.only_count:
         ops = ops[:1]
+    if args.ops:
+        ops = [o for o in ops if o[0] in args.ops.split(",")]
     ref_counts = {}
     for var in args.variants.split(";"):
         for kv in var.split(","):
