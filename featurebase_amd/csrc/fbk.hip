@@ -685,7 +685,7 @@ const OptionDesc kOptions[] = {
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
 #ifdef FBK_EXPERIMENTS
-    {"pair_ablate", &FbkOptions::pair_ablate, 0, 255},
+    {"pair_ablate", &FbkOptions::pair_ablate, 0, 511},
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
 #endif
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
@@ -1523,7 +1523,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
       // gains — and are no longer instantiated.)
       const int wpb = pair_wpb_for(ctx, p->a, p->b);
 #ifdef FBK_EXPERIMENTS
-      const uint32_t pair_flags = 3u | (uint32_t(ctx->opt.pair_ablate) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16);
+      const uint32_t pair_flags = 3u | (uint32_t(ctx->opt.pair_ablate & 255) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16);
 #else
       constexpr uint32_t pair_flags = 3u;  // bit 0: the small-array / probe paths, bit 1: array x run items probe the run container's table (both were A/B options until round 5)
 #endif

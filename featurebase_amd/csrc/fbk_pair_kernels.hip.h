@@ -826,41 +826,60 @@ __global__ void __launch_bounds__(256) k_sum_slot_n(const Slot* __restrict__ out
 // table exactly as in k_icount2 (shorter array scattered into the cleared table / bitmap copied in), the array PROBES it,
 // and the survivors are written straight into the output cell as the sorted array they already are: positions from two
 // ballots per dword row, the run count of the result (for Container.optimize()'s rule) from each survivor's predecessor.
-struct ProbeEmit {
-  uint32_t before = 0;             // survivors written so far (wave-uniform)
-  uint32_t runs = 0;               // this lane's survivors that start a run
+struct ProbeEmit {                 // (everything wave-uniform: scalar registers)
+  uint32_t before = 0;             // survivors written so far
+  uint32_t runs = 0;               // runs the survivors so far start
   uint32_t last_val = 0x7FFFFFFFu; // the array element in front of lane 0's of the coming dword row, and whether it
-  uint32_t last_kept = 0;          // survived (wave-uniform)
+  uint32_t last_kept = 0;          // survived
   bool nostore = false;            // (timing experiments only)
 };
 
+__device__ __forceinline__ uint32_t mbcnt64(u64 m, uint32_t add) {  // add + the bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, add));
+}
+
 // one batch of the probing array: KEEP = 1 keeps the values set in the table, 0 those that are not; MAP: the table holds a
-// run container as boundary masks, its full dwords are in the map at mb
+// run container as boundary masks, its full dwords are in the map at mb.
+// The emission is what this kernel costs beyond the count of the same pairs (scripts/bench_pairs.py with pair_ablate,
+// profiles/r05_setop_ablate.json: storing nothing changes nothing, the ~40 vector instructions per dword row of the first
+// version were the 90 us), so everything that is the same for the 64 lanes is kept in SCALAR registers: the survivor masks are
+// the comparisons' own lane masks, "which lanes hold a value" is two scalar bit-field masks per row, positions are two
+// v_mbcnt pairs, the run count is mask arithmetic (a survivor starts a run unless its predecessor in the array survived and
+// is its value - 1: two adjacency masks per row, the predecessor of a lane's low value through one wave-shift DPP), and a
+// row without survivors ends after its two probes.
 template <int KEEP, bool MAP>
 __device__ __forceinline__ void array_probe_emit_batch(uint32_t tb, uint32_t mb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch],
                                                        uint16_t* __restrict__ o16, ProbeEmit& e) {
-  const u64 lane_lt = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
   for (int k = 0; k < kPairBatch; ++k) {
-    if ((base + (uint32_t)k * kWave) * 2u >= len) break;  // (wave-uniform: no value in this dword row or after it)
-    const uint32_t i2 = (base + (uint32_t)k * kWave + (uint32_t)lane) * 2u;
-    const uint32_t lo = v[k] & 0xFFFFu, hi = v[k] >> 16;
+    const uint32_t first = (base + (uint32_t)k * kWave) * 2u;  // index of lane 0's low value
+    if (first >= len) break;  // (wave-uniform: no value in this dword row or after it)
+    const uint32_t rem = len - first;
+    const uint32_t n_lo = min((rem + 1u) >> 1, (uint32_t)kWave), n_hi = min(rem >> 1, (uint32_t)kWave);  // lanes whose low / high value exists
+    const u64 have_lo = n_lo >= (uint32_t)kWave ? ~0ull : ((1ull << n_lo) - 1ull), have_hi = n_hi >= (uint32_t)kWave ? ~0ull : ((1ull << n_hi) - 1ull);
     uint32_t t_lo = table_bit_lo(tb, v[k]), t_hi = table_bit_hi(tb, v[k]);  // (junk lanes read word 0: in bounds)
     if (MAP) {
       t_lo |= map_bit_lo(mb, v[k]);
       t_hi |= map_bit_hi(mb, v[k]);
     }
-    const bool k_lo = i2 < len && t_lo == (uint32_t)KEEP;
-    const bool k_hi = i2 + 1u < len && t_hi == (uint32_t)KEEP;
-    const u64 m_lo = __ballot(k_lo), m_hi = __ballot(k_hi);
-    // the element in front of this lane's `lo` is the previous lane's `hi` (lane 0: the previous row's last)
-    uint32_t pv = (uint32_t)__shfl_up((int)hi, 1, kWave);
-    if (lane == 0) pv = e.last_val;
-    const bool pk = (((m_hi << 1) | (u64)e.last_kept) >> lane) & 1ull;
-    const uint32_t pos = e.before + (uint32_t)__popcll(m_lo & lane_lt) + (uint32_t)__popcll(m_hi & lane_lt);
-    if (k_lo && !e.nostore) o16[pos] = (uint16_t)lo;
-    if (k_hi && !e.nostore) o16[pos + (k_lo ? 1u : 0u)] = (uint16_t)hi;
-    e.runs += ((k_lo && !(pk && pv + 1u == lo)) ? 1u : 0u) + ((k_hi && !(k_lo && lo + 1u == hi)) ? 1u : 0u);
+    const bool c_lo = t_lo == (uint32_t)KEEP, c_hi = t_hi == (uint32_t)KEEP;
+    const u64 m_lo = __ballot(c_lo) & have_lo, m_hi = __ballot(c_hi) & have_hi;
+    if ((m_lo | m_hi) == 0ull) {  // nothing of this row survives
+      e.last_kept = 0;
+      continue;
+    }
+    const uint32_t lo = v[k] & 0xFFFFu, hi = v[k] >> 16;
+    const uint32_t pos = mbcnt64(m_hi, mbcnt64(m_lo, e.before));
+    const bool k_lo = c_lo && (uint32_t)lane < n_lo, k_hi = c_hi && (uint32_t)lane < n_hi;
+    if (!e.nostore) {
+      if (k_lo) o16[pos] = (uint16_t)lo;
+      if (k_hi) o16[pos + (k_lo ? 1u : 0u)] = (uint16_t)hi;
+    }
+    // the element in front of this lane's low value is the previous lane's high value (lane 0: the previous row's last)
+    const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp((int)e.last_val, (int)hi, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    const u64 adj_lo = __ballot(pv + 1u == lo), adj_hi = __ballot(lo + 1u == hi);
+    const u64 prev_kept = (m_hi << 1) | (u64)e.last_kept;
+    e.runs += (uint32_t)__popcll(m_lo & ~(adj_lo & prev_kept)) + (uint32_t)__popcll(m_hi & ~(adj_hi & m_lo));
     e.before += (uint32_t)__popcll(m_lo) + (uint32_t)__popcll(m_hi);
     e.last_val = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
     e.last_kept = (uint32_t)(m_hi >> 63);
@@ -881,7 +900,7 @@ __device__ __forceinline__ void array_probe_emit_all(const uint8_t* __restrict__
   if (n_units > 3 * B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 3 * B, lane, t.v3, o16, e);
   // (len <= 4095 — the caller's condition: the survivors must fit the cell — is at most four batches)
   n_out = e.before;
-  runs_out = wave_reduce_add(e.runs);
+  runs_out = e.runs;
 }
 
 // probing array (pp, lp <= 4095 values, batch 0 in vp) against an ARRAY operand (pt, lt, batch 0 in vt)
@@ -1043,11 +1062,13 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
     const bool nostore = (abl & 64u) != 0;  // (experiment: the probe paths keep their arithmetic and store no survivor)
     uint32_t c = 0, r = 0;
     bool done = false;
-    // who probes: the array the result is a subset of (Difference: A; Intersect: the LONGER array, so that the shorter one is
+    // who probes: the array the result is a subset of (Difference: A; Intersect: the SHORTER array, the longer one is
     // the table; against a bitmap or a run: the array).  Wave-uniform; batch 0 of both payloads is requested after the roles
     // are known, so each type pair has ONE instance of the probe loop.
     const bool a_arr = ta == kTypeArray, b_arr = tb == kTypeArray;
-    const bool a_probes = a_arr && (OP == 3 || !b_arr || sa.len > sb.len);
+    // (Intersect of two arrays: the SHORTER one probes — a probed dword row costs ~3 x a scattered one once its survivors are
+    // emitted, the reverse of the count kernel's choice; experiments: pair_ablate bit 256 restores the longer array)
+    const bool a_probes = a_arr && (OP == 3 || !b_arr || ((abl & 256u) ? sa.len > sb.len : sa.len <= sb.len));
     const bool b_probes = OP == 0 && b_arr && !a_probes;
     if (a_probes || b_probes) {
       const uint8_t* pp = a_probes ? pa : pb;   // the probing array
