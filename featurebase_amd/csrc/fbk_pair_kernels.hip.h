@@ -850,6 +850,19 @@ __device__ __forceinline__ uint32_t mbcnt64(u64 m, uint32_t add) {  // add + the
 template <int KEEP, bool MAP>
 __device__ __forceinline__ void array_probe_emit_batch(uint32_t tb, uint32_t mb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch],
                                                        uint16_t* __restrict__ o16, ProbeEmit& e) {
+  // every probe of the batch first: 16 (MAP: 32) LDS reads in flight together.  (With the reads inside the row loop every row
+  // waited for its own LDS round trip — ~30 dependent round trips per item, which is what the emission cost once its arithmetic
+  // was out of the way: profiles/r05_setop_ablate_scalar_masks.json.)  Rows past the array's end hold zeros: they read word 0.
+  uint32_t t_lo[kPairBatch], t_hi[kPairBatch];
+#pragma unroll
+  for (int k = 0; k < kPairBatch; ++k) {
+    t_lo[k] = table_bit_lo(tb, v[k]);
+    t_hi[k] = table_bit_hi(tb, v[k]);
+    if (MAP) {
+      t_lo[k] |= map_bit_lo(mb, v[k]);
+      t_hi[k] |= map_bit_hi(mb, v[k]);
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kPairBatch; ++k) {
     const uint32_t first = (base + (uint32_t)k * kWave) * 2u;  // index of lane 0's low value
@@ -857,12 +870,7 @@ __device__ __forceinline__ void array_probe_emit_batch(uint32_t tb, uint32_t mb,
     const uint32_t rem = len - first;
     const uint32_t n_lo = min((rem + 1u) >> 1, (uint32_t)kWave), n_hi = min(rem >> 1, (uint32_t)kWave);  // lanes whose low / high value exists
     const u64 have_lo = n_lo >= (uint32_t)kWave ? ~0ull : ((1ull << n_lo) - 1ull), have_hi = n_hi >= (uint32_t)kWave ? ~0ull : ((1ull << n_hi) - 1ull);
-    uint32_t t_lo = table_bit_lo(tb, v[k]), t_hi = table_bit_hi(tb, v[k]);  // (junk lanes read word 0: in bounds)
-    if (MAP) {
-      t_lo |= map_bit_lo(mb, v[k]);
-      t_hi |= map_bit_hi(mb, v[k]);
-    }
-    const bool c_lo = t_lo == (uint32_t)KEEP, c_hi = t_hi == (uint32_t)KEEP;
+    const bool c_lo = t_lo[k] == (uint32_t)KEEP, c_hi = t_hi[k] == (uint32_t)KEEP;
     const u64 m_lo = __ballot(c_lo) & have_lo, m_hi = __ballot(c_hi) & have_hi;
     if ((m_lo | m_hi) == 0ull) {  // nothing of this row survives
       e.last_kept = 0;
