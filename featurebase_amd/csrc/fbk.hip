@@ -685,7 +685,7 @@ const OptionDesc kOptions[] = {
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
 #ifdef FBK_EXPERIMENTS
-    {"pair_ablate", &FbkOptions::pair_ablate, 0, 511},
+    {"pair_ablate", &FbkOptions::pair_ablate, 0, 4095},
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
 #endif
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},

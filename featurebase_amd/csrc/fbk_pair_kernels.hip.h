@@ -979,7 +979,8 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
   const bool probe = (direct & 0x100u) != 0;  // Intersect / Difference of an array by table + probe
   // timing experiments (option pair_ablate in the experiments build, WRONG results): 8 items with a run are skipped, 16 array x array
   // items, 32 bitmap x array items, 64 the probe paths keep their arithmetic but store no survivor, 128 the general path (both
-  // operands decoded into fragments) is skipped
+  // operands decoded into fragments) is skipped, 512 it encodes and writes nothing, 1024 it does not count runs, 2048 probe results that
+  // optimize() would store as runs are left as arrays, 256 the longer array probes in Intersect (the first version's roles)
 #ifdef FBK_EXPERIMENTS
   const uint32_t abl = direct >> 16;
 #else
@@ -1102,7 +1103,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
         }
       }
     }
-    if (done && !(c != 0 && r <= c / 2u)) {  // (survivors optimize() would store as runs take the general path below and overwrite the cell)
+    if (done && (!(c != 0 && r <= c / 2u) || (abl & 2048u))) {  // (survivors optimize() would store as runs take the general path below and overwrite the cell; 2048: experiment, they do not)
       if (lane == 0) {
         so.len = c;
         so.tn = make_tn(c ? kTypeArray : kTypeNil, c);
@@ -1128,10 +1129,10 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
   }
   uint32_t c = wave_reduce_add(frag_popcount(wa));
   uint32_t r = 0;
-  if (outRuns || direct == 2u) r = wave_reduce_add(frag_count_runs(wa, lane));
+  if ((outRuns || direct == 2u) && !(abl & 1024u)) r = wave_reduce_add(frag_count_runs(wa, lane));  // (1024: experiment, no run count)
   if (direct == 2u && c != 0) {  // Container.optimize() applied here (see k_setop / frag_store_encoded)
-    uint32_t t_out, l_out;
-    frag_store_encoded(wa, c, r, lane, lds[wv], arenaO + so.off, t_out, l_out);
+    uint32_t t_out = kTypeBitmap, l_out = kWords;
+    if (!(abl & 512u)) frag_store_encoded(wa, c, r, lane, lds[wv], arenaO + so.off, t_out, l_out);  // (512: experiment, nothing is encoded or written)
     if (lane == 0) {
       so.len = l_out;
       so.tn = make_tn(t_out, c);
