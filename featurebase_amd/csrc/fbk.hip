@@ -104,6 +104,7 @@ struct FbkOptions {
 #ifdef FBK_EXPERIMENTS
   int64_t pair_stamp = 0;                // timing experiment on k_icount2: waves report shader cycles of a phase instead of counts (WRONG results)
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
+  int64_t pair_spw = 1;                  // experiment: container slots per wave of k_icount2 (1 | 2 | 4): the next slot's first payload batch is in flight while the current one is decoded
 #endif
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
@@ -687,6 +688,7 @@ const OptionDesc kOptions[] = {
 #ifdef FBK_EXPERIMENTS
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 4095},
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
+    {"pair_spw", &FbkOptions::pair_spw, 1, 4},
 #endif
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
     {"setop_compact", &FbkOptions::setop_compact, 0, 1},
@@ -1527,12 +1529,17 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #else
       constexpr uint32_t pair_flags = 3u;  // bit 0: the small-array / probe paths, bit 1: array x run items probe the run container's table (both were A/B options until round 5)
 #endif
+      uint32_t spw = 1;
       if (wpb == 4) FBK_LAUNCH_ICOUNT2(1, 4);
+#ifdef FBK_EXPERIMENTS
+      else if (ctx->opt.pair_spw == 4) { spw = 4; FBK_LAUNCH_ICOUNT2(4, 1); }
+      else if (ctx->opt.pair_spw == 2) { spw = 2; FBK_LAUNCH_ICOUNT2(2, 1); }
+#endif
       else FBK_LAUNCH_ICOUNT2(1, 1);
 #undef FBK_LAUNCH_ICOUNT2
       if (resolved)
         hipLaunchKernelGGL(fbk::k_sum_wave_counts, dim3(uint32_t((p->n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, p->d_wave_counts,
-                           uint32_t(fbk::kSlots), p->n_pairs, p->d_counts);
+                           uint32_t(fbk::kSlots) / spw, p->n_pairs, p->d_counts);
     }
     else
       hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,

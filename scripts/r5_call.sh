@@ -29,6 +29,7 @@ scatter_ab) (for i in 1 2; do for lib in "" build_variants/${AB_VARIANT:-r4_cont
 pmc_fused) bash scripts/fused_pmc.sh $TAG/pmc_fused 256 0 fused_pmc.py count_matrix_fused > $O/pmc_fused_shipped.txt 2>&1 ;;
 fuzz) bash scripts/fuzz_parity.sh $O ${FUZZ_SEEDS:-0x5eed4001 0x5eed4002 0x5eed4003} > /dev/null 2>&1 ;;
 fusedprof) (timeout 200 python scripts/fused_prof.py 256 0 2 ${PROF_CFG:-4} 2>&1 | grep -v amdgpu.ids) > $O/fused_prof.txt ;;
+pairs_spw) timeout 300 python scripts/bench_pairs.py --shards ${SPW_SHARDS:-256} --iters 20 --only-count --variants 'pair_kernels=2,pair_spw=1;pair_kernels=2,pair_spw=2;pair_kernels=2,pair_spw=4;pair_kernels=2,pair_spw=1' --out $O/pairs_spw_${SPW_SHARDS:-256}.json > $O/pairs_spw.log 2>&1 ;;
 setop_ablate) V=''; for a in ${ABL_LIST:-0 8 16 32 56 64 128 192 256 0}; do V="$V;pair_kernels=2,pair_ablate=$a"; done; timeout 400 python scripts/bench_pairs.py --shards 256 --iters 20 --ops "${ABL_OPS:-intersectionCount,intersect + optimize(),intersect}" --variants "${V#;}" --out $O/setop_ablate.json > $O/setop_ablate.log 2>&1 ;;
 fused_ab) timeout 500 python scripts/fused_ab.py ${FUSED_AB_ARGS:-256 1024} > $O/fused_ab.json 2> $O/fused_ab.err ;;
 fused_ablate) (for c in ${ABL_CFGS:-4 3}; do timeout 300 python scripts/fused_ablate.py $c 2>> $O/fused_ablate.err | grep "^{" >> $O/fused_ablate.jsonl; done) ;;
