@@ -72,6 +72,23 @@ struct ApiScope {
     }                                                                                          \
   } while (0)
 
+// Every extern "C" entry point is a function-try-block closed by this handler: the host side of the library uses std::vector /
+// std::string / std::thread, and no exception may leave the C ABI (the caller is cgo: an exception unwinding into Go frames ends the
+// server).  The locals — locks, FBK_ENTER's scope — are gone when the handler runs, so the context is entered again for the message.
+#define FBK_ABI_CATCH(ctx)                                                                   \
+  catch (const std::bad_alloc&) {                                                            \
+    FBK_ENTER(ctx);                                                                          \
+    return fail(FBK_E_NOMEM, std::string(__func__) + ": host allocation failed");            \
+  }                                                                                          \
+  catch (const std::exception& e_) {                                                         \
+    FBK_ENTER(ctx);                                                                          \
+    return fail(FBK_E_HIP, std::string(__func__) + ": " + e_.what());                        \
+  }                                                                                          \
+  catch (...) {                                                                              \
+    FBK_ENTER(ctx);                                                                          \
+    return fail(FBK_E_HIP, std::string(__func__) + ": unknown exception");                   \
+  }
+
 inline uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
 
 }  // namespace
@@ -623,7 +640,7 @@ const char* fbk_last_error(fbk_ctx* ctx) {
   return copy.c_str();
 }
 
-int32_t fbk_last_error_r(fbk_ctx* ctx, char* buf, uint64_t cap, int32_t* out_code) {
+int32_t fbk_last_error_r(fbk_ctx* ctx, char* buf, uint64_t cap, int32_t* out_code) try {
   FBK_ENTER(ctx);
   std::string msg;
   int32_t code = 0;
@@ -641,9 +658,9 @@ int32_t fbk_last_error_r(fbk_ctx* ctx, char* buf, uint64_t cap, int32_t* out_cod
     buf[n] = 0;
   }
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_device_count(int32_t* out_n) {
+int32_t fbk_device_count(int32_t* out_n) try {
   if (!out_n) return fail(FBK_E_INVALID, "out_n is NULL");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -654,7 +671,7 @@ int32_t fbk_device_count(int32_t* out_n) {
   }
   *out_n = n;
   return FBK_OK;
-}
+} FBK_ABI_CATCH(nullptr)
 
 }  // extern "C"
 
@@ -760,21 +777,21 @@ int32_t open_on_device(int32_t device, fbk_ctx* root, fbk_ctx** out_ctx) {
 
 extern "C" {
 
-int32_t fbk_open(int32_t device, uint32_t /*flags*/, fbk_ctx** out_ctx) {
+int32_t fbk_open(int32_t device, uint32_t /*flags*/, fbk_ctx** out_ctx) try {
   if (!out_ctx) return fail(FBK_E_INVALID, "out_ctx is NULL");
   *out_ctx = nullptr;
   return open_on_device(device, nullptr, out_ctx);
-}
+} FBK_ABI_CATCH(nullptr)
 
-int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child) {
+int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child) try {
   FBK_ENTER(ctx);
   if (!ctx || !out_child) return fail(FBK_E_INVALID, "NULL argument");
   *out_child = nullptr;
   fbk_ctx* root = ctx->root ? ctx->root : ctx;
   return open_on_device(root->device, root, out_child);
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_close(fbk_ctx* ctx) {
+int32_t fbk_close(fbk_ctx* ctx) try {
   FBK_ENTER(ctx);
   if (!ctx) return FBK_OK;
   if (!ctx->root && ctx->children.load() != 0) {
@@ -794,16 +811,16 @@ int32_t fbk_close(fbk_ctx* ctx) {
   if (ctx->root) ctx->root->children.fetch_sub(1);
   delete ctx;
   return FBK_OK;
-}
+} FBK_ABI_CATCH(nullptr)  // (the context may be gone: nothing is recorded on it)
 
-int32_t fbk_set_option(fbk_ctx* ctx, const char* name, int64_t value) {
+int32_t fbk_set_option(fbk_ctx* ctx, const char* name, int64_t value) try {
   FBK_ENTER(ctx);
   if (!ctx || !name) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
   return option_set(ctx->opt, name, value);
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_get_option(fbk_ctx* ctx, const char* name, int64_t* out_value) {
+int32_t fbk_get_option(fbk_ctx* ctx, const char* name, int64_t* out_value) try {
   FBK_ENTER(ctx);
   if (!ctx || !name || !out_value) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -821,9 +838,9 @@ int32_t fbk_get_option(fbk_ctx* ctx, const char* name, int64_t* out_value) {
       return FBK_OK;
     }
   return fail(FBK_E_INVALID, std::string("unknown option ") + name);
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_set_stream(fbk_ctx* ctx, void* hip_stream) {
+int32_t fbk_set_stream(fbk_ctx* ctx, void* hip_stream) try {
   FBK_ENTER(ctx);
   if (!ctx) return fail(FBK_E_INVALID, "ctx is NULL");
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -832,18 +849,18 @@ int32_t fbk_set_stream(fbk_ctx* ctx, void* hip_stream) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_synchronize(fbk_ctx* ctx) {
+int32_t fbk_synchronize(fbk_ctx* ctx) try {
   FBK_ENTER(ctx);
   if (!ctx) return fail(FBK_E_INVALID, "ctx is NULL");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_batch_free(fbk_ctx* ctx, fbk_batch* b) {
+int32_t fbk_batch_free(fbk_ctx* ctx, fbk_batch* b) try {
   FBK_ENTER(ctx);
   if (!b) return FBK_OK;
   if (!ctx) ctx = b->ctx;
@@ -857,7 +874,7 @@ int32_t fbk_batch_free(fbk_ctx* ctx, fbk_batch* b) {
   if (b->d_shadow_slots) (void)ctx_free(b->ctx, b->d_shadow_slots);
   delete b;
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
 // ---- bulk host -> device copies -----------------------------------------------------------------------------------
 // `total` bytes of an image the caller describes by fill(off, len, dst): "write bytes [off, off + len) of the image to dst".
@@ -965,7 +982,7 @@ static int32_t batch_upload_impl(fbk_ctx* ctx, const fbk_container_desc* descs, 
                                  fbk_batch** out_batch);
 
 int32_t fbk_batch_upload(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t n_desc, uint32_t n_rows,
-                         const void* payload, uint64_t payload_len, fbk_batch** out_batch) {
+                         const void* payload, uint64_t payload_len, fbk_batch** out_batch) try {
   FBK_ENTER(ctx);
   // the host-side tables of an upload are std::vectors: their allocation failures must not leave the C ABI as exceptions
   try {
@@ -975,7 +992,7 @@ int32_t fbk_batch_upload(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t
   } catch (const std::exception& e) {
     return fail(FBK_E_INVALID, std::string("batch_upload: ") + e.what());
   }
-}
+} FBK_ABI_CATCH(ctx)
 
 static int32_t batch_upload_impl(fbk_ctx* ctx, const fbk_container_desc* descs, uint64_t n_desc, uint32_t n_rows, const void* payload, uint64_t payload_len,
                                  fbk_batch** out_batch) {
@@ -1121,7 +1138,7 @@ static int32_t batch_upload_impl(fbk_ctx* ctx, const fbk_container_desc* descs, 
   return FBK_OK;
 }
 
-int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_rows, fbk_batch** out_batch) {
+int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_rows, fbk_batch** out_batch) try {
   FBK_ENTER(ctx);
   if (!ctx || !out_batch || (n_rows && !words)) return fail(FBK_E_INVALID, "NULL argument");
   *out_batch = nullptr;
@@ -1177,10 +1194,10 @@ int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_r
   // `dense`); every kernel treats n == 0 as empty, and download skips it.
   *out_batch = b;
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
 int32_t fbk_batch_info(fbk_ctx* ctx, const fbk_batch* batch, uint32_t* n_rows, uint64_t* n_containers,
-                       uint64_t* payload_bytes) {
+                       uint64_t* payload_bytes) try {
   FBK_ENTER(ctx);
   if (!batch) return fail(FBK_E_INVALID, "batch is NULL");
   fbk_batch* b = const_cast<fbk_batch*>(batch);
@@ -1199,10 +1216,10 @@ int32_t fbk_batch_info(fbk_ctx* ctx, const fbk_batch* batch, uint32_t* n_rows, u
   if (n_containers) *n_containers = nc;
   if (payload_bytes) *payload_bytes = pb;
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
 int32_t fbk_batch_download(fbk_ctx* ctx, const fbk_batch* batch, fbk_container_desc* descs_out, uint64_t descs_cap,
-                           void* payload_out, uint64_t payload_cap) {
+                           void* payload_out, uint64_t payload_cap) try {
   FBK_ENTER(ctx);
   if (!batch) return fail(FBK_E_INVALID, "batch is NULL");
   fbk_batch* b = const_cast<fbk_batch*>(batch);
@@ -1246,9 +1263,9 @@ int32_t fbk_batch_download(fbk_ctx* ctx, const fbk_batch* batch, fbk_container_d
   HIP_TRY(hipMemcpyAsync(payload_out, dpack.p, pb, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));  // (also keeps `wd` alive until the descriptor copy has been made)
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n, uint64_t* out_counts) {
+int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n, uint64_t* out_counts) try {
   FBK_ENTER(ctx);
   if (!batch || (n && (!rows || !out_counts))) return fail(FBK_E_INVALID, "NULL argument");
   fbk_batch* b = const_cast<fbk_batch*>(batch);
@@ -1266,11 +1283,11 @@ int32_t fbk_count(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, ui
     out_counts[i] = c;
   }
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
 
 int32_t fbk_count_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* rows, uint64_t n, uint64_t start,
-                        uint64_t end, uint64_t* out_counts) {
+                        uint64_t end, uint64_t* out_counts) try {
   FBK_ENTER(ctx);
   if (!batch || (n && (!rows || !out_counts))) return fail(FBK_E_INVALID, "NULL argument");
   const uint64_t width = uint64_t(fbk::kSlots) << 16;
@@ -1292,7 +1309,7 @@ int32_t fbk_count_range(fbk_ctx* ctx, const fbk_batch* batch, const uint32_t* ro
   HIP_TRY(back.add(out_counts, dcnt.p, n * 8));
   HIP_TRY(back.finish());
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
 
 // ---- plans ---------------------------------------------------------------------------
@@ -1623,16 +1640,16 @@ int32_t plan_setop_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, int32_t op, bool wa
 extern "C" {
 
 int32_t fbk_plan_create(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
-                        const uint32_t* rows_b, uint64_t n_pairs, void* device_counts_or_null, fbk_plan** out_plan) {
+                        const uint32_t* rows_b, uint64_t n_pairs, void* device_counts_or_null, fbk_plan** out_plan) try {
   FBK_ENTER(ctx);
   if (!ctx || !a || !b || !out_plan || (n_pairs && (!rows_a || !rows_b))) return fail(FBK_E_INVALID, "NULL argument");
   *out_plan = nullptr;
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   return plan_create_locked(ctx, a, rows_a, b, rows_b, n_pairs, device_counts_or_null, out_plan);
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_plan_free(fbk_ctx* ctx, fbk_plan* plan) {
+int32_t fbk_plan_free(fbk_ctx* ctx, fbk_plan* plan) try {
   FBK_ENTER(ctx);
   if (!plan) return FBK_OK;
   if (!ctx) ctx = plan->ctx;
@@ -1641,34 +1658,34 @@ int32_t fbk_plan_free(fbk_ctx* ctx, fbk_plan* plan) {
   (void)hipStreamSynchronize(ctx->stream);
   free_plan_storage(plan);
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_plan_intersection_count(fbk_ctx* ctx, fbk_plan* plan) {
+int32_t fbk_plan_intersection_count(fbk_ctx* ctx, fbk_plan* plan) try {
   FBK_ENTER(ctx);
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   return plan_icount_enqueue_locked(ctx, plan);
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_plan_intersection_count_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null) {
+int32_t fbk_plan_intersection_count_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null) try {
   FBK_ENTER(ctx);
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   u64* dst = device_total_or_null ? static_cast<u64*>(device_total_or_null) : plan->d_total;
   return plan_icount_enqueue_locked(ctx, plan, dst);
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_plan_intersection_count_accumulate(fbk_ctx* ctx, fbk_plan* plan, void* device_accum) {
+int32_t fbk_plan_intersection_count_accumulate(fbk_ctx* ctx, fbk_plan* plan, void* device_accum) try {
   FBK_ENTER(ctx);
   if (!ctx || !plan || !device_accum) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   return plan_icount_enqueue_locked(ctx, plan, nullptr, static_cast<u64*>(device_accum));
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags) {
+int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags) try {
   FBK_ENTER(ctx);
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   if (op < 0 || op > 3) return fail(FBK_E_INVALID, "unknown set operation");
@@ -1679,9 +1696,9 @@ int32_t fbk_plan_setop(fbk_ctx* ctx, fbk_plan* plan, int32_t op, uint32_t flags)
   std::lock_guard<std::mutex> g(ctx->mu);
   if (int32_t rc = set_device(ctx)) return rc;
   return plan_setop_enqueue_locked(ctx, plan, op, opt);
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_plan_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null) {
+int32_t fbk_plan_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null) try {
   FBK_ENTER(ctx);
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -1690,9 +1707,9 @@ int32_t fbk_plan_total(fbk_ctx* ctx, fbk_plan* plan, void* device_total_or_null)
   hipLaunchKernelGGL(fbk::k_sum_u64, dim3(1), dim3(256), 0, ctx->stream, plan->d_counts, plan->n_pairs, dst);
   HIP_TRY(hipGetLastError());
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64_t* out_total) {
+int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64_t* out_total) try {
   FBK_ENTER(ctx);
   if (!ctx || !plan) return fail(FBK_E_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -1702,18 +1719,18 @@ int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64
   if (out_total) HIP_TRY(hipMemcpyAsync(out_total, plan->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_plan_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch) {
+int32_t fbk_plan_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch) try {
   FBK_ENTER(ctx);
   if (!plan || !out_batch) return fail(FBK_E_INVALID, "NULL argument");
   (void)ctx;
   *out_batch = plan->out;
   if (!plan->out) return fail(FBK_E_INVALID, "plan has no set-op output yet");
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
-int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch) {
+int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_batch) try {
   FBK_ENTER(ctx);
   if (!plan || !out_batch) return fail(FBK_E_INVALID, "NULL argument");
   if (!ctx) ctx = plan->ctx;
@@ -1722,12 +1739,12 @@ int32_t fbk_plan_detach_output(fbk_ctx* ctx, fbk_plan* plan, fbk_batch** out_bat
   *out_batch = plan->out;
   plan->out = nullptr;
   return FBK_OK;
-}
+} FBK_ABI_CATCH(ctx)
 
 // ---- one-shot calls (plan + enqueue + read) --------------------------------------------
 
 int32_t fbk_intersection_count(fbk_ctx* ctx, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
-                               const uint32_t* rows_b, uint64_t n_pairs, uint64_t* out_counts) {
+                               const uint32_t* rows_b, uint64_t n_pairs, uint64_t* out_counts) try {
   FBK_ENTER(ctx);
   if (!ctx || !a || !b || (n_pairs && (!rows_a || !rows_b || !out_counts))) return fail(FBK_E_INVALID, "NULL argument");
   if (n_pairs == 0) return FBK_OK;
@@ -1745,11 +1762,11 @@ int32_t fbk_intersection_count(fbk_ctx* ctx, const fbk_batch* a, const uint32_t*
   (void)hipStreamSynchronize(ctx->stream);
   free_plan_storage(p);
   return rc;
-}
+} FBK_ABI_CATCH(ctx)
 
 int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* rows_a, const fbk_batch* b,
                   const uint32_t* rows_b, uint64_t n_pairs, uint32_t flags, fbk_batch** out_batch,
-                  uint64_t* out_counts) {
+                  uint64_t* out_counts) try {
   FBK_ENTER(ctx);
   if (!ctx || !a || !b || !out_batch || (n_pairs && (!rows_a || !rows_b))) return fail(FBK_E_INVALID, "NULL argument");
   if (op < 0 || op > 3) return fail(FBK_E_INVALID, "unknown set operation");
@@ -1777,7 +1794,7 @@ int32_t fbk_setop(fbk_ctx* ctx, int32_t op, const fbk_batch* a, const uint32_t* 
   }
   free_plan_storage(p);
   return rc;
-}
+} FBK_ABI_CATCH(ctx)
 
 }  // extern "C"
 

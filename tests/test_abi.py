@@ -106,3 +106,31 @@ def test_option_names_in_the_header_are_the_library_s():
     assert not stale, f"names in the header that are not options (any more): {stale}"
     # round 5's prune: the product library registers at most 22 options (the experiment builds' three aside)
     assert len(registered - experiments) <= 22, sorted(registered - experiments)
+
+
+def test_no_exception_can_leave_an_entry_point():
+    """Every `int32_t fbk_*` definition of the library is a function-try-block closed by FBK_ABI_CATCH / FBK_ABI_CATCH_GROUP
+    (fbk.hip): the host side uses std::vector / std::string / std::thread, the caller is cgo, and SURVEY 8b's boundary has "no
+    exceptions / aborts across it".  (fbk_abi_version and fbk_last_error allocate nothing that could throw after the first
+    call and return no status.)"""
+    csrc = os.path.join(ROOT, "featurebase_amd", "csrc")
+    n = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".inc")):
+            continue
+        lines = open(os.path.join(csrc, f)).read().split("\n")
+        i = 0
+        while i < len(lines):
+            if lines[i].startswith("int32_t fbk_") and not lines[i].startswith("int32_t fbk_abi_version") and not lines[i].rstrip().endswith(";"):
+                j = i
+                while not lines[j].rstrip().endswith("{"):
+                    j += 1
+                assert lines[j].rstrip().endswith(") try {"), f"{f}:{i + 1}: {lines[i]}"
+                k = j + 1
+                while not lines[k].startswith("}"):
+                    k += 1
+                assert lines[k].startswith("} FBK_ABI_CATCH"), f"{f}:{k + 1}: {lines[k]}"
+                n += 1
+                i = k
+            i += 1
+    assert n == len(declared_symbols()) - 2, (n, len(declared_symbols()))
