@@ -121,8 +121,8 @@ struct FbkOptions {
 #ifdef FBK_EXPERIMENTS
   int64_t pair_stamp = 0;                // timing experiment on k_icount2: waves report shader cycles of a phase instead of counts (WRONG results)
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
+  int64_t pair_spw = 1;                  // experiment: container slots per wave of k_icount2 (1 | 2 | 4): the next slot's first payload batch is in flight while the current one is decoded
 #endif
-  int64_t pair_spw = 0;                  // container slots per wave of k_icount2's one-wave blocks: 1 | 2 | 4 (the next slot's first payload batch is in flight while the current one is decoded); 0 = by the plan's size (pair_spw_for)
   int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
 };
 
@@ -705,8 +705,8 @@ const OptionDesc kOptions[] = {
 #ifdef FBK_EXPERIMENTS
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 4095},
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
+    {"pair_spw", &FbkOptions::pair_spw, 1, 4},
 #endif
-    {"pair_spw", &FbkOptions::pair_spw, 0, 4},
     {"pair_wpb", &FbkOptions::pair_wpb, 0, 4},
     {"setop_compact", &FbkOptions::setop_compact, 0, 1},
     {"count_range_reference_quirk", &FbkOptions::count_range_reference_quirk, 0, 1},
@@ -719,7 +719,6 @@ int32_t option_set(FbkOptions& o, const char* name, int64_t v) {
       if (v < d.lo || v > d.hi) return fail(FBK_E_INVALID, std::string("option ") + name + ": value out of range");
       if ((d.field == &FbkOptions::dense_spb || (d.field == &FbkOptions::matrix_spb && v)) && (v & (v - 1)))
         return fail(FBK_E_INVALID, std::string("option ") + name + ": must be a power of two");
-      if (d.field == &FbkOptions::pair_spw && v == 3) return fail(FBK_E_INVALID, std::string("option ") + name + ": 0 (by the plan's size), 1, 2 or 4");
       o.*(d.field) = v;
       return FBK_OK;
     }
@@ -1375,23 +1374,12 @@ bool use_pair_kernels2(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* 
   if (lo < 256 && (a->arena_bytes == 0 || b->arena_bytes == 0 || (batch_avg_payload(a) < 256 ? b->dense : a->dense))) return false;
   return true;
 }
-constexpr uint64_t kPairSpw2MinPairs = ~0ull;  // (no plan size at which two slots per wave have measured ahead yet: see pair_spw_for)
 // Waves per block of the round-3 pair kernels (option pair_wpb pins it).  One-wave blocks release a wave's LDS table the
 // moment IT ends, which is what heterogeneous items (runs next to arrays) need; when one side's containers are tiny the
 // items are all alike and short, and four waves per block quarter the number of blocks to launch.
 int pair_wpb_for(const fbk_ctx* ctx, const fbk_batch* a, const fbk_batch* b) {
   if (ctx->opt.pair_wpb) return ctx->opt.pair_wpb >= 4 ? 4 : 1;  // (normalised once: 1 or 4.  Two-wave blocks were built and measured in round 4: count 182 against 166-173 us, set-ops equal — profiles/r04_pairs_wpb_ab.json — and removed)
   return std::min(batch_avg_payload(a), batch_avg_payload(b)) < 256 ? 4 : 1;
-}
-
-// Container slots per wave of k_icount2's one-wave blocks (option pair_spw pins it: 1 | 2 | 4).  Round 3 measured 2 / 4 slots per
-// wave on 2048 row pairs of config 3's rows — 32 768 items, seven rounds of waves on the chip — at 49.6 / 56 us against 46: with so
-// few rounds the halved number of waves loses more in the tail than the second payload in flight gains, and one slot per wave is
-// what every plan gets unless the option says otherwise (round 5 re-instantiated the 2 / 4 forms as an OPTION for plans of
-// many thousand row pairs, where the rounds are many; DESIGN section 9 has the A/B).
-int pair_spw_for(const fbk_ctx* ctx, uint64_t n_pairs) {
-  if (ctx->opt.pair_spw) return int(ctx->opt.pair_spw);
-  return n_pairs >= kPairSpw2MinPairs ? 2 : 1;
 }
 
 // The plan's item records: {A's descriptor, B's descriptor} per (pair, slot), resolved on the device once per version of the
@@ -1549,17 +1537,24 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
                      p->d_counts, pair_flags, resolved ? p->d_items : (const Slot*)nullptr,  \
                      resolved ? p->d_wave_counts : (uint32_t*)nullptr)
-      // SPW container slots per wave (pair_spw_for): the next slot's first payload batch is in flight while the current one is decoded.
+      // One container slot per wave.  (The kernel is written for SPW slots per wave with the next slot's payload in flight while the
+      // current one is decoded; SPW = 2 / 4 measured 49.6 / 56 us against 46 on 2048 row pairs in round 3 and 172 / 184 us against 157-162
+      // on 8192 in round 5 — profiles/r05_pairs_spw_8192_pairs.json: the same 6-10 % / 17-24 % behind at both sizes, so not a tail effect;
+      // a wave that decodes two items one after the other holds its table twice as long, and the second payload, requested before the
+      // first item's own later loads, has to land before those can be waited for (the vector memory counter is in order).  Instantiated in
+      // the experiments build only, option pair_spw there.)
       const int wpb = pair_wpb_for(ctx, p->a, p->b);
 #ifdef FBK_EXPERIMENTS
       const uint32_t pair_flags = 3u | (uint32_t(ctx->opt.pair_ablate & 255) << 8) | (uint32_t(ctx->opt.pair_stamp) << 16);
 #else
       constexpr uint32_t pair_flags = 3u;  // bit 0: the small-array / probe paths, bit 1: array x run items probe the run container's table (both were A/B options until round 5)
 #endif
-      const uint32_t spw = wpb == 4 ? 1u : uint32_t(pair_spw_for(ctx, p->n_pairs));
+      uint32_t spw = 1;
       if (wpb == 4) FBK_LAUNCH_ICOUNT2(1, 4);
-      else if (spw == 4) FBK_LAUNCH_ICOUNT2(4, 1);
-      else if (spw == 2) FBK_LAUNCH_ICOUNT2(2, 1);
+#ifdef FBK_EXPERIMENTS
+      else if (ctx->opt.pair_spw == 4) { spw = 4; FBK_LAUNCH_ICOUNT2(4, 1); }
+      else if (ctx->opt.pair_spw == 2) { spw = 2; FBK_LAUNCH_ICOUNT2(2, 1); }
+#endif
       else FBK_LAUNCH_ICOUNT2(1, 1);
 #undef FBK_LAUNCH_ICOUNT2
       if (resolved)

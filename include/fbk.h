@@ -10,7 +10,9 @@
  * maintainer would add on the Go side.
  *
  * Conventions
- *   - C linkage, plain pointers and sizes, no exceptions across the boundary.
+ *   - C linkage, plain pointers and sizes, no exceptions across the boundary: every entry point is a function-try-block
+ *     (a host allocation that fails inside the library comes back as FBK_E_NOMEM, anything else a C++ library could throw
+ *     as FBK_E_HIP with the message; tests/test_abi.py checks that no definition is left unwrapped).
  *   - Every function returns an int32 status: FBK_OK (0) or a negative FBK_E_* code;
  *     fbk_last_error_r(ctx, ...) returns the context's human readable message (see below).
  *     (roaring set-ops never return errors in Go — invariant breaks panic,
@@ -53,8 +55,7 @@ extern "C" {
 
 #define FBK_ABI_VERSION 5
 /* ABI history.
- *   5 (round 5): + fbk_topn_partials, options topn_semantics, matrix_shadow_arena_x, pair_spw (back as a kernel-selection option,
- *      values 0 / 1 / 2 / 4; 0 = the library's choice, which is what every earlier version did).  CHANGED: fbk_topn / fbk_query_topn /
+ *   5 (round 5): + fbk_topn_partials, options topn_semantics, matrix_shadow_arena_x.  CHANGED: fbk_topn / fbk_query_topn /
  *      fbk_group_topn with 0 < n < n_a return the reference's two-pass answer by default (topn_semantics = 1; = 0 restores
  *      round 4's exact top n of fbk_topn; round 4's per-member candidate rule of fbk_group_topn is gone — it was neither);
  *      count_range_reference_quirk defaults to 1 (the reference's number).
@@ -148,7 +149,7 @@ int32_t fbk_last_error_r(fbk_ctx* ctx, char* buf, uint64_t cap, int32_t* out_cod
  * closed with fbk_close, before its root. */
 int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
 
-/* Options (21; round 5 removed fifteen A/B switches together with the kernels and paths that had lost their comparison —
+/* Options (20; round 5 removed fifteen A/B switches together with the kernels and paths that had lost their comparison —
  * DESIGN.md section 4 lists them).  The environment variables FBK_<NAME> are read ONCE, by fbk_open; afterwards only these
  * calls change an option.
  *   semantics (DEFAULT 1 = the reference's result, 0 = the arithmetically exact one; see fbk_count_range, fbk_topn):
@@ -168,8 +169,7 @@ int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
  *     kernel that decodes the rows in place, 0 the generic pair kernel), matrix_fp4 (dense count matrix on the FP4 matrix
  *     instruction: -1 for matrices of several tiles), topk_device_sort (-1 by the field size), pair_kernels (0 by the rows'
  *     payload: the round-2 kernels for tiny containers, the table + probe kernels otherwise), pair_wpb (their waves per
- *     block: 0 by the rows' payload), pair_spw (container slots per wave of the pair count's one-wave blocks: 0 by the plan's
- *     size, 1 | 2 | 4), setop_direct_encode (pair set-ops with FBK_SETOP_OPTIMIZE: 2 Container.optimize() inside
+ *     block: 0 by the rows' payload), setop_direct_encode (pair set-ops with FBK_SETOP_OPTIMIZE: 2 Container.optimize() inside
  *     the kernel; 1 / 0 bitmap or small-array cells and a separate re-encode pass — the byte-for-byte cross-check of the
  *     in-kernel encoders, and what a plan's launch-only form refuses).
  * Every value of every kernel-selection option gives the same results (the tests run them against each other). */

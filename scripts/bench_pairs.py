@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--ops", default="", help="comma-separated subset of the operation names (e.g. 'intersectionCount,intersect + optimize()')")
     ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
-    if "pair_ablate" in args.variants or "pair_stamp" in args.variants or any("ablate" in o or "stamp" in o for o in args.opt):
+    if "pair_ablate" in args.variants or "pair_stamp" in args.variants or "pair_spw" in args.variants or any("ablate" in o or "stamp" in o for o in args.opt):
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import _experiments
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ("pair_ablate", "pair_stamp", "matrix_fused_ablate")
+KNOBS = ("pair_ablate", "pair_stamp", "pair_spw", "matrix_fused_ablate")
 
 
 def test_product_library_has_no_experiment_option_names():

@@ -110,17 +110,7 @@ def test_config3_row_pairs_every_pair_vs_oracle(gpu_ctx, config3):
     batch = gpu_ctx.upload_flat(c["d"], c["p"], c["n_rows"])
     ra = np.concatenate([g[:, :-1].reshape(-1), g[:, :32].reshape(-1)])
     rb = np.concatenate([g[:, 1:].reshape(-1), g[:, :31:-1].reshape(-1)])
-    exp_counts = PB.intersection_count(c["OA"], ra, c["OA"], rb)
-    assert (gpu_ctx.intersection_count(batch, ra, batch, rb) == exp_counts).all()
-    try:  # the pair count with 1 / 2 / 4 container slots per wave (option pair_spw; 0 = the library's choice, above)
-        gpu_ctx.set_option("pair_kernels", 2)
-        gpu_ctx.set_option("pair_wpb", 1)
-        for spw in (1, 2, 4):
-            gpu_ctx.set_option("pair_spw", spw)
-            assert (gpu_ctx.intersection_count(batch, ra, batch, rb) == exp_counts).all(), spw
-    finally:
-        for name in ("pair_kernels", "pair_wpb", "pair_spw"):
-            gpu_ctx.set_option(name, 0)
+    assert (gpu_ctx.intersection_count(batch, ra, batch, rb) == PB.intersection_count(c["OA"], ra, c["OA"], rb)).all()
     sel = slice(0, None, 7)  # every 7th pair materialised (3400 pairs x 16 containers per operation)
     for op in (L.OP_AND, L.OP_OR, L.OP_XOR, L.OP_ANDNOT):
         for flags in (0, L.SETOP_OPTIMIZE):

@@ -13,28 +13,15 @@ from featurebase_amd import lib as L
 pytestmark = pytest.mark.gpu
 
 
-# tests of this file whose inputs reach the pair count with heavy enough containers for the slots-per-wave forms to differ
-SPW_TESTS = {"test_golden_container_combinations_on_gpu", "test_mixed_rows_vs_oracle", "test_every_type_pair_every_kind", "test_empty_and_ragged_inputs"}
-
-
-@pytest.fixture(params=[(1, 0), (2, 0), (0, 0), (2, 2), (2, 4)],
-                ids=["pair-kernels-r2", "pair-kernels-r3", "pair-kernels-auto", "pair-kernels-r3-2-slots-per-wave", "pair-kernels-r3-4-slots-per-wave"], autouse=True)
+@pytest.fixture(params=[1, 2, 0], ids=["pair-kernels-r2", "pair-kernels-r3", "pair-kernels-auto"], autouse=True)
 def pair_kernel_generation(request, gpu_ctx):
     """Every test of this file runs with the round-2 pair kernels (k_icount / k_setop), with the round-3 ones (k_icount2 /
     k_setop2: table + probe, interior-map run decode, one-wave blocks; array x run by probing the run table) and with the
     library's own choice by payload size: each generation is checked against the oracle on every input of the file, not
-    only on the rows the dispatch would hand it.  The pair count's 2 / 4 container slots per wave (option pair_spw, one-wave
-    blocks pinned) see the tests in SPW_TESTS."""
-    gen, spw = request.param
-    if spw and request.node.originalname not in SPW_TESTS:
-        pytest.skip("slots-per-wave forms: covered by the tests in SPW_TESTS")
-    gpu_ctx.set_option("pair_kernels", gen)
-    if spw:
-        gpu_ctx.set_option("pair_wpb", 1)
-        gpu_ctx.set_option("pair_spw", spw)
-    yield gen
-    for name in ("pair_kernels", "pair_wpb", "pair_spw"):
-        gpu_ctx.set_option(name, 0)
+    only on the rows the dispatch would hand it."""
+    gpu_ctx.set_option("pair_kernels", request.param)
+    yield request.param
+    gpu_ctx.set_option("pair_kernels", 0)
 
 OPS = [(L.OP_AND, "intersect"), (L.OP_OR, "union"), (L.OP_XOR, "xor"), (L.OP_ANDNOT, "difference")]
 ZERO = np.zeros(1024, dtype=np.uint64)
