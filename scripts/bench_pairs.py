@@ -30,12 +30,14 @@ def main():
     ap.add_argument("--only-count", action="store_true")
     ap.add_argument("--ops", default="", help="comma-separated subset of the operation names (e.g. 'intersectionCount,intersect + optimize()')")
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--no-check", action="store_true", help="timing experiments on library builds that skip work: no comparison with the oracle")
     args = ap.parse_args()
     if "pair_ablate" in args.variants or "pair_stamp" in args.variants or "pair_spw" in args.variants or any("ablate" in o or "stamp" in o for o in args.opt):
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import _experiments
 
-        _experiments.use()  # those options exist in the -DFBK_EXPERIMENTS build only
+        if not os.environ.get("FBK_LIB_PATH"):  # (an A/B run names its own -DFBK_EXPERIMENTS build)
+            _experiments.use()  # those options exist in the -DFBK_EXPERIMENTS build only
     rows, groups, filt = D.config3_flat(args.shards, mp="fork")
     import torch
 
@@ -92,7 +94,7 @@ def main():
                 samples.append(e0.elapsed_time(e1) * 1e3 / args.iters)
             us = sorted(samples)[len(samples) // 2]
             counts = plan.read()
-            ablated = "pair_ablate" in var and "pair_ablate=0" not in var
+            ablated = args.no_check or ("pair_ablate" in var and "pair_ablate=0" not in var)
             if ablated:
                 pass  # timing experiment: results are wrong by construction
             elif op is None:
