@@ -90,19 +90,15 @@ __device__ __forceinline__ void toggle_hi(uint32_t base, uint32_t x) {
 __device__ __forceinline__ void sparse_xor_batch(uint32_t type, uint32_t tb, uint32_t len, uint32_t base, int lane,
                                                  const uint32_t (&v)[kPairBatch]) {
   if (type == kTypeArray) {
-    if ((base + kPairBatch * kWave) * 2u <= len) {  // every value of the batch exists
+    // ONE body, every value under its own test.  (Until round 5 a batch whose values all exist had an unpredicated copy of the loop:
+    // with two copies of every eight-row loop in every role of every type pair k_icount2 was 102 KB of code — the instruction cache
+    // of a pair of CUs holds 64 KB, and the waves of one CU run all the type pairs at once.  The array that is scattered is the shorter
+    // one: it rarely filled a batch anyway.)
 #pragma unroll
-      for (int k = 0; k < kPairBatch; ++k) {
-        toggle_lo(tb, v[k]);
-        toggle_hi(tb, v[k]);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < kPairBatch; ++k) {
-        const uint32_t i2 = (base + (uint32_t)k * kWave + (uint32_t)lane) * 2u;
-        if (i2 < len) toggle_lo(tb, v[k]);
-        if (i2 + 1u < len) toggle_hi(tb, v[k]);
-      }
+    for (int k = 0; k < kPairBatch; ++k) {
+      const uint32_t i2 = (base + (uint32_t)k * kWave + (uint32_t)lane) * 2u;
+      if (i2 < len) toggle_lo(tb, v[k]);
+      if (i2 + 1u < len) toggle_hi(tb, v[k]);
     }
   } else {
 #pragma unroll
@@ -133,42 +129,42 @@ __device__ __forceinline__ void sparse_xor_all(uint32_t type, const uint8_t* __r
   }
 }
 
-__device__ __forceinline__ uint32_t table_bit_lo(uint32_t tb, uint32_t x) { return __builtin_amdgcn_ubfe(*table_dword_lo(tb, x), x, 1u); }
-__device__ __forceinline__ uint32_t table_bit_hi(uint32_t tb, uint32_t x) { return __builtin_amdgcn_ubfe(*table_dword_hi(tb, x), x >> 16, 1u); }
+// (w: the bit field's width — 1, or 0 for a value that is not there: v_bfe_u32 then yields 0 whatever the dword holds)
+__device__ __forceinline__ uint32_t table_bit_lo(uint32_t tb, uint32_t x, uint32_t w = 1u) { return __builtin_amdgcn_ubfe(*table_dword_lo(tb, x), x, w); }
+__device__ __forceinline__ uint32_t table_bit_hi(uint32_t tb, uint32_t x, uint32_t w = 1u) { return __builtin_amdgcn_ubfe(*table_dword_hi(tb, x), x >> 16, w); }
 
 // bit (value >> 5) of a 2048-bit map at LDS byte offset mb: one bit per DWORD of the table (the interior map of a run
 // container after its parity prefix, see run_fill_batch); value in bits [15:0] / [31:16] of x
-__device__ __forceinline__ uint32_t map_bit_lo(uint32_t mb, uint32_t x) {
+__device__ __forceinline__ uint32_t map_bit_lo(uint32_t mb, uint32_t x, uint32_t width = 1u) {
   const uint32_t w = *(const lds_u32*)(uintptr_t)(mb + (__builtin_amdgcn_ubfe(x, 10u, 6u) << 2));
-  return __builtin_amdgcn_ubfe(w, x >> 5, 1u);  // (bit-field offsets use bits [4:0] only)
+  return __builtin_amdgcn_ubfe(w, x >> 5, width);  // (bit-field offsets use bits [4:0] only)
 }
-__device__ __forceinline__ uint32_t map_bit_hi(uint32_t mb, uint32_t x) {
+__device__ __forceinline__ uint32_t map_bit_hi(uint32_t mb, uint32_t x, uint32_t width = 1u) {
   const uint32_t w = *(const lds_u32*)(uintptr_t)(mb + ((x >> 26) << 2));
-  return __builtin_amdgcn_ubfe(w, x >> 21, 1u);
+  return __builtin_amdgcn_ubfe(w, x >> 21, width);
 }
 
 // this lane's hits of one batch of array dwords against the table (MAP: a run container as boundary masks in the table, its
-// full dwords in the map at mb — run_fill_batch)
+// full dwords in the map at mb — run_table_build).
+// ONE body for every batch (until round 5: an unpredicated copy for batches whose values all exist and a predicated one — see
+// sparse_xor_batch for what the two copies cost).  A value past the array's end is probed like any other — junk dwords read as zero,
+// the upper half of an odd array's last dword is whatever follows it in the arena: either way a read inside the table — and then
+// extracted with a bit-field WIDTH of 0, which yields 0: the widths are clamp(values left from this lane's value on, 0, 1), two
+// v_med3_i32 per dword row instead of index arithmetic, compares and selects.
 template <bool MAP = false>
 __device__ __forceinline__ uint32_t array_probe_batch(uint32_t tb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch], uint32_t mb = 0) {
   uint32_t hits = 0;
-  if ((base + kPairBatch * kWave) * 2u <= len) {
+  int32_t left = (int32_t)(len - 2u * base) - 2 * lane;  // values from this lane's low value of row 0 to the end of the array (<= 0: none)
 #pragma unroll
-    for (int k = 0; k < kPairBatch; ++k) {
-      if (MAP) hits += (table_bit_lo(tb, v[k]) | map_bit_lo(mb, v[k])) + (table_bit_hi(tb, v[k]) | map_bit_hi(mb, v[k]));
-      else hits += table_bit_lo(tb, v[k]) + table_bit_hi(tb, v[k]);
+  for (int k = 0; k < kPairBatch; ++k) {
+    const uint32_t w_lo = (uint32_t)min(max(left, 0), 1), w_hi = (uint32_t)min(max(left - 1, 0), 1);
+    uint32_t b0 = table_bit_lo(tb, v[k], w_lo), b1 = table_bit_hi(tb, v[k], w_hi);
+    if (MAP) {
+      b0 |= map_bit_lo(mb, v[k], w_lo);
+      b1 |= map_bit_hi(mb, v[k], w_hi);
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < kPairBatch; ++k) {
-      const uint32_t i2 = (base + (uint32_t)k * kWave + (uint32_t)lane) * 2u;
-      uint32_t b0 = table_bit_lo(tb, v[k]), b1 = table_bit_hi(tb, v[k]);  // (junk lanes read word 0: in bounds)
-      if (MAP) {
-        b0 |= map_bit_lo(mb, v[k]);
-        b1 |= map_bit_hi(mb, v[k]);
-      }
-      hits += (i2 < len ? b0 : 0u) + (i2 + 1u < len ? b1 : 0u);
-    }
+    hits += b0 + b1;
+    left -= 2 * kWave;
   }
   return hits;
 }
@@ -547,6 +543,16 @@ __device__ __forceinline__ void item_prefetch(const Slot& sa, const uint8_t* __r
   if (tb == kTypeArray || tb == kTypeRun) sparse_load(arenaB + sb.off, sparse_units(tb, sb.len), 0, lane, vb);
 }
 
+// the two operands' first batches change places (in place: one temporary at a time)
+__device__ __forceinline__ void batch_exchange(uint32_t (&a)[kPairBatch], uint32_t (&b)[kPairBatch]) {
+#pragma unroll
+  for (int k = 0; k < kPairBatch; ++k) {
+    const uint32_t t = a[k];
+    a[k] = b[k];
+    b[k] = t;
+  }
+}
+
 // shorter array -> table, longer array probes it; returns this lane's hits
 __device__ __forceinline__ uint32_t arrays_table_probe(const uint8_t* __restrict__ pt, uint32_t lt, uint32_t (&vt)[kPairBatch],
                                                        const uint8_t* __restrict__ pp, uint32_t lp, uint32_t (&vp)[kPairBatch], int lane,
@@ -642,23 +648,27 @@ __device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __res
         m_hi |= hi == sv;
       }
       part += ((2u * (uint32_t)lane < nl && m_lo) ? 1u : 0u) + ((2u * (uint32_t)lane + 1u < nl && m_hi) ? 1u : 0u);
-    } else if (sa.len <= sb.len) {
-      part += arrays_table_probe(pa, sa.len, va, pb, sb.len, vb, lane, table);
     } else {
-      part += arrays_table_probe(pb, sb.len, vb, pa, sa.len, va, lane, table);
+      // ONE instance of the table + probe loops for both assignments of the roles: the shorter array's batch 0 is brought into va by an
+      // IN-PLACE exchange (no register is added — role-named COPIES had cost 16 registers and 24 spilled ones in round 3, which is why
+      // every type pair carried two inlined instances of its loops until round 5: half of the kernel's 102 KB)
+      const bool a_tab = sa.len <= sb.len;  // wave-uniform
+      if (!a_tab) batch_exchange(va, vb);
+      part += arrays_table_probe(a_tab ? pa : pb, a_tab ? sa.len : sb.len, va, a_tab ? pb : pa, a_tab ? sb.len : sa.len, vb, lane, table);
     }
-  } else if (ta == kTypeArray && tb == kTypeBitmap) {
-    if ((sparse_paths & 1u) && sa.len <= kProbeArray) part += array_probe_global(va, sa.len, pb, lane);
-    else part += bitmap_table_probe(pb, pa, sa.len, va, lane, table);
-  } else if (ta == kTypeBitmap && tb == kTypeArray) {
-    if ((sparse_paths & 1u) && sb.len <= kProbeArray) part += array_probe_global(vb, sb.len, pa, lane);
-    else part += bitmap_table_probe(pa, pb, sb.len, vb, lane, table);
+  } else if ((ta == kTypeArray && tb == kTypeBitmap) || (ta == kTypeBitmap && tb == kTypeArray)) {
+    const bool a_arr = ta == kTypeArray;  // wave-uniform; the array's batch 0 goes to va (the bitmap side has none)
+    if (!a_arr) batch_exchange(va, vb);
+    const uint8_t* parr = a_arr ? pa : pb;
+    const uint8_t* pbm = a_arr ? pb : pa;
+    const uint32_t larr = a_arr ? sa.len : sb.len;
+    if ((sparse_paths & 1u) && larr <= kProbeArray) part += array_probe_global(va, larr, pbm, lane);
+    else part += bitmap_table_probe(pbm, parr, larr, va, lane, table);
   } else if ((sparse_paths & 2u) && ((ta == kTypeArray && tb == kTypeRun && sb.len <= kRunFillMax) || (ta == kTypeRun && tb == kTypeArray && sa.len <= kRunFillMax))) {
-    // array x run: the run container becomes the table, the array probes it (option pair_run_probe).  (Two instances of the
-    // probe loop rather than the operands' batches copied into role-named registers: the copies cost 16 registers, and the
-    // compiler answered with 24 spilled ones.)
-    if (ta == kTypeArray) part += run_table_probe(pb, sb.len, vb, pa, sa.len, va, lane, table, mini);
-    else part += run_table_probe(pa, sa.len, va, pb, sb.len, vb, lane, table, mini);
+    // array x run: the run container becomes the table, the array probes it — its batch 0 in va, the array's in vb
+    const bool a_run = ta == kTypeRun;  // wave-uniform
+    if (!a_run) batch_exchange(va, vb);
+    part += run_table_probe(a_run ? pa : pb, a_run ? sa.len : sb.len, va, a_run ? pb : pa, a_run ? sb.len : sa.len, vb, lane, table, mini);
   } else {
     // a run on at least one side: both operands 1 KiB at a time out of the table, one clear
     uint32_t acc = 0;
@@ -902,10 +912,31 @@ __device__ __forceinline__ void array_probe_emit_all(const uint8_t* __restrict__
   constexpr uint32_t B = kPairBatch * kWave;
   ProbeEmit e;
   e.nostore = nostore;
+#ifdef FBK_V_EMITLOOP  // (variant for an A/B: ONE copy of the batch body in a loop, the tail batches moved into its registers — a quarter of the emission's code)
+  uint32_t cur[kPairBatch];
+#pragma unroll
+  for (int k = 0; k < kPairBatch; ++k) cur[k] = v0[k];
+#pragma nounroll
+  for (uint32_t b = 0;; ++b) {
+    array_probe_emit_batch<KEEP, MAP>(tb, mb, len, b * B, lane, cur, o16, e);
+    if (b == 3u || (b + 1u) * B >= n_units) break;
+    if (b == 0u) {
+#pragma unroll
+      for (int k = 0; k < kPairBatch; ++k) cur[k] = t.v1[k];
+    } else if (b == 1u) {
+#pragma unroll
+      for (int k = 0; k < kPairBatch; ++k) cur[k] = t.v2[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPairBatch; ++k) cur[k] = t.v3[k];
+    }
+  }
+#else
   array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 0, lane, v0, o16, e);
   if (n_units > B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, B, lane, t.v1, o16, e);
   if (n_units > 2 * B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 2 * B, lane, t.v2, o16, e);
   if (n_units > 3 * B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 3 * B, lane, t.v3, o16, e);
+#endif
   // (len <= 4095 — the caller's condition: the survivors must fit the cell — is at most four batches)
   n_out = e.before;
   runs_out = e.runs;
