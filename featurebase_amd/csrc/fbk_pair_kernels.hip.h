@@ -91,9 +91,10 @@ __device__ __forceinline__ void sparse_xor_batch(uint32_t type, uint32_t tb, uin
                                                  const uint32_t (&v)[kPairBatch]) {
   if (type == kTypeArray) {
     // ONE body, every value under its own test.  (Until round 5 a batch whose values all exist had an unpredicated copy of the loop:
-    // with two copies of every eight-row loop in every role of every type pair k_icount2 was 102 KB of code — the instruction cache
-    // of a pair of CUs holds 64 KB, and the waves of one CU run all the type pairs at once.  The array that is scattered is the shorter
-    // one: it rarely filled a batch anyway.)
+    // with two copies of every eight-row loop in every role of every type pair k_icount2 was 102 KB of code, now 49 KB.  Measured on
+    // config 3's 8192 row pairs, old and new library in one call: 159-160 against 161 us — the instruction cache (64 KB per pair of
+    // CUs) was NOT what the kernel waits for, profiles/r05_pairs_code_size_ab.txt; the smaller form stays because it is the simpler one.
+    // The array that is scattered is the shorter one: it rarely filled a batch anyway.)
 #pragma unroll
     for (int k = 0; k < kPairBatch; ++k) {
       const uint32_t i2 = (base + (uint32_t)k * kWave + (uint32_t)lane) * 2u;
@@ -651,7 +652,7 @@ __device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __res
     } else {
       // ONE instance of the table + probe loops for both assignments of the roles: the shorter array's batch 0 is brought into va by an
       // IN-PLACE exchange (no register is added — role-named COPIES had cost 16 registers and 24 spilled ones in round 3, which is why
-      // every type pair carried two inlined instances of its loops until round 5: half of the kernel's 102 KB)
+      // every type pair carried two inlined instances of its loops until round 5: half of the kernel's 102 KB of code)
       const bool a_tab = sa.len <= sb.len;  // wave-uniform
       if (!a_tab) batch_exchange(va, vb);
       part += arrays_table_probe(a_tab ? pa : pb, a_tab ? sa.len : sb.len, va, a_tab ? pb : pa, a_tab ? sb.len : sa.len, vb, lane, table);
@@ -912,31 +913,10 @@ __device__ __forceinline__ void array_probe_emit_all(const uint8_t* __restrict__
   constexpr uint32_t B = kPairBatch * kWave;
   ProbeEmit e;
   e.nostore = nostore;
-#ifdef FBK_V_EMITLOOP  // (variant for an A/B: ONE copy of the batch body in a loop, the tail batches moved into its registers — a quarter of the emission's code)
-  uint32_t cur[kPairBatch];
-#pragma unroll
-  for (int k = 0; k < kPairBatch; ++k) cur[k] = v0[k];
-#pragma nounroll
-  for (uint32_t b = 0;; ++b) {
-    array_probe_emit_batch<KEEP, MAP>(tb, mb, len, b * B, lane, cur, o16, e);
-    if (b == 3u || (b + 1u) * B >= n_units) break;
-    if (b == 0u) {
-#pragma unroll
-      for (int k = 0; k < kPairBatch; ++k) cur[k] = t.v1[k];
-    } else if (b == 1u) {
-#pragma unroll
-      for (int k = 0; k < kPairBatch; ++k) cur[k] = t.v2[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < kPairBatch; ++k) cur[k] = t.v3[k];
-    }
-  }
-#else
   array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 0, lane, v0, o16, e);
   if (n_units > B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, B, lane, t.v1, o16, e);
   if (n_units > 2 * B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 2 * B, lane, t.v2, o16, e);
   if (n_units > 3 * B) array_probe_emit_batch<KEEP, MAP>(tb, mb, len, 3 * B, lane, t.v3, o16, e);
-#endif
   // (len <= 4095 — the caller's condition: the survivors must fit the cell — is at most four batches)
   n_out = e.before;
   runs_out = e.runs;
