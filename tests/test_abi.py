@@ -134,3 +134,34 @@ def test_no_exception_can_leave_an_entry_point():
                 i = k
             i += 1
     assert n == len(declared_symbols()) - 2, (n, len(declared_symbols()))
+
+
+def test_cgo_snippets_of_integration_md_call_the_header_s_functions():
+    """Go is not installed here, so the cgo shim of INTEGRATION.md cannot be compiled; what CAN be checked is that every `C.fbk_*(...)`
+    call in it names a function include/fbk.h declares and passes as many arguments as the prototype has."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int32_t|const char\*)\s+(fbk_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    assert len(protos) == len(declared_symbols())
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    calls, bad = 0, []
+    for m in re.finditer(r"C\.(fbk_[a-z0-9_]+)\(", md):
+        j, depth, n_args, cur = m.end(), 1, 0, ""
+        while depth and j < len(md):
+            c = md[j]
+            if c in "([{":
+                depth += 1
+            elif c in ")]}":
+                depth -= 1
+            if depth == 1 and c == ",":
+                n_args, cur = n_args + 1, ""
+            elif depth >= 1:
+                cur += c
+            j += 1
+        n_args += 1 if cur.strip() else 0
+        calls += 1
+        if protos.get(m.group(1)) != n_args:
+            bad.append((m.group(1), protos.get(m.group(1)), n_args))
+    assert calls >= 20 and not bad, bad
