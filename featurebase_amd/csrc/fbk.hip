@@ -19,6 +19,7 @@
 
 #include "fbk_kernels.hip.h"
 #include "fbk_pair_kernels.hip.h"
+#include "fbk_pair_ring.hip.h"
 #include "fbk_query_kernels.hip.h"
 #include "fbk_fold_kernels.hip.h"
 #include "fbk_topk_kernels.hip.h"
@@ -123,7 +124,10 @@ struct FbkOptions {
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
   int64_t pair_spw = 1;                  // experiment: container slots per wave of k_icount2 (1 | 2 | 4): the next slot's first payload batch is in flight while the current one is decoded
 #endif
-  int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
+  int64_t pair_kernels = 0;              // 3: the persistent loader / decoder count k_icount3 (fbk_pair_ring.hip.h; set-ops as 2); 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
+  int64_t ring_geom = 0;                 // k_icount3's block: 0 = 10 decoders + 64 KiB ring, one block per CU; 1 = 5 decoders + 32 KiB ring, two blocks per CU; 2 = 12 decoders + 32 KiB ring, one block per CU
+  int64_t ring_lag = 8;                  //   items between the loader's issue point and the item it waits for and publishes
+  int64_t ring_nt = 0;                   //   1: the payload DMAs carry the non-temporal hint
 };
 
 struct fbk_ctx {
@@ -701,7 +705,10 @@ const OptionDesc kOptions[] = {
     {"upload_threads", &FbkOptions::upload_threads, 0, 64},
     {"upload_chunk_mb", &FbkOptions::upload_chunk_mb, 1, 1024},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
-    {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
+    {"pair_kernels", &FbkOptions::pair_kernels, 0, 3},
+    {"ring_geom", &FbkOptions::ring_geom, 0, 2},
+    {"ring_lag", &FbkOptions::ring_lag, 1, 48},
+    {"ring_nt", &FbkOptions::ring_nt, 0, 1},
 #ifdef FBK_EXPERIMENTS
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 4095},
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
@@ -1337,6 +1344,7 @@ struct fbk_plan {
   // rewritten since) and one count per wave, summed per pair by k_sum_wave_counts
   Slot* d_items = nullptr;
   uint32_t* d_wave_counts = nullptr;
+  uint32_t* d_ring_ctl = nullptr;  // k_icount3: word 0 is OR-ed with 1 by a block that gave up on a wait (never in a correct run; fbk_plan_read reports it)
   uint64_t items_va = ~0ull, items_vb = ~0ull;
 };
 
@@ -1457,6 +1465,7 @@ void free_plan_storage(fbk_plan* p) {
   if (p->d_runs) (void)ctx_free(p->ctx, p->d_runs);
   if (p->d_items) (void)ctx_free(p->ctx, p->d_items);
   if (p->d_wave_counts) (void)ctx_free(p->ctx, p->d_wave_counts);
+  if (p->d_ring_ctl) (void)ctx_free(p->ctx, p->d_ring_ctl);
   free_batch_storage(p->out);
   delete p;
 }
@@ -1526,12 +1535,33 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #undef FBK_LAUNCH_DENSE
   } else {
     const bool pk2 = use_pair_kernels2(ctx, p->a, p->b, -1);
+    const bool pk3 = ctx->opt.pair_kernels == 3;
     // (resolved item records + a count per wave pay for their second launch only where the items are heavy: one-wave blocks)
-    const bool resolved = pk2 && pair_wpb_for(ctx, p->a, p->b) == 1;
+    const bool resolved = pk3 || (pk2 && pair_wpb_for(ctx, p->a, p->b) == 1);
     if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     if (resolved)
       if (int32_t rc = plan_resolve_items(ctx, p)) return rc;
-    if (pk2) {
+    if (pk3) {
+      // the persistent loader / decoder kernel: a block per compute unit (or two), every block walks its share of the item records
+      if (!p->d_ring_ctl) {
+        HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_ring_ctl), 16));
+        HIP_TRY(hipMemsetAsync(p->d_ring_ctl, 0, 16, ctx->stream));
+      }
+      const uint64_t n_items = p->n_pairs * fbk::kSlots, n_chunks = (n_items + fbk::kRgChunk - 1) / fbk::kRgChunk;
+      const uint32_t cus = uint32_t(ctx->n_cu > 0 ? ctx->n_cu : 256);
+#define FBK_LAUNCH_ICOUNT3(D, R, NT, PER_CU)                                                                                                   \
+  hipLaunchKernelGGL((fbk::k_icount3<D, R, NT>), dim3(uint32_t(std::min<uint64_t>(n_chunks, uint64_t(cus) * PER_CU))), dim3(64 * (D + 1)), 0, \
+                     ctx->stream, p->d_items, p->a->d_arena, p->b->d_arena, n_items, p->d_wave_counts, uint32_t(ctx->opt.ring_lag), p->d_ring_ctl)
+      const bool nt = ctx->opt.ring_nt != 0;
+      switch (ctx->opt.ring_geom) {
+        case 1: if (nt) FBK_LAUNCH_ICOUNT3(5, 32768, true, 2); else FBK_LAUNCH_ICOUNT3(5, 32768, false, 2); break;
+        case 2: if (nt) FBK_LAUNCH_ICOUNT3(12, 32768, true, 1); else FBK_LAUNCH_ICOUNT3(12, 32768, false, 1); break;
+        default: if (nt) FBK_LAUNCH_ICOUNT3(10, 65536, true, 1); else FBK_LAUNCH_ICOUNT3(10, 65536, false, 1); break;
+      }
+#undef FBK_LAUNCH_ICOUNT3
+      hipLaunchKernelGGL(fbk::k_sum_wave_counts, dim3(uint32_t((p->n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, p->d_wave_counts,
+                         uint32_t(fbk::kSlots), p->n_pairs, p->d_counts);
+    } else if (pk2) {
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \
@@ -1712,7 +1742,10 @@ int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64
   if (out_counts && plan->n_pairs)
     HIP_TRY(hipMemcpyAsync(out_counts, plan->d_counts, plan->n_pairs * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
   if (out_total) HIP_TRY(hipMemcpyAsync(out_total, plan->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t ring_abort = 0;
+  if (plan->d_ring_ctl) HIP_TRY(hipMemcpyAsync(&ring_abort, plan->d_ring_ctl, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ring_abort) return fail(FBK_E_HIP, "k_icount3: a block gave up on a wait (protocol error): the counts of this plan are not valid");
   return FBK_OK;
 } FBK_ABI_CATCH(ctx)
 

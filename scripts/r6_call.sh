@@ -1,0 +1,23 @@
+#!/bin/bash
+# one gpurun call of round 6: scripts/r6_call.sh <tag> <what> [...]   (output under gpurun_out/<tag>/)
+R=$GRAFT_REPO_ROOT
+TAG=$1; shift
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+for what in "$@"; do
+case $what in
+ring_smoke)   # first contact: small parity run of the ring kernel, then config 3's row pairs
+  timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "ring" > $O/parity_ring.log 2>&1; echo "parity_ring rc $?"; tail -3 $O/parity_ring.log ;;
+ring_pairs)
+  timeout 300 python scripts/bench_pairs.py --shards ${SHARDS:-256} --iters 20 --only-count --variants "${VARS:-pair_kernels=2;pair_kernels=3;pair_kernels=3,ring_geom=1;pair_kernels=3,ring_geom=2;pair_kernels=3,ring_geom=0,ring_nt=1}" --out $O/pairs_${SHARDS:-256}.json > $O/pairs_${SHARDS:-256}.log 2>&1; echo "pairs rc $?"; grep -h '"us"\|Error\|error\|assert' $O/pairs_${SHARDS:-256}.log | head -20 ;;
+ring_fuzz)
+  timeout 600 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_fuzz_struct.py -x -q -m gpu -k "ring or 3" > $O/fuzz_ring.log 2>&1; echo "fuzz_ring rc $?"; tail -3 $O/fuzz_ring.log ;;
+gpu_tests)
+  timeout 1500 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu_tests rc $?"; tail -3 $O/gpu_tests.log ;;
+bench)
+  timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"; cut -c1-600 $O/bench.json ;;
+*) echo "unknown: $what" ;;
+esac
+done

@@ -14,7 +14,7 @@ from featurebase_amd import lib as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 2, 0], ids=["pair-kernels-r2", "pair-kernels-r3", "pair-kernels-auto"], autouse=True)
+@pytest.fixture(params=[1, 2, 3, 0], ids=["pair-kernels-r2", "pair-kernels-r3", "pair-kernels-ring", "pair-kernels-auto"], autouse=True)
 def pair_kernel_generation(request, gpu_ctx):
     """Every test of this file runs with the round-2 pair kernels (k_icount / k_setop), with the round-3 ones (k_icount2 /
     k_setop2: table + probe, interior-map run decode, one-wave blocks) and with the library's own choice by payload size:

@@ -64,7 +64,7 @@ def as_int(w):
     return int.from_bytes(w.tobytes(), "little")
 
 
-@pytest.mark.parametrize("gen", [1, 2])
+@pytest.mark.parametrize("gen", [1, 2, 3])
 @pytest.mark.parametrize("it", range(ITERS))
 def test_fuzz_pairwise_and_folds(gpu_ctx, oracle, it, gen):
     gpu_ctx.set_option("pair_kernels", gen)  # both generations of the pair kernels see every case

@@ -13,10 +13,11 @@ from featurebase_amd import lib as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 2, 0], ids=["pair-kernels-r2", "pair-kernels-r3", "pair-kernels-auto"], autouse=True)
+@pytest.fixture(params=[1, 2, 3, 0], ids=["pair-kernels-r2", "pair-kernels-r3", "pair-kernels-ring", "pair-kernels-auto"], autouse=True)
 def pair_kernel_generation(request, gpu_ctx):
     """Every test of this file runs with the round-2 pair kernels (k_icount / k_setop), with the round-3 ones (k_icount2 /
-    k_setop2: table + probe, interior-map run decode, one-wave blocks; array x run by probing the run table) and with the
+    k_setop2: table + probe, interior-map run decode, one-wave blocks; array x run by probing the run table) with the round-6
+    persistent loader / decoder count (k_icount3: payloads through an LDS ring; set-ops as round 3) and with the
     library's own choice by payload size: each generation is checked against the oracle on every input of the file, not
     only on the rows the dispatch would hand it."""
     gpu_ctx.set_option("pair_kernels", request.param)
