@@ -125,9 +125,10 @@ struct FbkOptions {
   int64_t pair_spw = 1;                  // experiment: container slots per wave of k_icount2 (1 | 2 | 4): the next slot's first payload batch is in flight while the current one is decoded
 #endif
   int64_t pair_kernels = 0;              // 3: the persistent loader / decoder count k_icount3 (fbk_pair_ring.hip.h; set-ops as 2); 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
-  int64_t ring_geom = 0;                 // k_icount3's block: 0 = 10 decoders + 64 KiB ring, one block per CU; 1 = 5 decoders + 32 KiB ring, two blocks per CU; 2 = 12 decoders + 32 KiB ring, one block per CU
-  int64_t ring_lag = 8;                  //   items between the loader's issue point and the item it waits for and publishes
+  int64_t ring_geom = 0;                 // k_icount3's block: 0 = 10 decoders + 64 KiB ring, one block per CU; 1 = 8 decoders; 2 = 6 decoders; 3 = 5 decoders + 32 KiB ring, two blocks per CU
   int64_t ring_nt = 0;                   //   1: the payload DMAs carry the non-temporal hint
+  int64_t ring_flags = 0;                //   experiments on k_icount3 (bit 0: ring space is released after the decode)
+  int64_t ring_debug = 0;                //   1: every block reports the cycles its loader and decoders spent waiting; the averages go to stderr after each launch (which is then synchronous)
 };
 
 struct fbk_ctx {
@@ -208,7 +209,11 @@ struct fbk_batch {
   std::mutex slots_mu;  // refresh_slots: h_slots / slots_stale
   uint64_t version = 0;  // bumped whenever the device descriptors are rewritten (a plan's resolved item records follow it)
   bool borrowed = false;  // the output of a plan / prepared query: owned by it and rewritten in place (n_rows x 16 cells of 8 KiB) by its next run
+  // every sparse container fits a k_icount3 decoder's registers (arrays <= 4096 values, run lists <= 2048 intervals); false = not
+  // known: uploads check their descriptors, kernel outputs are 8 KiB cells.  Batches that are not go to k_icount2.
+  bool ring_regular = false;
 };
+inline bool ring_fits(uint32_t type, uint32_t len) { return !((type == fbk::kTypeArray && len > 4096u) || (type == fbk::kTypeRun && len > 2048u)); }
 
 namespace {
 
@@ -706,9 +711,10 @@ const OptionDesc kOptions[] = {
     {"upload_chunk_mb", &FbkOptions::upload_chunk_mb, 1, 1024},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 3},
-    {"ring_geom", &FbkOptions::ring_geom, 0, 2},
-    {"ring_lag", &FbkOptions::ring_lag, 1, 48},
+    {"ring_geom", &FbkOptions::ring_geom, 0, 3},
     {"ring_nt", &FbkOptions::ring_nt, 0, 1},
+    {"ring_debug", &FbkOptions::ring_debug, 0, 1},
+    {"ring_flags", &FbkOptions::ring_flags, 0, 255},
 #ifdef FBK_EXPERIMENTS
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 4095},
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
@@ -1065,6 +1071,9 @@ static int32_t batch_upload_impl(fbk_ctx* ctx, const fbk_container_desc* descs, 
   }
   b->arena_bytes = off;
   b->dense = dense;
+  b->ring_regular = true;
+  for (uint64_t s = 0; s < n_slots; ++s)
+    if (src[s] >= 0 && !ring_fits(fbk::slot_type(b->h_slots[s]), b->h_slots[s].len)) b->ring_regular = false;
   // the arena image in (row, slot) order: payload bytes, then zeros up to the next 16-byte boundary
   struct Piece {
     uint64_t at, bytes, src;
@@ -1158,6 +1167,7 @@ int32_t fbk_batch_upload_dense(fbk_ctx* ctx, const uint64_t* words, uint32_t n_r
   b->n_rows = n_rows;
   b->arena_bytes = bytes;
   b->dense = n_rows > 0;
+  b->ring_regular = true;
   b->h_slots.resize(n_slots);
   b->h_keys.resize(n_slots);
   for (uint64_t s = 0; s < n_slots; ++s) {
@@ -1535,7 +1545,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #undef FBK_LAUNCH_DENSE
   } else {
     const bool pk2 = use_pair_kernels2(ctx, p->a, p->b, -1);
-    const bool pk3 = ctx->opt.pair_kernels == 3;
+    const bool pk3 = ctx->opt.pair_kernels == 3 && p->a->ring_regular && p->b->ring_regular;
     // (resolved item records + a count per wave pay for their second launch only where the items are heavy: one-wave blocks)
     const bool resolved = pk3 || (pk2 && pair_wpb_for(ctx, p->a, p->b) == 1);
     if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
@@ -1544,23 +1554,54 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
     if (pk3) {
       // the persistent loader / decoder kernel: a block per compute unit (or two), every block walks its share of the item records
       if (!p->d_ring_ctl) {
-        HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_ring_ctl), 16));
-        HIP_TRY(hipMemsetAsync(p->d_ring_ctl, 0, 16, ctx->stream));
+        HIP_TRY(ctx_malloc(ctx, reinterpret_cast<void**>(&p->d_ring_ctl), 32));
+        HIP_TRY(hipMemsetAsync(p->d_ring_ctl, 0, 32, ctx->stream));
       }
       const uint64_t n_items = p->n_pairs * fbk::kSlots, n_chunks = (n_items + fbk::kRgChunk - 1) / fbk::kRgChunk;
       const uint32_t cus = uint32_t(ctx->n_cu > 0 ? ctx->n_cu : 256);
 #define FBK_LAUNCH_ICOUNT3(D, R, NT, PER_CU)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount3<D, R, NT>), dim3(uint32_t(std::min<uint64_t>(n_chunks, uint64_t(cus) * PER_CU))), dim3(64 * (D + 1)), 0, \
-                     ctx->stream, p->d_items, p->a->d_arena, p->b->d_arena, n_items, p->d_wave_counts, uint32_t(ctx->opt.ring_lag), p->d_ring_ctl)
+                     ctx->stream, p->d_items, p->a->d_arena, p->b->d_arena, n_items, p->d_wave_counts, p->d_ring_ctl, d_dbg, uint32_t(ctx->opt.ring_flags))
       const bool nt = ctx->opt.ring_nt != 0;
+      const uint32_t per_cu = ctx->opt.ring_geom == 3 ? 2u : 1u;
+      const uint32_t dbg_blocks = uint32_t(std::min<uint64_t>(n_chunks, uint64_t(cus) * per_cu));
+      DevBuf dbgbuf;
+      uint32_t* d_dbg = nullptr;
+      if (ctx->opt.ring_debug) {
+        HIP_TRY(dbgbuf.alloc(ctx, uint64_t(dbg_blocks) * 32 * 4));
+        HIP_TRY(hipMemsetAsync(dbgbuf.p, 0, uint64_t(dbg_blocks) * 32 * 4, ctx->stream));
+        d_dbg = dbgbuf.as<uint32_t>();
+      }
       switch (ctx->opt.ring_geom) {
-        case 1: if (nt) FBK_LAUNCH_ICOUNT3(5, 32768, true, 2); else FBK_LAUNCH_ICOUNT3(5, 32768, false, 2); break;
-        case 2: if (nt) FBK_LAUNCH_ICOUNT3(12, 32768, true, 1); else FBK_LAUNCH_ICOUNT3(12, 32768, false, 1); break;
+        case 1: if (nt) FBK_LAUNCH_ICOUNT3(8, 65536, true, 1); else FBK_LAUNCH_ICOUNT3(8, 65536, false, 1); break;
+        case 2: if (nt) FBK_LAUNCH_ICOUNT3(6, 65536, true, 1); else FBK_LAUNCH_ICOUNT3(6, 65536, false, 1); break;
+        case 3: if (nt) FBK_LAUNCH_ICOUNT3(5, 32768, true, 2); else FBK_LAUNCH_ICOUNT3(5, 32768, false, 2); break;
         default: if (nt) FBK_LAUNCH_ICOUNT3(10, 65536, true, 1); else FBK_LAUNCH_ICOUNT3(10, 65536, false, 1); break;
       }
 #undef FBK_LAUNCH_ICOUNT3
+      if (d_dbg) {
+        std::vector<uint32_t> h(uint64_t(dbg_blocks) * 32);
+        HIP_TRY(hipMemcpyAsync(h.data(), d_dbg, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        double sum[32] = {0};
+        uint32_t tmax = 0, tmin = ~0u;
+        for (uint32_t b = 0; b < dbg_blocks; ++b) {
+          for (int k = 0; k < 32; ++k) sum[k] += h[uint64_t(b) * 32 + k];
+          tmax = std::max(tmax, h[uint64_t(b) * 32]);
+          tmin = std::min(tmin, h[uint64_t(b) * 32]);
+        }
+        std::fprintf(stderr, "[ring_debug] blocks %u planner cycles avg %.0f min %u max %u | wait records %.0f slots %.0f | reclaim polls %.0f entries %.0f | decoders (summed per block): wait entry %.0f issue %.0f wait payload %.0f decode %.0f items %.0f deferred %.0f\n",
+                     dbg_blocks, sum[0] / dbg_blocks, tmin, tmax, sum[1] / dbg_blocks, sum[2] / dbg_blocks, sum[6] / dbg_blocks, sum[7] / dbg_blocks, sum[8] / dbg_blocks,
+                     sum[12] / dbg_blocks, sum[11] / dbg_blocks, sum[9] / dbg_blocks, sum[10] / dbg_blocks, sum[13] / dbg_blocks);
+        if (sum[21] > 0 && sum[26] > 0)
+          std::fprintf(stderr, "[ring_debug]   array x array phases, cycles per item: payload -> registers %.0f, take next %.0f, scatter %.0f, probe + reduce %.0f (dwords per item: table side %.0f, probing side %.0f)\n",
+                       sum[26] / sum[21], sum[27] / sum[21], sum[28] / sum[21], sum[29] / sum[21], sum[30] / sum[21], sum[31] / sum[21]);
+        static const char* kCls[5] = {"array x array", "array x bitmap", "array x run (<= 600)", "general (run x run, run x bitmap, long runs)", "outside the ring / bitmap x bitmap"};
+        for (int k = 0; k < 5; ++k)
+          if (sum[21 + k] > 0) std::fprintf(stderr, "[ring_debug]   %-48s items %8.0f  decode cycles per item %7.0f\n", kCls[k], sum[21 + k], sum[16 + k] / sum[21 + k]);
+      }
       hipLaunchKernelGGL(fbk::k_sum_wave_counts, dim3(uint32_t((p->n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, p->d_wave_counts,
-                         uint32_t(fbk::kSlots), p->n_pairs, p->d_counts);
+                         uint32_t(fbk::kSlots), p->n_pairs, p->d_counts, p->d_ring_ctl + 1);
     } else if (pk2) {
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
@@ -1589,7 +1630,7 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #undef FBK_LAUNCH_ICOUNT2
       if (resolved)
         hipLaunchKernelGGL(fbk::k_sum_wave_counts, dim3(uint32_t((p->n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, p->d_wave_counts,
-                           uint32_t(fbk::kSlots) / spw, p->n_pairs, p->d_counts);
+                           uint32_t(fbk::kSlots) / spw, p->n_pairs, p->d_counts, (uint32_t*)nullptr);
     }
     else
       hipLaunchKernelGGL(fbk::k_icount, dim3(np * (fbk::kSlots / 4)), dim3(256), 0, ctx->stream, p->a->d_slots,
@@ -1615,6 +1656,7 @@ int32_t plan_setop_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, int32_t op, bool wa
     o->ctx = ctx;
     o->n_rows = uint32_t(p->n_pairs);
     o->arena_bytes = n_slots * 8192ull;
+    o->ring_regular = true;  // (8 KiB cells)
     o->h_slots.assign(n_slots, Slot{0, 0, 0});
     o->h_keys.assign(n_slots, 0);
     for (uint64_t i = 0; i < p->n_pairs; ++i)
@@ -1742,10 +1784,15 @@ int32_t fbk_plan_read(fbk_ctx* ctx, fbk_plan* plan, uint64_t* out_counts, uint64
   if (out_counts && plan->n_pairs)
     HIP_TRY(hipMemcpyAsync(out_counts, plan->d_counts, plan->n_pairs * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
   if (out_total) HIP_TRY(hipMemcpyAsync(out_total, plan->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-  uint32_t ring_abort = 0;
-  if (plan->d_ring_ctl) HIP_TRY(hipMemcpyAsync(&ring_abort, plan->d_ring_ctl, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t ring_ctl[8] = {0};
+  if (plan->d_ring_ctl) HIP_TRY(hipMemcpyAsync(ring_ctl, plan->d_ring_ctl, sizeof(ring_ctl), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (ring_abort) return fail(FBK_E_HIP, "k_icount3: a block gave up on a wait (protocol error): the counts of this plan are not valid");
+  if (ring_ctl[0]) {
+    char buf[256];
+    std::snprintf(buf, sizeof(buf), "k_icount3: a block gave up on a wait (protocol error): the counts of this plan are not valid [where %u block %u wave %u: %u %u %u | pub %u tail %u]",
+                  ring_ctl[2] & 255u, (ring_ctl[2] >> 8) & 0xFFFFu, ring_ctl[2] >> 24, ring_ctl[3], ring_ctl[4], ring_ctl[5], ring_ctl[6], ring_ctl[7]);
+    return fail(FBK_E_HIP, buf);
+  }
   return FBK_OK;
 } FBK_ABI_CATCH(ctx)
 

@@ -790,7 +790,10 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
 // removed in round 5 with its option.)
 
 // out[pair] = the sum of the pair's waves' counts (per = 16 / SPW of them, consecutive)
-__global__ void __launch_bounds__(256) k_sum_wave_counts(const uint32_t* __restrict__ wave_counts, uint32_t per, uint64_t n_pairs, u64* __restrict__ out) {
+// (reset: a word this launch puts back to zero — k_icount3's chunk counter — or null)
+__global__ void __launch_bounds__(256) k_sum_wave_counts(const uint32_t* __restrict__ wave_counts, uint32_t per, uint64_t n_pairs, u64* __restrict__ out,
+                                                        uint32_t* __restrict__ reset) {
+  if (reset && blockIdx.x == 0 && threadIdx.x == 0) *reset = 0u;
   const uint64_t pair = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (pair >= n_pairs) return;
   const uint32_t* w = wave_counts + pair * per;

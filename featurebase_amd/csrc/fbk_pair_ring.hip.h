@@ -5,16 +5,21 @@
 // the decode at 85 us on config 3's 8192 row pairs — one after the other, 150-168 us in all, whatever the occupancy, the
 // instruction mix or the code size.  Here the two halves belong to different waves of a block that stays on its compute unit:
 //
-//   LOADER wave (wave 0)   walks the plan's resolved item records (k_resolve_items) 32 at a time — the records themselves arrive
-//                          by one 1 KiB LDS-DMA — classifies the 32 items lane-parallel (sizes, ring positions by a wave scan,
-//                          the short circuits of intersectionCount roaring.go:4478-4486 answered on the spot) and streams every
-//                          item's encoded payload into an LDS RING with global_load_lds_dwordx4, allocated by the payload's
-//                          ACTUAL bytes (16-byte granules, A then B).  Its vector-memory counter holds nothing but these DMAs, in
-//                          order, so "item i has landed" is `s_waitcnt vmcnt(pieces issued after it)` — a counted wait, kLag items
-//                          behind the issue point — and the item is PUBLISHED to the block's queue.
-//   DECODER waves (1..D)   claim published items (one LDS ticket), decode them out of the ring with their own 8 KiB table and
-//                          write ONE count per item; when the last ring byte of an item has been read the entry is RELEASED and
-//                          the loader reclaims the space in allocation order.  A decoder never waits for HBM.
+//   PLANNER wave (wave 0)  walks the plan's resolved item records (k_resolve_items) 32 at a time — the records themselves arrive
+//                          by one 1 KiB LDS-DMA — and classifies the 32 items LANE-PARALLEL: sizes, the short circuits of
+//                          intersectionCount (roaring.go:4478-4486, answered on the spot), and a place in the block's LDS RING for
+//                          every payload by a wave scan, allocated by the payload's ACTUAL bytes (16-byte granules, A then B).  It
+//                          writes one queue entry per item and reclaims the ring space of released entries in allocation order.
+//   DECODER waves (1..D)   claim entries (one LDS ticket each).  A decoder first starts the global -> LDS DMA of the entry it has
+//                          just claimed (global_load_lds_dwordx4 into the item's place in the ring: no registers, nothing waits),
+//                          THEN decodes the item it claimed one round earlier, whose payload landed meanwhile: its vector-memory
+//                          counter holds its own DMAs in issue order, so "my item has landed" is the counted wait `s_waitcnt
+//                          vmcnt(pieces issued after it)`.  Decoding works out of the ring with the wave's own 8 KiB table and
+//                          ends with ONE count per item; the entry is then RELEASED.  With D decoders a compute unit has D
+//                          payloads in flight while D others are decoded, and no wave waits for HBM in front of its own decode.
+// (The first version of this file had ONE loader wave issue every DMA and publish landed items: correct, and 3.5 x slower than
+// k_icount2 — ~1800 cycles of scalar bookkeeping and DMA issue per item in one instruction stream, decoders idle 70 % of the time,
+// profiles/r06_ring_v1_debug.txt.)
 //
 // Type pairs, as the reference dispatches them (intersectionCount roaring.go:4477-4512):
 //   array x array    shorter array scattered into the cleared table, longer one probes      (intersectionCountArrayArray :4514)
@@ -22,8 +27,8 @@
 //   array x run      runs of <= kRunFillMax intervals: boundary masks + interior map, the array probes both  (ArrayRun :4537)
 //   bitmap x bitmap  AND + popcount straight out of the ring                                  (BitmapBitmap :4611)
 //   run x run / run x bitmap / long run lists: both operands 1 KiB at a time out of the table (RunRun :4573, BitmapRun :4563)
-// Items whose payload exceeds kRingItemMax (arrays beyond 4096 values are legal intermediates, roaring.go:5054) and tiny arrays
-// against bitmaps (a few gathered dwords beat streaming 8 KiB) keep k_icount2's path: the decoder runs icount_item on them.
+// Batches that may hold an oversized container (arrays beyond 4096 values are legal intermediates, roaring.go:5054) stay with
+// k_icount2: the host knows (fbk_batch::ring_regular).
 //
 // Every wait loop is bounded (kSpinLimit polls with s_sleep): a protocol error ends the block with the abort word set instead of
 // hanging the device; the host reports it (plan_read).
@@ -33,7 +38,8 @@
 namespace fbk {
 
 constexpr int kRgChunk = 32;            // items per record chunk: 32 x 32 bytes = one 1 KiB DMA
-constexpr int kRgQ = 64;                // queue entries (power of two; the loader's per-entry FIFO is one lane each)
+constexpr int kRgQ = 64;                // queue entries (power of two; one reclaim pass looks at 64 release words, one per lane)
+constexpr int kRgEntry = 64;            // bytes per queue entry
 constexpr uint32_t kRingItemMax = 16384;  // payload bytes of an item that goes through the ring
 constexpr uint32_t kSpinLimit = 1u << 22;
 
@@ -44,16 +50,25 @@ struct RingLayout {
   static constexpr uint32_t kMini = kTab + D * 8192;            // D x 512 B run maps
   static constexpr uint32_t kRing = kMini + D * 512;
   static constexpr uint32_t kStage = kRing + RING;              // 2 x 1 KiB record chunks (also the slack a ragged last batch reads into)
-  static constexpr uint32_t kQueue = kStage + 2048;             // kRgQ x 32 B entries
-  static constexpr uint32_t kRel = kQueue + kRgQ * 32;          // kRgQ release words: 0 = held, else the entry's end position + 1
-  static constexpr uint32_t kCtl = kRel + kRgQ * 4;             // pub, claim, fin, abort
-  static constexpr uint32_t kTotal = kCtl + 16;
+  static constexpr uint32_t kQueue = kStage + 2048;             // kRgQ x 64 B entries
+  static constexpr uint32_t kRel = kQueue + kRgQ * kRgEntry;    // kRgQ release words: 0 = held, 1 = done (the planner reuses queue slots in order)
+  static constexpr uint32_t kCtl = kRel + kRgQ * 4;             // pub, claim, fin, abort, -, heartbeat, page mask (8 bytes)
+  static constexpr uint32_t kTotal = kCtl + 32;
+  static_assert(RING / 1024 <= 64, "one bit per 1 KiB page of the ring");
   static_assert((RING & (RING - 1)) == 0, "ring size must be a power of two");
   static_assert(kTotal <= 160 * 1024, "LDS carve exceeds a compute unit");
 };
 
-// queue entry, 8 dwords: meta (ta | tb << 4 | direct << 8), item, off_a, len_a, off_b, len_b, end position + 1, 0
-// (offsets are byte offsets inside the block's LDS carve)
+// queue entry, 12 dwords: meta (ta | tb << 4), item, off_a, len_a | bytes_a (16-byte granules rounded up), len_b, first page,
+// need (payload bytes: A then B) | A's global address, B's global address
+// (off_a: byte offset inside the block's LDS carve, at a 1 KiB page boundary of the ring; B follows A)
+//
+// RING SPACE is handed out in 1 KiB pages, one bit each in a 64-bit word of the control block.  The planner gives every item the
+// pages FOLLOWING the previous item's (so that consecutive tickets land side by side); a decoder owns them from the moment its
+// atomic OR finds them all clear to its release, whatever other waves do meanwhile.  (Until this version the ring was reclaimed IN
+// ORDER behind a tail position: one slow item — a run x run decode takes twice the average — held back every payload behind it,
+// 40-70 % of the DMAs could not start when their entry was taken and the waves waited for HBM after all:
+// profiles/r06_ring_v3_inorder_debug.txt.)
 
 // ---- loader primitives ---------------------------------------------------------------------------------------------------------
 
@@ -71,18 +86,45 @@ __device__ __forceinline__ void wait_vmcnt_le(uint32_t n) {
 #undef FBK_W
 }
 
-// one LDS-DMA piece: lanes [0, nlanes) copy 16 bytes each from gbase + voff to LDS byte address lds_dst + 16 lane.
-// (M0 and EXEC are saved and restored inside the statement: the compiler does not model either.)
+// LDS-DMA pieces: lanes [0, nlanes) copy 16 bytes each from gbase + voff (+ 1024 k) to LDS byte address lds_dst + 16 lane (+ 1024 k)
+// — the instruction's immediate offset moves BOTH addresses, so up to four pieces share one M0.  (M0 and EXEC are saved and
+// restored inside the statement: the compiler does not model either.)
+#define FBK_GLDS_ASM(NTS)                                                                                                                  \
+  switch (nfull) {                                                                                                                         \
+    case 4:                                                                                                                                \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" NTS                                 \
+                   "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" NTS "\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048" NTS                \
+                   "\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072" NTS "\n\ts_mov_b32 m0, %0"                                              \
+                   : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");                                                        \
+      break;                                                                                                                               \
+    case 3:                                                                                                                                \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" NTS                                 \
+                   "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" NTS "\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048" NTS                \
+                   "\n\ts_mov_b32 m0, %0"                                                                                                   \
+                   : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");                                                        \
+      break;                                                                                                                               \
+    case 2:                                                                                                                                \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" NTS                                 \
+                   "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" NTS "\n\ts_mov_b32 m0, %0"                                              \
+                   : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");                                                        \
+      break;                                                                                                                               \
+    case 1:                                                                                                                                \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" NTS "\n\ts_mov_b32 m0, %0"         \
+                   : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");                                                        \
+      break;                                                                                                                               \
+    default: break;                                                                                                                        \
+  }
+// nfull (0..4) full pieces
 template <bool NT>
-__device__ __forceinline__ void glds_piece_full(uint64_t gbase, uint32_t voff, uint32_t lds_dst) {
+__device__ __forceinline__ void glds_full(uint64_t gbase, uint32_t voff, uint32_t lds_dst, uint32_t nfull) {
   uint32_t keep;
-  if (NT)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+  if (NT) {
+    FBK_GLDS_ASM(" nt")
+  } else {
+    FBK_GLDS_ASM("")
+  }
 }
+#undef FBK_GLDS_ASM
 template <bool NT>
 __device__ __forceinline__ void glds_piece_part(uint64_t gbase, uint32_t voff, uint32_t lds_dst, uint32_t nlanes /* 1..63 */) {
   uint32_t keep;
@@ -99,14 +141,17 @@ __device__ __forceinline__ void glds_piece_part(uint64_t gbase, uint32_t voff, u
 // bytes16 (a multiple of 16, > 0) from gbase to LDS byte address lds_dst; returns the number of pieces issued
 template <bool NT>
 __device__ __forceinline__ uint32_t glds_stream(uint64_t gbase, uint32_t bytes16, uint32_t lds_dst, uint32_t voff) {
-  const uint32_t nfull = bytes16 >> 10, rem = bytes16 & 1023u;
-  for (uint32_t k = 0; k < nfull; ++k) {
-    glds_piece_full<NT>(gbase, voff, lds_dst);
-    gbase += 1024;
-    lds_dst += 1024;
+  const uint32_t pieces = (bytes16 + 1023u) >> 10;
+  while (bytes16 >= 4096u) {
+    glds_full<NT>(gbase, voff, lds_dst, 4u);
+    gbase += 4096;
+    lds_dst += 4096;
+    bytes16 -= 4096u;
   }
-  if (rem) glds_piece_part<NT>(gbase, voff, lds_dst, rem >> 4);
-  return nfull + (rem ? 1u : 0u);
+  const uint32_t nfull = bytes16 >> 10, rem = bytes16 & 1023u;
+  glds_full<NT>(gbase, voff, lds_dst, nfull);
+  if (rem) glds_piece_part<NT>(gbase + 1024u * nfull, voff, lds_dst + 1024u * nfull, rem >> 4);
+  return pieces;
 }
 
 __device__ __forceinline__ uint32_t rg_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
@@ -179,6 +224,50 @@ __device__ __forceinline__ void ring_fill_all(const uint8_t* rp, uint32_t len, i
   ring_batches(rp, len, lane, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { run_fill_batch(tb, mb, len, base, lane, v); });
 }
 
+// ---- a sparse payload WHOLE in registers: up to four batches (an array of 4096 values, 2048 runs) ---------------------------------
+// A decoder's time was not instructions but dependent LDS round trips (rocprofv3: vector ALU 39 % busy, LDS 32 %, ~6000 cycles
+// per item in a wave whose instructions need ~2500): batch by batch, every load waited for before the next step.  LDS operations
+// of one wave execute in order, so everything an item needs can be REQUESTED up front — both payloads, then the table clear —
+// and the three phases (scatter, probe, reduce) each wait once.
+constexpr uint32_t kRgWholeUnits = 4u * kPairBatch * kWave;  // 2048 dwords
+struct Whole {
+  uint32_t b0[kPairBatch], b1[kPairBatch], b2[kPairBatch], b3[kPairBatch];
+};
+__device__ __forceinline__ void whole_load(const uint8_t* rp, uint32_t n_units, int lane, Whole& w) {
+  constexpr uint32_t B = kPairBatch * kWave;
+  ring_load(rp, 0, lane, w.b0);
+  if (n_units > B) ring_load(rp, B, lane, w.b1);
+  if (n_units > 2 * B) ring_load(rp, 2 * B, lane, w.b2);
+  if (n_units > 3 * B) ring_load(rp, 3 * B, lane, w.b3);
+}
+// a register of the LAST batch requested
+__device__ __forceinline__ uint32_t whole_last(const Whole& w, uint32_t n_units) {
+  constexpr uint32_t B = kPairBatch * kWave;
+  return n_units > 3 * B ? w.b3[kPairBatch - 1] : n_units > 2 * B ? w.b2[kPairBatch - 1] : n_units > B ? w.b1[kPairBatch - 1] : w.b0[kPairBatch - 1];
+}
+// f(base, batch) for the batches that exist
+template <class F>
+__device__ __forceinline__ void whole_each(const Whole& w, uint32_t n_units, F f) {
+  constexpr uint32_t B = kPairBatch * kWave;
+  f(0u, w.b0);
+  if (n_units > B) f(B, w.b1);
+  if (n_units > 2 * B) f(2 * B, w.b2);
+  if (n_units > 3 * B) f(3 * B, w.b3);
+}
+
+// XOR one batch of array dwords into the table, no branch: a value past the array's end toggles nothing (its mask is 0 << bit;
+// its dword — whatever the ring held — is still an address inside the table)
+__device__ __forceinline__ void array_xor_batch_w(uint32_t tb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch]) {
+  int32_t left = (int32_t)(len - 2u * base) - 2 * lane;
+#pragma unroll
+  for (int k = 0; k < kPairBatch; ++k) {
+    const uint32_t w_lo = (uint32_t)min(max(left, 0), 1), w_hi = (uint32_t)min(max(left - 1, 0), 1);
+    (void)__hip_atomic_fetch_xor(table_dword_lo(tb, v[k]), w_lo << (v[k] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    (void)__hip_atomic_fetch_xor(table_dword_hi(tb, v[k]), w_hi << ((v[k] >> 16) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    left -= 2 * kWave;
+  }
+}
+
 // sum over the wave, wave-uniform result (DPP row sums + four lane reads: no LDS round trip)
 __device__ __forceinline__ uint32_t wave_sum_uniform(uint32_t v) {
   v = wave_rows_sum(v);
@@ -241,8 +330,19 @@ __device__ __forceinline__ void ring_pair_stream(uint32_t ta, const uint8_t* ra,
 }
 
 // one ring item: this lane's part of |A ∩ B|
+// release(): called once, as soon as no ring byte of the item will be read again — for the table + probe pairs that is right after
+// both payloads have reached registers, BEFORE the decode (the ring then holds what is in flight, not what is being worked on)
+// next(): called once — the point where the wave should take its following entry and start that entry's DMA: right after the
+// release where the release is early (the space just freed may be what the next payload needs), first thing otherwise.
+template <class R, class N>
 __device__ __forceinline__ uint32_t ring_icount_item(uint32_t ta, const uint8_t* ra, uint32_t lena, uint32_t tb, const uint8_t* rb, uint32_t lenb, int lane,
-                                                     u64* table, uint32_t* mini) {
+                                                     u64* table, uint32_t* mini, R release, N next, uint32_t* ph = nullptr) {
+  // the payload's LAST requested dword has arrived, so every earlier one has (LDS operations of a wave return in order): the
+  // compiler turns the register dependence into a counted lgkmcnt wait that leaves younger operations (the table clear) in flight
+  auto landed = [&](uint32_t last) {
+    asm volatile("" ::"v"(last) : "memory");
+    release();
+  };
   asm volatile("" : "+v"(lane));  // (see icount_item: keeps per-lane addresses of every path from being hoisted out of the item loop)
   uint32_t part = 0;
   if (ta == kTypeBitmap && tb == kTypeBitmap) {
@@ -253,138 +353,288 @@ __device__ __forceinline__ uint32_t ring_icount_item(uint32_t ta, const uint8_t*
       const ulonglong2 x = qa[j * kWave + lane], y = qb[j * kWave + lane];
       part += (uint32_t)__popcll(x.x & y.x) + (uint32_t)__popcll(x.y & y.y);
     }
+    landed(part);
+    next();
   } else if (ta == kTypeArray && tb == kTypeArray) {
     const bool a_tab = lena <= lenb;  // wave-uniform: the shorter array becomes the table
     const uint8_t* rt = a_tab ? ra : rb;
     const uint8_t* rp = a_tab ? rb : ra;
     const uint32_t lt = a_tab ? lena : lenb, lp = a_tab ? lenb : lena;
+    const uint32_t ut = (lt + 1u) >> 1, up = (lp + 1u) >> 1;
     const uint32_t tbase = lds_table_base(table);
+    Whole wt, wp;
+    const u64 p0 = ph ? __builtin_readcyclecounter() : 0;  // (ring_flags bit 1: cycle stamps per phase of the array x array items; every stamp drains the LDS queue)
+    whole_load(rt, ut, lane, wt);
+    whole_load(rp, up, lane, wp);
     lds_zero(table, lane);
+    landed(whole_last(wp, up));
+    const u64 p1 = ph ? __builtin_readcyclecounter() : 0;
+    next();
+    const u64 p2 = ph ? __builtin_readcyclecounter() : 0;
     wave_lds_sync();
-    ring_xor_all(kTypeArray, rt, lt, lane, tbase);
+    whole_each(wt, ut, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { array_xor_batch_w(tbase, lt, base, lane, v); });
     wave_lds_sync();
-    ring_batches(rp, (lp + 1u) >> 1, lane, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { part += array_probe_batch(tbase, lp, base, lane, v); });
+    const u64 p3 = ph ? __builtin_readcyclecounter() : 0;
+    whole_each(wp, up, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { part += array_probe_batch(tbase, lp, base, lane, v); });
     wave_lds_sync();
+    if (ph) {
+      asm volatile("" ::"v"(part));
+      const u64 p4 = __builtin_readcyclecounter();
+      ph[0] += (uint32_t)(p1 - p0), ph[1] += (uint32_t)(p2 - p1), ph[2] += (uint32_t)(p3 - p2), ph[3] += (uint32_t)(p4 - p3), ph[4] += ut, ph[5] += up;
+    }
   } else if ((ta == kTypeArray && tb == kTypeBitmap) || (ta == kTypeBitmap && tb == kTypeArray)) {
     const bool a_arr = ta == kTypeArray;
     const uint8_t* rarr = a_arr ? ra : rb;
     const uint8_t* rbm = a_arr ? rb : ra;
-    const uint32_t larr = a_arr ? lena : lenb;
+    const uint32_t larr = a_arr ? lena : lenb, ua = (larr + 1u) >> 1;
     const uint32_t bb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)rbm);
-    ring_batches(rarr, (larr + 1u) >> 1, lane, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { part += ring_probe_bits_batch(bb, larr, base, lane, v); });
+    next();
+    Whole wa;
+    whole_load(rarr, ua, lane, wa);
+    whole_each(wa, ua, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { part += ring_probe_bits_batch(bb, larr, base, lane, v); });
+    landed(part);  // (the bitmap is probed where it lies)
   } else if ((ta == kTypeArray && tb == kTypeRun && lenb <= kRunFillMax) || (ta == kTypeRun && tb == kTypeArray && lena <= kRunFillMax)) {
     const bool a_run = ta == kTypeRun;
     const uint8_t* rr = a_run ? ra : rb;
     const uint8_t* rp = a_run ? rb : ra;
-    const uint32_t lr = a_run ? lena : lenb, lp = a_run ? lenb : lena;
+    const uint32_t lr = a_run ? lena : lenb, lp = a_run ? lenb : lena, up = (lp + 1u) >> 1;
     const uint32_t tbase = lds_table_base(table);
     const uint32_t mbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)mini);
+    Whole wr, wp;
+    whole_load(rr, lr, lane, wr);  // (<= kRunFillMax intervals: two batches)
+    whole_load(rp, up, lane, wp);
     lds_zero(table, lane);
     mini[lane] = 0;
+    landed(whole_last(wp, up));
+    next();
     wave_lds_sync();
-    ring_fill_all(rr, lr, lane, tbase, mbase);
+    whole_each(wr, lr, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { run_fill_batch(tbase, mbase, lr, base, lane, v); });
     wave_lds_sync();
     mini_prefix(mini, lane);
     wave_lds_sync();
-    ring_batches(rp, (lp + 1u) >> 1, lane, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { part += array_probe_batch<true>(tbase, lp, base, lane, v, mbase); });
+    whole_each(wp, up, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { part += array_probe_batch<true>(tbase, lp, base, lane, v, mbase); });
     wave_lds_sync();
   } else {
+    next();
     uint32_t acc = 0;
     ring_pair_stream(ta, ra, lena, tb, rb, lenb, lane, table, mini,
                      [&acc](u64 a0, u64 a1, u64 b0, u64 b1) { acc += (uint32_t)__popcll(a0 & b0) + (uint32_t)__popcll(a1 & b1); });
     part = acc;
+    landed(part);
   }
   return part;
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------------------
 //
-// grid: any number of blocks (the host launches blocks-per-CU x CUs); block b takes the record chunks b, b + G, b + 2 G, ...
+// grid: any number of blocks (the host launches blocks-per-CU x CUs); block b starts with record chunk b and draws the following
+// ones from the counter ctl_global[1] (zero at launch: k_sum_wave_counts, which follows on the stream, puts it back).
 // items: 2 Slots per item (A's descriptor, B's), item = pair * 16 + slot; wave_out[item] = |A_item ∩ B_item|.
-// ctl_global[0] is OR-ed with 1 if a block gave up on a wait (never in a correct run).
+// ctl_global[0] is OR-ed with 1 if a block gave up on a wait (never in a correct run).  dbg (option ring_debug, else null): 32 words
+// per block of cycle counts.
+
+struct RingEntry {  // a queue entry in scalar registers
+  uint32_t meta, item, off_a, len_a, bytes_a, len_b, page0, need;
+  uint64_t ga, gb;
+};
+
 template <int D, int RING, bool NT>
 __global__ void __launch_bounds__(64 * (D + 1)) k_icount3(const Slot* __restrict__ items, const uint8_t* __restrict__ arenaA,
                                                          const uint8_t* __restrict__ arenaB, uint64_t n_items, uint32_t* __restrict__ wave_out,
-                                                         uint32_t lag, uint32_t* __restrict__ ctl_global) {
+                                                         uint32_t* __restrict__ ctl_global, uint32_t* __restrict__ dbg, uint32_t flags) {
   using L = RingLayout<D, RING>;
   __shared__ __attribute__((aligned(8192))) uint8_t smem[L::kTotal];
   const int lane = threadIdx.x & 63;
   const uint32_t wv = rg_uniform(threadIdx.x >> 6);
-  // control block, release words
-  for (uint32_t i = threadIdx.x; i < (uint32_t)kRgQ + 4u; i += 64u * (D + 1)) reinterpret_cast<uint32_t*>(smem + L::kRel)[i] = i == (uint32_t)kRgQ + 2u ? 0xFFFFFFFFu : 0u;
+  // release words and control block: pub, claim, fin (0xFFFFFFFF: the planner is still producing), abort, tail position
+  for (uint32_t i = threadIdx.x; i < (uint32_t)kRgQ + 8u; i += 64u * (D + 1)) reinterpret_cast<uint32_t*>(smem + L::kRel)[i] = i == (uint32_t)kRgQ + 2u ? 0xFFFFFFFFu : 0u;
   __syncthreads();
-  uint8_t* const ctl = smem + L::kCtl;  // +0 pub, +4 claim, +8 fin (0xFFFFFFFF: the loader is still producing), +12 abort
+  uint8_t* const ctl = smem + L::kCtl;  // +0 pub (entries written), +4 claim, +8 fin, +12 abort, +16 tail position
+  const uint32_t smem_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem);
+  const uint32_t voff = 16u * (uint32_t)lane;
+  auto tick = [&]() { return dbg ? __builtin_readcyclecounter() : (u64)0; };
+  auto give_up = [&](uint32_t where, uint32_t x0, uint32_t x1, uint32_t x2) {  // (the first block to give up leaves where and what it saw in ctl_global[2..7])
+    const uint32_t already = rg_uniform(lds_peek(ctl + 12));
+    lds_poke(ctl + 12, 1u);
+    if (lane == 0 && !already && atomicOr(ctl_global, 1u) == 0u) {
+      ctl_global[2] = where | (blockIdx.x << 8) | (wv << 24);
+      ctl_global[3] = x0, ctl_global[4] = x1, ctl_global[5] = x2;
+      ctl_global[6] = lds_peek(ctl), ctl_global[7] = lds_peek(ctl + 20);  // (entries written, the planner's last heartbeat)
+    }
+  };
 
   if (wv != 0) {
     // ------------------------------------------------ decoder ------------------------------------------------
+    // One round: the payload of the entry in hand has landed -> its sparse operands go to registers and its ring space goes back
+    // -> the NEXT entry is taken and its DMA started (into space this very round may just have freed) -> the entry in hand is
+    // decoded while that DMA flies.  A wave holds one place in the ring for all but a few hundred cycles of a round.
     u64* table = reinterpret_cast<u64*>(smem + L::kTab + (wv - 1u) * 8192u);
     uint32_t* mini = reinterpret_cast<uint32_t*>(smem + L::kMini + (wv - 1u) * 512u);
-    for (;;) {
+    uint32_t d_poll = 0, d_land = 0, d_dec = 0, d_n = 0, d_defer = 0;  // (ring_debug: cycles waiting for an entry / for the payload / in the decode; items; deferred issues)
+    uint32_t d_cls[5] = {0, 0, 0, 0, 0}, d_cln[5] = {0, 0, 0, 0, 0};  // (ring_debug: decode cycles / items per class: a x a, a x b, a x run(short), general, b x b)
+    uint32_t d_ph[6] = {0, 0, 0, 0, 0, 0};
+    RingEntry cur, nxt;
+    uint32_t cur_slot = 0, nxt_slot = 0;
+    bool cur_issued = false, nxt_issued = false, got = false, bad = false;
+    auto issue = [&](const RingEntry& e) {  // the item's payload, A then B, into its place in the ring
+      const uint32_t dst = smem_base + e.off_a;
+      (void)glds_stream<NT>(e.ga, e.bytes_a, dst, voff);
+      (void)glds_stream<NT>(e.gb, e.need - e.bytes_a, dst + e.bytes_a, voff);
+    };
+    u64* const pages = reinterpret_cast<u64*>(ctl + 24);
+    auto pages_of = [&](const RingEntry& e) { return (~0ull >> (64u - ((e.need + 1023u) >> 10))) << e.page0; };  // (1..16 pages)
+    auto acquire = [&](const RingEntry& e) {  // all of the item's pages, or none
+      const u64 my = pages_of(e);
+      u64 old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_or(pages, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      old = ((u64)rg_uniform((uint32_t)(old >> 32)) << 32) | rg_uniform((uint32_t)old);
+      if ((old & my) == 0ull) return true;
+      if (lane == 0) (void)__hip_atomic_fetch_and(pages, ~(my & ~old), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (give back the ones that were clear)
+      return false;
+    };
+    auto claim = [&]() {  // a ticket (lane 0's register; read with rg_uniform when it is needed: the LDS round trip hides behind a decode)
       uint32_t t = 0;
       if (lane == 0) t = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ctl + 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      t = rg_uniform(t);
-      bool stop = false;
+      return t;
+    };
+    uint32_t ticket = claim();
+    uint32_t t_nxt = 0;
+    // the entry of ticket t_nxt, if the planner has written it: one LDS round trip (the counters, then — LDS operations of a wave execute
+    // in order — the entry's words), then its DMA if its place in the ring is free
+    auto take = [&]() {
+      const uint32_t pub0 = lds_peek(ctl);
+      asm volatile("" ::: "memory");
+      const uint4* qe = reinterpret_cast<const uint4*>(smem + L::kQueue + (t_nxt & (uint32_t)(kRgQ - 1)) * (uint32_t)kRgEntry);
+      const uint4 e0 = qe[0], e1 = qe[1], e2 = qe[2];
+      got = (int32_t)(rg_uniform(pub0) - t_nxt) > 0;
+      if (!got) return;
+      nxt_slot = t_nxt & (uint32_t)(kRgQ - 1);
+      nxt.meta = rg_uniform(e0.x), nxt.item = rg_uniform(e0.y), nxt.off_a = rg_uniform(e0.z), nxt.len_a = rg_uniform(e0.w);
+      nxt.bytes_a = rg_uniform(e1.x), nxt.len_b = rg_uniform(e1.y), nxt.page0 = rg_uniform(e1.z), nxt.need = rg_uniform(e1.w);
+      nxt.ga = ((uint64_t)rg_uniform(e2.y) << 32) | rg_uniform(e2.x);
+      nxt.gb = ((uint64_t)rg_uniform(e2.w) << 32) | rg_uniform(e2.z);
+      nxt_issued = acquire(nxt);
+      if (nxt_issued) issue(nxt);
+    };
+    // the same when the wave has nothing in hand: it may wait for the planner (or for the end).  (A wave that still holds an undecoded
+    // entry never does: the planner may itself be waiting for queue slots, which only released entries give back — the first version
+    // of this loop did, and hung as soon as the decoders caught up.)
+    auto take_blocking = [&]() {
       for (uint32_t spins = 0;; ++spins) {
-        const uint32_t pub = rg_uniform(lds_peek(ctl)), fin = rg_uniform(lds_peek(ctl + 8)), ab = rg_uniform(lds_peek(ctl + 12));
-        if ((int32_t)(pub - t) > 0) break;
-        if (fin != 0xFFFFFFFFu && (int32_t)(t - fin) >= 0) { stop = true; break; }
+        take();
+        if (got) return;
+        const uint32_t fin = rg_uniform(lds_peek(ctl + 8)), ab = rg_uniform(lds_peek(ctl + 12));
+        if (fin != 0xFFFFFFFFu && (int32_t)(t_nxt - fin) >= 0) return;
         if (ab || spins > kSpinLimit) {
-          lds_poke(ctl + 12, 1u);
-          if (lane == 0) atomicOr(ctl_global, 1u);
-          stop = true;
+          bad = true;
+          give_up(1u, t_nxt, fin, rg_uniform(lds_peek(ctl + 4)));
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    };
+    // the first entry
+    {
+      const u64 c0 = tick();
+      t_nxt = rg_uniform(ticket);
+      ticket = claim();
+      take_blocking();
+      d_poll += (uint32_t)(tick() - c0);
+    }
+    while (got && !bad) {
+      cur = nxt;
+      cur_slot = nxt_slot;
+      cur_issued = nxt_issued;
+      got = false;
+      t_nxt = rg_uniform(ticket);
+      ticket = claim();  // (the ticket after the next one)
+      const u64 c0 = tick();
+      if (!cur_issued) {
+        // its pages were not all free when the entry was taken: their owners are other waves in the middle of a round — this wave
+        // holds nothing, so it can wait
+        ++d_defer;
+        for (uint32_t spins = 0; !acquire(cur); ++spins) {
+          if (rg_uniform(lds_peek(ctl + 12)) || spins > kSpinLimit) {
+            bad = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (bad) {
+          give_up(2u, cur.page0 | (cur.need << 8), lds_peek(ctl + 24), lds_peek(ctl + 28));
           break;
         }
-        __builtin_amdgcn_s_sleep(2);
+        issue(cur);
       }
-      if (stop) break;
-      asm volatile("" ::: "memory");  // (the entry and the payload are read after the poll that saw them published)
-      const uint32_t e = t & (uint32_t)(kRgQ - 1);
-      const uint4 e0 = *reinterpret_cast<const uint4*>(smem + L::kQueue + e * 32u);
-      const uint4 e1 = *reinterpret_cast<const uint4*>(smem + L::kQueue + e * 32u + 16u);
-      const uint32_t meta = rg_uniform(e0.x), item = rg_uniform(e0.y), offa = rg_uniform(e0.z), lena = rg_uniform(e0.w);
-      const uint32_t offb = rg_uniform(e1.x), lenb = rg_uniform(e1.y), endp1 = rg_uniform(e1.z);
-      const uint32_t ta = meta & 15u, tb = (meta >> 4) & 15u;
-      uint32_t c;
-      if (meta & 0x100u) {
-        // outside the ring: k_icount2's item, payloads from global memory
-        const Slot sa = items[2ull * item], sb = items[2ull * item + 1];
-        uint32_t va[kPairBatch], vb[kPairBatch], part = 0, spart = 0;
-        item_prefetch(sa, arenaA, sb, arenaB, lane, va, vb);
-        icount_item(sa, arenaA, sb, arenaB, lane, table, mini, va, vb, 3u, part, spart);
-        c = wave_sum_uniform(part) + spart;
-      } else {
-        c = wave_sum_uniform(ring_icount_item(ta, smem + offa, lena, tb, smem + offb, lenb, lane, table, mini));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the payload has landed (this wave's only vector-memory operations in flight)
+      const u64 c1 = tick();
+      const uint32_t ta = cur.meta & 15u, tb = (cur.meta >> 4) & 15u;
+      const uint8_t* ra = smem + cur.off_a;
+      uint8_t* const relw = smem + L::kRel + cur_slot * 4u;
+      const u64 my_pages = pages_of(cur);
+      bool taken = false;
+      const uint32_t c = wave_sum_uniform(ring_icount_item(
+          ta, ra, cur.len_a, tb, ra + cur.bytes_a, cur.len_b, lane, table, mini,
+          [&]() {  // release: every ring byte of the item has been read (LDS operations of a wave retire in order)
+            if (flags & 1u) return;  // (experiment: release after the decode)
+            if (lane == 0) (void)__hip_atomic_fetch_and(pages, ~my_pages, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_poke(relw, 1u);
+          },
+          [&]() {                            // next: take the following entry and start its DMA
+            take();
+            taken = true;
+          },
+          (dbg && (flags & 2u)) ? d_ph : nullptr));
+      if (flags & 1u) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) (void)__hip_atomic_fetch_and(pages, ~my_pages, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_poke(relw, 1u);
       }
-      // every ring byte of the item has been read (LDS operations of a wave retire in order): hand the space back
-      asm volatile("" ::: "memory");
-      lds_poke(smem + L::kRel + e * 4u, endp1);
-      if (lane == 0) wave_out[item] = c;
+      if (lane == 0) wave_out[cur.item] = c;
+      ++d_n;
+      const u64 c2 = tick();
+      if (!taken) take();
+      if (!got) take_blocking();  // (nothing in hand)
+      if (dbg) {
+        const uint32_t dd = (uint32_t)(c2 - c1);
+        d_land += (uint32_t)(c1 - c0);
+        d_dec += dd;
+        d_poll += (uint32_t)(tick() - c2);
+        const uint32_t cls = (ta == kTypeBitmap && tb == kTypeBitmap) ? 4u
+                             : (ta == kTypeArray && tb == kTypeArray) ? 0u
+                             : ((ta == kTypeArray && tb == kTypeBitmap) || (ta == kTypeBitmap && tb == kTypeArray)) ? 1u
+                             : ((ta == kTypeArray && tb == kTypeRun && cur.len_b <= kRunFillMax) || (ta == kTypeRun && tb == kTypeArray && cur.len_a <= kRunFillMax)) ? 2u : 3u;
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k)
+          if (cls == k) d_cls[k] += dd, ++d_cln[k];
+      }
+    }
+    if (dbg && lane == 0) {
+      uint32_t* o = dbg + 32u * blockIdx.x;
+      atomicAdd(o + 8, d_poll);
+      atomicAdd(o + 9, d_dec);
+      atomicAdd(o + 10, d_n);
+      atomicAdd(o + 11, d_land);
+      atomicAdd(o + 13, d_defer);
+      for (int k = 0; k < 6; ++k) atomicAdd(o + 26 + k, d_ph[k]);
+      for (int k = 0; k < 5; ++k) {
+        atomicAdd(o + 16 + k, d_cls[k]);
+        atomicAdd(o + 21 + k, d_cln[k]);
+      }
     }
     return;
   }
 
-  // -------------------------------------------------- loader --------------------------------------------------
-  const uint32_t smem_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem);
-  const uint32_t voff = 16u * (uint32_t)lane;
+  // -------------------------------------------------- planner --------------------------------------------------
   const uint64_t n_chunks = (n_items + kRgChunk - 1) / kRgChunk;
-  uint32_t seq = 0, pub_seq = 0, tail_seq = 0;  // entries created / published / reclaimed
-  uint32_t head_pos = 0, tail_pos = 0;          // ring positions (bytes, monotonic mod 2^32; RING divides 2^32)
-  uint32_t cum = 0;                             // DMA pieces issued
-  uint32_t fifo = 0;                            // lane (seq & 63): `cum` after entry seq's pieces
+  uint32_t seq = 0, tail_seq = 0;  // entries written / queue slots taken back
+  uint32_t head_pos = 0;           // the next item's ring position (bytes, a multiple of 1024, mod 2^32; RING divides 2^32)
+  uint32_t l_rec = 0, l_slots = 0, l_polls = 0;
+  const u64 l_t0 = tick();
   bool dead = false;
-  lag = lag < 1u ? 1u : (lag > 48u ? 48u : lag);
-
-  auto publish_to = [&](uint32_t upto) {  // entries [pub_seq, upto) have landed
-    pub_seq = upto;
-    asm volatile("" ::: "memory");  // (the entries' plain LDS stores stay in front: LDS operations of a wave retire in order)
-    lds_poke(ctl, upto);
-  };
-  auto publish_oldest = [&]() {  // the oldest unpublished entry: wait for exactly its pieces
-    wait_vmcnt_le(cum - rg_readlane(fifo, pub_seq & 63u));
-    publish_to(pub_seq + 1u);
-  };
-  // released entries, in allocation order: one LDS round trip reclaims up to 64 of them
+  // queue slots of finished entries, in order: one LDS round trip takes back up to 64 of them
   auto reclaim = [&]() {
+    ++l_polls;
     const uint32_t e = (tail_seq + (uint32_t)lane) & (uint32_t)(kRgQ - 1);
     uint8_t* w = smem + L::kRel + e * 4u;
     const uint32_t r = ((uint32_t)lane < seq - tail_seq) ? lds_peek(w) : 0u;
@@ -392,47 +642,38 @@ __global__ void __launch_bounds__(64 * (D + 1)) k_icount3(const Slot* __restrict
     const uint32_t k = held ? (uint32_t)__builtin_ctzll(held) : 64u;  // leading released entries
     if (k) {
       if ((uint32_t)lane < k) lds_poke(w, 0u);
-      tail_pos = rg_readlane(r, k - 1u) - 1u;
       tail_seq += k;
     }
     return k;
   };
-  // until enough(): space comes back only from decoders, and decoders need published entries — so whatever is still unpublished
-  // is published while waiting, oldest first, each with its own counted wait (the younger DMAs stay in flight)
-  auto wait_reclaim = [&](auto enough) {
-    for (uint32_t spins = 0; !enough(); ++spins) {
-      if (reclaim()) continue;
-      if (pub_seq != seq) {
-        publish_oldest();
-        continue;
-      }
-      if (rg_uniform(lds_peek(ctl + 12)) || spins > kSpinLimit) {
-        dead = true;
-        return;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  };
   auto dma_records = [&](uint64_t chunk, uint32_t buf) {
     const uint64_t first = chunk * kRgChunk;
     const uint32_t n = (uint32_t)min((uint64_t)kRgChunk, n_items - first);
-    cum += glds_stream<false>(reinterpret_cast<uint64_t>(items + 2 * first), n * 32u, smem_base + L::kStage + buf * 1024u, voff);
+    (void)glds_stream<false>(reinterpret_cast<uint64_t>(items + 2 * first), n * 32u, smem_base + L::kStage + buf * 1024u, voff);
   };
 
   uint64_t chunk = blockIdx.x;
-  uint32_t buf = 0, rec_cum = 0;
-  if (chunk < n_chunks) {
-    dma_records(chunk, 0);
-    rec_cum = cum;
-  }
+  uint32_t buf = 0;
+  if (chunk < n_chunks) dma_records(chunk, 0);
   while (chunk < n_chunks && !dead) {
-    const uint64_t next = chunk + gridDim.x;
-    uint32_t next_cum = 0;
-    if (next < n_chunks) {
-      dma_records(next, buf ^ 1u);
-      next_cum = cum;
+    lds_poke(ctl + 20, 0x10000000u | (uint32_t)chunk);
+    // the chunk after this one: a ticket from the launch's counter (blocks that draw light chunks draw more of them)
+    uint32_t tkt = 0;
+    if (lane == 0) tkt = atomicAdd(ctl_global + 1, 1u);
+    const uint64_t next = (uint64_t)gridDim.x + rg_uniform(tkt);
+    lds_poke(ctl + 20, 0x20000000u | (uint32_t)next);
+    {
+      const u64 c = tick();
+      // this chunk's records have landed (the planner's vector-memory counter: record DMAs in order, plus stores that only make a wait stricter)
+      if (next < n_chunks) {
+        dma_records(next, buf ^ 1u);
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      l_rec += (uint32_t)(tick() - c);
     }
-    wait_vmcnt_le(cum - rec_cum);  // this chunk's records have landed
+    lds_poke(ctl + 20, 0x30000000u | (uint32_t)chunk);
     // ---- 32 items, one per lane ----
     const uint64_t item = chunk * kRgChunk + (uint64_t)lane;
     const bool valid = lane < kRgChunk && item < n_items;
@@ -443,77 +684,81 @@ __global__ void __launch_bounds__(64 * (D + 1)) k_icount3(const Slot* __restrict
     if (valid && triv) wave_out[item] = (na == 0 || nb == 0) ? 0u : (na == 65536u ? nb : na);  // intersectionCount's short circuits, roaring.go:4478-4486
     const bool active = valid && !triv;
     const uint32_t ba = (container_bytes(ta, ra.z) + 15u) & ~15u, bb = (container_bytes(tb, rb.z) + 15u) & ~15u;
-    const bool tiny_probe = (ta == kTypeArray && tb == kTypeBitmap && ra.z <= kProbeArray) || (tb == kTypeArray && ta == kTypeBitmap && rb.z <= kProbeArray);
-    const bool direct = ba + bb > kRingItemMax || tiny_probe;
-    const uint32_t need = (active && !direct) ? ba + bb : 0u;
-    const uint32_t pieces = need ? ((ba + 1023u) >> 10) + ((bb + 1023u) >> 10) : 0u;
+    // (a sparse payload of more than four batches — an array beyond 4096 values, roaring.go:5054, more than 2048 runs — does not fit
+    // a decoder's registers: the host sends batches that may hold one to k_icount2, ring_regular() in fbk.hip; meeting one here is
+    // a protocol error)
+    const bool long_a = (ta == kTypeArray && ra.z > 2u * kRgWholeUnits) || (ta == kTypeRun && ra.z > kRgWholeUnits);
+    const bool long_b = (tb == kTypeArray && rb.z > 2u * kRgWholeUnits) || (tb == kTypeRun && rb.z > kRgWholeUnits);
+    if (__ballot(active && (long_a || long_b))) {
+      dead = true;
+      break;
+    }
+    const uint32_t need = active ? ba + bb : 0u;
+    const uint32_t room = (need + 1023u) & ~1023u;  // whole pages
     const u64 amask = __ballot(active);
     const uint32_t cnt = (uint32_t)__popcll(amask);
-    const uint32_t rank = mbcnt64(amask, 0);
-    const uint32_t incl = wave_incl_scan(need);
-    uint32_t pos = head_pos + incl - need;
-    // an item does not straddle the ring's end: the first one that would is moved to the start, everything after it follows
-    for (;;) {
-      const u64 st = __ballot(need != 0u && (pos & (uint32_t)(RING - 1)) + need > (uint32_t)RING);
-      if (!st) break;
-      const uint32_t f = (uint32_t)__builtin_ctzll(st);
-      const uint32_t bump = (uint32_t)RING - (rg_readlane(pos, f) & (uint32_t)(RING - 1));
-      if ((uint32_t)lane >= f) pos += bump;
-    }
-    const uint32_t endpos = pos + need;
-    const uint32_t cum_after = cum + wave_incl_scan(pieces);
     if (cnt) {
-      // queue entries for the whole chunk (their slots must have been reclaimed)
-      wait_reclaim([&]() { return seq + cnt - tail_seq <= (uint32_t)kRgQ; });
+      const uint32_t rank = mbcnt64(amask, 0);
+      uint32_t pos = head_pos + wave_incl_scan(room) - room;
+      // an item does not straddle the ring's end: the first one that would is moved to the start, everything after it follows
+      for (;;) {
+        const u64 st = __ballot(need != 0u && (pos & (uint32_t)(RING - 1)) + room > (uint32_t)RING);
+        if (!st) break;
+        const uint32_t f = (uint32_t)__builtin_ctzll(st);
+        const uint32_t bump = (uint32_t)RING - (rg_readlane(pos, f) & (uint32_t)(RING - 1));
+        if ((uint32_t)lane >= f) pos += bump;
+      }
+      const uint32_t endpos = pos + room;
+      lds_poke(ctl + 20, 0x40000000u | seq);
+      // queue slots for the whole chunk
+      {
+        const u64 c = tick();
+        for (uint32_t spins = 0; seq + cnt - tail_seq > (uint32_t)kRgQ; ++spins) {
+          if (reclaim()) continue;
+          if (rg_uniform(lds_peek(ctl + 12)) || spins > kSpinLimit) {
+            dead = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        l_slots += (uint32_t)(tick() - c);
+      }
       if (dead) break;
       if (active) {
-        const uint32_t phys = L::kRing + (pos & (uint32_t)(RING - 1));
-        uint4 q0, q1;
-        q0.x = ta | (tb << 4) | (direct ? 0x100u : 0u);
+        const uint64_t ga = reinterpret_cast<uint64_t>(arenaA) + (((uint64_t)ra.y << 32) | ra.x), gb = reinterpret_cast<uint64_t>(arenaB) + (((uint64_t)rb.y << 32) | rb.x);
+        uint4 q0, q1, q2;
+        q0.x = ta | (tb << 4);
         q0.y = (uint32_t)item;
-        q0.z = phys;
+        q0.z = L::kRing + (pos & (uint32_t)(RING - 1));
         q0.w = ra.z;
-        q1.x = phys + ba;
+        q1.x = ba;
         q1.y = rb.z;
-        q1.z = endpos + 1u;
-        q1.w = 0;
-        uint4* q = reinterpret_cast<uint4*>(smem + L::kQueue + ((seq + rank) & (uint32_t)(kRgQ - 1)) * 32u);
+        q1.z = (pos & (uint32_t)(RING - 1)) >> 10;
+        q1.w = need;
+        q2.x = (uint32_t)ga, q2.y = (uint32_t)(ga >> 32), q2.z = (uint32_t)gb, q2.w = (uint32_t)(gb >> 32);
+        uint4* q = reinterpret_cast<uint4*>(smem + L::kQueue + ((seq + rank) & (uint32_t)(kRgQ - 1)) * (uint32_t)kRgEntry);
         q[0] = q0;
         q[1] = q1;
+        q[2] = q2;
       }
-      const uint64_t ga = reinterpret_cast<uint64_t>(arenaA) + (((uint64_t)ra.y << 32) | ra.x), gb = reinterpret_cast<uint64_t>(arenaB) + (((uint64_t)rb.y << 32) | rb.x);
-      const uint32_t ga_lo = (uint32_t)ga, ga_hi = (uint32_t)(ga >> 32), gb_lo = (uint32_t)gb, gb_hi = (uint32_t)(gb >> 32);
-      // ---- the items one after the other: space, DMA, publication kLag items behind ----
-      for (u64 m = amask; m && !dead; m &= m - 1) {
-        const uint32_t j = (uint32_t)__builtin_ctzll(m);
-        const uint32_t need_j = rg_readlane(need, j);
-        if (need_j) {
-          const uint32_t end_j = rg_readlane(endpos, j);
-          wait_reclaim([&]() { return end_j - tail_pos <= (uint32_t)RING; });
-          if (dead) break;
-          const uint32_t ba_j = rg_readlane(ba, j), dst = smem_base + L::kRing + (rg_readlane(pos, j) & (uint32_t)(RING - 1));
-          const uint64_t pa = ((uint64_t)rg_readlane(ga_hi, j) << 32) | rg_readlane(ga_lo, j), pb = ((uint64_t)rg_readlane(gb_hi, j) << 32) | rg_readlane(gb_lo, j);
-          glds_stream<NT>(pa, ba_j, dst, voff);
-          glds_stream<NT>(pb, need_j - ba_j, dst + ba_j, voff);
-        }
-        cum = rg_readlane(cum_after, j);
-        fifo = (uint32_t)lane == (seq & 63u) ? cum : fifo;
-        ++seq;
-        if (seq - pub_seq > lag) publish_oldest();
-      }
+      seq += cnt;
       head_pos = rg_readlane(endpos, 63u - (uint32_t)__builtin_clzll(amask));
+      asm volatile("" ::: "memory");  // (the entries' plain LDS stores stay in front of the counter: LDS operations of a wave retire in order)
+      lds_poke(ctl, seq);
     }
+    lds_poke(ctl + 20, 0x50000000u | seq);
+    (void)reclaim();
     chunk = next;
     buf ^= 1u;
-    rec_cum = next_cum;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (dead) {
-    lds_poke(ctl + 12, 1u);
-    if (lane == 0) atomicOr(ctl_global, 1u);
+  lds_poke(ctl + 8, seq);  // fin: a decoder whose ticket is past it leaves
+  if (dead) give_up(3u, seq, tail_seq, head_pos);
+  if (dbg && lane == 0) {
+    uint32_t* o = dbg + 32u * blockIdx.x;
+    o[0] = (uint32_t)(__builtin_readcyclecounter() - l_t0);
+    o[1] = l_rec, o[2] = l_slots, o[6] = l_polls, o[7] = seq;
   }
-  publish_to(seq);
-  lds_poke(ctl + 8, seq);  // fin: decoders leave once their ticket is past it
 }
 
 }  // namespace fbk

@@ -14,6 +14,8 @@ ring_pairs)
   timeout 300 python scripts/bench_pairs.py --shards ${SHARDS:-256} --iters 20 --only-count --variants "${VARS:-pair_kernels=2;pair_kernels=3;pair_kernels=3,ring_geom=1;pair_kernels=3,ring_geom=2;pair_kernels=3,ring_geom=0,ring_nt=1}" --out $O/pairs_${SHARDS:-256}.json > $O/pairs_${SHARDS:-256}.log 2>&1; echo "pairs rc $?"; grep -h '"us"\|Error\|error\|assert' $O/pairs_${SHARDS:-256}.log | head -20 ;;
 ring_fuzz)
   timeout 600 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_fuzz_struct.py -x -q -m gpu -k "ring or 3" > $O/fuzz_ring.log 2>&1; echo "fuzz_ring rc $?"; tail -3 $O/fuzz_ring.log ;;
+ring_pmc)   # SQ counters of the ring kernel (three rocprofv3 --pmc passes)
+  bash scripts/fused_pmc.sh $TAG/pmc_ring ${PMC_SHARDS:-256} "${PMC_OPTS:-pair_kernels=3}" pairs_pmc.py icount3 > $O/pmc_ring.txt 2>&1; cat $O/pmc_ring.txt | head -40 ;;
 gpu_tests)
   timeout 1500 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu_tests rc $?"; tail -3 $O/gpu_tests.log ;;
 bench)
