@@ -268,6 +268,111 @@ __device__ __forceinline__ void array_xor_batch_w(uint32_t tb, uint32_t len, uin
   }
 }
 
+// ---- row-exact scatter and probe -----------------------------------------------------------------------------------------------
+// A wave's time per item is its instruction count (~5.5 cycles per instruction in a stream without waits) plus the LDS round
+// trips it cannot overlap.  The batch functions above execute all eight dword rows of a batch whatever the array holds and carry
+// every value's bit-field width along (v_cmp + v_cndmask per value); but of an array's rows only the LAST can be ragged.  Here a
+// batch executes exactly its rows: the full ones (128 values each, no width arithmetic) through a fall-through switch — one
+// branch tree per batch — and the one ragged row, if it lies in the batch, with its widths.
+template <class F>
+__device__ __forceinline__ void rows_desc(uint32_t n, const uint32_t (&v)[kPairBatch], F f) {  // rows n - 1 .. 0
+  switch (n) {
+    default: f(7, v[7]); [[fallthrough]];
+    case 7: f(6, v[6]); [[fallthrough]];
+    case 6: f(5, v[5]); [[fallthrough]];
+    case 5: f(4, v[4]); [[fallthrough]];
+    case 4: f(3, v[3]); [[fallthrough]];
+    case 3: f(2, v[2]); [[fallthrough]];
+    case 2: f(1, v[1]); [[fallthrough]];
+    case 1: f(0, v[0]); [[fallthrough]];
+    case 0: break;
+  }
+}
+template <class F>
+__device__ __forceinline__ void row_at(uint32_t k, const uint32_t (&v)[kPairBatch], F f) {  // row k (0..7)
+  switch (k) {
+    case 0: f(0, v[0]); break;
+    case 1: f(1, v[1]); break;
+    case 2: f(2, v[2]); break;
+    case 3: f(3, v[3]); break;
+    case 4: f(4, v[4]); break;
+    case 5: f(5, v[5]); break;
+    case 6: f(6, v[6]); break;
+    default: f(7, v[7]); break;
+  }
+}
+// the rows of an array of len values that lie in the batch starting at dword `base`: full rows [0, nfull), then at most one ragged
+// row at index nfull holding `left` (1..127) values
+struct BatchRows {
+  uint32_t nfull, left;
+};
+__device__ __forceinline__ BatchRows batch_rows(uint32_t len, uint32_t base) {
+  const uint32_t first = 2u * base;                      // the batch's first value
+  const uint32_t have = len > first ? len - first : 0u;  // values from there on
+  BatchRows r;
+  r.nfull = min(have >> 7, (uint32_t)kPairBatch);
+  r.left = r.nfull < (uint32_t)kPairBatch ? have - (r.nfull << 7) : 0u;  // (< 128: nfull is the floor)
+  return r;
+}
+// one dword row (two values per lane) into the table at tb
+__device__ __forceinline__ void xor_row_full(uint32_t tb, uint32_t x) {
+  (void)__hip_atomic_fetch_xor(table_dword_lo(tb, x), 1u << (x & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  (void)__hip_atomic_fetch_xor(table_dword_hi(tb, x), 1u << ((x >> 16) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void xor_row_part(uint32_t tb, uint32_t x, int32_t mine /* values of the row from this lane's low one on */) {
+  const uint32_t w_lo = (uint32_t)min(max(mine, 0), 1), w_hi = (uint32_t)min(max(mine - 1, 0), 1);
+  (void)__hip_atomic_fetch_xor(table_dword_lo(tb, x), w_lo << (x & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  (void)__hip_atomic_fetch_xor(table_dword_hi(tb, x), w_hi << ((x >> 16) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the whole array (in registers) into the cleared table
+__device__ __forceinline__ void whole_xor(const Whole& w, uint32_t len, int lane, uint32_t tb) {
+  whole_each(w, (len + 1u) >> 1, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) {
+    const BatchRows r = batch_rows(len, base);
+    rows_desc(r.nfull, v, [&](int, uint32_t x) { xor_row_full(tb, x); });
+    if (r.left) row_at(r.nfull, v, [&](int, uint32_t x) { xor_row_part(tb, x, (int32_t)r.left - 2 * lane); });
+  });
+}
+// this lane's hits of the whole array (in registers) against the bitmap at LDS byte address tb: ALIGNED = an 8 KiB aligned table
+// (the base is OR-ed in), else any address (added); MAP: a run container's boundary masks at tb, its full dwords in the map at mb.
+// Every table read of a batch is requested before the first one is looked at.
+template <bool ALIGNED, bool MAP>
+__device__ __forceinline__ uint32_t whole_probe(const Whole& w, uint32_t len, int lane, uint32_t tb, uint32_t mb = 0) {
+  uint32_t hits = 0;
+  whole_each(w, (len + 1u) >> 1, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) {
+    const BatchRows r = batch_rows(len, base);
+    const uint32_t nrows = r.nfull + (r.left ? 1u : 0u);
+    uint32_t t_lo[kPairBatch], t_hi[kPairBatch], m_lo[kPairBatch], m_hi[kPairBatch];
+    rows_desc(nrows, v, [&](int k, uint32_t x) {
+      t_lo[k] = ALIGNED ? *table_dword_lo(tb, x) : *bits_dword_lo(tb, x);
+      t_hi[k] = ALIGNED ? *table_dword_hi(tb, x) : *bits_dword_hi(tb, x);
+      if (MAP) {
+        m_lo[k] = *(const lds_u32*)(uintptr_t)(mb + (__builtin_amdgcn_ubfe(x, 10u, 6u) << 2));
+        m_hi[k] = *(const lds_u32*)(uintptr_t)(mb + ((x >> 26) << 2));
+      }
+    });
+    rows_desc(r.nfull, v, [&](int k, uint32_t x) {
+      uint32_t b0 = __builtin_amdgcn_ubfe(t_lo[k], x, 1u), b1 = __builtin_amdgcn_ubfe(t_hi[k], x >> 16, 1u);
+      if (MAP) {
+        b0 |= __builtin_amdgcn_ubfe(m_lo[k], x >> 5, 1u);
+        b1 |= __builtin_amdgcn_ubfe(m_hi[k], x >> 21, 1u);
+      }
+      hits += b0 + b1;
+    });
+    if (r.left)
+      row_at(r.nfull, v, [&](int k, uint32_t x) {
+        const int32_t mine = (int32_t)r.left - 2 * lane;
+        const uint32_t w_lo = (uint32_t)min(max(mine, 0), 1), w_hi = (uint32_t)min(max(mine - 1, 0), 1);
+        uint32_t b0 = __builtin_amdgcn_ubfe(t_lo[k], x, w_lo), b1 = __builtin_amdgcn_ubfe(t_hi[k], x >> 16, w_hi);
+        if (MAP) {
+          b0 |= __builtin_amdgcn_ubfe(m_lo[k], x >> 5, w_lo);
+          b1 |= __builtin_amdgcn_ubfe(m_hi[k], x >> 21, w_hi);
+        }
+        hits += b0 + b1;
+      });
+  });
+  return hits;
+}
+
 // sum over the wave, wave-uniform result (DPP row sums + four lane reads: no LDS round trip)
 __device__ __forceinline__ uint32_t wave_sum_uniform(uint32_t v) {
   v = wave_rows_sum(v);
@@ -372,10 +477,10 @@ __device__ __forceinline__ uint32_t ring_icount_item(uint32_t ta, const uint8_t*
     next();
     const u64 p2 = ph ? __builtin_readcyclecounter() : 0;
     wave_lds_sync();
-    whole_each(wt, ut, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { array_xor_batch_w(tbase, lt, base, lane, v); });
+    whole_xor(wt, lt, lane, tbase);
     wave_lds_sync();
     const u64 p3 = ph ? __builtin_readcyclecounter() : 0;
-    whole_each(wp, up, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { part += array_probe_batch(tbase, lp, base, lane, v); });
+    part += whole_probe<true, false>(wp, lp, lane, tbase);
     wave_lds_sync();
     if (ph) {
       asm volatile("" ::"v"(part));
@@ -391,7 +496,7 @@ __device__ __forceinline__ uint32_t ring_icount_item(uint32_t ta, const uint8_t*
     next();
     Whole wa;
     whole_load(rarr, ua, lane, wa);
-    whole_each(wa, ua, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { part += ring_probe_bits_batch(bb, larr, base, lane, v); });
+    part += whole_probe<false, false>(wa, larr, lane, bb);
     landed(part);  // (the bitmap is probed where it lies)
   } else if ((ta == kTypeArray && tb == kTypeRun && lenb <= kRunFillMax) || (ta == kTypeRun && tb == kTypeArray && lena <= kRunFillMax)) {
     const bool a_run = ta == kTypeRun;
@@ -412,7 +517,7 @@ __device__ __forceinline__ uint32_t ring_icount_item(uint32_t ta, const uint8_t*
     wave_lds_sync();
     mini_prefix(mini, lane);
     wave_lds_sync();
-    whole_each(wp, up, [&](uint32_t base, const uint32_t (&v)[kPairBatch]) { part += array_probe_batch<true>(tbase, lp, base, lane, v, mbase); });
+    part += whole_probe<true, true>(wp, lp, lane, tbase, mbase);
     wave_lds_sync();
   } else {
     next();
@@ -719,7 +824,7 @@ __global__ void __launch_bounds__(64 * (D + 1)) k_icount3(const Slot* __restrict
             dead = true;
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(16);
         }
         l_slots += (uint32_t)(tick() - c);
       }

@@ -86,11 +86,14 @@ def topn_reduce(local_totals: np.ndarray, local_candidates: Optional[np.ndarray]
     c = None if local_candidates is None else np.ascontiguousarray(local_candidates, dtype=np.uint64)
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     if multi:
-        if c is None:
-            t = reduce_count_vector(t, device)
-        else:
-            both = reduce_count_vector(np.concatenate([t, c]), device)
-            t, c = both[: t.size], both[t.size:]
+        # ALWAYS the same collective on every rank — [totals | candidates | 1 if this rank passed candidates] — so that ranks that
+        # disagree about the candidate pass fail together instead of hanging in all_reduces of different lengths
+        flag = np.array([0 if c is None else 1], dtype=np.uint64)
+        both = reduce_count_vector(np.concatenate([t, np.zeros_like(t) if c is None else c, flag]), device)
+        with_c = int(both[-1])
+        if with_c not in (0, dist.get_world_size()):
+            raise ValueError(f"topn_reduce: {with_c} of {dist.get_world_size()} ranks passed candidate flags (every rank must use the same topn_semantics)")
+        t, c = both[: t.size], (both[t.size:-1] if with_c else None)
     if c is not None:
         t = np.where(c != 0, t, np.uint64(0))
     return order_totals(t, n)
@@ -187,12 +190,13 @@ class PerQueryReducer:
     the context's stream): `reduce()` then records an event on it and makes the current stream wait for that event
     before the all-reduce is enqueued.  With neither, the collective may read a cell before it is written."""
 
-    def __init__(self, width: int, depth: int, device=None, producer_stream=None):
+    def __init__(self, width: int, depth: int, device=None, producer_stream=None, always: bool = False):
         import torch
 
         if int(width) < 1 or int(depth) < 1:
             raise ValueError("PerQueryReducer: width and depth must be >= 1")
         self.producer_stream = producer_stream
+        self.always = bool(always)  # issue the collective even in a one-rank group (scripts/collective_host_cost.py: what a call costs the launching thread)
         self.width, self.depth = int(width), int(depth)
         self.buf = torch.zeros((self.depth, self.width), dtype=torch.int64, device=device)
         self.work = [None] * self.depth
@@ -210,7 +214,7 @@ class PerQueryReducer:
         import torch.distributed as dist
 
         i = self.k % self.depth
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.always):
             if self.producer_stream is not None and self.buf.is_cuda:
                 import torch
 

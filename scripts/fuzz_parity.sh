@@ -6,6 +6,6 @@ out=$1; shift
 mkdir -p "$out"
 for s in "$@"; do
   echo "== seed $s"
-  FBK_TEST_SEED=$s timeout 400 python -m pytest tests -m gpu -q -x -p no:cacheprovider \
+  FBK_TEST_SEED=$s timeout 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider \
     --deselect tests/test_gpu_fullsize.py --deselect tests/test_gpu_group.py 2>&1 | tail -15
 done | tee "$out/fuzz_parity.log"

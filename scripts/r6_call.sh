@@ -16,6 +16,10 @@ ring_fuzz)
   timeout 600 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_fuzz_struct.py -x -q -m gpu -k "ring or 3" > $O/fuzz_ring.log 2>&1; echo "fuzz_ring rc $?"; tail -3 $O/fuzz_ring.log ;;
 ring_pmc)   # SQ counters of the ring kernel (three rocprofv3 --pmc passes)
   bash scripts/fused_pmc.sh $TAG/pmc_ring ${PMC_SHARDS:-256} "${PMC_OPTS:-pair_kernels=3}" pairs_pmc.py icount3 > $O/pmc_ring.txt 2>&1; cat $O/pmc_ring.txt | head -40 ;;
+collective)  # host cost of one collective per headline step, on one GPU
+  timeout 600 python scripts/collective_host_cost.py --out $O/collective_host_cost.json > $O/collective.log 2>&1; echo "collective rc $?"; tail -12 $O/collective.log ;;
+fuzz)  # the seeded GPU parity tests re-rolled with fresh seeds
+  bash scripts/fuzz_parity.sh $O ${SEEDS:-0x5eed6001 0x5eed6002 0x5eed6003 0x5eed6004} > $O/fuzz.out 2>&1; grep -h "== seed\|passed\|failed\|error" $O/fuzz_parity.log | head -20 ;;
 gpu_tests)
   timeout 1500 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu_tests rc $?"; tail -3 $O/gpu_tests.log ;;
 bench)

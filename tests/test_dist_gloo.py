@@ -288,6 +288,12 @@ def _topn_worker(rank: int, world: int, port: int, q):
     # BSI Sum: {psum, nsum, count} per rank, with a negative total and a wrap-around of the uint64 partial sums
     parts = [(5, 1 << 63, 3), ((1 << 64) - 7, (1 << 63) + 10, 4)]
     s, c = fd.bsi_sum_reduce(*parts[rank])
+    # ranks that disagree about the candidate pass: the same collective on both, then the same error on both (no hang)
+    try:
+        fd.topn_reduce(np.ones(4, dtype=np.uint64), np.ones(4, dtype=np.uint64) if rank == 0 else None, 2)
+        out.append(("no error", "ValueError"))
+    except ValueError:
+        pass
     q.put((rank, out, (s, c)))
     dist.barrier()
     dist.destroy_process_group()

@@ -663,6 +663,47 @@ def shadow_mode(request, gpu_ctx):
     gpu_ctx.set_option("matrix_shadow_array", 2048)
 
 
+def test_count_matrix_fused_duplicated_and_broadcast_rows(gpu_ctx, oracle, B):
+    """Row lists may name a batch row any number of times (check_rows only range-checks): one row of long arrays listed 32 times
+    on each side, and ONE filter row and one B row set broadcast to every shard.  The program of the matrix-core kernel emits an
+    item per row OCCURRENCE (k_fused_program), far more than the payload-based first guess of its item area allows for: the
+    build counts what it needs and launches again (fused_program_build).  Checked against the oracle and the generic kernel."""
+    O = oracle
+    rng = D.rng_for(58)
+    n_shards, n = 6, 32
+
+    def obm(row):
+        return O.OBitmap.from_containers(list(row.items()))
+
+    def long_arrays(seed):  # 16 arrays of ~2000 values: 16 items each per occurrence and stage range
+        r = np.random.default_rng(seed)
+        return {k: O.OContainer.array(np.sort(r.choice(65536, size=int(r.integers(1800, 2200)), replace=False)).astype(np.uint16)) for k in range(16)}
+
+    a_rows = [long_arrays(100 + i) for i in range(3)]
+    b_rows = [long_arrays(200 + i) for i in range(2)]
+    f_row = D.random_row(rng, 0, p_missing=0.1)
+    A, Bt, F = gpu_ctx.upload([D.to_fbk_row(r) for r in a_rows]), gpu_ctx.upload([D.to_fbk_row(r) for r in b_rows]), gpu_ctx.upload([D.to_fbk_row(f_row)])
+    ra = np.zeros((n_shards, n), dtype=np.uint32)
+    ra[:, ::5] = 1
+    ra[3] = 2                      # every A row of shard 3 is batch row 2
+    rb = np.ones((n_shards, n), dtype=np.uint32)
+    rb[:, 7] = 0
+    rf = np.zeros(n_shards, dtype=np.uint32)  # the one filter row, for every shard
+    try:
+        gpu_ctx.set_option("matrix_fused", 1)
+        tot, ps = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf, per_shard=True)
+        gpu_ctx.set_option("matrix_fused", 0)
+        tot_g, ps_g = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf, per_shard=True)
+    finally:
+        gpu_ctx.set_option("matrix_fused", -1)
+    for s in range(n_shards):
+        e = B.groupby_counts(B.Fragment([obm(a_rows[i]) for i in ra[s]]), B.Fragment([obm(b_rows[j]) for j in rb[s]]), obm(f_row))
+        assert (ps[s] == e).all(), s
+    assert (tot == ps.sum(axis=0)).all() and (tot_g == tot).all() and (ps_g == ps).all()
+    for b in (A, Bt, F):
+        b.free()
+
+
 @pytest.mark.parametrize("a_dense,b_dense,f_mode", [(False, False, "mixed"), (True, False, "none"), (False, True, "dense"), (False, False, "none")])
 def test_count_matrix_mixed_rows_fused_and_generic_paths(gpu_ctx, oracle, B, a_dense, b_dense, f_mode, shadow_mode):
     """nA x nB >= 16 with array / run containers among the rows: fbk_count_matrix decodes the rows inside the

@@ -262,3 +262,60 @@ def test_flip_golden_triples_and_random_ranges(gpu_ctx, oracle):
     with pytest.raises(L.FbkError):
         gpu_ctx.flip(batch, [0], 0, 1 << 20)
     batch.free()
+
+
+def _interval_row(lo, hi):
+    """columns [lo, hi) of a shard as run containers, one interval per touched slot"""
+    row = {}
+    for slot in range(lo >> 16, ((hi - 1) >> 16) + 1 if hi > lo else 0):
+        a, b = max(lo, slot << 16), min(hi, (slot + 1) << 16)
+        row[slot] = Container.run([(a & 0xFFFF, (b - 1) & 0xFFFF)])
+    return row
+
+
+def test_topn_tanimoto_rule_at_shard_scale_counts_vs_float64(gpu_ctx):
+    """The device's TopnRule (integer arithmetic, fbk_query_kernels.hip.h) against the LITERAL float64 expressions of fragment.top
+    (fragment.go:1334-1385: float64(srcCount*t)/100, float64(srcCount*100)/float64(t), math.Ceil(float64(count*100)/float64(cnt+
+    srcCount-count))) on rows whose counts reach 2^20: one shard, every row an interval of columns (run containers), the source row
+    an interval too, so cnt, count and srcCount are chosen freely — including the integer neighbours of all three boundaries.
+    Exact semantics, n = 0: every row is judged by the rule and reported with its count (the candidate pass of the reference's
+    semantics applies the same TopnRule; its heap walk is pinned at small scale by the executor vectors)."""
+    from test_oracle_topn import _literal_float64_rule
+
+    W = 1 << 20
+    rng = np.random.default_rng(0x70b9)
+    for t, src_n in ((30, 600_000), (50, 333_333), (7, 1 << 20), (99, 1000), (10, 65_536)):
+        rows = []  # (lo, hi)
+        # boundary neighbours: cnt around src * t / 100 and src * 100 / t, count around t (cnt + src) / (100 + t)
+        for cnt0 in {src_n * t // 100, -(-src_n * t // 100), src_n * 100 // t, -(-src_n * 100 // t)}:
+            for cnt in (cnt0 - 1, cnt0, cnt0 + 1):
+                if not 1 <= cnt <= W:
+                    continue
+                lo_c, hi_c = max(0, cnt + src_n - W), min(cnt, src_n)
+                c0 = t * (cnt + src_n) // (100 + t)
+                for count in {lo_c, hi_c, c0 - 1, c0, c0 + 1}:
+                    if lo_c <= count <= hi_c:
+                        rows.append((src_n - count, src_n - count + cnt))  # [lo, hi) overlaps the source [0, src_n) in `count` columns
+        while len(rows) < 160:
+            cnt = int(rng.integers(1, W + 1))
+            lo_c, hi_c = max(0, cnt + src_n - W), min(cnt, src_n)
+            count = int(rng.integers(lo_c, hi_c + 1))
+            rows.append((src_n - count, src_n - count + cnt))
+        rows = [r for r in rows if 0 <= r[0] and r[1] <= W]
+        n_a = len(rows)
+        batch = gpu_ctx.upload([_interval_row(lo, hi) for lo, hi in rows])
+        F = gpu_ctx.upload([_interval_row(0, src_n)])
+        ra, rf = np.arange(n_a).reshape(1, -1), np.zeros(1, dtype=np.uint32)
+        exp = {}
+        for i, (lo, hi) in enumerate(rows):
+            cnt, count = hi - lo, max(0, min(hi, src_n) - lo)
+            if _literal_float64_rule(cnt, count, src_n, True, 0, t):
+                exp[i] = count
+        try:
+            gpu_ctx.set_option("topn_semantics", 0)
+            idx, cnt = gpu_ctx.topn(batch, ra, 0, F, rf, tanimoto_threshold=t)
+            assert dict(zip(idx.tolist(), [int(x) for x in cnt])) == exp, (t, src_n)
+        finally:
+            gpu_ctx.set_option("topn_semantics", 1)
+        batch.free()
+        F.free()

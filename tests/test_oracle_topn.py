@@ -124,3 +124,57 @@ def test_execute_topn_random_against_the_candidate_definition():
         cand = T.topn_candidates(shards, n, srcs, mt, tt)
         exp = T.top_exact(shards, cand, n, srcs, max(mt, 1), tt)
         assert T.execute_topn(shards, n, srcs, None, mt, tt) == exp, trial
+
+
+def _literal_float64_rule(cnt, count, src_count, has_src, min_threshold, tanimoto_threshold):
+    """fragment.go:1334-1385 as written: float64 comparisons and math.Ceil (numpy float64 = Go float64, IEEE 754 binary64)."""
+    if cnt == 0 or count == 0:
+        return False
+    if tanimoto_threshold > 0 and has_src:
+        min_t = np.float64(src_count * tanimoto_threshold) / np.float64(100)
+        max_t = np.float64(src_count * 100) / np.float64(tanimoto_threshold)
+        if np.float64(cnt) <= min_t or np.float64(cnt) >= max_t:
+            return False
+        t = np.ceil(np.float64(count * 100) / np.float64(cnt + src_count - count))
+        return not (t <= np.float64(tanimoto_threshold))
+    return not (cnt < min_threshold) and not (count < min_threshold)
+
+
+def test_integer_rule_equals_the_float64_rule_at_shard_scale_counts():
+    """oracle/pytopn.row_passes (and the device's TopnRule, fbk_query_kernels.hip.h) replace fragment.top's float64 comparisons
+    (fragment.go:1334-1385) by integer ones.  They are the same predicate for every count a shard can hold: 10^5 random
+    (cnt, count, src_count, threshold) with counts up to 2^20, and every neighbour of the boundaries cnt * 100 = src * t,
+    cnt * t = src * 100 and count * 100 = t * (cnt + src - count) that an integer triple can reach."""
+    from oracle import pytopn as T
+
+    rng = np.random.default_rng(0x70b9)
+    n = 100_000
+    W = 1 << 20
+    cnts = rng.integers(1, W + 1, n)
+    srcs = rng.integers(1, W + 1, n)
+    counts = np.minimum(np.minimum(cnts, srcs), rng.integers(0, W + 1, n))
+    counts = np.maximum(counts, cnts + srcs - W).clip(0)  # |row ∪ src| <= 2^20
+    tts = rng.choice([1, 3, 10, 25, 30, 33, 50, 66, 70, 90, 99, 100], n)
+    mts = rng.integers(0, W, n)
+    for i in range(n):
+        args = (int(cnts[i]), int(counts[i]), int(srcs[i]), True, 0, int(tts[i]))
+        assert T.row_passes(*args) == _literal_float64_rule(*args), args
+        args = (int(cnts[i]), int(counts[i]), int(srcs[i]), bool(i & 1), int(mts[i]) if i % 3 else int(cnts[i]), 0)
+        assert T.row_passes(*args) == _literal_float64_rule(*args), args
+    # the boundaries themselves and their neighbours
+    checked = 0
+    for t in (1, 7, 10, 30, 50, 75, 99, 100):
+        for src in (1, 3, 100, 1000, 4097, 65536, 333_333, 999_999, W):
+            for cnt0 in {src * t // 100, -(-src * t // 100), src * 100 // t, -(-src * 100 // t)}:
+                for cnt in (cnt0 - 1, cnt0, cnt0 + 1):
+                    if not 1 <= cnt <= W:
+                        continue
+                    lo, hi = max(0, cnt + src - W), min(cnt, src)
+                    # count * 100 = t * (cnt + src - count)  <=>  count = t (cnt + src) / (100 + t)
+                    c0 = t * (cnt + src) // (100 + t)
+                    for count in {lo, hi, (lo + hi) // 2, c0 - 1, c0, c0 + 1, c0 + 2}:
+                        if lo <= count <= hi:
+                            args = (cnt, count, src, True, 0, t)
+                            assert T.row_passes(*args) == _literal_float64_rule(*args), args
+                            checked += 1
+    assert checked > 1500
