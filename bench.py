@@ -855,16 +855,34 @@ def main():
     # the communicator's stream, PER_QUERY_RING cells rotating so that the next steps' kernels never touch a cell a
     # collective still reads).  The ring is cleared once per revolution.
     pq = fdist.PerQueryReducer(1, PER_QUERY_RING, dev)
+    # The collective is issued by the LIBRARY when it can be (fbk_comm_*: its own RCCL communicator and stream; torch only carries
+    # the 128-byte unique id at start-up): one torch all-reduce costs the launching thread ~28 us, more than half of a 41 us step
+    # (profiles/r06_collective_host_cost.json, measured on a one-rank group).  Any rank failing to set it up — no librccl, gloo
+    # ranks sharing a device — leaves every rank on torch's collectives (the cross-check path either way).
+    lib_comm = False
+    if n_gpus > 1 and backend == "nccl" and os.environ.get("FBK_BENCH_LIBCOMM", "1") != "0":
+        lib_comm = fdist.library_comm_init(ctx)
+    lpq = fdist.LibraryPerQueryReducer(ctx, 1, PER_QUERY_RING, dev) if lib_comm else None
 
-    def step_per_query():
+    def step_per_query_torch():
         if pq.k % PER_QUERY_RING == 0:
             pq.flush()
             pq.buf.zero_()
         plan.intersection_count_accumulate(pq.cell().data_ptr())
         pq.reduce()
 
+    def step_per_query_library():
+        if lpq.k % PER_QUERY_RING == 0:
+            lpq.flush()  # (one event: the context's stream waits for the collectives of the last revolution)
+            lpq.buf.zero_()
+        plan.intersection_count_accumulate(lpq.cell_ptr())
+        lpq.reduce()
+
+    step_per_query = step_per_query_library if lib_comm else step_per_query_torch
+
     step = step_per_query if n_gpus > 1 else step_bucketed
-    flush = (lambda: pq.flush()) if n_gpus > 1 else (lambda: red.flush())
+    flush = ((lambda: lpq.flush()) if lib_comm else (lambda: pq.flush())) if n_gpus > 1 else (lambda: red.flush())
+    host_enqueue = []  # seconds the launching thread spent in each timed region's loop (before anything is waited for)
 
     def barrier():
         if n_gpus > 1:
@@ -877,6 +895,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(k):
             step()
+        host_enqueue.append((time.perf_counter() - t0) / k)
         reduced = flush()  # every outstanding collective (N = 1: nothing to wait for): inside the timed region
         torch.cuda.synchronize()
         barrier()
@@ -1143,16 +1162,23 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        set_ops = n_gpus * n * 16 * args.steps
-        ms_per_step = dt / args.steps * 1e3
+        # the headline: the MEDIAN of the timed regions of exactly --steps steps each (the first one, whose result is parity-checked
+        # above, and the --repeats further ones; every region bracketed by barrier + synchronize, max over ranks): with the driver's
+        # --steps 20 one region is 0.8 ms of wall clock, and a single sample of that moved by 1-2 % from run to run
+        regions_ms = sorted([dt / args.steps * 1e3] + list(rep))
+        ms_per_step = regions_ms[len(regions_ms) // 2] if len(regions_ms) % 2 else 0.5 * (regions_ms[len(regions_ms) // 2 - 1] + regions_ms[len(regions_ms) // 2])
+        henq = sorted(host_enqueue)
         out = {
             "metric": "container set-ops/sec + bits-scanned GB/s, 1M-col Intersect+Count",
-            "value": set_ops / dt,
+            "value": n_gpus * n * 16 / (ms_per_step * 1e-3),
             "unit": "set-ops/s",
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_first_region": dt / args.steps * 1e3,
+            "timed_regions": len(regions_ms),
+            "host_enqueue_us_per_step": henq[len(henq) // 2] * 1e6 if henq else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -1165,13 +1191,14 @@ def main():
                 "op": "Count(Intersect(Row,Row)) as IntersectionCount + per-node sum"
                 + (f" + one {'RCCL' if backend == 'nccl' else backend} all-reduce of the partial total PER STEP (asynchronous, {PER_QUERY_RING} result cells in rotation)" if n_gpus > 1 else ""),
                 "collectives_per_step": 1 if n_gpus > 1 else 0,
+                "collective_path": (("library-rccl (fbk_comm_all_reduce_u64)" if lib_comm else "torch.distributed") if n_gpus > 1 else None),
                 "parallelism": f"shards/{n_gpus}gpu",
                 "backend": (("rccl" if backend == "nccl" else backend) if n_gpus > 1 else None),
                 "ranks": n_gpus,
                 "oversubscribed": bool(n_gpus > 1 and backend != "nccl"),
             },
             "ms_per_step_distribution": dict(dist_of(rep), note=f"{args.repeats} further timed regions of {args.steps} steps each") if rep else None,
-            "bits_scanned_GBps": n_gpus * 2 * n * 16 * 8192 / (dt / args.steps) / 1e9,
+            "bits_scanned_GBps": n_gpus * 2 * n * 16 * 8192 / (ms_per_step * 1e-3) / 1e9,
             "roofline": {
                 "kernel": "k_icount_dense<16>",
                 "bound": "hbm",

@@ -175,6 +175,11 @@ def compact_line(full: dict, detail_name: str = "bench_detail.json") -> dict:
             "streaming_pass": _r((cb.get("streaming_pass") or {}).get("value")),
         }
     out["bits_scanned_GBps"] = _r(full.get("bits_scanned_GBps"), 1)
+    for k, nd in (("ms_per_step_first_region", 6), ("host_enqueue_us_per_step", 2)):
+        if isinstance(full.get(k), (int, float)):
+            out[k] = _r(full[k], nd)
+    if full.get("timed_regions") is not None:
+        out["timed_regions"] = full["timed_regions"]
     d = full.get("ms_per_step_distribution")
     if d:
         out["ms_per_step_distribution"] = {k: _r(d.get(k), 5) for k in ("median", "p10", "p90", "n")}

@@ -19,7 +19,9 @@
 
 #include "fbk_kernels.hip.h"
 #include "fbk_pair_kernels.hip.h"
-#include "fbk_pair_ring.hip.h"
+#ifdef FBK_EXPERIMENTS
+#include "fbk_pair_ring.hip.h"  // k_icount3 (round 6): parity-green and 1.5 x SLOWER than k_icount2 — kept as an experiment, not shipped
+#endif
 #include "fbk_query_kernels.hip.h"
 #include "fbk_fold_kernels.hip.h"
 #include "fbk_topk_kernels.hip.h"
@@ -47,6 +49,7 @@ thread_local fbk_ctx* g_scope_ctx = nullptr;  // context of the API call running
 thread_local fbk_group* g_scope_group = nullptr;  // group of the fbk_group_* call running on this thread
 void ctx_record_error(fbk_ctx* ctx, int32_t code, const std::string& msg);  // defined after fbk_ctx
 void group_record_error(fbk_group* g, int32_t code, const std::string& msg);  // fbk_group_api.inc
+void comm_release(fbk_ctx* ctx);                                                // fbk_group_api.inc
 
 int32_t fail(int32_t code, const std::string& msg) {
   g_err = msg;
@@ -124,11 +127,13 @@ struct FbkOptions {
   int64_t pair_ablate = 0;               // timing experiments on k_icount2 (skips parts of it: WRONG results)
   int64_t pair_spw = 1;                  // experiment: container slots per wave of k_icount2 (1 | 2 | 4): the next slot's first payload batch is in flight while the current one is decoded
 #endif
-  int64_t pair_kernels = 0;              // 3: the persistent loader / decoder count k_icount3 (fbk_pair_ring.hip.h; set-ops as 2); 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2)
+  int64_t pair_kernels = 0;              // 2: type-pair specialised k_icount2 / k_setop2 (one LDS clear per pair, probing); 1: the round-2 kernels; 0: by the rows' average payload (use_pair_kernels2); experiments builds only: 3 = the persistent loader / decoder count k_icount3 (fbk_pair_ring.hip.h; set-ops as 2)
+#ifdef FBK_EXPERIMENTS
   int64_t ring_geom = 0;                 // k_icount3's block: 0 = 10 decoders + 64 KiB ring, one block per CU; 1 = 8 decoders; 2 = 6 decoders; 3 = 5 decoders + 32 KiB ring, two blocks per CU
   int64_t ring_nt = 0;                   //   1: the payload DMAs carry the non-temporal hint
   int64_t ring_flags = 0;                //   experiments on k_icount3 (bit 0: ring space is released after the decode)
-  int64_t ring_debug = 0;                //   1: every block reports the cycles its loader and decoders spent waiting; the averages go to stderr after each launch (which is then synchronous)
+  int64_t ring_debug = 0;                //   1: every block reports the cycles its loader and decoders spent waiting; the averages go to stderr after each launch (which is then synchronous)#endif
+#endif
 };
 
 struct fbk_ctx {
@@ -136,6 +141,10 @@ struct fbk_ctx {
   int n_cu = 0;  // compute units of the device (sizes persistent grids)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  // fbk_comm_*: this rank's RCCL communicator (one process per GPU), its stream and the two events that order it against `stream`
+  void* comm = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ev_in = nullptr, comm_ev_out = nullptr;
   std::mutex mu;
   FbkOptions opt;
   // last failing call on this context (fbk_last_error_r): guarded by err_mu, NOT by mu, so that
@@ -710,12 +719,14 @@ const OptionDesc kOptions[] = {
     {"upload_threads", &FbkOptions::upload_threads, 0, 64},
     {"upload_chunk_mb", &FbkOptions::upload_chunk_mb, 1, 1024},
     {"setop_direct_encode", &FbkOptions::setop_direct_encode, 0, 2},
+#ifndef FBK_EXPERIMENTS
+    {"pair_kernels", &FbkOptions::pair_kernels, 0, 2},
+#else
     {"pair_kernels", &FbkOptions::pair_kernels, 0, 3},
     {"ring_geom", &FbkOptions::ring_geom, 0, 3},
     {"ring_nt", &FbkOptions::ring_nt, 0, 1},
     {"ring_debug", &FbkOptions::ring_debug, 0, 1},
     {"ring_flags", &FbkOptions::ring_flags, 0, 255},
-#ifdef FBK_EXPERIMENTS
     {"pair_ablate", &FbkOptions::pair_ablate, 0, 4095},
     {"pair_stamp", &FbkOptions::pair_stamp, 0, 4},
     {"pair_spw", &FbkOptions::pair_spw, 1, 4},
@@ -812,6 +823,7 @@ int32_t fbk_close(fbk_ctx* ctx) try {
   }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  comm_release(ctx);
   if (!ctx->root) cache_release_all(ctx);
   pool_release_all(ctx);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -1545,12 +1557,17 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
 #undef FBK_LAUNCH_DENSE
   } else {
     const bool pk2 = use_pair_kernels2(ctx, p->a, p->b, -1);
+#ifdef FBK_EXPERIMENTS
     const bool pk3 = ctx->opt.pair_kernels == 3 && p->a->ring_regular && p->b->ring_regular;
+#else
+    constexpr bool pk3 = false;
+#endif
     // (resolved item records + a count per wave pay for their second launch only where the items are heavy: one-wave blocks)
     const bool resolved = pk3 || (pk2 && pair_wpb_for(ctx, p->a, p->b) == 1);
     if (!resolved) HIP_TRY(hipMemsetAsync(p->d_counts, 0, p->n_pairs * sizeof(u64), ctx->stream));
     if (resolved)
       if (int32_t rc = plan_resolve_items(ctx, p)) return rc;
+#ifdef FBK_EXPERIMENTS
     if (pk3) {
       // the persistent loader / decoder kernel: a block per compute unit (or two), every block walks its share of the item records
       if (!p->d_ring_ctl) {
@@ -1602,7 +1619,9 @@ int32_t plan_icount_enqueue_locked(fbk_ctx* ctx, fbk_plan* p, u64* fused_total =
       }
       hipLaunchKernelGGL(fbk::k_sum_wave_counts, dim3(uint32_t((p->n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, p->d_wave_counts,
                          uint32_t(fbk::kSlots), p->n_pairs, p->d_counts, p->d_ring_ctl + 1);
-    } else if (pk2) {
+    } else
+#endif
+    if (pk2) {
 #define FBK_LAUNCH_ICOUNT2(S, W)                                                                                                   \
   hipLaunchKernelGGL((fbk::k_icount2<S, W>), dim3(uint32_t((p->n_pairs * (fbk::kSlots / S) + W - 1) / W)), dim3(64 * W), 0, ctx->stream, \
                      p->a->d_slots, p->a->d_arena, p->d_rows_a, p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs,            \

@@ -145,27 +145,66 @@ __device__ __forceinline__ uint32_t map_bit_hi(uint32_t mb, uint32_t x, uint32_t
   return __builtin_amdgcn_ubfe(w, x >> 21, width);
 }
 
-// this lane's hits of one batch of array dwords against the table (MAP: a run container as boundary masks in the table, its
-// full dwords in the map at mb — run_table_build).
-// ONE body for every batch (until round 5: an unpredicated copy for batches whose values all exist and a predicated one — see
-// sparse_xor_batch for what the two copies cost).  A value past the array's end is probed like any other — junk dwords read as zero,
-// the upper half of an odd array's last dword is whatever follows it in the arena: either way a read inside the table — and then
-// extracted with a bit-field WIDTH of 0, which yields 0: the widths are clamp(values left from this lane's value on, 0, 1), two
-// v_med3_i32 per dword row instead of index arithmetic, compares and selects.
-template <bool MAP = false>
-__device__ __forceinline__ uint32_t array_probe_batch(uint32_t tb, uint32_t len, uint32_t base, int lane, const uint32_t (&v)[kPairBatch], uint32_t mb = 0) {
-  uint32_t hits = 0;
-  int32_t left = (int32_t)(len - 2u * base) - 2 * lane;  // values from this lane's low value of row 0 to the end of the array (<= 0: none)
+// ---- the array forms of the COUNT (round 6) ---------------------------------------------------------------------------------------
+// An array that is scattered into the table or that probes one (arrays_table_probe, bitmap_table_probe, run_table_probe) is read
+// as its floor(len / 2) FULL dwords — `nd` below; item_prefetch asks count_units for the unit count — and an odd last value goes
+// by itself (one scalar load, one LDS operation).  What that buys: no value of a dword row needs a test of its own.
+//   * the SCATTER predicates a ROW (`lane < dwords left`, one compare per two values; rows past the end are not executed);
+//   * the PROBE predicates nothing: a dword past the end was loaded as zero (sparse_load), so each of its two junk values
+//     "hits" exactly when value 0 is in the table — the same answer z in every lane — and the wave takes junk x z off its
+//     scalar partial instead.
+// Round 5's form tested every value (compare + select, a third of the probe's ~6 vector instructions per value), and the
+// compiler interleaved its reads and uses two at a time: EIGHT LDS round trips per batch one after the other
+// (`s_waitcnt lgkmcnt(0)` behind every second read), where all sixteen reads of a batch can be in flight at once.  The SQ
+// counters of the shipped kernel on config 3's 8192 row pairs (profiles/r04_pmc_pairs_shipped.txt; the counters tick in
+// QUAD cycles) say what that costs: 49.8 M vector instructions = 85 us of every SIMD's issue slots out of the kernel's 150,
+// and waves waiting 61 % of their lives.
+
+// value x (bits [15:0]) is in the table (MAP: or in a dword the run map marks full)
+template <bool MAP>
+__device__ __forceinline__ uint32_t probe_value(uint32_t tb, uint32_t mb, uint32_t x) {
+  uint32_t b = table_bit_lo(tb, x);
+  if (MAP) b |= map_bit_lo(mb, x);
+  return b;
+}
+
+// rows K0 .. K1 - 1 of a batch: every table read is issued before the first one is used (the scheduling barrier)
+template <bool MAP, int K0, int K1>
+__device__ __forceinline__ uint32_t array_probe_rows(uint32_t tb, uint32_t mb, const uint32_t (&v)[kPairBatch]) {
+  uint32_t tl[kPairBatch], th[kPairBatch], ml[kPairBatch], mh[kPairBatch];
 #pragma unroll
-  for (int k = 0; k < kPairBatch; ++k) {
-    const uint32_t w_lo = (uint32_t)min(max(left, 0), 1), w_hi = (uint32_t)min(max(left - 1, 0), 1);
-    uint32_t b0 = table_bit_lo(tb, v[k], w_lo), b1 = table_bit_hi(tb, v[k], w_hi);
+  for (int k = K0; k < K1; ++k) {
+    tl[k] = *table_dword_lo(tb, v[k]);
+    th[k] = *table_dword_hi(tb, v[k]);
     if (MAP) {
-      b0 |= map_bit_lo(mb, v[k], w_lo);
-      b1 |= map_bit_hi(mb, v[k], w_hi);
+      ml[k] = *(const lds_u32*)(uintptr_t)(mb + (__builtin_amdgcn_ubfe(v[k], 10u, 6u) << 2));
+      mh[k] = *(const lds_u32*)(uintptr_t)(mb + ((v[k] >> 26) << 2));
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t hits = 0;
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
+    uint32_t b0 = __builtin_amdgcn_ubfe(tl[k], v[k], 1u), b1 = __builtin_amdgcn_ubfe(th[k], v[k] >> 16, 1u);  // (bit-field offsets use bits [4:0] only)
+    if (MAP) {
+      b0 |= __builtin_amdgcn_ubfe(ml[k], v[k] >> 5, 1u);
+      b1 |= __builtin_amdgcn_ubfe(mh[k], v[k] >> 21, 1u);
     }
     hits += b0 + b1;
-    left -= 2 * kWave;
+  }
+  return hits;
+}
+
+// this lane's RAW hits of the batch at dword `base` (nd > base), junk values included; `junk` counts those (wave-uniform)
+template <bool MAP = false>
+__device__ __forceinline__ uint32_t array_probe_batch(uint32_t tb, uint32_t nd, uint32_t base, const uint32_t (&v)[kPairBatch], uint32_t mb, uint32_t& junk) {
+  const uint32_t rem = nd - base;  // dwords from this batch on
+  uint32_t hits = array_probe_rows<MAP, 0, kPairBatch / 2>(tb, mb, v);
+  if (rem > (kPairBatch / 2) * kWave) {
+    hits += array_probe_rows<MAP, kPairBatch / 2, kPairBatch>(tb, mb, v);
+    junk += rem >= kPairBatch * kWave ? 0u : 2u * (kPairBatch * kWave - rem);
+  } else {
+    junk += 2u * ((kPairBatch / 2) * kWave - rem);
   }
   return hits;
 }
@@ -177,30 +216,71 @@ __device__ __forceinline__ uint32_t array_probe_batch(uint32_t tb, uint32_t len,
 struct ProbeTail {
   uint32_t v1[kPairBatch], v2[kPairBatch], v3[kPairBatch];
 };
-__device__ __forceinline__ void probe_tail_load(const uint8_t* __restrict__ p, uint32_t len, int lane, ProbeTail& t) {
-  const uint32_t n_units = (len + 1u) >> 1;
+// (nd: the dword units that are read — len >> 1 in the count, (len + 1) >> 1 where the odd last value rides in the last dword)
+__device__ __forceinline__ void probe_tail_load(const uint8_t* __restrict__ p, uint32_t nd, int lane, ProbeTail& t) {
   constexpr uint32_t B = kPairBatch * kWave;
-  if (n_units > B) sparse_load(p, n_units, B, lane, t.v1);
-  if (n_units > 2 * B) sparse_load(p, n_units, 2 * B, lane, t.v2);
-  if (n_units > 3 * B) sparse_load(p, n_units, 3 * B, lane, t.v3);
+  if (nd > B) sparse_load(p, nd, B, lane, t.v1);
+  if (nd > 2 * B) sparse_load(p, nd, 2 * B, lane, t.v2);
+  if (nd > 3 * B) sparse_load(p, nd, 3 * B, lane, t.v3);
 }
-// number of this lane's array values that are set in the table
+// number of this lane's array values that are set in the table; the junk correction and an odd last value go to `spart`
+// (wave-uniform, added once per wave)
 template <bool MAP = false>
 __device__ __forceinline__ uint32_t array_probe_all(const uint8_t* __restrict__ p, uint32_t len, int lane, uint32_t tb,
-                                                    const uint32_t (&v0)[kPairBatch], const ProbeTail& t, uint32_t mb = 0) {
-  const uint32_t n_units = (len + 1u) >> 1;
+                                                    const uint32_t (&v0)[kPairBatch], const ProbeTail& t, uint32_t& spart, uint32_t mb = 0) {
+  const uint32_t nd = len >> 1;
   constexpr uint32_t B = kPairBatch * kWave;
-  uint32_t hits = array_probe_batch<MAP>(tb, len, 0, lane, v0, mb);
-  if (n_units > B) hits += array_probe_batch<MAP>(tb, len, B, lane, t.v1, mb);
-  if (n_units > 2 * B) hits += array_probe_batch<MAP>(tb, len, 2 * B, lane, t.v2, mb);
-  if (n_units > 3 * B) hits += array_probe_batch<MAP>(tb, len, 3 * B, lane, t.v3, mb);
-  for (uint32_t base = 4 * B; base < n_units; base += B) {  // arrays beyond 4096 values (roaring.go:5054)
+  uint32_t odd_value = 0;
+  if (len & 1u) odd_value = reinterpret_cast<const uint32_t*>(p)[nd] & 0xFFFFu;  // (wave-uniform address: a scalar load)
+  uint32_t hits = 0, junk = 0;
+  if (nd > 0) hits += array_probe_batch<MAP>(tb, nd, 0, v0, mb, junk);
+  if (nd > B) hits += array_probe_batch<MAP>(tb, nd, B, t.v1, mb, junk);
+  if (nd > 2 * B) hits += array_probe_batch<MAP>(tb, nd, 2 * B, t.v2, mb, junk);
+  if (nd > 3 * B) hits += array_probe_batch<MAP>(tb, nd, 3 * B, t.v3, mb, junk);
+  for (uint32_t base = 4 * B; base < nd; base += B) {  // arrays beyond 4096 values (roaring.go:5054)
     uint32_t v[kPairBatch];
-    sparse_load(p, n_units, base, lane, v);
-    hits += array_probe_batch<MAP>(tb, len, base, lane, v, mb);
+    sparse_load(p, nd, base, lane, v);
+    hits += array_probe_batch<MAP>(tb, nd, base, v, mb, junk);
   }
+  if (junk) spart -= junk * (uint32_t)__builtin_amdgcn_readfirstlane((int)probe_value<MAP>(tb, mb, 0u));
+  if (len & 1u) spart += (uint32_t)__builtin_amdgcn_readfirstlane((int)probe_value<MAP>(tb, mb, odd_value));
   return hits;
 }
+
+// one batch of an array's full dwords ORed into the table (the values of an array are distinct: OR = the toggle of sparse_xor_batch)
+__device__ __forceinline__ void array_or_batch(uint32_t tb, uint32_t nd, uint32_t base, int lane, const uint32_t (&v)[kPairBatch]) {
+#pragma unroll
+  for (int k = 0; k < kPairBatch; ++k) {
+    const int32_t left = (int32_t)(nd - base) - k * kWave;  // dwords from this row on (wave-uniform)
+    if (left <= 0) break;
+    if (lane < left) {
+      (void)__hip_atomic_fetch_or(table_dword_lo(tb, v[k]), 1u << (v[k] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_or(table_dword_hi(tb, v[k]), 1u << ((v[k] >> 16) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+// the whole array (batch 0 in v; an odd last value by one lane)
+__device__ __forceinline__ void array_or_all(const uint8_t* __restrict__ p, uint32_t len, int lane, uint32_t tb, uint32_t (&v)[kPairBatch]) {
+  const uint32_t nd = len >> 1;
+  uint32_t odd_value = 0;
+  if (len & 1u) odd_value = reinterpret_cast<const uint32_t*>(p)[nd] & 0xFFFFu;
+  for (uint32_t base = 0; base < nd;) {
+    const uint32_t nb = base + kPairBatch * kWave;
+    uint32_t nv[kPairBatch];
+    if (nb < nd) sparse_load(p, nd, nb, lane, nv);
+    array_or_batch(tb, nd, base, lane, v);
+    if (nb >= nd) break;
+#pragma unroll
+    for (int k = 0; k < kPairBatch; ++k) v[k] = nv[k];
+    base = nb;
+  }
+  if ((len & 1u) && lane == 0)
+    (void)__hip_atomic_fetch_or((lds_u32*)(uintptr_t)(tb + ((odd_value >> 5) << 2)), 1u << (odd_value & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// dword units of the two payloads' batches as the count kernel reads them: floor(len / 2) for an array on one of the table
+// paths above (the dispatch of icount_item, restated), sparse_units otherwise
+__device__ __forceinline__ void count_units(uint32_t ta, uint32_t la, uint32_t tb, uint32_t lb, uint32_t sparse_paths, uint32_t& ua, uint32_t& ub);
 
 // toggles -> filled runs: the inclusive parity prefix over the 65536 bits of a fragment (see frag_load_run)
 __device__ __forceinline__ void frag_parity_prefix(u64 (&w)[kWordsPerLane], int lane) {
@@ -323,12 +403,12 @@ __device__ __forceinline__ void run_table_build(const uint8_t* __restrict__ pr, 
 // |array ∩ run container| by probing (intersectionCountArrayRun, roaring.go:4537-4557, walks both lists; pair_stream below
 // decodes both operands into 8 KiB): this lane's hits.  Round 4.
 __device__ __forceinline__ uint32_t run_table_probe(const uint8_t* __restrict__ pr, uint32_t lr, uint32_t (&vr)[kPairBatch], const uint8_t* __restrict__ pp,
-                                                    uint32_t lp, const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint32_t* mini) {
+                                                    uint32_t lp, const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint32_t* mini, uint32_t& spart) {
   ProbeTail tail;
-  probe_tail_load(pp, lp, lane, tail);
+  probe_tail_load(pp, lp >> 1, lane, tail);
   uint32_t tbase, mbase;
   run_table_build(pr, lr, vr, lane, table, mini, tbase, mbase);
-  const uint32_t h = array_probe_all<true>(pp, lp, lane, tbase, vp, tail, mbase);
+  const uint32_t h = array_probe_all<true>(pp, lp, lane, tbase, vp, tail, spart, mbase);
   wave_lds_sync();
   return h;
 }
@@ -534,14 +614,31 @@ __device__ __forceinline__ void frag_load_pair(const Slot& sa, const uint8_t* __
 // is worked on, and the wave adds ONE count to out[pair].
 
 // batch 0 of both operands of an item, if the item will be decoded at all
+__device__ __forceinline__ void count_units(uint32_t ta, uint32_t la, uint32_t tb, uint32_t lb, uint32_t sparse_paths, uint32_t& ua, uint32_t& ub) {
+  ua = sparse_units(ta, la);
+  ub = sparse_units(tb, lb);
+  bool fl = false;  // wave-uniform
+  if (ta == kTypeArray && tb == kTypeArray) fl = !((sparse_paths & 1u) && la <= kSmallArray && lb <= kSmallArray);
+  else if (ta == kTypeArray && tb == kTypeBitmap) fl = !((sparse_paths & 1u) && la <= kProbeArray);
+  else if (ta == kTypeBitmap && tb == kTypeArray) fl = !((sparse_paths & 1u) && lb <= kProbeArray);
+  else if (ta == kTypeArray && tb == kTypeRun) fl = (sparse_paths & 2u) && lb <= kRunFillMax;
+  else if (ta == kTypeRun && tb == kTypeArray) fl = (sparse_paths & 2u) && la <= kRunFillMax;
+  if (fl) {
+    if (ta == kTypeArray) ua = la >> 1;
+    if (tb == kTypeArray) ub = lb >> 1;
+  }
+}
+
 __device__ __forceinline__ void item_prefetch(const Slot& sa, const uint8_t* __restrict__ arenaA, const Slot& sb,
                                               const uint8_t* __restrict__ arenaB, int lane, uint32_t (&va)[kPairBatch],
-                                              uint32_t (&vb)[kPairBatch]) {
+                                              uint32_t (&vb)[kPairBatch], uint32_t sparse_paths) {
   const uint32_t na = slot_n(sa), nb = slot_n(sb);
   if (na == 0 || nb == 0 || na == 65536u || nb == 65536u) return;
   const uint32_t ta = slot_type(sa), tb = slot_type(sb);
-  if (ta == kTypeArray || ta == kTypeRun) sparse_load(arenaA + sa.off, sparse_units(ta, sa.len), 0, lane, va);
-  if (tb == kTypeArray || tb == kTypeRun) sparse_load(arenaB + sb.off, sparse_units(tb, sb.len), 0, lane, vb);
+  uint32_t ua, ub;
+  count_units(ta, sa.len, tb, sb.len, sparse_paths, ua, ub);
+  if (ta == kTypeArray || ta == kTypeRun) sparse_load(arenaA + sa.off, ua, 0, lane, va);
+  if (tb == kTypeArray || tb == kTypeRun) sparse_load(arenaB + sb.off, ub, 0, lane, vb);
 }
 
 // the two operands' first batches change places (in place: one temporary at a time)
@@ -557,26 +654,26 @@ __device__ __forceinline__ void batch_exchange(uint32_t (&a)[kPairBatch], uint32
 // shorter array -> table, longer array probes it; returns this lane's hits
 __device__ __forceinline__ uint32_t arrays_table_probe(const uint8_t* __restrict__ pt, uint32_t lt, uint32_t (&vt)[kPairBatch],
                                                        const uint8_t* __restrict__ pp, uint32_t lp, uint32_t (&vp)[kPairBatch], int lane,
-                                                       u64* table) {
+                                                       u64* table, uint32_t& spart) {
   ProbeTail tail;
-  probe_tail_load(pp, lp, lane, tail);
+  probe_tail_load(pp, lp >> 1, lane, tail);
   const uint32_t tbase = lds_table_base(table);
   lds_zero(table, lane);
   wave_lds_sync();
-  sparse_xor_all(kTypeArray, pt, lt, lane, tbase, vt);
+  array_or_all(pt, lt, lane, tbase, vt);
   wave_lds_sync();
-  const uint32_t h = array_probe_all(pp, lp, lane, tbase, vp, tail);
+  const uint32_t h = array_probe_all(pp, lp, lane, tbase, vp, tail, spart);
   wave_lds_sync();
   return h;
 }
 
 // bitmap -> table (no clear), array probes it; returns this lane's hits
 __device__ __forceinline__ uint32_t bitmap_table_probe(const uint8_t* __restrict__ pbm, const uint8_t* __restrict__ parr, uint32_t larr,
-                                                       uint32_t (&vp)[kPairBatch], int lane, u64* table) {
+                                                       uint32_t (&vp)[kPairBatch], int lane, u64* table, uint32_t& spart) {
   u64 wb[kWordsPerLane];
   frag_load_bitmap(pbm, lane, wb);
   ProbeTail tail;
-  probe_tail_load(parr, larr, lane, tail);
+  probe_tail_load(parr, larr >> 1, lane, tail);
   ulonglong2* q = reinterpret_cast<ulonglong2*>(table);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -586,7 +683,7 @@ __device__ __forceinline__ uint32_t bitmap_table_probe(const uint8_t* __restrict
     q[j * kWave + lane] = x;  // fragment layout -> natural word order in the table
   }
   wave_lds_sync();
-  const uint32_t h = array_probe_all(parr, larr, lane, lds_table_base(table), vp, tail);
+  const uint32_t h = array_probe_all(parr, larr, lane, lds_table_base(table), vp, tail, spart);
   wave_lds_sync();
   return h;
 }
@@ -655,7 +752,7 @@ __device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __res
       // every type pair carried two inlined instances of its loops until round 5: half of the kernel's 102 KB of code)
       const bool a_tab = sa.len <= sb.len;  // wave-uniform
       if (!a_tab) batch_exchange(va, vb);
-      part += arrays_table_probe(a_tab ? pa : pb, a_tab ? sa.len : sb.len, va, a_tab ? pb : pa, a_tab ? sb.len : sa.len, vb, lane, table);
+      part += arrays_table_probe(a_tab ? pa : pb, a_tab ? sa.len : sb.len, va, a_tab ? pb : pa, a_tab ? sb.len : sa.len, vb, lane, table, spart);
     }
   } else if ((ta == kTypeArray && tb == kTypeBitmap) || (ta == kTypeBitmap && tb == kTypeArray)) {
     const bool a_arr = ta == kTypeArray;  // wave-uniform; the array's batch 0 goes to va (the bitmap side has none)
@@ -664,12 +761,12 @@ __device__ __forceinline__ void icount_item(const Slot& sa, const uint8_t* __res
     const uint8_t* pbm = a_arr ? pb : pa;
     const uint32_t larr = a_arr ? sa.len : sb.len;
     if ((sparse_paths & 1u) && larr <= kProbeArray) part += array_probe_global(va, larr, pbm, lane);
-    else part += bitmap_table_probe(pbm, parr, larr, va, lane, table);
+    else part += bitmap_table_probe(pbm, parr, larr, va, lane, table, spart);
   } else if ((sparse_paths & 2u) && ((ta == kTypeArray && tb == kTypeRun && sb.len <= kRunFillMax) || (ta == kTypeRun && tb == kTypeArray && sa.len <= kRunFillMax))) {
     // array x run: the run container becomes the table, the array probes it — its batch 0 in va, the array's in vb
     const bool a_run = ta == kTypeRun;  // wave-uniform
     if (!a_run) batch_exchange(va, vb);
-    part += run_table_probe(a_run ? pa : pb, a_run ? sa.len : sb.len, va, a_run ? pb : pa, a_run ? sb.len : sa.len, vb, lane, table, mini);
+    part += run_table_probe(a_run ? pa : pb, a_run ? sa.len : sb.len, va, a_run ? pb : pa, a_run ? sb.len : sa.len, vb, lane, table, mini, spart);
   } else {
     // a run on at least one side: both operands 1 KiB at a time out of the table, one clear
     uint32_t acc = 0;
@@ -687,7 +784,7 @@ __device__ __forceinline__ void icount_items(const Slot (&sa)[SPW], const uint8_
                                              uint32_t (&vb)[kPairBatch], uint32_t sparse_paths, uint32_t& part, uint32_t& spart) {
   if constexpr (K < SPW) {
     uint32_t xa[kPairBatch], xb[kPairBatch];
-    if constexpr (K + 1 < SPW) item_prefetch(sa[K + 1], arenaA, sb[K + 1], arenaB, lane, xa, xb);
+    if constexpr (K + 1 < SPW) item_prefetch(sa[K + 1], arenaA, sb[K + 1], arenaB, lane, xa, xb, sparse_paths);
     icount_item(sa[K], arenaA, sb[K], arenaB, lane, table, mini, va, vb, sparse_paths, part, spart);
     if constexpr (K + 1 < SPW) icount_items<K + 1, SPW>(sa, arenaA, sb, arenaB, lane, table, mini, xa, xb, sparse_paths, part, spart);
   }
@@ -752,7 +849,7 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
     if (stamp != 4) t_prev = t_mark;
   }
   if (!(sparse_paths & 0x400u)) {  // (0x400: timing experiment, descriptors only)
-    item_prefetch(sa[0], arenaA, sb[0], arenaB, lane, va, vb);
+    item_prefetch(sa[0], arenaA, sb[0], arenaB, lane, va, vb, sparse_paths);
     if (stamp) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       t_mark = __builtin_readcyclecounter();
@@ -931,7 +1028,7 @@ __device__ __forceinline__ void array_vs_array_emit(const uint8_t* __restrict__ 
                                                     uint32_t lp, const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint16_t* __restrict__ o16,
                                                     uint32_t& n_out, uint32_t& runs_out, bool nostore = false) {
   ProbeTail tail;
-  probe_tail_load(pp, lp, lane, tail);
+  probe_tail_load(pp, (lp + 1u) >> 1, lane, tail);
   const uint32_t tbase = lds_table_base(table);
   lds_zero(table, lane);
   wave_lds_sync();
@@ -949,7 +1046,7 @@ __device__ __forceinline__ void array_vs_bitmap_emit(const uint8_t* __restrict__
   u64 wb[kWordsPerLane];
   frag_load_bitmap(pbm, lane, wb);
   ProbeTail tail;
-  probe_tail_load(pp, lp, lane, tail);
+  probe_tail_load(pp, (lp + 1u) >> 1, lane, tail);
   ulonglong2* q = reinterpret_cast<ulonglong2*>(table);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -971,7 +1068,7 @@ __device__ __forceinline__ void array_vs_run_emit(const uint8_t* __restrict__ pr
                                                   uint32_t lp, const uint32_t (&vp)[kPairBatch], int lane, u64* table, uint32_t* mini,
                                                   uint16_t* __restrict__ o16, uint32_t& n_out, uint32_t& runs_out, bool nostore = false) {
   ProbeTail tail;
-  probe_tail_load(pp, lp, lane, tail);
+  probe_tail_load(pp, (lp + 1u) >> 1, lane, tail);
   uint32_t tbase, mbase;
   run_table_build(pr, lr, vr, lane, table, mini, tbase, mbase);
   array_probe_emit_all<KEEP, true>(pp, lp, lane, tbase, vp, tail, o16, n_out, runs_out, mbase, nostore);

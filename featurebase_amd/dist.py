@@ -9,6 +9,7 @@ exchanged (executor.go:1767).
 from __future__ import annotations
 
 import os
+import sys
 from typing import List, Optional
 
 import numpy as np
@@ -231,6 +232,75 @@ class PerQueryReducer:
             if self.work[i] is not None:
                 self.work[i].wait()
                 self.work[i] = None
+        return self.buf
+
+
+def library_comm_init(ctx) -> bool:
+    """Give the fbk context `ctx` of THIS rank a communicator of its own over all ranks of the torch process group
+    (fbk_comm_*): rank 0 draws the unique id, torch broadcasts the 128 bytes — its only part — and every rank enters
+    ncclCommInitRank.  True if EVERY rank succeeded (agreed through one all-reduce); False leaves no communicator behind,
+    and the caller stays on torch's collectives."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [None]
+    ok = 1
+    try:
+        if rank == 0:
+            box[0] = ctx.comm_unique_id()
+    except Exception as e:  # noqa: BLE001 — no librccl in this process: every rank learns it below
+        print(f"[fbk dist] library communicator unavailable: {e}", file=sys.stderr, flush=True)
+        box[0] = b""
+    dist.broadcast_object_list(box, src=0)
+    if not box[0]:
+        return False
+    try:
+        ctx.comm_init(box[0], world, rank)
+    except Exception as e:  # noqa: BLE001
+        print(f"[fbk dist] rank {rank}: fbk_comm_init failed: {e}", file=sys.stderr, flush=True)
+        ok = 0
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else None
+    t = torch.tensor([ok], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t.item()) == 0:
+        if ok:
+            ctx.comm_close()
+        return False
+    return True
+
+
+class LibraryPerQueryReducer:
+    """PerQueryReducer with the collective issued by the LIBRARY (fbk_comm_all_reduce_u64: RCCL through the library's own
+    communicator, on the communicator's stream, ordered after the context's stream by one event) instead of through
+    torch.distributed — whose call path costs the launching thread ~28 us per all-reduce, more than half of a 41 us headline
+    step (profiles/r06_collective_host_cost.json).  Same cells, same rotation: `cell()` hands out the next cell, `reduce()`
+    starts the all-reduce of the cell just written, `fence()` (once per revolution, before the ring is cleared, and before
+    the cells are read) makes the context's stream wait for every collective so far — no host wait anywhere."""
+
+    def __init__(self, ctx, width: int, depth: int, device=None):
+        import torch
+
+        if int(width) < 1 or int(depth) < 1:
+            raise ValueError("LibraryPerQueryReducer: width and depth must be >= 1")
+        self.ctx, self.width, self.depth = ctx, int(width), int(depth)
+        self.buf = torch.zeros((self.depth, self.width), dtype=torch.int64, device=device)
+        self.base = self.buf.data_ptr()
+        self.k = 0
+        self.collectives = 0
+
+    def cell_ptr(self) -> int:
+        return self.base + (self.k % self.depth) * self.width * 8
+
+    def reduce(self) -> int:
+        i = self.k % self.depth
+        self.ctx.comm_all_reduce(self.base + i * self.width * 8, self.width)
+        self.collectives += 1
+        self.k += 1
+        return i
+
+    def flush(self):
+        self.ctx.comm_fence()
         return self.buf
 
 

@@ -164,7 +164,13 @@ SIGNATURES = {
     "fbk_group_bsi_sum": (C.c_int32, [_vp, C.POINTER(BsiArgs), C.c_uint32, C.POINTER(C.c_int64), _u64p]),
     "fbk_group_topn": (C.c_int32, [_vp, C.POINTER(TopnArgs), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint32, _u32p]),
     "fbk_group_last_error_r": (C.c_int32, [_vp, C.c_char_p, C.c_uint64, _i32p]),
+    "fbk_comm_unique_id": (C.c_int32, [_vp]),
+    "fbk_comm_init": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32]),
+    "fbk_comm_all_reduce_u64": (C.c_int32, [_vp, _vp, C.c_uint64]),
+    "fbk_comm_fence": (C.c_int32, [_vp]),
+    "fbk_comm_close": (C.c_int32, [_vp]),
 }
+COMM_ID_BYTES = 128
 
 BSI_EQ, BSI_NEQ, BSI_LT, BSI_LTE, BSI_GT, BSI_GTE = 1, 2, 3, 4, 5, 6
 BSI_OPS = {"EQ": BSI_EQ, "NEQ": BSI_NEQ, "LT": BSI_LT, "LTE": BSI_LTE, "GT": BSI_GT, "GTE": BSI_GTE}

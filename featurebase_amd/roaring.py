@@ -292,6 +292,30 @@ class Context:
     def set_stream(self, hip_stream: int) -> None:
         L.check(self.lib.fbk_set_stream(self.h, C.c_void_p(hip_stream or None)))
 
+    # ---- one process per GPU: the exchange issued by the library (fbk_comm_*) -------------------
+    def comm_unique_id(self) -> bytes:
+        """rank 0: the 128 bytes every rank passes to comm_init (hand them over with whatever channel the host has)"""
+        buf = (C.c_uint8 * L.COMM_ID_BYTES)()
+        L.check(self.lib.fbk_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, uid: bytes, n_ranks: int, rank: int) -> None:
+        """collective: returns when every rank has called it"""
+        assert len(uid) == L.COMM_ID_BYTES
+        buf = (C.c_uint8 * L.COMM_ID_BYTES).from_buffer_copy(uid)
+        L.check(self.lib.fbk_comm_init(self.h, buf, n_ranks, rank))
+
+    def comm_all_reduce(self, device_ptr: int, n_words: int) -> None:
+        """asynchronous in-place sum of n_words uint64 over the ranks: after what the context's stream holds, on the
+        communicator's stream; the words must not be touched before comm_fence()"""
+        L.check(self.lib.fbk_comm_all_reduce_u64(self.h, C.c_void_p(device_ptr), n_words))
+
+    def comm_fence(self) -> None:
+        L.check(self.lib.fbk_comm_fence(self.h))
+
+    def comm_close(self) -> None:
+        L.check(self.lib.fbk_comm_close(self.h))
+
     def synchronize(self) -> None:
         L.check(self.lib.fbk_synchronize(self.h))
 

@@ -53,8 +53,11 @@
 extern "C" {
 #endif
 
-#define FBK_ABI_VERSION 5
+#define FBK_ABI_VERSION 6
 /* ABI history.
+ *   6 (round 6): + fbk_comm_unique_id / fbk_comm_init / fbk_comm_all_reduce_u64 / fbk_comm_fence / fbk_comm_close (the
+ *      one-process-per-GPU exchange issued by the library itself).  fbk_batch_compact refuses a batch of another context;
+ *      fbk_group_topn refuses members whose topn_semantics differ.
  *   5 (round 5): + fbk_topn_partials, options topn_semantics, matrix_shadow_arena_x.  CHANGED: fbk_topn / fbk_query_topn /
  *      fbk_group_topn with 0 < n < n_a return the reference's two-pass answer by default (topn_semantics = 1; = 0 restores
  *      round 4's exact top n of fbk_topn; round 4's per-member candidate rule of fbk_group_topn is gone — it was neither);
@@ -798,6 +801,27 @@ int32_t fbk_group_topn(fbk_group* group, const fbk_topn_args* per_member, uint32
  * sums, TopK counts, fold counts): device_partials[m] = `words` uint64 on member m's device (NULL =
  * zeros), produced on member m's stream. */
 int32_t fbk_group_reduce_u64(fbk_group* group, void* const* device_partials, uint64_t words, uint64_t* out_total);
+
+/* ---- one process per GPU: the exchange step issued by the library -------------------------------
+ * The deployment of executor.go:6449-6533 on one node is one process per GPU, each with a context over the shards it
+ * owns; the only exchange is the sum of count-valued partials (reduceFn).  Issued through PyTorch that all-reduce costs
+ * the launching thread ~28 us per call (profiles/r06_collective_host_cost.json) — more than half of a 41 us headline step.
+ * These calls put it on the library's side: a communicator per context over RCCL (dlopen'ed, as for fbk_group), created
+ * from a unique id that rank 0 draws and the host code hands to the other ranks by whatever channel it has (the Go shim:
+ * its cluster RPC; bench.py / featurebase_amd.dist: torch.distributed.broadcast_object_list).
+ *   fbk_comm_unique_id      rank 0: 128 bytes (ncclGetUniqueId)
+ *   fbk_comm_init           every rank: ncclCommInitRank on the context's device; collective (blocks until all ranks arrive)
+ *   fbk_comm_all_reduce_u64 in place sum of n_words uint64 at device_words over the ranks, ASYNCHRONOUS: ordered after what
+ *                           the context's stream holds at the call, run on the communicator's own stream, so the kernels
+ *                           of the following queries overlap it.  The words must not be touched until a fence.
+ *   fbk_comm_fence          the context's stream waits for every all-reduce enqueued so far (one event: no host wait)
+ *   fbk_comm_close          destroys the communicator (fbk_close does it too) */
+#define FBK_COMM_ID_BYTES 128
+int32_t fbk_comm_unique_id(uint8_t* out_id /* FBK_COMM_ID_BYTES */);
+int32_t fbk_comm_init(fbk_ctx* ctx, const uint8_t* id /* FBK_COMM_ID_BYTES */, int32_t n_ranks, int32_t rank);
+int32_t fbk_comm_all_reduce_u64(fbk_ctx* ctx, void* device_words, uint64_t n_words);
+int32_t fbk_comm_fence(fbk_ctx* ctx);
+int32_t fbk_comm_close(fbk_ctx* ctx);
 
 /* Message (and status code) of the last failing fbk_group_* call on THIS group, copied into a caller
  * buffer: the form a cgo binding must use (see fbk_last_error_r).  Group-level failures — argument

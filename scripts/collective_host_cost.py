@@ -10,6 +10,8 @@ four loops on one device and reports ms per step of each, wall clock over `--ste
   torch_nccl_per_step    the same + dist.all_reduce(cell, async_op=True) on a ONE-RANK nccl process group, ring of cells
                          (exactly the N > 1 headline's loop)
   host_enqueue_only      the torch loop's host time per step: perf_counter around the loop WITHOUT the final synchronize
+  library_comm_per_step  the headline's loop with the all-reduce issued by the library: fbk_comm_all_reduce_u64 on the context's
+                         own RCCL communicator and stream (no torch call on the hot loop)
   library_rccl_per_step  fbk_group_plan_intersection_count_total with FBK_REDUCE_RCCL on a group of one member: the kernel, then
                          ncclAllReduce through the library's dlopen'ed RCCL on the context's own stream, total read back (a
                          synchronous per-query call: includes the D2H of the total)
@@ -97,6 +99,28 @@ def main():
         assert (vals[vals != 0] == expected).all(), "reduced totals differ"
         res["torch_nccl_per_step"] = {"ms_per_step": ms, "host_enqueue_ms_per_step": host, "collectives": pq.collectives}
 
+        # the same loop with the collective issued by the LIBRARY (fbk_comm_all_reduce_u64: its own communicator and stream)
+        if fdist.library_comm_init(ctx):
+            lpq = fdist.LibraryPerQueryReducer(ctx, 1, args.ring, dev)
+
+            def step_lib():
+                if lpq.k % args.ring == 0:
+                    lpq.flush()
+                    lpq.buf.zero_()
+                plan.intersection_count_accumulate(lpq.cell_ptr())
+                lpq.reduce()
+
+            loop(step_lib, lpq.flush, 2 * args.ring)
+            ms, host = loop(step_lib, lpq.flush, args.steps)
+            lpq.flush()
+            torch.cuda.synchronize()
+            vals = lpq.buf.reshape(-1).cpu().numpy()
+            assert (vals[vals != 0] == expected).all(), "reduced totals differ (library communicator)"
+            res["library_comm_per_step"] = {"ms_per_step": ms, "host_enqueue_ms_per_step": host, "collectives": lpq.collectives}
+            ctx.comm_close()
+        else:
+            res["library_comm_per_step"] = {"error": "fbk_comm_init failed"}
+
         # a bare all_reduce per step (no kernel): the call path alone
         t = torch.zeros(1, dtype=torch.int64, device=dev)
         works = []
@@ -146,6 +170,8 @@ def main():
         "collective_adds_ms": res["torch_nccl_per_step"]["ms_per_step"] - k0,
         "host_enqueue_ms_per_step_with_collective": res["torch_nccl_per_step"]["host_enqueue_ms_per_step"],
         "host_bound": res["torch_nccl_per_step"]["host_enqueue_ms_per_step"] > k0,
+        "library_comm_per_step_ms": res["library_comm_per_step"].get("ms_per_step"),
+        "library_comm_host_enqueue_ms_per_step": res["library_comm_per_step"].get("host_enqueue_ms_per_step"),
     }
     print(json.dumps(res, indent=1))
     if args.out:

@@ -24,6 +24,10 @@ gpu_tests)
   timeout 1500 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu_tests rc $?"; tail -3 $O/gpu_tests.log ;;
 bench)
   timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"; cut -c1-600 $O/bench.json ;;
+pair_tests)  # every test file that drives the pair kernels
+  timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_fuzz_struct.py tests/test_gpu_fullsize.py tests/test_gpu_queries.py -x -q -m gpu -n ${WORKERS:-4} > $O/pair_tests.log 2>&1; echo "pair_tests rc $?"; tail -3 $O/pair_tests.log ;;
+ab)  # the pair kernels of several library builds side by side (LIBS, SHARDS, OPS as scripts/ab_pairs.sh)
+  TAG=$TAG bash scripts/ab_pairs.sh ;;
 *) echo "unknown: $what" ;;
 esac
 done

@@ -50,7 +50,7 @@ def test_struct_layout_matches_header(lib):
 
 
 def test_abi_version(lib):
-    assert lib.load().fbk_abi_version() == 5
+    assert lib.load().fbk_abi_version() == 6
 
 
 def test_no_device_fails_loudly(lib):
@@ -96,7 +96,7 @@ def test_option_names_in_the_header_are_the_library_s():
     table = hip[hip.index("const OptionDesc kOptions[] = {"):]
     table = table[: table.index("};")]
     registered = set(re.findall(r'\{"([a-z_0-9]+)", &FbkOptions::', table))
-    experiments = {"pair_ablate", "pair_stamp", "pair_spw", "matrix_fused_ablate"}
+    experiments = {"pair_ablate", "pair_stamp", "pair_spw", "matrix_fused_ablate", "ring_geom", "ring_nt", "ring_debug", "ring_flags"}  # (-DFBK_EXPERIMENTS builds only)
     header = open(os.path.join(root, "include", "fbk.h")).read()
     doc = header[header.index("/* Options ("): header.index("int32_t fbk_set_option")]
     words = set(re.findall(r"\b[a-z]+(?:_[a-z0-9]+)+\b", doc))

@@ -74,6 +74,12 @@ def _check_compact(c, n, steps, shards4_total):
     assert c["n_gpus"] == n and c["config"]["ranks"] == n and c["steps"] == steps and c["scaling"] == "weak" and c["unit"] == "set-ops/s"
     assert c["value"] > 0 and c["ms_per_step"] > 0 and c["higher_is_better"] is True and c["dtype"] == "u64" and c["data"] == "synthetic"
     assert c["config"]["workload"].startswith("configs[1]") and c["config"]["collectives_per_step"] == 1
+    # who issues the per-step collective (the library's own RCCL communicator when every rank has a device of its own; ranks that
+    # share a device reduce over gloo through torch) and what the loop costs the launching thread; the headline is the median of
+    # the timed regions
+    assert c["config"]["collective_path"] in ("torch.distributed", "library-rccl (fbk_comm_all_reduce_u64)")
+    assert (c["config"]["backend"] == "rccl") or c["config"]["collective_path"] == "torch.distributed"
+    assert c["host_enqueue_us_per_step"] > 0 and c["timed_regions"] >= 1 and c["ms_per_step_first_region"] > 0
     rf, cb = c["roofline"], c["cpu_baseline"]
     assert rf["bound"] == "hbm" and rf["frac"] > 0 and rf["peak"] == 8000.0 and rf["kernel"].startswith("k_icount_dense")
     assert cb["kind"] == "port" and cb["unit"] == "set-ops/s" and cb["value"] > 0 and cb["cores"] >= 1 and "rank 0" in cb["sample"]

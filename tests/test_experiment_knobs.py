@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ("pair_ablate", "pair_stamp", "pair_spw", "matrix_fused_ablate")
+KNOBS = ("pair_ablate", "pair_stamp", "pair_spw", "matrix_fused_ablate", "ring_geom", "ring_nt", "ring_debug", "ring_flags")  # (ring_*: k_icount3, round 6: bit-exact and slower, an experiment)
 
 
 def test_product_library_has_no_experiment_option_names():

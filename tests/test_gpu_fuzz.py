@@ -20,7 +20,12 @@ def pair_kernel_generation(request, gpu_ctx):
     k_setop2: table + probe, interior-map run decode, one-wave blocks) and with the library's own choice by payload size:
     each generation is checked against the oracle on every input of the file, not only on the rows the dispatch would
     hand it."""
-    gpu_ctx.set_option("pair_kernels", request.param)
+    try:
+        gpu_ctx.set_option("pair_kernels", request.param)
+    except Exception:
+        if request.param != 3:
+            raise
+        pytest.skip("k_icount3 exists in -DFBK_EXPERIMENTS builds only")
     yield request.param
     gpu_ctx.set_option("pair_kernels", 0)
 

@@ -67,7 +67,12 @@ def as_int(w):
 @pytest.mark.parametrize("gen", [1, 2, 3])
 @pytest.mark.parametrize("it", range(ITERS))
 def test_fuzz_pairwise_and_folds(gpu_ctx, oracle, it, gen):
-    gpu_ctx.set_option("pair_kernels", gen)  # both generations of the pair kernels see every case
+    try:
+        gpu_ctx.set_option("pair_kernels", gen)  # both generations of the pair kernels see every case
+    except Exception:
+        if gen != 3:
+            raise
+        pytest.skip("k_icount3 exists in -DFBK_EXPERIMENTS builds only")
     try:
         _fuzz_pairwise_and_folds(gpu_ctx, oracle, it)
     finally:

@@ -377,3 +377,44 @@ def test_group_rccl_over_every_visible_device():
     for b in keep:
         b.free()
     grp.close()
+
+
+def test_library_communicator_one_rank(gpu_ctx):
+    """fbk_comm_*: the per-context RCCL communicator of the one-process-per-GPU deployment, on the hardware this box has — ONE
+    rank: unique id, ncclCommInitRank, asynchronous all-reduces of ring cells behind the count kernels (ordered after the
+    context's stream, run on the communicator's stream), one fence, values read back.  More than one rank: 8-GPU nodes only
+    (bench.py --gpus N uses it there and falls back to torch's collectives if any rank fails to set it up)."""
+    import torch
+
+    from featurebase_amd import dist as fd
+
+    w = D.dense_rows(2 * 8, 0.5, 2240)
+    A = gpu_ctx.upload_dense(w)
+    plan = gpu_ctx.plan(A, np.arange(8) * 2, A, np.arange(8) * 2 + 1)
+    exp = int(sum(np.bitwise_count(w[2 * i] & w[2 * i + 1]).sum() for i in range(8)))
+    uid = gpu_ctx.comm_unique_id()
+    assert len(uid) == L.COMM_ID_BYTES
+    gpu_ctx.comm_init(uid, 1, 0)
+    try:
+        with pytest.raises(Exception):
+            gpu_ctx.comm_init(uid, 1, 0)  # a context has one communicator
+        red = fd.LibraryPerQueryReducer(gpu_ctx, 1, 4, torch.device("cuda:0"))
+        torch.cuda.synchronize()
+        for _ in range(10):
+            if red.k % 4 == 0:
+                red.flush()
+                gpu_ctx.synchronize()
+                red.buf.zero_()
+                torch.cuda.synchronize()
+            plan.intersection_count_accumulate(red.cell_ptr())
+            red.reduce()
+        red.flush()
+        gpu_ctx.synchronize()
+        vals = red.buf.reshape(-1).cpu().numpy()
+        assert vals[0] == exp and vals[1] == exp and red.collectives == 10  # (cells 0 and 1 were written in the last revolution)
+    finally:
+        gpu_ctx.comm_close()
+    with pytest.raises(Exception):
+        gpu_ctx.comm_fence()  # no communicator any more
+    plan.free()
+    A.free()

@@ -17,10 +17,16 @@ pytestmark = pytest.mark.gpu
 def pair_kernel_generation(request, gpu_ctx):
     """Every test of this file runs with the round-2 pair kernels (k_icount / k_setop), with the round-3 ones (k_icount2 /
     k_setop2: table + probe, interior-map run decode, one-wave blocks; array x run by probing the run table) with the round-6
-    persistent loader / decoder count (k_icount3: payloads through an LDS ring; set-ops as round 3) and with the
+    persistent loader / decoder count (k_icount3: payloads through an LDS ring; set-ops as round 3 — experiments builds
+    only, skipped on the product library) and with the
     library's own choice by payload size: each generation is checked against the oracle on every input of the file, not
     only on the rows the dispatch would hand it."""
-    gpu_ctx.set_option("pair_kernels", request.param)
+    try:
+        gpu_ctx.set_option("pair_kernels", request.param)
+    except Exception:
+        if request.param != 3:
+            raise
+        pytest.skip("k_icount3 (parity-green, 1.5 x slower than k_icount2) exists in -DFBK_EXPERIMENTS builds only")
     yield request.param
     gpu_ctx.set_option("pair_kernels", 0)
 
