@@ -1113,85 +1113,217 @@ __global__ void __launch_bounds__(256) k_bsi_add(const Slot* __restrict__ slotsX
 //   rows[shard] = ordinal of the exists row; +1 sign, +2+i plane i.   `split` blocks per (shard, slot), 16 / split rounds of
 //   1024 columns per wave each (round 5: it was ONE block per (shard, slot) — 64 blocks for a 4-shard field on 256 CUs,
 //   0.03 of the HBM rate; the launch code splits until the grid holds ~2048 blocks).
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
-  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, kWave), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, kWave);
+// ---- the 64 x 64 bit-matrix transpose of a wavefront, in registers (round 6) ----------------------------------------------------
+// Lane i holds row i (a u64: bit c = column c); afterwards lane j holds column j (bit i = row i).  Six index-bit swaps (lane bit s
+// <-> bit-position bit s), none through the LDS: 32 = ONE v_permlane32_swap between the two halves of the u64; 16 = a
+// v_permlane16_swap of the dword and its upper half + one v_perm; 8 = DPP row_ror:8 + v_perm; 4 = two bank-masked DPP row shifts +
+// rotate + v_bfi; 2, 1 = DPP quad_perm + rotate + v_bfi: 31 vector instructions per word.  (Until round 5 every stage was two
+// ds_bpermute through __shfl_xor and ~8 vector instructions: 12 LDS operations and ~50 vector instructions per word, each stage a
+// full LDS round trip behind the one before.)
+struct TrConst {
+  uint32_t sel8, rot4, m4, rot2, m2, rot1, m1;
+};
+__device__ __forceinline__ TrConst tr_const(int lane) {
+  TrConst c;
+  c.sel8 = (lane & 8) ? 0x03070105u : 0x06020400u;
+  c.rot4 = (lane & 4) ? 4u : 28u;
+  c.m4 = (lane & 4) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+  c.rot2 = (lane & 2) ? 2u : 30u;
+  c.m2 = (lane & 2) ? 0xCCCCCCCCu : 0x33333333u;
+  c.rot1 = (lane & 1) ? 1u : 31u;
+  c.m1 = (lane & 1) ? 0xAAAAAAAAu : 0x55555555u;
+  return c;
+}
+__device__ __forceinline__ uint32_t tr_low_stages(uint32_t d, const TrConst& c) {
+  // 16: the dword's halves change places between the lane rows r and r ^ 1
+  {
+    auto r = __builtin_amdgcn_permlane16_swap(d, d >> 16, false, false);  // r[0] (odd rows) <- the partner's upper half; r[1] (even rows) <- the partner's dword
+    d = __builtin_amdgcn_perm(r[1], r[0], 0x05040100u);                   // {r[1].lo16 : r[0].lo16}
+  }
+  // 8: bytes, partner = lane ^ 8 (row_ror:8 inside the 16-lane row)
+  {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x128, 0xF, 0xF, false);
+    d = __builtin_amdgcn_perm(x, d, c.sel8);
+  }
+  // 4: nibbles, partner = lane ^ 4 (lanes of banks 0 / 2 read four lanes up, banks 1 / 3 four lanes down)
+  {
+    uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x104, 0xF, 0x5, false);
+    x = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)d, 0x114, 0xF, 0xA, false);
+    const uint32_t t = __builtin_amdgcn_alignbit(x, x, c.rot4);
+    d = (d & c.m4) | (t & ~c.m4);
+  }
+  // 2: bit pairs, partner = lane ^ 2
+  {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x4E, 0xF, 0xF, false);
+    const uint32_t t = __builtin_amdgcn_alignbit(x, x, c.rot2);
+    d = (d & c.m2) | (t & ~c.m2);
+  }
+  // 1: bits, partner = lane ^ 1
+  {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0xB1, 0xF, 0xF, false);
+    const uint32_t t = __builtin_amdgcn_alignbit(x, x, c.rot1);
+    d = (d & c.m1) | (t & ~c.m1);
+  }
+  return d;
+}
+__device__ __forceinline__ u64 wave_transpose64(u64 v, const TrConst& c) {
+  // 32: lanes 0..31 hand their upper dword to lanes 32..63 and get those lanes' lower dword
+  auto r = __builtin_amdgcn_permlane32_swap((uint32_t)v, (uint32_t)(v >> 32), false, false);
+  const uint32_t lo = tr_low_stages(r[0], c), hi = tr_low_stages(r[1], c);
   return ((u64)hi << 32) | lo;
 }
 
+// columns of exists ∩ filter per (shard, slot) cell: one wavefront per cell (dense rows); the Distinct with a filter needs them
+// before it can say where a cell's values go (without a filter the stored cardinalities of the exists row are the counts)
+__global__ void __launch_bounds__(256) k_bsi_cell_counts(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ rows, uint32_t n_shards,
+                                                        const uint8_t* __restrict__ farena, const uint32_t* __restrict__ frows,
+                                                        uint32_t* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= n_shards * kSlots) return;
+  const uint32_t shard = cell >> 4, slot = cell & 15;
+  const uint64_t rowBytes = (uint64_t)kSlots * 8192;
+  const ulonglong2* e = reinterpret_cast<const ulonglong2*>(arena + (uint64_t)rows[shard] * rowBytes + slot * 8192ull);
+  const ulonglong2* f = reinterpret_cast<const ulonglong2*>(farena + (uint64_t)frows[shard] * rowBytes + slot * 8192ull);
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const ulonglong2 a = e[j * kWave + lane], b = f[j * kWave + lane];
+    c += (uint32_t)__popcll(a.x & b.x) + (uint32_t)__popcll(a.y & b.y);
+  }
+  c = wave_reduce_add(c);
+  if (lane == 0) counts[cell] = c;
+}
+
+// cell_base[0 .. n_cells] = *carry + the exclusive prefix of the cells' counts (counts[] if given, else the stored cardinality of
+// the exists row's container); *carry moves on by the total.  One block.
+__global__ void __launch_bounds__(1024) k_bsi_cell_scan(const Slot* __restrict__ slots, const uint32_t* __restrict__ rows, const uint32_t* __restrict__ counts,
+                                                       uint32_t n_cells, u64* __restrict__ cell_base, u64* __restrict__ carry) {
+  __shared__ u64 wsum[16];
+  __shared__ u64 run;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) run = *carry;
+  __syncthreads();
+  for (uint32_t c0 = 0; c0 < n_cells; c0 += 1024) {
+    const uint32_t c = c0 + (uint32_t)t;
+    u64 v = 0;
+    if (c < n_cells) v = counts ? (u64)counts[c] : (u64)slot_n(slots[(uint64_t)rows[c >> 4] * kSlots + (c & 15)]);
+    u64 incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, o, kWave), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o, kWave);
+      if (lane >= o) incl += ((u64)hi << 32) | lo;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    u64 before = run;
+    for (int w = 0; w < wv; ++w) before += wsum[w];
+    if (c < n_cells) cell_base[c] = before + incl - v;
+    __syncthreads();
+    if (t == 1023) run = before + incl;
+    __syncthreads();
+  }
+  if (t == 0) {
+    cell_base[n_cells] = run;
+    *carry = run;
+  }
+}
+
 constexpr int kBsiValStride = 144;  // bytes per plane row of the staging tile (128 + 16)
+// Round 6.  `split` blocks per (shard, slot) cell, 16 / split rounds of 1024 columns per wave.  Where a value goes is ARITHMETIC:
+// cell_base[cell] (k_bsi_cell_scan) + the columns of the cell's earlier units — parts before this one, then waves before this one,
+// then rounds — which the block counts from the exists (∩ filter) words it reads anyway.  (Until round 5 every block reserved its
+// space with an atomic on ONE global cursor: 1024 serialised L2 round trips for a 4-shard field, a third of the kernel's 35 us.)
+// flag: set if a cell holds another number of columns than cell_base says (a stored cardinality that is wrong).
 __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ rows,
                                                    uint32_t n_shards, uint32_t depth, const uint8_t* __restrict__ farena,
                                                    const uint32_t* __restrict__ frows, long long* __restrict__ out,
-                                                   u64 out_cap, u64* __restrict__ cursor, uint32_t split) {
+                                                   u64 out_cap, const u64* __restrict__ cell_base, uint32_t* __restrict__ flag, uint32_t split) {
   __shared__ ulonglong2 stage[4][64 * kBsiValStride / 16];  // 4 x 9216 bytes: one 64-plane x 128-byte tile per wave
+  __shared__ uint32_t wtot[4], wpre[4];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t part = blockIdx.x % split, cell = blockIdx.x / split;  // split: 1, 2, 4, 8 or 16
   const uint32_t shard = cell >> 4, slot = cell & 15;
   if (shard >= n_shards) return;
-  const int rounds = 16 / (int)split;
+  const uint32_t R = 16u / split;  // rounds per wave
   const uint64_t rowBytes = (uint64_t)kSlots * 8192;
   const uint8_t* ex = arena + (uint64_t)rows[shard] * rowBytes + slot * 8192ull;
   const uint8_t* sg = ex + rowBytes;
   const uint8_t* fl = farena ? farena + (uint64_t)frows[shard] * rowBytes + slot * 8192ull : nullptr;
-  // Where this block's values go: ONE atomic on the global cursor per block (round 4 and the first cut of round 5 took one per wave and
-  // round: 4096 atomics on one address for a 4-shard field — ~50 us of serialised L2 round trips, which is what the kernel's 70 us were
-  // once it had enough blocks).  Each wave adds up the columns of its rounds (exists ∩ filter, 16 words per round), the block reserves
-  // the sum, a wave starts behind the waves before it.
-  __shared__ uint32_t wtot[4];
-  __shared__ u64 block_base;
-  {
-    uint32_t mine_tot = 0;
-    for (int round = (int)part * rounds; round < (int)(part + 1) * rounds; ++round) {
-      const uint32_t w0 = (uint32_t)wv * 256u + (uint32_t)round * 16u;
-      u64 e = 0;
-      if (lane < 16) {
-        e = reinterpret_cast<const u64*>(ex)[w0 + lane];
-        if (fl) e &= reinterpret_cast<const u64*>(fl)[w0 + lane];
-      }
-      mine_tot += (uint32_t)__popcll(e);
-    }
-    mine_tot = wave_reduce_add(mine_tot);
-    if (lane == 0) wtot[wv] = mine_tot;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t t = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-      block_base = t ? atomicAdd(cursor, (u64)t) : 0ull;
-    }
-    __syncthreads();
-  }
-  u64 wave_pos = block_base;
-  for (int w = 0; w < wv; ++w) wave_pos += wtot[w];
-  for (int round = (int)part * rounds; round < (int)(part + 1) * rounds; ++round) {
-    const uint32_t w0 = (uint32_t)wv * 256u + (uint32_t)round * 16u;  // first word of this round
-    // the 16 exists / filter / sign words of the round: lanes 0..15 fetch one each
-    u64 e = 0, sgn = 0;
-    if (lane < 16) {
-      e = reinterpret_cast<const u64*>(ex)[w0 + lane];
-      if (fl) e &= reinterpret_cast<const u64*>(fl)[w0 + lane];
-      sgn = reinterpret_cast<const u64*>(sg)[w0 + lane];
-    }
-    uint32_t pc = __popcll(e);  // lanes >= 16 hold 0
-    uint32_t incl = pc;         // inclusive prefix over the 16 words
+  const u64* exw = reinterpret_cast<const u64*>(ex);
+  const u64* flw = reinterpret_cast<const u64*>(fl);
+  const u64* sgw = reinterpret_cast<const u64*>(sg);
+  const u64 cbase = cell_base[cell], cnext = cell_base[cell + 1];
+  // this wave's exists ∩ filter and sign words: register j, lane l = word (4 j + l / 16) * 16 + l % 16 of the wave's rounds
+  const uint32_t wave_w0 = (uint32_t)wv * 256u + part * R * 16u;
+  u64 e[4], sn[4];
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      const uint32_t v = __shfl_up(incl, o, kWave);
-      if (lane >= o) incl += v;
+  for (int j = 0; j < 4; ++j) {
+    e[j] = 0;
+    sn[j] = 0;
+    if ((uint32_t)(4 * j) < R && (uint32_t)(4 * j) + ((uint32_t)lane >> 4) < R) {
+      const uint32_t w = wave_w0 + (uint32_t)j * 64u + (uint32_t)lane;
+      e[j] = exw[w];
+      if (fl) e[j] &= flw[w];
+      sn[j] = sgw[w];
     }
-    const uint32_t total = __shfl(incl, 15, kWave);
+  }
+  // columns of the cell's earlier parts in this wave's 256-word segment (and, for the last part, the whole cell: the check)
+  uint32_t pre = 0;
+  for (uint32_t w = (uint32_t)lane; w < part * R * 16u; w += kWave) {
+    u64 x = exw[(uint32_t)wv * 256u + w];
+    if (fl) x &= flw[(uint32_t)wv * 256u + w];
+    pre += (uint32_t)__popcll(x);
+  }
+  uint32_t pc[4], incl[4], mine = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    pc[j] = (uint32_t)__popcll(e[j]);
+    mine += pc[j];
+    // inclusive prefix inside each 16-lane row = inside each round
+    uint32_t v = pc[j];
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    incl[j] = v;
+  }
+  pre = wave_reduce_add(pre);
+  mine = wave_reduce_add(mine);
+  if (lane == 0) {
+    wpre[wv] = pre;
+    wtot[wv] = mine;
+  }
+  __syncthreads();
+  u64 wave_pos = cbase + wpre[0] + wpre[1] + wpre[2] + wpre[3];
+  for (int w = 0; w < wv; ++w) wave_pos += wtot[w];
+  if (part == split - 1 && threadIdx.x == 0) {
+    const u64 total = (u64)wpre[0] + wpre[1] + wpre[2] + wpre[3] + wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (total != cnext - cbase) atomicOr(flag, 1u);
+  }
+  if (mine == 0) return;  // (wave-uniform; no barrier follows)
+  const TrConst tc = tr_const(lane);
+  uint8_t* stg = reinterpret_cast<uint8_t*>(&stage[wv][0]);
+  for (uint32_t r = 0; r < R; ++r) {
+    const int j = (int)(r >> 2), row0 = (int)(r & 3u) * 16;  // register and first lane of this round's 16 words
+    const u64 ej = j == 0 ? e[0] : j == 1 ? e[1] : j == 2 ? e[2] : e[3];
+    const u64 sj = j == 0 ? sn[0] : j == 1 ? sn[1] : j == 2 ? sn[2] : sn[3];
+    const uint32_t inj = j == 0 ? incl[0] : j == 1 ? incl[1] : j == 2 ? incl[2] : incl[3];
+    const uint32_t pcj = j == 0 ? pc[0] : j == 1 ? pc[1] : j == 2 ? pc[2] : pc[3];
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inj, row0 + 15);
     if (total == 0) continue;  // wave-uniform: no column of these 1024 has a value
     const u64 basepos = wave_pos;
     wave_pos += total;
-    // this lane's plane: 16 words = one 128-byte line.  Loaded COALESCED — instruction j brings the lines of planes 8 j .. 8 j + 7,
+    const uint32_t w0 = wave_w0 + r * 16u;  // first word of this round
+    // this lane's plane: 16 words = one 128-byte line.  Loaded COALESCED — instruction i brings the lines of planes 8 i .. 8 i + 7,
     // eight lanes per line — and handed to lane `plane` through the wave's LDS staging (row stride 144 B: the eight lanes of a
-    // 16-byte-per-lane access fall into eight different bank groups both ways).  Round 4's form had every lane read its own
-    // plane's line directly: 64 different lines per load instruction, 0.03 of the HBM rate.
+    // 16-byte-per-lane access fall into eight different bank groups both ways).
     u64 pw[16];
     {
-      uint8_t* stg = reinterpret_cast<uint8_t*>(&stage[wv][0]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int plane = 8 * j + (lane >> 3), piece = lane & 7;
+      for (int i = 0; i < 8; ++i) {
+        const int plane = 8 * i + (lane >> 3), piece = lane & 7;
         ulonglong2 v;
         v.x = v.y = 0;
         if (plane < (int)depth) v = ld_stream(reinterpret_cast<const ulonglong2*>(ex + (uint64_t)(2 + plane) * rowBytes + (uint64_t)w0 * 8) + piece);
@@ -1206,31 +1338,20 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
       }
       wave_lds_sync();  // (the next round writes the staging again)
     }
+    const uint32_t exc = inj - pcj;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const u64 ek = ((u64)(uint32_t)__shfl((int)(uint32_t)(e >> 32), k, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)e, k, kWave);
-      if (ek != 0) {  // wave-uniform
-      const u64 sk = ((u64)(uint32_t)__shfl((int)(uint32_t)(sgn >> 32), k, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)sgn, k, kWave);
-      const uint32_t before = __shfl(incl - pc, k, kWave);  // values emitted by words 0..k-1 of the round
-      // 64 x 64 transpose: row = lane (plane), bit = column  ->  row = column, bit = plane
-      u64 v = pw[k];
-#pragma unroll
-      for (int st = 0; st < 6; ++st) {
-        const int j = 32 >> st;
-        const u64 km = st == 0 ? 0x00000000FFFFFFFFull : st == 1 ? 0x0000FFFF0000FFFFull : st == 2 ? 0x00FF00FF00FF00FFull
-                     : st == 3 ? 0x0F0F0F0F0F0F0F0Full : st == 4 ? 0x3333333333333333ull : 0x5555555555555555ull;
-        const u64 x = shfl_xor_u64(v, j);
-        v = (lane & j) ? (((x >> j) & km) | (v & ~km)) : ((v & km) | ((x & km) << j));
-      }
+      const u64 v = wave_transpose64(pw[k], tc);  // (all sixteen transposes are independent: straight-line code)
+      const uint32_t elo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ej, row0 + k), ehi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ej >> 32), row0 + k);
+      const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sj, row0 + k), shi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sj >> 32), row0 + k);
+      const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)exc, row0 + k);  // values emitted by words 0..k-1 of the round
+      const u64 ek = ((u64)ehi << 32) | elo, sk = ((u64)shi << 32) | slo;
       if ((ek >> lane) & 1ull) {
         const u64 below = lane ? (ek & (~0ull >> (64 - lane))) : 0ull;
         // value *= -1 for negative columns (int64 wrap-around as in the reference, executor.go:2123)
         const long long val = ((sk >> lane) & 1ull) ? (long long)(0ull - v) : (long long)v;
-        // out was sized from the stored cardinalities of the exists row; the cursor still counts
-        // every value, so the host sees an overflow instead of a write past the buffer
         const u64 at = basepos + before + __popcll(below);
-        if (at < out_cap) out[at] = val;
-      }
+        if (at < out_cap && at < cnext) out[at] = val;
       }
     }
   }
