@@ -1060,44 +1060,154 @@ __global__ void __launch_bounds__(256) k_bsi_add(const Slot* __restrict__ slotsX
   __shared__ u64 scratch[kWords];
   __shared__ u64 part[4];
   __shared__ uint8_t tops[512];
+  // Round 6.  The (group, slot)'s descriptors come into the LDS ONCE, in one parallel round of loads (until round 5 every plane
+  // step walked row index -> descriptor -> payload: three dependent round trips per plane), and when every plane is a bitmap (or
+  // nil: the usual case) the planes go FOUR AT A TIME — sixteen 16-byte loads per thread in flight where there were four — with no
+  // barrier in the loop: a wave leaves its share of each plane's cardinality and run count in the LDS and the block adds them up
+  // once at the end.
+  __shared__ Slot dsc[2][65];
+  __shared__ uint32_t wpc[66][4], wrr[66][4];
+  __shared__ uint8_t wedge[66][4][4];  // per plane and wave: bit 0 of the first lane's z0 and z2, top bit of the last lane's z1 and z3
+  __shared__ int slow;
   const int t = threadIdx.x;
   const uint64_t g = blockIdx.x >> 4;
   const uint32_t slot = blockIdx.x & 15;
   if (g >= n_groups) return;
   const uint32_t D = max(dx, dy);
+  if (t == 0) slow = 0;
+  __syncthreads();
+  if ((uint32_t)t < dx) {
+    const Slot sl = slotsX[(uint64_t)rowsX[g * dx + t] * kSlots + slot];
+    dsc[0][t] = sl;
+    if (!bfrag_is_fast(sl)) slow = 1;
+  } else if (t >= 128 && (uint32_t)(t - 128) < dy) {
+    const Slot sl = slotsY[(uint64_t)rowsY[g * dy + (t - 128)] * kSlots + slot];
+    dsc[1][t - 128] = sl;
+    if (!bfrag_is_fast(sl)) slow = 1;
+  }
+  __syncthreads();
   u64 c[kBW], x[kBW], y[kBW], z[kBW];
   bfrag_zero(c);
-  for (uint32_t i = 0; i <= D; ++i) {
-    bfrag_zero(x);
-    bfrag_zero(y);
-    if (i < dx) bfrag_load(slotsX[(uint64_t)rowsX[g * dx + i] * kSlots + slot], arenaX, t, scratch, x);
-    if (i < dy) bfrag_load(slotsY[(uint64_t)rowsY[g * dy + i] * kSlots + slot], arenaY, t, scratch, y);
+  if (slow) {
+    // array / run containers among the planes: the decoding path (block barriers inside bfrag_load), one plane per step
+    for (uint32_t i = 0; i <= D; ++i) {
+      bfrag_zero(x);
+      bfrag_zero(y);
+      if (i < dx) bfrag_load(dsc[0][i], arenaX, t, scratch, x);
+      if (i < dy) bfrag_load(dsc[1][i], arenaY, t, scratch, y);
 #pragma unroll
-    for (int q = 0; q < kBW; ++q) {
-      z[q] = x[q] ^ y[q] ^ c[q];
-      c[q] = (x[q] & y[q]) | (c[q] & (x[q] ^ y[q]));
+      for (int q = 0; q < kBW; ++q) {
+        z[q] = x[q] ^ y[q] ^ c[q];
+        c[q] = (x[q] & y[q]) | (c[q] & (x[q] ^ y[q]));
+      }
+      const uint64_t cell = (g * (D + 1) + i) * kSlots + slot;
+      const uint32_t n = (uint32_t)block_reduce_add_u64(bfrag_popcount(z), part);
+      Slot so;
+      so.off = cell * 8192ull;
+      so.len = kWords;
+      so.tn = make_tn(n ? kTypeBitmap : kTypeNil, n);
+      if (n) bfrag_store_bitmap(arenaO + so.off, t, z);
+      uint32_t rr = 0;
+      if (outRuns) {  // bitmapCountRuns for the optimize() pass
+        __syncthreads();
+        tops[t] = (uint8_t)(z[1] >> 63);
+        tops[256 + t] = (uint8_t)(z[3] >> 63);
+        __syncthreads();
+        const u64 l0 = t ? tops[t - 1] : 0, l1 = tops[255 + t];
+        const uint32_t r = __popcll(z[0] & ~((z[0] << 1) | l0)) + __popcll(z[1] & ~((z[1] << 1) | (z[0] >> 63))) +
+                           __popcll(z[2] & ~((z[2] << 1) | l1)) + __popcll(z[3] & ~((z[3] << 1) | (z[2] >> 63)));
+        rr = (uint32_t)block_reduce_add_u64(r, part);
+      }
+      if (t == 0) {
+        outSlots[cell] = so;
+        if (outRuns) outRuns[cell] = rr;
+      }
     }
-    const uint64_t cell = (g * (D + 1) + i) * kSlots + slot;
-    const uint32_t n = (uint32_t)block_reduce_add_u64(bfrag_popcount(z), part);
+    return;
+  }
+  const int lane = t & 63, wv = t >> 6;
+  constexpr int U = 4;  // planes per round of loads
+  const uint64_t cell0 = g * (D + 1) * kSlots + slot;  // cell of plane i: cell0 + i * kSlots
+  for (uint32_t i0 = 0; i0 <= D; i0 += U) {
+    ulonglong2 xa[U][2], ya[U][2];
+    u64 mx[U], my[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // a plane that is not there (past an operand's depth, nil, empty) reads this step's own output cell — valid memory — under a zero mask
+      const uint32_t i = min(i0 + (uint32_t)u, D);
+      const uint8_t* dummy = arenaO + (cell0 + (uint64_t)i * kSlots) * 8192ull;
+      const Slot sx = dsc[0][min(i, 64u)], sy = dsc[1][min(i, 64u)];
+      const bool lx = i0 + u < dx && slot_n(sx) != 0 && slot_type(sx) == kTypeBitmap, ly = i0 + u < dy && slot_n(sy) != 0 && slot_type(sy) == kTypeBitmap;
+      mx[u] = lx ? ~0ull : 0ull;
+      my[u] = ly ? ~0ull : 0ull;
+      const ulonglong2* qx = reinterpret_cast<const ulonglong2*>(lx ? arenaX + sx.off : dummy);
+      const ulonglong2* qy = reinterpret_cast<const ulonglong2*>(ly ? arenaY + sy.off : dummy);
+      xa[u][0] = ld_stream(&qx[t]);
+      xa[u][1] = ld_stream(&qx[256 + t]);
+      ya[u][0] = ld_stream(&qy[t]);
+      ya[u][1] = ld_stream(&qy[256 + t]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + (uint32_t)u;
+      if (i > D) break;  // (block-uniform)
+      x[0] = xa[u][0].x & mx[u];
+      x[1] = xa[u][0].y & mx[u];
+      x[2] = xa[u][1].x & mx[u];
+      x[3] = xa[u][1].y & mx[u];
+      y[0] = ya[u][0].x & my[u];
+      y[1] = ya[u][0].y & my[u];
+      y[2] = ya[u][1].x & my[u];
+      y[3] = ya[u][1].y & my[u];
+#pragma unroll
+      for (int q = 0; q < kBW; ++q) {
+        z[q] = x[q] ^ y[q] ^ c[q];
+        c[q] = (x[q] & y[q]) | (c[q] & (x[q] ^ y[q]));
+      }
+      // always stored (an empty plane's cell is described as nil below: its bytes are never read)
+      bfrag_store_bitmap(arenaO + (cell0 + (uint64_t)i * kSlots) * 8192ull, t, z);
+      const uint32_t pc = wave_reduce_add(bfrag_popcount(z));
+      if (lane == 0) wpc[i][wv] = pc;
+      if (outRuns) {
+        // run starts with the predecessor bit taken from the lane below (words 2t, 2t + 1 and 512 + 2t, 513 + 2t); a wave's first
+        // lane assumes "no predecessor" and the block corrects that from the waves' edge bits at the end
+        const uint32_t t1 = (uint32_t)(z[1] >> 63), t3 = (uint32_t)(z[3] >> 63);
+        uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t1, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        uint32_t p3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t3, 0x138, 0xF, 0xF, false);
+        if (lane == 0) p1 = p3 = 0;
+        uint32_t r = __popcll(z[0] & ~((z[0] << 1) | (u64)p1)) + __popcll(z[1] & ~((z[1] << 1) | (z[0] >> 63))) +
+                     __popcll(z[2] & ~((z[2] << 1) | (u64)p3)) + __popcll(z[3] & ~((z[3] << 1) | (z[2] >> 63)));
+        r = wave_reduce_add(r);
+        if (lane == 0) {
+          wrr[i][wv] = r;
+          wedge[i][wv][0] = (uint8_t)(z[0] & 1ull);
+          wedge[i][wv][1] = (uint8_t)(z[2] & 1ull);
+        }
+        if (lane == 63) {
+          wedge[i][wv][2] = (uint8_t)t1;
+          wedge[i][wv][3] = (uint8_t)t3;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if ((uint32_t)t <= D) {
+    const uint32_t i = (uint32_t)t;
+    const uint32_t n = wpc[i][0] + wpc[i][1] + wpc[i][2] + wpc[i][3];
+    const uint64_t cell = cell0 + (uint64_t)i * kSlots;
     Slot so;
     so.off = cell * 8192ull;
     so.len = kWords;
     so.tn = make_tn(n ? kTypeBitmap : kTypeNil, n);
-    if (n) bfrag_store_bitmap(arenaO + so.off, t, z);
-    uint32_t rr = 0;
-    if (outRuns) {  // bitmapCountRuns for the optimize() pass
-      __syncthreads();
-      tops[t] = (uint8_t)(z[1] >> 63);
-      tops[256 + t] = (uint8_t)(z[3] >> 63);
-      __syncthreads();
-      const u64 l0 = t ? tops[t - 1] : 0, l1 = tops[255 + t];
-      const uint32_t r = __popcll(z[0] & ~((z[0] << 1) | l0)) + __popcll(z[1] & ~((z[1] << 1) | (z[0] >> 63))) +
-                         __popcll(z[2] & ~((z[2] << 1) | l1)) + __popcll(z[3] & ~((z[3] << 1) | (z[2] >> 63)));
-      rr = (uint32_t)block_reduce_add_u64(r, part);
-    }
-    if (t == 0) {
-      outSlots[cell] = so;
-      if (outRuns) outRuns[cell] = rr;
+    outSlots[cell] = so;
+    if (outRuns) {
+      uint32_t rr = wrr[i][0] + wrr[i][1] + wrr[i][2] + wrr[i][3];
+      // a wave's first word continues a run that ends in the word before it: words 0..511 — wave w's first is 128 w, its
+      // predecessor the last of wave w - 1's z1; words 512..1023 — wave w's first is 512 + 128 w, predecessor wave w - 1's z3
+      // (wave 0's: word 511 = wave 3's z1)
+      for (int w = 1; w < 4; ++w) rr -= (uint32_t)(wedge[i][w][0] & wedge[i][w - 1][2]) + (uint32_t)(wedge[i][w][1] & wedge[i][w - 1][3]);
+      rr -= (uint32_t)(wedge[i][0][1] & wedge[i][3][2]);
+      outRuns[cell] = rr;
     }
   }
 }
@@ -1142,25 +1252,25 @@ __device__ __forceinline__ uint32_t tr_low_stages(uint32_t d, const TrConst& c) 
   }
   // 8: bytes, partner = lane ^ 8 (row_ror:8 inside the 16-lane row)
   {
-    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x128, 0xF, 0xF, false);
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x128, 0xF, 0xF, true);
     d = __builtin_amdgcn_perm(x, d, c.sel8);
   }
   // 4: nibbles, partner = lane ^ 4 (lanes of banks 0 / 2 read four lanes up, banks 1 / 3 four lanes down)
   {
-    uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x104, 0xF, 0x5, false);
+    uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x104, 0xF, 0xF, true);  // (every lane written: no initialisation; banks 1 / 3 are replaced next)
     x = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)d, 0x114, 0xF, 0xA, false);
     const uint32_t t = __builtin_amdgcn_alignbit(x, x, c.rot4);
     d = (d & c.m4) | (t & ~c.m4);
   }
   // 2: bit pairs, partner = lane ^ 2
   {
-    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x4E, 0xF, 0xF, false);
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x4E, 0xF, 0xF, true);
     const uint32_t t = __builtin_amdgcn_alignbit(x, x, c.rot2);
     d = (d & c.m2) | (t & ~c.m2);
   }
   // 1: bits, partner = lane ^ 1
   {
-    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0xB1, 0xF, 0xF, false);
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0xB1, 0xF, 0xF, true);
     const uint32_t t = __builtin_amdgcn_alignbit(x, x, c.rot1);
     d = (d & c.m1) | (t & ~c.m1);
   }
@@ -1255,39 +1365,18 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
   const u64* flw = reinterpret_cast<const u64*>(fl);
   const u64* sgw = reinterpret_cast<const u64*>(sg);
   const u64 cbase = cell_base[cell], cnext = cell_base[cell + 1];
-  // this wave's exists ∩ filter and sign words: register j, lane l = word (4 j + l / 16) * 16 + l % 16 of the wave's rounds
+  // columns of this wave's own rounds and of the cell's earlier parts in this wave's 256-word segment
   const uint32_t wave_w0 = (uint32_t)wv * 256u + part * R * 16u;
-  u64 e[4], sn[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    e[j] = 0;
-    sn[j] = 0;
-    if ((uint32_t)(4 * j) < R && (uint32_t)(4 * j) + ((uint32_t)lane >> 4) < R) {
-      const uint32_t w = wave_w0 + (uint32_t)j * 64u + (uint32_t)lane;
-      e[j] = exw[w];
-      if (fl) e[j] &= flw[w];
-      sn[j] = sgw[w];
-    }
+  uint32_t mine = 0, pre = 0;
+  for (uint32_t w = (uint32_t)lane; w < R * 16u; w += kWave) {
+    u64 x = exw[wave_w0 + w];
+    if (fl) x &= flw[wave_w0 + w];
+    mine += (uint32_t)__popcll(x);
   }
-  // columns of the cell's earlier parts in this wave's 256-word segment (and, for the last part, the whole cell: the check)
-  uint32_t pre = 0;
   for (uint32_t w = (uint32_t)lane; w < part * R * 16u; w += kWave) {
     u64 x = exw[(uint32_t)wv * 256u + w];
     if (fl) x &= flw[(uint32_t)wv * 256u + w];
     pre += (uint32_t)__popcll(x);
-  }
-  uint32_t pc[4], incl[4], mine = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    pc[j] = (uint32_t)__popcll(e[j]);
-    mine += pc[j];
-    // inclusive prefix inside each 16-lane row = inside each round
-    uint32_t v = pc[j];
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
-    incl[j] = v;
   }
   pre = wave_reduce_add(pre);
   mine = wave_reduce_add(mine);
@@ -1304,18 +1393,25 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
   }
   if (mine == 0) return;  // (wave-uniform; no barrier follows)
   const TrConst tc = tr_const(lane);
+  const uint32_t bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane < 32 ? 0u : 1u << (lane - 32);
   uint8_t* stg = reinterpret_cast<uint8_t*>(&stage[wv][0]);
   for (uint32_t r = 0; r < R; ++r) {
-    const int j = (int)(r >> 2), row0 = (int)(r & 3u) * 16;  // register and first lane of this round's 16 words
-    const u64 ej = j == 0 ? e[0] : j == 1 ? e[1] : j == 2 ? e[2] : e[3];
-    const u64 sj = j == 0 ? sn[0] : j == 1 ? sn[1] : j == 2 ? sn[2] : sn[3];
-    const uint32_t inj = j == 0 ? incl[0] : j == 1 ? incl[1] : j == 2 ? incl[2] : incl[3];
-    const uint32_t pcj = j == 0 ? pc[0] : j == 1 ? pc[1] : j == 2 ? pc[2] : pc[3];
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inj, row0 + 15);
-    if (total == 0) continue;  // wave-uniform: no column of these 1024 has a value
-    const u64 basepos = wave_pos;
-    wave_pos += total;
     const uint32_t w0 = wave_w0 + r * 16u;  // first word of this round
+    // the round's sixteen exists (∩ filter) and sign words: wave-uniform addresses, i.e. SCALAR loads — the per-word masks, their
+    // popcounts and the running position stay in scalar registers (until round 6 lanes 0..15 held them and every word cost five
+    // v_readlane and a lane-wise prefix)
+    u64 ew[16], sw[16];
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      ew[k] = exw[w0 + k];
+      if (fl) ew[k] &= flw[w0 + k];
+      sw[k] = sgw[w0 + k];
+      total += (uint32_t)__popcll(ew[k]);
+    }
+    if (total == 0) continue;  // wave-uniform: no column of these 1024 has a value
+    u64 pos = wave_pos;
+    wave_pos += total;
     // this lane's plane: 16 words = one 128-byte line.  Loaded COALESCED — instruction i brings the lines of planes 8 i .. 8 i + 7,
     // eight lanes per line — and handed to lane `plane` through the wave's LDS staging (row stride 144 B: the eight lanes of a
     // 16-byte-per-lane access fall into eight different bank groups both ways).
@@ -1338,21 +1434,20 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
       }
       wave_lds_sync();  // (the next round writes the staging again)
     }
-    const uint32_t exc = inj - pcj;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pw[k] = wave_transpose64(pw[k], tc);  // sixteen independent transposes: straight-line code the scheduler interleaves
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const u64 v = wave_transpose64(pw[k], tc);  // (all sixteen transposes are independent: straight-line code)
-      const uint32_t elo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ej, row0 + k), ehi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ej >> 32), row0 + k);
-      const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sj, row0 + k), shi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sj >> 32), row0 + k);
-      const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)exc, row0 + k);  // values emitted by words 0..k-1 of the round
-      const u64 ek = ((u64)ehi << 32) | elo, sk = ((u64)shi << 32) | slo;
-      if ((ek >> lane) & 1ull) {
-        const u64 below = lane ? (ek & (~0ull >> (64 - lane))) : 0ull;
+      const u64 v = pw[k];
+      const uint32_t elo = (uint32_t)ew[k], ehi = (uint32_t)(ew[k] >> 32), slo = (uint32_t)sw[k], shi = (uint32_t)(sw[k] >> 32);
+      if (((elo & bit_lo) | (ehi & bit_hi)) != 0u) {
         // value *= -1 for negative columns (int64 wrap-around as in the reference, executor.go:2123)
-        const long long val = ((sk >> lane) & 1ull) ? (long long)(0ull - v) : (long long)v;
-        const u64 at = basepos + before + __popcll(below);
+        const long long val = (((slo & bit_lo) | (shi & bit_hi)) != 0u) ? (long long)(0ull - v) : (long long)v;
+        const u64 at = pos + __builtin_amdgcn_mbcnt_hi(ehi, __builtin_amdgcn_mbcnt_lo(elo, 0u));  // + the existing columns below this lane
         if (at < out_cap && at < cnext) out[at] = val;
       }
+      pos += (uint32_t)__popcll(ew[k]);
     }
   }
 }

@@ -23,11 +23,18 @@ fuzz)  # the seeded GPU parity tests re-rolled with fresh seeds
 gpu_tests)
   timeout 1500 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu_tests rc $?"; tail -3 $O/gpu_tests.log ;;
 bench)
-  timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"; cut -c1-600 $O/bench.json ;;
+  timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"; cut -c1-600 $O/bench.json; cp bench_detail.json $O/bench_detail.json 2>/dev/null ;;
 pair_tests)  # every test file that drives the pair kernels
   timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_fuzz_struct.py tests/test_gpu_fullsize.py tests/test_gpu_queries.py -x -q -m gpu -n ${WORKERS:-4} > $O/pair_tests.log 2>&1; echo "pair_tests rc $?"; tail -3 $O/pair_tests.log ;;
 ab)  # the pair kernels of several library builds side by side (LIBS, SHARDS, OPS as scripts/ab_pairs.sh)
   TAG=$TAG bash scripts/ab_pairs.sh ;;
+first_launches)  # slow first launches after an upload / after idling
+  timeout 900 python scripts/first_launches.py --shards ${SHARDS:-512} --out $O/first_launches.json > $O/first_launches.txt 2>&1; echo "first_launches rc $?"; grep -v "^\[" $O/first_launches.txt | tail -20 ;;
+misc)  # rocprofv3 per-grid trace of the kernels the bench line does not reach
+  cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/misc_trace -- python $R/scripts/profile_misc.py > $O/misc.log 2>&1; cd $R
+  f=$(find $O/misc_trace -name "*kernel_trace.csv" | head -1); python scripts/kernel_trace_by_grid.py $f 3 > $O/misc_kernel_trace_by_grid.csv; grep -h "k_bsi_values\|k_bsi_cell\|k_bsi_add\|outlier" $O/misc_kernel_trace_by_grid.csv | head ;;
+distinct_tests)
+  timeout 600 python -m pytest tests/test_gpu_queries.py -x -q -m gpu -k "distinct or bsi" > $O/distinct_tests.log 2>&1; echo "distinct_tests rc $?"; tail -3 $O/distinct_tests.log ;;
 *) echo "unknown: $what" ;;
 esac
 done
