@@ -1266,6 +1266,56 @@ def test_fragment_topn_vectors_through_fbk_topk(gpu_ctx, oracle):
             F.free()
 
 
+def test_bsi_add_all_bitmap_planes_fast_path(gpu_ctx, oracle):
+    """k_bsi_add's round-6 path for operands whose planes are all bitmaps (or nil): descriptors staged in the LDS, four planes per
+    round of loads, cardinalities and run counts left per wave and added up once at the end.  Dense planes (every column holds a
+    value), operands of different depth, a nil plane in the middle, and planes that are long RUNS across wave and half-container
+    boundaries (words 127 / 128, 511 / 512 ...): x + y per column against numpy, and with FBK_SETOP_OPTIMIZE every result
+    container in Container.optimize()'s encoding (the run counts the kernel hands to the encoder are what decides it)."""
+    O = oracle
+    rng = D.rng_for(6061)
+    n_groups, ncol = 2, 1 << 20
+    for dx, dy in ((12, 12), (9, 13), (5, 2)):
+        xv = rng.integers(0, 1 << dx, size=(n_groups, ncol), dtype=np.uint64)
+        yv = rng.integers(0, 1 << dy, size=(n_groups, ncol), dtype=np.uint64)
+        # group 1: long constant stretches, so that planes are runs whose ends fall on the boundaries between waves' words
+        edges = [0, 64 * 127 + 63, 64 * 128, 64 * 511 + 1, 64 * 512, 64 * 640 - 1, 65536, 65536 + 64 * 256, 3 * 65536 - 5, 5 * 65536 + 64 * 384 + 63, ncol]
+        for a, b in zip(edges[:-1], edges[1:]):
+            xv[1, a:b] = rng.integers(0, 1 << dx)
+            yv[1, a:b] = rng.integers(0, 1 << dy)
+        xv[:, :] &= ~np.uint64(1 << 2)  # plane 2 of x is nil in every group
+        def planes(v, depth):
+            out = np.zeros((n_groups * depth, 16, 1024), dtype=np.uint64)
+            for g in range(n_groups):
+                for i in range(depth):
+                    bits = ((v[g] >> np.uint64(i)) & np.uint64(1)).astype(np.uint8)
+                    out[g * depth + i] = np.packbits(bits, bitorder="little").view(np.uint64).reshape(16, 1024)
+            return out
+        X, Y = gpu_ctx.upload_dense(planes(xv, dx)), gpu_ctx.upload_dense(planes(yv, dy))
+        rx = np.arange(n_groups * dx).reshape(n_groups, dx)
+        ry = np.arange(n_groups * dy).reshape(n_groups, dy)
+        zv = xv + yv
+        Dp = max(dx, dy) + 1
+        for flags in (0, L.SETOP_OPTIMIZE):
+            out = gpu_ctx.bsi_add(X, rx, Y, ry, flags)
+            rows = out.download()
+            assert len(rows) == n_groups * Dp
+            for g in range(n_groups):
+                for i in range(Dp):
+                    bits = ((zv[g] >> np.uint64(i)) & np.uint64(1)).astype(np.uint8)
+                    exp_w = np.packbits(bits, bitorder="little").view(np.uint64).reshape(16, 1024)
+                    got = rows[g * Dp + i]
+                    exp_bm = {s: O.OContainer.bitmap(exp_w[s]) for s in range(16) if exp_w[s].any()}
+                    assert {k & 15 for k in got} == set(exp_bm), (dx, dy, flags, g, i)
+                    for k, c in got.items():
+                        assert np.array_equal(c.words(), exp_w[k & 15]), (dx, dy, flags, g, i, k)
+                    if flags & L.SETOP_OPTIMIZE:
+                        assert_optimized_like_oracle(O, got, exp_bm)
+            out.free()
+        X.free()
+        Y.free()
+
+
 def test_bsi_add_reference_cases(gpu_ctx, oracle):
     """TestBSIAddCases (bsi_test.go:116-160): the reference's own AddBSI inputs — twenty positions
     with counts up to 9 023 592 401, and the two-position case — through fbk_bsi_add; every
