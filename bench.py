@@ -497,8 +497,10 @@ def secondary_configs(torch, dev, ctx, stream, pre3, args, want_cpu):
             OA.free()
             OF.free()
         types = np.bincount(d4["type"], minlength=4)
-        # (this kernel's first ~10 launches after an upload run 10-15 % slower than its sustained rate — clock ramp or TLB warm-up, not
-        # chased: both are reported, the entry's kernel_us is the SUSTAINED one, SURVEY 8d's protocol being "warm-up, then >= 20 timed")
+        # (this kernel's first ~10 launches after ANY pause of the device — here: seconds of host-only oracle work — run up to 30 %
+        # slower than its sustained rate: the shader clock dips to ~1.7 GHz on the load step and is back at 2.2 GHz after ~15 ms,
+        # scripts/first_launches.py, profiles/r06_first_launches.txt.  Both are reported; the entry's kernel_us is the SUSTAINED one,
+        # SURVEY 8d's protocol being "warm-up, then >= 20 timed")
         _, _, kq_first = _timed_query(torch, stream, q4m, 5, ctx, warm=0)
         g, w, kq = _timed_query(torch, stream, q4m, 20, ctx, warm=10)
         out.append(_entry(f"c4.loguniform_slice|config4 slice as SURVEY 8d writes it: {n4m} shards x (32 x 32 rows, densities log-uniform [0.001, 0.5] + filter p = 0.5), IntersectionCount matrix on ENCODED rows",

@@ -1400,13 +1400,12 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
     // the round's sixteen exists (∩ filter) and sign words: wave-uniform addresses, i.e. SCALAR loads — the per-word masks, their
     // popcounts and the running position stay in scalar registers (until round 6 lanes 0..15 held them and every word cost five
     // v_readlane and a lane-wise prefix)
-    u64 ew[16], sw[16];
+    u64 ew[16];
     uint32_t total = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       ew[k] = exw[w0 + k];
       if (fl) ew[k] &= flw[w0 + k];
-      sw[k] = sgw[w0 + k];
       total += (uint32_t)__popcll(ew[k]);
     }
     if (total == 0) continue;  // wave-uniform: no column of these 1024 has a value
@@ -1440,7 +1439,8 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const u64 v = pw[k];
-      const uint32_t elo = (uint32_t)ew[k], ehi = (uint32_t)(ew[k] >> 32), slo = (uint32_t)sw[k], shi = (uint32_t)(sw[k] >> 32);
+      const u64 swk = sgw[w0 + k];  // (a scalar load per word, next to its use: all sixteen held from the top of the round overflow the scalar file)
+      const uint32_t elo = (uint32_t)ew[k], ehi = (uint32_t)(ew[k] >> 32), slo = (uint32_t)swk, shi = (uint32_t)(swk >> 32);
       if (((elo & bit_lo) | (ehi & bit_hi)) != 0u) {
         // value *= -1 for negative columns (int64 wrap-around as in the reference, executor.go:2123)
         const long long val = (((slo & bit_lo) | (shi & bit_hi)) != 0u) ? (long long)(0ull - v) : (long long)v;

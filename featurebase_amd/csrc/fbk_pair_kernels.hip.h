@@ -848,6 +848,9 @@ __global__ void __launch_bounds__(64 * WPB) k_icount2(const Slot* __restrict__ s
     if (stamp == 1) spart = (uint32_t)(t_mark - t_prev);
     if (stamp != 4) t_prev = t_mark;
   }
+  // (Round 6 tried an L2 PREFETCH here — one dword per 128-byte line of the payloads of the item 1536 / 4608 / 9216 waves ahead, so
+  // that the wave that takes this wave's slot a generation later finds them in the L2 / Infinity Cache: 162.5 / 171.4 / 174.1 us
+  // against 156.5-156.7, profiles/r06_pairs_prefetch_ahead_ab.txt.  More bytes in flight make this access pattern SLOWER.)
   if (!(sparse_paths & 0x400u)) {  // (0x400: timing experiment, descriptors only)
     item_prefetch(sa[0], arenaA, sb[0], arenaB, lane, va, vb, sparse_paths);
     if (stamp) {
