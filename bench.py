@@ -659,13 +659,20 @@ def config4_strong_mixed(torch, dist, fdist, dev, ctx, stream, rank, world, args
     t_chk, PB = 0.0, None
     if want_cpu:
         from oracle import pybatch as PB
+    first_run_us = []
     for s0 in range(0, ns, 1024):
         m = min(1024, ns - s0)
         d, p, nr, g, fd, fp, nb = D.config3_flat_subprocess(m, n_a + n_b, 4000, config4=True, first_shard=first + s0)
         batch, F = ctx.upload_flat(d, p, nr), ctx.upload_flat(fd, fp, m)
         ga, gb, fidx = np.ascontiguousarray(g[:, :n_a]), np.ascontiguousarray(g[:, n_a:]), np.arange(m)
         q = ctx.prepare_count_matrix(batch, ga, batch, gb, F, fidx, keep_per_shard=True)
+        # (the FIRST execution of each slice's query — window index, shadows and program are built in front of it — is timed by itself:
+        # rocprofv3 shows this launch at 22-35 ms in round 5's and round 6's traces, profiles/r06_kernel_trace_by_grid.csv)
+        ctx.set_option("time_kernels", 1)
         q.run()
+        torch.cuda.synchronize()
+        first_run_us.append(round(ctx.get_option("last_kernel_ns") / 1e3, 1))
+        ctx.set_option("time_kernels", 0)
         tot, ps = q.read(per_shard=True)
         if want_cpu:  # EVERY shard of the slice against the oracle
             t1 = time.perf_counter()
@@ -720,6 +727,7 @@ def config4_strong_mixed(torch, dist, fdist, dev, ctx, stream, rank, world, args
             "shards_total": total, "shards_this_rank": ns, "slices": len(qs), "resident_bytes_this_rank": int(nbytes), "make_resident_s": resident_s,
             "ms_per_query_pipelined": tv[0] * 1e3, "set_ops_per_s": total * 16 * n_a * n_b / tv[0] if tv[0] else None, "kernel": "k_count_matrix_fusedq", "kernel_us": k_med,
             "kernel_us_max_over_ranks": tv[1], "kernel_frac": (nbytes / (k_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) if k_med else None, "parity": parity,
+            "kernel_us_first_run_of_each_slice": first_run_us,
             "collectives": res["collectives"], "latency_s": res["latency_s"]}
 
 

@@ -1367,6 +1367,21 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
   const u64 cbase = cell_base[cell], cnext = cell_base[cell + 1];
   // columns of this wave's own rounds and of the cell's earlier parts in this wave's 256-word segment
   const uint32_t wave_w0 = (uint32_t)wv * 256u + part * R * 16u;
+  // The planes of round 0 are REQUESTED here, before the exists words are even counted (a round without a column has loaded them
+  // for nothing: rare, a BSI's exists row is dense): the two memory round trips of a one-round wave — a small field — overlap.
+  // Instruction i brings the lines of planes 8 i .. 8 i + 7, eight lanes per 128-byte line.  Later rounds are requested at the END
+  // of the round before (a set held across the sixteen transposes would cost 32 registers and an occupancy step); !live — behind
+  // a wave's last round — every lane re-reads one line, so that the set is REDEFINED on every path and is not kept allocated.
+  ulonglong2 pl[8];
+  auto request = [&](uint32_t w0, bool live) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int plane = 8 * i + (lane >> 3), piece = lane & 7;
+      const uint8_t* a = live && plane < (int)depth ? ex + (uint64_t)(2 + plane) * rowBytes + (uint64_t)w0 * 8 + (uint32_t)piece * 16u : ex;
+      pl[i] = ld_stream(reinterpret_cast<const ulonglong2*>(a));  // (planes past the depth are zeroed where the set is USED: a select here would wait for the load)
+    }
+  };
+  request(wave_w0, true);
   uint32_t mine = 0, pre = 0;
   for (uint32_t w = (uint32_t)lane; w < R * 16u; w += kWave) {
     u64 x = exw[wave_w0 + w];
@@ -1408,20 +1423,15 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
       if (fl) ew[k] &= flw[w0 + k];
       total += (uint32_t)__popcll(ew[k]);
     }
-    if (total == 0) continue;  // wave-uniform: no column of these 1024 has a value
-    u64 pos = wave_pos;
-    wave_pos += total;
-    // this lane's plane: 16 words = one 128-byte line.  Loaded COALESCED — instruction i brings the lines of planes 8 i .. 8 i + 7,
-    // eight lanes per line — and handed to lane `plane` through the wave's LDS staging (row stride 144 B: the eight lanes of a
-    // 16-byte-per-lane access fall into eight different bank groups both ways).
+    // this lane's plane: 16 words = one 128-byte line, handed to lane `plane` through the wave's LDS staging (row stride 144 B: the
+    // eight lanes of a 16-byte-per-lane access fall into eight different bank groups both ways)
     u64 pw[16];
     {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int plane = 8 * i + (lane >> 3), piece = lane & 7;
-        ulonglong2 v;
-        v.x = v.y = 0;
-        if (plane < (int)depth) v = ld_stream(reinterpret_cast<const ulonglong2*>(ex + (uint64_t)(2 + plane) * rowBytes + (uint64_t)w0 * 8) + piece);
+        ulonglong2 v = pl[i];
+        if (plane >= (int)depth) v.x = v.y = 0;
         *reinterpret_cast<ulonglong2*>(stg + plane * kBsiValStride + piece * 16) = v;
       }
       wave_lds_sync();
@@ -1433,6 +1443,9 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
       }
       wave_lds_sync();  // (the next round writes the staging again)
     }
+    if (total != 0) {  // (wave-uniform; 0: no column of these 1024 has a value)
+    u64 pos = wave_pos;
+    wave_pos += total;
 #pragma unroll
     for (int k = 0; k < 16; ++k) pw[k] = wave_transpose64(pw[k], tc);  // sixteen independent transposes: straight-line code the scheduler interleaves
     __builtin_amdgcn_sched_barrier(0);
@@ -1449,6 +1462,8 @@ __global__ void __launch_bounds__(256) k_bsi_values(const uint8_t* __restrict__ 
       }
       pos += (uint32_t)__popcll(ew[k]);
     }
+    }
+    request(w0 + 16u, r + 1 < R);
   }
 }
 

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--shards", type=int, default=512)
     ap.add_argument("--launches", type=int, default=24)
     ap.add_argument("--out", default="")
+    ap.add_argument("--fresh-sleep", type=float, default=2.0, help="seconds the device idles before each group-H upload (bench.py: ~9 s of host-side data generation)")
+    ap.add_argument("--only-fresh", action="store_true", help="group H only (for a run under rocprofv3 --kernel-trace: the same launches on the profiler's clock)")
     args = ap.parse_args()
     import torch
 
@@ -114,58 +116,81 @@ def main():
         print(f"{name:58s} sclk {clk}  first {us[0]:8.1f}  first5 {g['mean_first_5']:8.1f}  sustained {g['median_last_10']:8.1f}  ratio {g['ratio_first5_to_sustained']:.3f}", flush=True)
 
     launches(q, 40)  # settle
-    for idle in (0.0, 0.001, 0.01, 0.05, 0.2, 1.0, 3.0):
+    for idle in (() if args.only_fresh else (0.0, 0.001, 0.01, 0.05, 0.2, 1.0, 3.0)):
         torch.cuda.synchronize()
         time.sleep(idle)
         clk = sclk()
         group(f"A idle {idle * 1e3:g} ms, no upload", launches(q, args.launches), clk)
-    # B: upload without idling
-    busy(0.05)
-    q.free()
-    b.free()
-    f.free()
-    b, f, q = resident()
-    clk = sclk()
-    group("B re-upload + prepare, launched at once", launches(q, args.launches), clk)
-    assert (q.read() == ref).all()
-    # C: upload, busy 30 ms on another kernel, then launch
-    q.free()
-    b.free()
-    f.free()
-    b, f, q = resident()
-    busy(0.03)
-    clk = sclk()
-    group("C re-upload + prepare, 30 ms of another kernel, then", launches(q, args.launches), clk)
-    # D: idle 1 s, busy 30 ms, launch
-    time.sleep(1.0)
-    busy(0.03)
-    clk = sclk()
-    group("D idle 1 s, 30 ms of another kernel, then", launches(q, args.launches), clk)
-    # F: what bench.py does between the upload and its "first launches": seconds of host work on every core, device idle
-    import threading
+    if not args.only_fresh:
+        # B: upload without idling
+        busy(0.05)
+        q.free()
+        b.free()
+        f.free()
+        b, f, q = resident()
+        clk = sclk()
+        group("B re-upload + prepare, launched at once", launches(q, args.launches), clk)
+        assert (q.read() == ref).all()
+        # C: upload, busy 30 ms on another kernel, then launch
+        q.free()
+        b.free()
+        f.free()
+        b, f, q = resident()
+        busy(0.03)
+        clk = sclk()
+        group("C re-upload + prepare, 30 ms of another kernel, then", launches(q, args.launches), clk)
+        # D: idle 1 s, busy 30 ms, launch
+        time.sleep(1.0)
+        busy(0.03)
+        clk = sclk()
+        group("D idle 1 s, 30 ms of another kernel, then", launches(q, args.launches), clk)
+        # F: what bench.py does between the upload and its "first launches": seconds of host work on every core, device idle
+        import threading
 
-    def burn(sec):
-        a = np.random.default_rng(1).random((384, 384))
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < sec:
-            a = a @ a
-            a /= np.abs(a).max()
+        def burn(sec):
+            a = np.random.default_rng(1).random((384, 384))
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < sec:
+                a = a @ a
+                a /= np.abs(a).max()
 
-    th = [threading.Thread(target=burn, args=(3.0,)) for _ in range(min(64, os.cpu_count() or 8))]
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    clk = sclk()
-    group("F 3 s of host work on up to 64 threads (device idle), then", launches(q, args.launches), clk)
-    # G: 5 launches only, after 3 s idle (bench.py's kernel_us_first_launches protocol), three times
+        th = [threading.Thread(target=burn, args=(3.0,)) for _ in range(min(64, os.cpu_count() or 8))]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        clk = sclk()
+        group("F 3 s of host work on up to 64 threads (device idle), then", launches(q, args.launches), clk)
+        # G: 5 launches only, after 3 s idle (bench.py's kernel_us_first_launches protocol), three times
+        for rep in range(3):
+            time.sleep(3.0)
+            us = launches(q, 5)
+            res["groups"].append({"name": f"G 3 s idle, then 5 launches (#{rep})", "us": us, "shader_MHz_behind_each_launch": mhz_log[-1]})
+            print(f"G 3 s idle, then 5 launches (#{rep}): {us}  MHz {mhz_log[-1]}", flush=True)
+    # H: what the strong-scaling loop of bench.py does per slice — rows uploaded into FRESH device memory (the earlier batches stay
+    # resident, so nothing comes back from the pool), a new prepared query, its FIRST run (window index, shadows, program are built
+    # by their own kernels in front of it) — the launch that took 29-31 ms in profiles/r06_kernel_trace_by_grid.csv
+    held = []
     for rep in range(3):
-        time.sleep(3.0)
-        us = launches(q, 5)
-        res["groups"].append({"name": f"G 3 s idle, then 5 launches (#{rep})", "us": us, "shader_MHz_behind_each_launch": mhz_log[-1]})
-        print(f"G 3 s idle, then 5 launches (#{rep}): {us}  MHz {mhz_log[-1]}", flush=True)
+        time.sleep(args.fresh_sleep)
+        t_up = time.perf_counter()
+        b2, f2 = ctx.upload_flat(d4, p4, nr4), ctx.upload_flat(fd4, fp4, n)
+        q2 = ctx.prepare_count_matrix(b2, ga, b2, gb, f2, fidx, keep_per_shard=True)
+        t_up = time.perf_counter() - t_up
+        ctx.set_option("time_kernels", 1)
+        t_run = time.perf_counter()
+        q2.run()
+        torch.cuda.synchronize()
+        t_run = time.perf_counter() - t_run
+        first_ns = ctx.get_option("last_kernel_ns")
+        ctx.set_option("time_kernels", 0)
+        us = launches(q2, 6)
+        held += [b2, f2, q2]
+        res["groups"].append({"name": f"H {args.fresh_sleep:g} s idle, fresh memory, first run of a new query (#{rep})", "upload_prepare_s": round(t_up, 4), "first_run_wall_ms": round(t_run * 1e3, 2),
+                              "first_run_kernel_us": round(first_ns / 1e3, 1), "next_us": us})
+        print(f"H {args.fresh_sleep:g} s idle, fresh memory (#{rep}): upload + prepare {t_up * 1e3:.1f} ms, first run wall {t_run * 1e3:.2f} ms, its k_count_matrix_fusedq {first_ns / 1e3:.1f} us, next {us}", flush=True)
     # E: back-to-back enqueue (no host round trip between launches): 24 launches between two events, after 1 s idle and sustained
-    for name, idle in (("E 24 launches enqueued back to back after 1 s idle", 1.0), ("E 24 launches enqueued back to back, sustained", 0.0)):
+    for name, idle in (() if args.only_fresh else (("E 24 launches enqueued back to back after 1 s idle", 1.0), ("E 24 launches enqueued back to back, sustained", 0.0))):
         time.sleep(idle)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)

@@ -35,6 +35,24 @@ misc)  # rocprofv3 per-grid trace of the kernels the bench line does not reach
   f=$(find $O/misc_trace -name "*kernel_trace.csv" | head -1); python scripts/kernel_trace_by_grid.py $f 3 > $O/misc_kernel_trace_by_grid.csv; grep -h "k_bsi_values\|k_bsi_cell\|k_bsi_add\|outlier" $O/misc_kernel_trace_by_grid.csv | head ;;
 distinct_tests)
   timeout 600 python -m pytest tests/test_gpu_queries.py -x -q -m gpu -k "distinct or bsi" > $O/distinct_tests.log 2>&1; echo "distinct_tests rc $?"; tail -3 $O/distinct_tests.log ;;
+ctops_ab)  # the reference's container-archetype matrix on two library builds (LIB_OLD: a build_variants/ name), every cell oracle-checked
+  FBK_LIB_PATH=$R/build_variants/${LIB_OLD:-r5probe}/libfbk.so timeout 900 python scripts/bench_ctops.py --rows 1024 --iters 20 --out $O/ctops_old.json > $O/ctops_old.log 2>&1; echo "ctops old rc $?"
+  timeout 900 python scripts/bench_ctops.py --rows 1024 --iters 20 --out $O/ctops_new.json > $O/ctops_new.log 2>&1; echo "ctops new rc $?"
+  python scripts/ctops_ab.py $O/ctops_old.json $O/ctops_new.json > $O/ctops_ab.txt 2>&1; head -30 $O/ctops_ab.txt ;;
+fresh_under_rocprof)  # the first run of a new query on fresh memory: the library's HIP events against rocprofv3's dispatch timestamps
+  (cd /tmp; timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/fresh_trace -- python $R/scripts/first_launches.py --shards ${SHARDS:-1024} --only-fresh --fresh-sleep ${FRESH_SLEEP:-10} --out $O/fresh.json > $O/fresh.txt 2>&1)
+  grep "^H " $O/fresh.txt; f=$(find $O/fresh_trace -name "*kernel_trace.csv" | head -1); python scripts/kernel_trace_by_grid.py $f 3 > $O/fresh_by_grid.csv; grep "fusedq\|outlier" $O/fresh_by_grid.csv | head
+  python - $f <<'PY'
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+for i, r in enumerate(rows):
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    if "fusedq" in r["Kernel_Name"] and d > 5000:
+        print("--- context of a %.0f us launch of k_count_matrix_fusedq (rocprofv3 clock):" % d)
+        for q in rows[max(0, i - 8): i + 2]:
+            print("   %-60s start +%10.1f us  dur %10.1f us" % (q["Kernel_Name"][:60], (int(q["Start_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3, (int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) / 1e3))
+PY
+  rm -rf $O/fresh_trace ;;
 *) echo "unknown: $what" ;;
 esac
 done
