@@ -501,3 +501,61 @@ def _mask_range(w, s, e):
     bits[:s] = 0
     bits[e:] = 0
     return np.packbits(bits, bitorder="little").view(np.uint64)
+
+
+def test_count_array_forms_odd_lengths_and_value_zero(gpu_ctx, oracle):
+    """The count path's array forms of round 6 (fbk_pair_kernels.hip.h: floor(len / 2) full dwords + an odd last value by itself;
+    the probe takes no per-value predicate and corrects `junk x [0 in the table]` on its scalar partial; the scatter predicates
+    rows): probing and scattered arrays of every length class — 1, 2, odd, just under / at / over a 128-value row, a half batch
+    (512), a batch (1024), 1025, 2047, 4095 — against tables that DO and do NOT hold value 0: the other array, a bitmap
+    (copied into the table), a run container of <= 600 runs (boundary masks: [0, 5]; a full first dword: [0, 200]) and a long run
+    list (the streaming path).  Both orders; numpy is the expectation."""
+    from featurebase_amd.roaring import Container
+
+    rng = D.rng_for(6262)
+    lens = [1, 2, 3, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 3001, 4095]
+
+    def arr(n, zero):
+        v = np.sort(rng.choice(np.arange(1, 65536), size=n - (1 if zero else 0), replace=False)).astype(np.uint16)
+        return np.concatenate([[0], v]).astype(np.uint16) if zero else v
+
+    def bits(vals):
+        w = np.zeros(65536, dtype=np.uint8)
+        w[np.asarray(vals, dtype=np.int64)] = 1
+        return w
+
+    others = []  # (container, bit vector)
+    for zero in (False, True):
+        for n in (1, 7, 130, 700, 1500, 4000):
+            a = arr(n, zero)
+            others.append((Container.array(a), bits(a)))
+        bm = rng.random(65536) < 0.3
+        bm[0] = zero
+        others.append((Container.bitmap(np.packbits(bm.astype(np.uint8), bitorder="little").view(np.uint64)), bm.astype(np.uint8)))
+        for runs in ([(0, 5), (40, 100), (3000, 3000), (65000, 65535)] if zero else [(1, 5), (40, 100), (3000, 3000), (65000, 65535)],
+                     [(0, 200), (300, 301), (9000, 20000)] if zero else [(2, 200), (300, 301), (9000, 20000)],
+                     [(0 if zero else 1, 1)] + [(10 + 64 * i, 10 + 64 * i + 20) for i in range(900)]):
+            b = np.zeros(65536, dtype=np.uint8)
+            for s, l in runs:
+                b[s:l + 1] = 1
+            others.append((Container.run(runs), b))
+    rows_a, rows_b, want = [], [], []
+    for n in lens:
+        for zero in (False, True):
+            a = arr(n, zero)
+            ba = bits(a)
+            for k0 in range(0, len(others), 16):
+                grp = others[k0:k0 + 16]
+                rows_a.append({s: Container.array(a) for s in range(len(grp))})
+                rows_b.append({s: c for s, (c, _) in enumerate(grp)})
+                want.append(int(sum(int((ba & bv).sum()) for _, bv in grp)))
+    A, B = gpu_ctx.upload(rows_a), gpu_ctx.upload(rows_b)
+    idx = np.arange(len(rows_a))
+    assert gpu_ctx.intersection_count(A, idx, B, idx).tolist() == want
+    assert gpu_ctx.intersection_count(B, idx, A, idx).tolist() == want
+    plan = gpu_ctx.plan(A, idx, B, idx)  # (the launch-only form resolves item records: the one-wave-per-item kernel)
+    plan.intersection_count()
+    assert plan.read().tolist() == want
+    plan.free()
+    A.free()
+    B.free()
