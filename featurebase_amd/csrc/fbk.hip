@@ -108,7 +108,8 @@ struct FbkOptions {
   int64_t time_kernels = 0;              // 1: HIP events around the dominant kernel of a query-level call (count matrix, fold, BSI range / sum)
   int64_t last_kernel_ns = 0;            //    ... read its duration back here (fbk_get_option) after the call
   int64_t matrix_shadow = 1;             // count matrix over encoded rows: dense shadows of the heavy containers, built per batch on first use (heavy_shadow); 0: decode every container in every query
-  int64_t matrix_shadow_array = 2048;    //   arrays longer than this are heavy (run containers always are)
+  int64_t matrix_shadow_array = 2048;    //   arrays longer than this are heavy
+  int64_t matrix_shadow_run = 0;         //   run containers of more than this many runs are heavy (0: every run container — rounds 3-5)
   int64_t matrix_shadow_max_mb = 16384;  //   no shadow for a batch that would need more than this (nor more than twice its arena, nor a quarter of the free device memory)
   int64_t matrix_shadow_arena_x = 8;     //   ... nor more than this many times the batch's own arena (0: no such rule); fbk_batch_memory reports what a batch got
 #ifdef FBK_EXPERIMENTS  // (scripts/ build their own variant with -DFBK_EXPERIMENTS into build_variants/; the product library has neither the options nor the device branches)
@@ -499,12 +500,12 @@ int32_t heavy_shadow(fbk_ctx* ctx, const fbk_batch* b, const Slot** out_slots, b
   std::lock_guard<std::mutex> g(b->win_mu);
   if (b->shadow_state == 0) {
     const uint64_t n_slots = uint64_t(b->n_rows) * fbk::kSlots;
-    const uint32_t thr = uint32_t(ctx->opt.matrix_shadow_array);
+    const uint32_t thr = uint32_t(ctx->opt.matrix_shadow_array), thr_run = uint32_t(ctx->opt.matrix_shadow_run);
     std::vector<uint32_t> list;
     for (uint64_t i = 0; i < n_slots && i < b->h_slots.size(); ++i) {
       const Slot& s = b->h_slots[i];
       const uint32_t n = s.tn & 0xFFFFFFu, t = s.tn >> 24;
-      if (n != 0 && (t == fbk::kTypeRun || (t == fbk::kTypeArray && s.len > thr))) list.push_back(uint32_t(i));
+      if (n != 0 && ((t == fbk::kTypeRun && s.len > thr_run) || (t == fbk::kTypeArray && s.len > thr))) list.push_back(uint32_t(i));
     }
     b->shadow_state = 2;
     const uint64_t bytes = uint64_t(list.size()) * 8192ull;
@@ -708,6 +709,7 @@ const OptionDesc kOptions[] = {
     {"matrix_fp4", &FbkOptions::matrix_fp4, -1, 1},
     {"matrix_shadow", &FbkOptions::matrix_shadow, 0, 1},
     {"matrix_shadow_array", &FbkOptions::matrix_shadow_array, 0, 65536},
+    {"matrix_shadow_run", &FbkOptions::matrix_shadow_run, 0, 65536},
     {"matrix_shadow_max_mb", &FbkOptions::matrix_shadow_max_mb, 0, 1 << 20},
     {"matrix_shadow_arena_x", &FbkOptions::matrix_shadow_arena_x, 0, 1 << 20},
 #ifdef FBK_EXPERIMENTS

@@ -157,8 +157,8 @@ int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
  * calls change an option.
  *   semantics (DEFAULT 1 = the reference's result, 0 = the arithmetically exact one; see fbk_count_range, fbk_topn):
  *     count_range_reference_quirk, topn_semantics;
- *   memory: matrix_shadow (1: the count matrix over encoded rows reads run containers and arrays of more than
- *     matrix_shadow_array values through dense shadows built per batch on first use — up to matrix_shadow_max_mb of device
+ *   memory: matrix_shadow (1: the count matrix over encoded rows reads run containers of more than matrix_shadow_run runs and
+ *     arrays of more than matrix_shadow_array values through dense shadows built per batch on first use — up to matrix_shadow_max_mb of device
  *     memory per batch and matrix_shadow_arena_x times its own arena (0: no such rule), fbk_batch_memory reports what a batch
  *     got; 0: every container is decoded in every query), setop_compact (fbk_batch_compact applied to the outputs of one-shot
  *     calls with FBK_SETOP_OPTIMIZE), matrix_pass_kb (per-shard matrices are produced in passes of at most this size),

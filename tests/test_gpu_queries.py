@@ -650,17 +650,21 @@ def test_fold_n_more_than_64_rows_per_group(gpu_ctx, oracle):
     batch.free()
 
 
-@pytest.fixture(params=[(1, 2048), (1, 64), (0, 2048)], ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows"])
+@pytest.fixture(params=[(1, 2048, 0), (1, 64, 0), (0, 2048, 0), (1, 2048, 20)],
+                ids=["heavy-shadows", "shadows-of-arrays-over-64-values", "no-shadows", "shadows-of-runs-over-20-intervals"])
 def shadow_mode(request, gpu_ctx):
     """Count matrix over encoded rows: run containers and long arrays as dense shadows built per batch on first use (default), the
-    same with nearly every array shadowed (more than 42 bitmap rows per slot: the in-place path of the bitmap waves), and every
-    container decoded in every query (run rows, long arrays).  Each result is compared with the oracle's groupByIterator counts
-    per shard, and with the generic pair kernel on the same call (two kernels that share no code)."""
+    same with nearly every array shadowed (more than 42 bitmap rows per slot: the in-place path of the bitmap waves), every
+    container decoded in every query (run rows, long arrays), and (round 6, option matrix_shadow_run) only the run containers of
+    more than 20 intervals shadowed — shadowed and in-place run rows side by side in one slot.  Each result is compared with the
+    oracle's groupByIterator counts per shard, and with the generic pair kernel on the same call (two kernels that share no code)."""
     gpu_ctx.set_option("matrix_shadow", request.param[0])
     gpu_ctx.set_option("matrix_shadow_array", request.param[1])
+    gpu_ctx.set_option("matrix_shadow_run", request.param[2])
     yield request.param
     gpu_ctx.set_option("matrix_shadow", 1)
     gpu_ctx.set_option("matrix_shadow_array", 2048)
+    gpu_ctx.set_option("matrix_shadow_run", 0)
 
 
 def test_count_matrix_fused_duplicated_and_broadcast_rows(gpu_ctx, oracle, B):
