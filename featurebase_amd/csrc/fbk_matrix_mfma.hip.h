@@ -64,6 +64,12 @@ typedef uint32_t mm_u4 __attribute__((ext_vector_type(4)));
 typedef int mm_v8i __attribute__((ext_vector_type(8)));
 typedef float mm_v16f __attribute__((ext_vector_type(16)));
 
+// -DFBK_MM_STAMPS (scripts/matrix_xcd_hist.hip only, never the library): every block records when it started and ended
+// (s_memrealtime, 100 MHz) and where it ran (XCC_ID, HW_ID) — four words per block at g_mm_stamps.
+#ifdef FBK_MM_STAMPS
+__device__ unsigned long long* g_mm_stamps;
+#endif
+
 template <bool HAS_F, int WAVES = kMmWaves, int DEPTH = kMmDepth, int AUX = kMmAux, int TM = 1, int TN = 1, bool FP4 = false>
 __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
     const uint8_t* __restrict__ arenaA, const uint32_t* __restrict__ rowsA, uint32_t nA, const uint8_t* __restrict__ arenaB,
@@ -78,6 +84,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
   // with the arithmetic.  vmcnt / lgkmcnt are managed by hand below.
   __shared__ uint4 ring[DEPTH][WAVES][kStageBytes / 16];
   static_assert(kStageBytes >= TM * TN * 16 * 64 * 4, "the final reduction parks the partial counts in stage 0");
+#ifdef FBK_MM_STAMPS
+  const unsigned long long stamp_t0 = wall_clock64();
+#endif
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int lane = threadIdx.x & 63;
@@ -309,6 +318,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
       else atomicAdd(dst, (u64)tot);
     }
   }
+#ifdef FBK_MM_STAMPS
+  __syncthreads();
+  if (threadIdx.x == 0 && g_mm_stamps) {
+    unsigned long long* st = g_mm_stamps + 4ull * blockIdx.x;
+    st[0] = stamp_t0;
+    st[1] = wall_clock64();
+    st[2] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (3 << 11));   // HW_REG_XCC_ID[3:0]
+    st[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_REG_HW_ID
+  }
+#endif
 }
 
 }  // namespace fbk

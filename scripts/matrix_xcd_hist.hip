@@ -1,0 +1,170 @@
+// matrix_xcd_hist.hip — where does a dense count-matrix launch lose time against a longer one?  (not part of the product)
+//
+// BASELINE configs[3]'s per-rank launch — 1024 shards x (32 A rows + 32 B rows + filter), dense rows, k_count_matrix_mfma<true, 4, 2, nt, 1, 1>,
+// 4 slots per block = 4096 blocks — reaches 0.77-0.79 of 8 TB/s where the same kernel over 8192 shards (one block per shard) reaches 0.79-0.80.
+// This harness runs the kernel built with -DFBK_MM_STAMPS: every block records its start and end (s_memrealtime, 100 MHz) and the XCD / CU it
+// ran on.  From the stamps of one launch:
+//   * ramp: slot-time lost before each of the 512 block slots (2 per CU) got its first block; drain: slot-time lost behind each slot's last block;
+//   * the blocks' own durations by position in the launch (first wave of blocks, middle, last);
+//   * per XCD: blocks executed, when its last block ended relative to the launch's end, CUs seen.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFBK_MM_STAMPS scripts/matrix_xcd_hist.hip -o scripts/matrix_xcd_hist
+//   scripts/matrix_xcd_hist [shards=1024] [spb=4] [launches=5] > profiles/r06_matrix_xcd_hist_1024.txt
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <vector>
+
+#include "../featurebase_amd/csrc/fbk_matrix_mfma.hip.h"
+
+using fbk::u64;
+
+#define CK(x)                                                \
+  do {                                                       \
+    hipError_t e = (x);                                      \
+    if (e != hipSuccess) {                                   \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); \
+      exit(1);                                               \
+    }                                                        \
+  } while (0)
+
+__global__ void k_fill(u64* p, size_t n, u64 seed) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    u64 z = (i + seed) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    p[i] = z ^ (z >> 31);
+  }
+}
+
+static double med(std::vector<double> v) {
+  if (v.empty()) return 0;
+  std::sort(v.begin(), v.end());
+  return v[v.size() / 2];
+}
+
+int main(int argc, char** argv) {
+  const uint32_t shards = argc > 1 ? atoi(argv[1]) : 1024, spb = argc > 2 ? atoi(argv[2]) : 4;
+  const int launches = argc > 3 ? atoi(argv[3]) : 5;
+  const uint32_t nA = 32, nB = 32;
+  const size_t rowBytes = 16 * 8192;
+  uint8_t *A, *B, *F;
+  CK(hipMalloc(&A, (size_t)shards * nA * rowBytes));
+  CK(hipMalloc(&B, (size_t)shards * nB * rowBytes));
+  CK(hipMalloc(&F, (size_t)shards * rowBytes));
+  hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (u64*)A, (size_t)shards * nA * rowBytes / 8, 1ull);
+  hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (u64*)B, (size_t)shards * nB * rowBytes / 8, 77777777ull);
+  hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (u64*)F, (size_t)shards * rowBytes / 8, 999999999ull);
+  std::vector<uint32_t> ra((size_t)shards * nA), rb((size_t)shards * nB), rf(shards);
+  for (size_t i = 0; i < ra.size(); ++i) ra[i] = (uint32_t)i;
+  for (size_t i = 0; i < rb.size(); ++i) rb[i] = (uint32_t)i;
+  for (size_t i = 0; i < rf.size(); ++i) rf[i] = (uint32_t)i;
+  uint32_t *rowsA, *rowsB, *rowsF;
+  CK(hipMalloc(&rowsA, ra.size() * 4));
+  CK(hipMalloc(&rowsB, rb.size() * 4));
+  CK(hipMalloc(&rowsF, rf.size() * 4));
+  CK(hipMemcpy(rowsA, ra.data(), ra.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(rowsB, rb.data(), rb.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(rowsF, rf.data(), rf.size() * 4, hipMemcpyHostToDevice));
+  u64* out;
+  const size_t outBytes = (size_t)shards * nA * nB * 8;
+  CK(hipMalloc(&out, outBytes));
+  const uint32_t blocks = shards * (16 / spb);
+  u64* dstamps;
+  CK(hipMalloc(&dstamps, (size_t)blocks * 32));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(fbk::g_mm_stamps), &dstamps, sizeof(dstamps)));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  auto launch = [&] {
+    hipLaunchKernelGGL((fbk::k_count_matrix_mfma<true, 4, 2, 2, 1, 1>), dim3(blocks), dim3(256), 0, 0, A, rowsA, nA, B, rowsB, nB, F, rowsF, shards, spb, out);
+  };
+  const double bytes = (double)shards * (nA + nB + 1) * 16 * 8192;
+  printf("# k_count_matrix_mfma<F, 4 waves, depth 2, nt, 1x1>: %u shards x (32 + 32 + 1) dense rows, %u slots per block = %u blocks of %.2f MB; %.1f MB per launch\n", shards, spb,
+         blocks, bytes / blocks * 1e-6, bytes * 1e-6);
+  for (int i = 0; i < 5; ++i) {
+    CK(hipMemsetAsync(out, 0, outBytes, 0));
+    launch();
+  }
+  CK(hipDeviceSynchronize());
+  std::vector<u64> st((size_t)blocks * 4);
+  const uint32_t kSlotsRunning = 512;
+  for (int it = 0; it < launches; ++it) {
+    CK(hipMemsetAsync(out, 0, outBytes, 0));
+    CK(hipMemsetAsync(dstamps, 0, (size_t)blocks * 32, 0));
+    CK(hipEventRecord(e0, 0));
+    launch();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(st.data(), dstamps, (size_t)blocks * 32, hipMemcpyDeviceToHost));
+    u64 T0 = ~0ull, T1 = 0;
+    for (uint32_t b = 0; b < blocks; ++b) T0 = std::min(T0, st[4 * b]), T1 = std::max(T1, st[4 * b + 1]);
+    const double dur = (double)(T1 - T0) * 0.01;  // us
+    std::vector<double> starts(blocks), ends(blocks), durs(blocks);
+    double busy = 0;
+    for (uint32_t b = 0; b < blocks; ++b) {
+      starts[b] = (double)(st[4 * b] - T0) * 0.01, ends[b] = (double)(st[4 * b + 1] - T0) * 0.01, durs[b] = ends[b] - starts[b];
+      busy += durs[b];
+    }
+    std::vector<uint32_t> by_start(blocks), by_end(blocks);
+    for (uint32_t b = 0; b < blocks; ++b) by_start[b] = by_end[b] = b;
+    std::sort(by_start.begin(), by_start.end(), [&](uint32_t x, uint32_t y) { return starts[x] < starts[y]; });
+    std::sort(by_end.begin(), by_end.end(), [&](uint32_t x, uint32_t y) { return ends[x] < ends[y]; });
+    const uint32_t ns = std::min(kSlotsRunning, blocks);
+    double ramp = 0, drain = 0;
+    for (uint32_t i = 0; i < ns; ++i) ramp += starts[by_start[i]], drain += dur - ends[by_end[blocks - 1 - i]];
+    printf("\nlaunch %d: %.1f us between HIP events (%.3f of 8 TB/s); first block start -> last block end %.1f us (%.3f); slot-time in blocks %.1f %% of %u slots x that\n", it, ms * 1e3,
+           bytes / (ms * 1e-3) / 8e12, dur, bytes / (dur * 1e-6) / 8e12, 100.0 * busy / (ns * dur), ns);
+    printf("  ramp : the %u slots' first blocks start %.2f us after the first on average (last of them at %.2f us)\n", ns, ramp / ns, starts[by_start[ns - 1]]);
+    printf("  drain: the %u slots' last blocks end %.2f us before the launch's end on average (first of them %.2f us before); the last block STARTED %.2f us before the end\n", ns,
+           drain / ns, dur - ends[by_end[blocks - ns]], dur - starts[by_start[blocks - 1]]);
+    // durations by position in the launch
+    const uint32_t groups = std::max(1u, blocks / ns);
+    printf("  block durations by start order, groups of %u (median us | GB/s per block slot):", ns);
+    for (uint32_t g = 0; g < groups; ++g) {
+      std::vector<double> d;
+      for (uint32_t i = g * ns; i < std::min(blocks, (g + 1) * ns); ++i) d.push_back(durs[by_start[i]]);
+      const double m = med(d);
+      if (groups <= 16 || g < 4 || g + 4 >= groups) printf(" %.1f", m);
+      else if (g == 4) printf(" ...");
+    }
+    printf("\n");
+    {
+      std::vector<double> all(durs);
+      std::sort(all.begin(), all.end());
+      printf("  all blocks: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f us; %u slots x block bytes / median = %.3f of 8 TB/s\n", all[0], all[blocks / 10], all[blocks / 2],
+             all[blocks * 9 / 10], all[blocks - 1], ns, ns * (bytes / blocks) / (all[blocks / 2] * 1e-6) / 8e12);
+    }
+    // per XCD
+    printf("  per XCD: blocks | CUs seen | first start | last end before the launch's end (us) | slot-time in blocks (%% of 64 slots x launch)\n");
+    for (uint32_t x = 0; x < 8; ++x) {
+      uint32_t n = 0;
+      double fs = 1e30, le = 0, bz = 0;
+      std::set<uint32_t> cus;
+      for (uint32_t b = 0; b < blocks; ++b)
+        if ((st[4 * b + 2] & 15u) == x) {
+          ++n, fs = std::min(fs, starts[b]), le = std::max(le, ends[b]), bz += durs[b];
+          cus.insert((uint32_t)(st[4 * b + 3] >> 8) & 0xFFu);  // CU_ID, SH_ID, SE_ID
+        }
+      if (n) printf("    xcd %u: %5u | %2zu | %7.2f | %7.2f | %.1f\n", x, n, cus.size(), fs, dur - le, 100.0 * bz / (64.0 * dur));
+    }
+    // running blocks over time, 20 bins
+    printf("  running blocks at 5 %% steps of the launch:");
+    for (int k = 0; k <= 20; ++k) {
+      const double t = dur * k / 20.0;
+      uint32_t r = 0;
+      for (uint32_t b = 0; b < blocks; ++b) r += starts[b] <= t && ends[b] > t;
+      printf(" %u", r);
+    }
+    printf("\n");
+  }
+  return 0;
+}
