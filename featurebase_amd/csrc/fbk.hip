@@ -102,6 +102,7 @@ inline uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
 struct FbkOptions {
   int64_t dense_spb = 16;                // slots per block of k_icount_dense: 1|2|4|8|16
   int64_t matrix_spb = 0;                // slots per block of the dense count matrix; 0 = chosen per launch
+  int64_t matrix_tickets = 1;            // dense single-tile count matrix: 1 the blocks take their units from a ticket counter, long units first (the XCDs run at different paces); 0 by block id
   int64_t matrix_pass_kb = 1 << 20;      // per-shard matrices are produced in passes of at most this many KiB
   int64_t matrix_fused = -1;             // count matrix over encoded rows: 1 decode inside the matrix-core kernel, 0 the generic pair kernel, -1 by the matrix size
   int64_t matrix_fp4 = -1;               // dense count matrix on the FP4 matrix instruction: 1 always, 0 never, -1 when it has several tiles
@@ -183,6 +184,8 @@ struct fbk_ctx {
   // option time_kernels: events around the dominant kernel of the last query-level call
   hipEvent_t kt0 = nullptr, kt1 = nullptr;
   bool kt_armed = false;
+  // ticket counters of the launches whose blocks take their work by ticket (ticket_counter): 64 words, zero between launches
+  uint32_t* d_tickets = nullptr;
   // device fragment cache (fbk_cache_api.inc)
   std::unordered_map<std::string, struct fbk_cache_entry*> cache;
   std::unordered_map<const fbk_batch*, struct fbk_cache_entry*> cache_by_batch;  // release() looks entries up by handle
@@ -242,6 +245,25 @@ uint64_t pool_bucket(uint64_t bytes) {
     return b;
   }
   return (bytes + (1ull << 21) - 1) & ~((1ull << 21) - 1);  // 2 MiB granules
+}
+
+// The context's ticket counters (kernels whose blocks take their work by ticket: the counter wraps back to zero inside the
+// launch, so it is allocated and cleared ONCE; everything on a context runs on one stream).  Caller holds ctx->mu.
+int32_t ticket_counter(fbk_ctx* ctx, uint32_t** out) {
+  if (!ctx->d_tickets) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, 256));
+    hipError_t e = hipMemsetAsync(p, 0, 256, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (once per context: the caller may move the context to another stream afterwards)
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(p);
+      return fail(FBK_E_HIP, std::string("ticket counter: ") + hipGetErrorString(e));
+    }
+    ctx->d_tickets = static_cast<uint32_t*>(p);
+  }
+  *out = ctx->d_tickets;
+  return FBK_OK;
 }
 
 hipError_t ctx_malloc(fbk_ctx* ctx, void** out, uint64_t bytes) {
@@ -704,6 +726,7 @@ struct OptionDesc {
 const OptionDesc kOptions[] = {
     {"dense_spb", &FbkOptions::dense_spb, 1, 16},
     {"matrix_spb", &FbkOptions::matrix_spb, 0, 16},
+    {"matrix_tickets", &FbkOptions::matrix_tickets, 0, 1},
     {"matrix_pass_kb", &FbkOptions::matrix_pass_kb, 1, int64_t(1) << 40},
     {"matrix_fused", &FbkOptions::matrix_fused, -1, 1},
     {"matrix_fp4", &FbkOptions::matrix_fp4, -1, 1},
@@ -828,6 +851,7 @@ int32_t fbk_close(fbk_ctx* ctx) try {
   comm_release(ctx);
   if (!ctx->root) cache_release_all(ctx);
   pool_release_all(ctx);
+  if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (int k = 0; k < 2; ++k) {
     if (ctx->up_ring[k]) (void)hipHostFree(ctx->up_ring[k]);

@@ -70,11 +70,33 @@ typedef float mm_v16f __attribute__((ext_vector_type(16)));
 __device__ unsigned long long* g_mm_stamps;
 #endif
 
+// The tiers of a ticketed launch (see TICKETS in the kernel): `resident` = the blocks the device holds at a time (2 per CU).  A tier's
+// work has to outlast the raggedness the tier before it leaves behind — one unit of that tier per resident block — so tier k + 1
+// gets the shards that `resident` units of tier k amount to; what is left over is tier 0, in units of spb0 slots.  Returns false
+// (launch by block id) when the launch is too short for that: fewer than four rounds of tier-0 units.
+struct MmTickets {
+  uint32_t tier0_shards, tier1_shards, tier_spb, grid;
+};
+inline bool mm_ticket_plan(uint32_t n_shards, uint32_t spb0, uint32_t resident, MmTickets& t) {
+  if (spb0 < 2 || uint64_t(n_shards) * (kSlots / spb0) < 4ull * resident) return false;
+  const uint32_t spb1 = spb0 >= 8 ? spb0 / 4 : spb0 / 2, spb2 = 1;
+  uint32_t s1 = (resident * spb0 + kSlots - 1) / kSlots;                 // shards of tier 1
+  uint32_t s2 = spb1 > 1 ? (resident * spb1 + kSlots - 1) / kSlots : 0;  // shards of tier 2 (none when tier 1 is already single slots)
+  if (s1 + s2 > n_shards / 2) return false;
+  t.tier0_shards = n_shards - s1 - s2;
+  t.tier1_shards = s1;
+  t.tier_spb = spb1 | (spb2 << 8);
+  const uint64_t units = uint64_t(t.tier0_shards) * (kSlots / spb0) + uint64_t(s1) * (kSlots / spb1) + uint64_t(s2) * (kSlots / spb2);
+  t.grid = uint32_t((units + units / 8 + 64 + 7) & ~7ull);  // spare blocks: an XCD may take an eighth more than its share
+  return true;
+}
+
 template <bool HAS_F, int WAVES = kMmWaves, int DEPTH = kMmDepth, int AUX = kMmAux, int TM = 1, int TN = 1, bool FP4 = false>
 __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
     const uint8_t* __restrict__ arenaA, const uint32_t* __restrict__ rowsA, uint32_t nA, const uint8_t* __restrict__ arenaB,
     const uint32_t* __restrict__ rowsB, uint32_t nBtot, const uint8_t* __restrict__ arenaF,
-    const uint32_t* __restrict__ rowsF, uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard) {
+    const uint32_t* __restrict__ rowsF, uint32_t n_shards, uint32_t spb, u64* __restrict__ out_shard,
+    uint32_t* __restrict__ ticket = nullptr, uint32_t tier0_shards = 0, uint32_t tier1_shards = 0, uint32_t tier_spb = 0) {
   // stage of one wave and one step: A rows, B rows (128 bytes each), the filter piece
   constexpr uint32_t kABytes = TM * 32 * kMmPiece, kBBytes = TN * 32 * kMmPiece;
   constexpr uint32_t kStageBytes = kABytes + kBBytes + 256;
@@ -93,12 +115,42 @@ __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t agroups = (nA + 32 * TM - 1) / (32 * TM);
   const uint32_t btiles = (nBtot + 32 * TN - 1) / (32 * TN);
-  const uint32_t sgroups = kSlots / spb;
+  uint32_t sgroups = kSlots / spb;
   uint32_t b = blockIdx.x;
   // The tiles of one (shard, slot group) read the same rows.  Workgroups go to the 8 XCDs round
   // robin and every XCD has its own L2, so consecutive block ids would put those tiles on 8
   // different L2s; with ids that differ by 8 they share one and the rows come from HBM once.
   if (agroups * btiles > 1 && (gridDim.x & 7u) == 0) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
+  // TICKETS (round 6, single-tile matrices = the HBM-bound shape).  Block ids go to the XCDs round robin, an eighth of the grid
+  // each whatever their pace — and their paces differ: scripts/matrix_xcd_hist.hip (profiles/r06_matrix_xcd_hist_*.txt) shows the
+  // even XCDs through their share 5-8 % before the odd ones, every launch, and the last blocks of a launch running on a half-empty
+  // device (4-5 % of a 1024-shard launch is that drain).  With a ticket counter a block's unit is the NEXT one, not its id: the
+  // grid is launched with spare blocks (they find no unit and end at once), so an XCD that is ahead simply takes more units; and
+  // the units come in three TIERS of shards — the first tier0_shards in units of `spb` slots, the next tier1_shards in units of
+  // tier_spb[7:0] slots, the rest in units of tier_spb[15:8] — long units first, so that the end of the launch is ragged by a
+  // short unit's time, not by a long one's.  atomicInc wraps at the grid size: every block takes exactly one ticket and the
+  // counter is back at zero when the last one has (stream order does the rest).
+  if (ticket) {
+    __shared__ uint32_t s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicInc(ticket, gridDim.x - 1u);
+    __syncthreads();
+    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket);
+    const uint32_t units0 = tier0_shards * sgroups;
+    if (b >= units0) {
+      b -= units0;
+      spb = tier_spb & 0xFFu;
+      sgroups = kSlots / spb;
+      uint32_t first = tier0_shards;  // the tier's first shard
+      const uint32_t units1 = tier1_shards * sgroups;
+      if (b >= units1) {
+        b -= units1;
+        spb = (tier_spb >> 8) & 0xFFu;
+        sgroups = kSlots / spb;
+        first += tier1_shards;
+      }
+      b += first * sgroups;
+    }
+  }
   const uint32_t bt = b % btiles;
   b /= btiles;
   const uint32_t ag = b % agroups;

@@ -152,7 +152,7 @@ int32_t fbk_last_error_r(fbk_ctx* ctx, char* buf, uint64_t cap, int32_t* out_cod
  * closed with fbk_close, before its root. */
 int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
 
-/* Options (20; round 5 removed fifteen A/B switches together with the kernels and paths that had lost their comparison —
+/* Options (22; round 5 removed fifteen A/B switches together with the kernels and paths that had lost their comparison —
  * DESIGN.md section 4 lists them).  The environment variables FBK_<NAME> are read ONCE, by fbk_open; afterwards only these
  * calls change an option.
  *   semantics (DEFAULT 1 = the reference's result, 0 = the arithmetically exact one; see fbk_count_range, fbk_topn):
@@ -168,7 +168,8 @@ int32_t fbk_ctx_fork(fbk_ctx* ctx, fbk_ctx** out_child);
  *     then returns that kernel's duration for the last such call;
  *   kernel selection, each a choice the library makes by itself (the default) that a test or a measurement can pin — BOTH
  *     sides are product paths, chosen by the shape of the call or of the rows: dense_spb and matrix_spb (container slots per
- *     block of the dense count / the count matrices), matrix_fused (encoded rows: -1 by the matrix size, 1 the matrix-core
+ *     block of the dense count / the count matrices), matrix_tickets (dense single-tile count matrix: 1 its blocks take their units
+ *     from a ticket counter, long units first — the device's XCDs run at different paces; 0 by block id), matrix_fused (encoded rows: -1 by the matrix size, 1 the matrix-core
  *     kernel that decodes the rows in place, 0 the generic pair kernel), matrix_fp4 (dense count matrix on the FP4 matrix
  *     instruction: -1 for matrices of several tiles), topk_device_sort (-1 by the field size), pair_kernels (0 by the rows'
  *     payload: the round-2 kernels for tiny containers, the table + probe kernels otherwise), pair_wpb (their waves per

@@ -9,7 +9,9 @@
 //   * per XCD: blocks executed, when its last block ended relative to the launch's end, CUs seen.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFBK_MM_STAMPS scripts/matrix_xcd_hist.hip -o scripts/matrix_xcd_hist
-//   scripts/matrix_xcd_hist [shards=1024] [spb=4] [launches=5] > profiles/r06_matrix_xcd_hist_1024.txt
+//   scripts/matrix_xcd_hist [shards=1024] [spb=4] [launches=5] [tickets=0] > profiles/r06_matrix_xcd_hist_1024.txt
+// tickets = 1: the launch as the library issues it since round 6 (units by ticket, three tiers, spare blocks: mm_ticket_plan);
+// tickets = 2: both forms alternating, launch by launch, on the same memory.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -52,6 +54,7 @@ static double med(std::vector<double> v) {
 int main(int argc, char** argv) {
   const uint32_t shards = argc > 1 ? atoi(argv[1]) : 1024, spb = argc > 2 ? atoi(argv[2]) : 4;
   const int launches = argc > 3 ? atoi(argv[3]) : 5;
+  const int tickets = argc > 4 ? atoi(argv[4]) : 0;
   const uint32_t nA = 32, nB = 32;
   const size_t rowBytes = 16 * 8192;
   uint8_t *A, *B, *F;
@@ -75,36 +78,71 @@ int main(int argc, char** argv) {
   u64* out;
   const size_t outBytes = (size_t)shards * nA * nB * 8;
   CK(hipMalloc(&out, outBytes));
-  const uint32_t blocks = shards * (16 / spb);
+  const uint32_t blocks_static = shards * (16 / spb);
+  fbk::MmTickets tk{0, 0, 0, 0};
+  const bool have_plan = fbk::mm_ticket_plan(shards, spb, 512, tk);
+  if (tickets && !have_plan) {
+    printf("no ticket plan for %u shards at %u slots per block\n", shards, spb);
+    return 1;
+  }
+  uint32_t* dticket;
+  CK(hipMalloc(&dticket, 256));
+  CK(hipMemset(dticket, 0, 256));
+  uint32_t blocks = blocks_static;
+  bool by_ticket = false;
   u64* dstamps;
-  CK(hipMalloc(&dstamps, (size_t)blocks * 32));
+  CK(hipMalloc(&dstamps, (size_t)std::max(blocks_static, tk.grid) * 32));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(fbk::g_mm_stamps), &dstamps, sizeof(dstamps)));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   auto launch = [&] {
-    hipLaunchKernelGGL((fbk::k_count_matrix_mfma<true, 4, 2, 2, 1, 1>), dim3(blocks), dim3(256), 0, 0, A, rowsA, nA, B, rowsB, nB, F, rowsF, shards, spb, out);
+    if (by_ticket)
+      hipLaunchKernelGGL((fbk::k_count_matrix_mfma<true, 4, 2, 2, 1, 1>), dim3(tk.grid), dim3(256), 0, 0, A, rowsA, nA, B, rowsB, nB, F, rowsF, shards, spb, out, dticket,
+                         tk.tier0_shards, tk.tier1_shards, tk.tier_spb);
+    else
+      hipLaunchKernelGGL((fbk::k_count_matrix_mfma<true, 4, 2, 2, 1, 1>), dim3(blocks_static), dim3(256), 0, 0, A, rowsA, nA, B, rowsB, nB, F, rowsF, shards, spb, out);
   };
   const double bytes = (double)shards * (nA + nB + 1) * 16 * 8192;
   printf("# k_count_matrix_mfma<F, 4 waves, depth 2, nt, 1x1>: %u shards x (32 + 32 + 1) dense rows, %u slots per block = %u blocks of %.2f MB; %.1f MB per launch\n", shards, spb,
-         blocks, bytes / blocks * 1e-6, bytes * 1e-6);
-  for (int i = 0; i < 5; ++i) {
+         blocks_static, bytes / blocks_static * 1e-6, bytes * 1e-6);
+  if (tickets)
+    printf("# by ticket: %u shards in units of %u slots, %u in units of %u, %u in units of %u; grid %u\n", tk.tier0_shards, spb, tk.tier1_shards, tk.tier_spb & 255u,
+           shards - tk.tier0_shards - tk.tier1_shards, (tk.tier_spb >> 8) & 255u, tk.grid);
+  std::vector<u64> ref;
+  for (int i = 0; i < 6; ++i) {
+    by_ticket = tickets == 1 || (tickets == 2 && (i & 1));
     CK(hipMemsetAsync(out, 0, outBytes, 0));
     launch();
+    if (tickets == 2 && i < 2) {  // both forms give the same matrices
+      std::vector<u64> got(outBytes / 8);
+      CK(hipMemcpy(got.data(), out, outBytes, hipMemcpyDeviceToHost));
+      if (i == 0) ref = got;
+      else printf("# by ticket == by block id: %s\n", got == ref ? "yes" : "NO");
+    }
   }
   CK(hipDeviceSynchronize());
-  std::vector<u64> st((size_t)blocks * 4);
+  std::vector<u64> st_all((size_t)std::max(blocks_static, tk.grid) * 4);
   const uint32_t kSlotsRunning = 512;
+  std::vector<double> ev_us[2];
   for (int it = 0; it < launches; ++it) {
+    by_ticket = tickets == 1 || (tickets == 2 && (it & 1));
+    const uint32_t grid = by_ticket ? tk.grid : blocks_static;
     CK(hipMemsetAsync(out, 0, outBytes, 0));
-    CK(hipMemsetAsync(dstamps, 0, (size_t)blocks * 32, 0));
+    CK(hipMemsetAsync(dstamps, 0, (size_t)grid * 32, 0));
     CK(hipEventRecord(e0, 0));
     launch();
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    CK(hipMemcpy(st.data(), dstamps, (size_t)blocks * 32, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(st_all.data(), dstamps, (size_t)grid * 32, hipMemcpyDeviceToHost));
+    ev_us[by_ticket ? 1 : 0].push_back(ms * 1e3);
+    std::vector<u64> st;  // the blocks that ran a unit (a spare block of a ticketed launch leaves no stamp)
+    for (uint32_t b = 0; b < grid; ++b)
+      if (st_all[4 * (size_t)b + 1])
+        for (int k = 0; k < 4; ++k) st.push_back(st_all[4 * (size_t)b + k]);
+    blocks = (uint32_t)(st.size() / 4);
     u64 T0 = ~0ull, T1 = 0;
     for (uint32_t b = 0; b < blocks; ++b) T0 = std::min(T0, st[4 * b]), T1 = std::max(T1, st[4 * b + 1]);
     const double dur = (double)(T1 - T0) * 0.01;  // us
@@ -121,7 +159,7 @@ int main(int argc, char** argv) {
     const uint32_t ns = std::min(kSlotsRunning, blocks);
     double ramp = 0, drain = 0;
     for (uint32_t i = 0; i < ns; ++i) ramp += starts[by_start[i]], drain += dur - ends[by_end[blocks - 1 - i]];
-    printf("\nlaunch %d: %.1f us between HIP events (%.3f of 8 TB/s); first block start -> last block end %.1f us (%.3f); slot-time in blocks %.1f %% of %u slots x that\n", it, ms * 1e3,
+    printf("\nlaunch %d (%s, %u units): %.1f us between HIP events (%.3f of 8 TB/s); first block start -> last block end %.1f us (%.3f); slot-time in blocks %.1f %% of %u slots x that\n", it, by_ticket ? "by ticket" : "by block id", blocks, ms * 1e3,
            bytes / (ms * 1e-3) / 8e12, dur, bytes / (dur * 1e-6) / 8e12, 100.0 * busy / (ns * dur), ns);
     printf("  ramp : the %u slots' first blocks start %.2f us after the first on average (last of them at %.2f us)\n", ns, ramp / ns, starts[by_start[ns - 1]]);
     printf("  drain: the %u slots' last blocks end %.2f us before the launch's end on average (first of them %.2f us before); the last block STARTED %.2f us before the end\n", ns,
@@ -166,5 +204,7 @@ int main(int argc, char** argv) {
     }
     printf("\n");
   }
+  for (int m = 0; m < 2; ++m)
+    if (!ev_us[m].empty()) printf("\n# %s: median %.1f us of %zu launches = %.3f of 8 TB/s\n", m ? "by ticket" : "by block id", med(ev_us[m]), ev_us[m].size(), bytes / (med(ev_us[m]) * 1e-6) / 8e12);
   return 0;
 }

@@ -578,6 +578,55 @@ def test_count_matrix_dense_kernel_vs_numpy(gpu_ctx, n_shards, n_a, n_b, use_fil
         F.free()
 
 
+def test_count_matrix_dense_by_ticket_vs_numpy(gpu_ctx):
+    """Round 6: a single-tile dense count matrix of many shards takes its units by TICKET (option matrix_tickets, default 1:
+    three tiers of unit sizes, spare blocks that find no unit — fbk_matrix_mfma.hip.h).  520 shards (not a multiple of anything)
+    x 3 x 2 rows + filter against numpy popcounts, with the launch by block id (matrix_tickets = 0) beside it, for every
+    slots-per-block value: 0 (the library's choice: 2 here), 2 and 4 have a ticket plan at this size, 8 and 16 do not — and
+    twice in a row, since the counter has to be back at zero after every launch."""
+    n_shards, n_a, n_b = 520, 3, 2
+    wa = D.dense_rows(n_shards * n_a, 0.5, 911)
+    wb = D.dense_rows(n_shards * n_b, 0.5, 912)
+    wf = D.dense_rows(n_shards, 0.5, 913)
+    wa[7] = 0  # an empty row, a full one
+    wb[-1] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    A, Bt, F = gpu_ctx.upload_dense(wa), gpu_ctx.upload_dense(wb), gpu_ctx.upload_dense(wf)
+    ra = np.arange(n_shards * n_a).reshape(n_shards, n_a)
+    rb = np.arange(n_shards * n_b).reshape(n_shards, n_b)
+    rf = np.arange(n_shards)
+    exp = np.zeros((n_shards, n_a, n_b), dtype=np.uint64)
+    for i in range(n_a):
+        x = wa[i::n_a] & wf
+        for j in range(n_b):
+            exp[:, i, j] = np.bitwise_count(x & wb[j::n_b]).sum(axis=(1, 2))
+    try:
+        for tickets in (1, 0):
+            gpu_ctx.set_option("matrix_tickets", tickets)
+            for spb in (0, 2, 4, 8, 16):
+                gpu_ctx.set_option("matrix_spb", spb)
+                for rep in range(2):
+                    tot, ps = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf, per_shard=True)
+                    assert (ps == exp).all(), (tickets, spb, rep)
+                    assert (tot == exp.sum(axis=0)).all(), (tickets, spb, rep)
+        # without the filter row, and the total alone in passes of ~130 shards
+        gpu_ctx.set_option("matrix_tickets", 1)
+        gpu_ctx.set_option("matrix_spb", 0)
+        exp2 = np.zeros((n_a, n_b), dtype=np.uint64)
+        for i in range(n_a):
+            for j in range(n_b):
+                exp2[i, j] = np.bitwise_count(wa[i::n_a] & wb[j::n_b]).sum()
+        assert (gpu_ctx.count_matrix(A, ra, Bt, rb, None, None) == exp2).all()
+        gpu_ctx.set_option("matrix_pass_kb", max(1, (130 * n_a * n_b * 8) // 1024))
+        assert (gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf) == exp.sum(axis=0)).all()
+    finally:
+        gpu_ctx.set_option("matrix_tickets", 1)
+        gpu_ctx.set_option("matrix_spb", 0)
+        gpu_ctx.set_option("matrix_pass_kb", 1048576)
+    A.free()
+    Bt.free()
+    F.free()
+
+
 def test_rows_vs_filter_kernel_vs_oracle(gpu_ctx, oracle):
     """fbk_count_matrix with one B row per shard and no extra filter = doTopK / fragment.top:
     every encoding of the rows against every encoding of the filter, incl. full / empty / nil
