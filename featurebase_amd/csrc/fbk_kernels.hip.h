@@ -39,6 +39,12 @@ __host__ __device__ inline uint32_t make_tn(uint32_t type, uint32_t n) { return 
 
 typedef unsigned long long u64;
 
+// -DFBK_MM_STAMPS (scripts/matrix_xcd_hist.hip only, never the library): every block of k_count_matrix_mfma / k_icount_dense records
+// when it started and ended (s_memrealtime, 100 MHz) and where it ran (XCC_ID, HW_ID) — four words per block at g_mm_stamps.
+#ifdef FBK_MM_STAMPS
+__device__ unsigned long long* g_mm_stamps;
+#endif
+
 // XCD-aware block index.  The dispatcher places block b on XCD b % 8, each XCD with its own L2: blocks with
 // CONSECUTIVE indexes share nothing in cache.  Kernels whose neighbouring blocks read the same lines — the 16
 // slots of one row's descriptor table (256 bytes = two lines per row, one block per slot), the rows of one
@@ -571,6 +577,9 @@ __global__ void __launch_bounds__(256) k_icount_dense(const uint8_t* __restrict_
                                                      uint32_t* __restrict__ done, uint32_t n_pairs,
                                                      u64* __restrict__ accum) {
   constexpr int kGroups = kSlots / SPB;
+#ifdef FBK_MM_STAMPS
+  const unsigned long long stamp_t0 = wall_clock64();
+#endif
   const uint32_t pair = blockIdx.x / kGroups;
   const uint32_t grp = blockIdx.x % kGroups;
   const uint64_t rowBytes = (uint64_t)kSlots * 8192;
@@ -579,6 +588,10 @@ __global__ void __launch_bounds__(256) k_icount_dense(const uint8_t* __restrict_
   constexpr int kIters = SPB * 8192 / 16 / 256;  // 16-byte chunks per thread
   constexpr int kUnroll = kIters < 8 ? kIters : 8;
   uint32_t c = 0;
+  // (Round 6 tried a per-block rotation of the 4 KiB chunks — every row is 128 KiB aligned and all blocks start together, so they
+  // ask for the same offsets of their rows at the same time: 42.3-42.5 us with or without it, profiles/r06_icount_dense_blocks.txt.
+  // The same stamps show what the end of a launch looks like: a CU serves its four blocks oldest first — they end at ~13, ~24, ~32
+  // and ~37 us — and the CUs themselves end between 34 and 39 us.)
   for (int i0 = 0; i0 < kIters; i0 += kUnroll) {
     ulonglong2 va[kUnroll], vb[kUnroll];
 #pragma unroll
@@ -593,6 +606,15 @@ __global__ void __launch_bounds__(256) k_icount_dense(const uint8_t* __restrict_
   __shared__ uint32_t s_last;
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
   __syncthreads();
+#ifdef FBK_MM_STAMPS
+  if (threadIdx.x == 0 && g_mm_stamps) {
+    unsigned long long* st = g_mm_stamps + 4ull * blockIdx.x;
+    st[0] = stamp_t0;
+    st[1] = wall_clock64();
+    st[2] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (3 << 11));  // HW_REG_XCC_ID[3:0]
+    st[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));  // HW_REG_HW_ID
+  }
+#endif
   if (threadIdx.x == 0) {
     u64 tot = (u64)part[0] + part[1] + part[2] + part[3];
     s_last = 0;

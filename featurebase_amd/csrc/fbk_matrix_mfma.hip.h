@@ -64,12 +64,6 @@ typedef uint32_t mm_u4 __attribute__((ext_vector_type(4)));
 typedef int mm_v8i __attribute__((ext_vector_type(8)));
 typedef float mm_v16f __attribute__((ext_vector_type(16)));
 
-// -DFBK_MM_STAMPS (scripts/matrix_xcd_hist.hip only, never the library): every block records when it started and ended
-// (s_memrealtime, 100 MHz) and where it ran (XCC_ID, HW_ID) — four words per block at g_mm_stamps.
-#ifdef FBK_MM_STAMPS
-__device__ unsigned long long* g_mm_stamps;
-#endif
-
 // The tiers of a ticketed launch (see TICKETS in the kernel): `resident` = the blocks the device holds at a time (2 per CU).  A tier's
 // work has to outlast the raggedness the tier before it leaves behind — one unit of that tier per resident block — so tier k + 1
 // gets the shards that `resident` units of tier k amount to; what is left over is tier 0, in units of spb0 slots.  Returns false
@@ -89,6 +83,32 @@ inline bool mm_ticket_plan(uint32_t n_shards, uint32_t spb0, uint32_t resident, 
   const uint64_t units = uint64_t(t.tier0_shards) * (kSlots / spb0) + uint64_t(s1) * (kSlots / spb1) + uint64_t(s2) * (kSlots / spb2);
   t.grid = uint32_t((units + units / 8 + 64 + 7) & ~7ull);  // spare blocks: an XCD may take an eighth more than its share
   return true;
+}
+
+// A block's unit by ticket (see TICKETS in k_count_matrix_mfma): the ticket as the block id of the launch-by-id form of the unit's
+// tier — its slots per block and slot groups per shard come back in spb / sgroups.  Called by every thread of the block.
+__device__ __forceinline__ uint32_t mm_ticket_unit(uint32_t* __restrict__ ticket, uint32_t tier0_shards, uint32_t tier1_shards, uint32_t tier_spb, uint32_t& spb,
+                                                   uint32_t& sgroups) {
+  __shared__ uint32_t s_ticket;
+  if (threadIdx.x == 0) s_ticket = atomicInc(ticket, gridDim.x - 1u);
+  __syncthreads();
+  uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket);
+  const uint32_t units0 = tier0_shards * sgroups;
+  if (b >= units0) {
+    b -= units0;
+    spb = tier_spb & 0xFFu;
+    sgroups = kSlots / spb;
+    uint32_t first = tier0_shards;  // the tier's first shard
+    const uint32_t units1 = tier1_shards * sgroups;
+    if (b >= units1) {
+      b -= units1;
+      spb = (tier_spb >> 8) & 0xFFu;
+      sgroups = kSlots / spb;
+      first += tier1_shards;
+    }
+    b += first * sgroups;
+  }
+  return b;
 }
 
 template <bool HAS_F, int WAVES = kMmWaves, int DEPTH = kMmDepth, int AUX = kMmAux, int TM = 1, int TN = 1, bool FP4 = false>
@@ -130,27 +150,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_count_matrix_mfma(
   // tier_spb[7:0] slots, the rest in units of tier_spb[15:8] — long units first, so that the end of the launch is ragged by a
   // short unit's time, not by a long one's.  atomicInc wraps at the grid size: every block takes exactly one ticket and the
   // counter is back at zero when the last one has (stream order does the rest).
-  if (ticket) {
-    __shared__ uint32_t s_ticket;
-    if (threadIdx.x == 0) s_ticket = atomicInc(ticket, gridDim.x - 1u);
-    __syncthreads();
-    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket);
-    const uint32_t units0 = tier0_shards * sgroups;
-    if (b >= units0) {
-      b -= units0;
-      spb = tier_spb & 0xFFu;
-      sgroups = kSlots / spb;
-      uint32_t first = tier0_shards;  // the tier's first shard
-      const uint32_t units1 = tier1_shards * sgroups;
-      if (b >= units1) {
-        b -= units1;
-        spb = (tier_spb >> 8) & 0xFFu;
-        sgroups = kSlots / spb;
-        first += tier1_shards;
-      }
-      b += first * sgroups;
-    }
-  }
+  if (ticket) b = mm_ticket_unit(ticket, tier0_shards, tier1_shards, tier_spb, spb, sgroups);
   const uint32_t bt = b % btiles;
   b /= btiles;
   const uint32_t ag = b % agroups;
