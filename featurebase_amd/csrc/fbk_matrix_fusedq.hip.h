@@ -23,10 +23,16 @@
 
 namespace fbk {
 
-constexpr int kFqNA = 5;                 // array waves: producer waves 0 .. 4
+#ifndef FBK_V_FQNA  // (build variants: scripts/build_variant.sh x -DFBK_V_FQNA=6 -DFBK_V_FQBP=7)
+#define FBK_V_FQNA 5
+#endif
+#ifndef FBK_V_FQBP
+#define FBK_V_FQBP 6
+#endif
+constexpr int kFqNA = FBK_V_FQNA;        // array waves: producer waves 0 .. 4
 constexpr int kFqNB = kFxProducers - kFqNA;  // bitmap waves: producer waves 5 .. 11
 constexpr int kFqAP = 4;                 // array items per group and stage loaded ahead
-constexpr int kFqBP = 6;                 // bitmap rows per bitmap wave and slot loaded ahead
+constexpr int kFqBP = FBK_V_FQBP;        // bitmap rows per bitmap wave and slot loaded ahead
 constexpr int kFqGroups = kFqNA * 4;     // 16-lane groups of the array waves: item x of a stage goes to group x mod 20
 
 template <bool HAS_F, bool PROF = false>
@@ -86,7 +92,12 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
     struct Oct {
       mm_u4 a, b, f;
     };
-    constexpr int kLdOps = (HAS_F ? 3 : 2) + 2;  // LDS instructions of one octet's loads: the reads and the two clean-up writes behind them
+#ifdef FBK_V_NOZB  // (timing variant, WRONG results: nothing is cleaned behind the reads)
+    constexpr int kZb = 0;
+#else
+    constexpr int kZb = 2;
+#endif
+    constexpr int kLdOps = (HAS_F ? 3 : 2) + kZb;  // LDS instructions of one octet's loads: the reads and the two clean-up writes behind them
     constexpr int kBOff = 32 * kFxStride;        // (33 280: the offset field of a DS instruction is 16 bits)
     auto issue = [&](Oct& o, uint32_t bufoff, int t) {
       const uint32_t aa = addrA + bufoff, ff = addrF + bufoff;
@@ -94,8 +105,10 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o.b) : "v"(aa), "n"(kBOff + 32 * t));
       if (HAS_F) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o.f) : "v"(ff), "n"(32 * t));
       // clean behind the read (LDS operations of one wave execute in order): the producers get the buffer back zeroed
-      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aa), "v"(zero4), "n"(32 * t) : "memory");
-      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aa), "v"(zero4), "n"(kBOff + 32 * t) : "memory");
+      if (kZb) {
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aa), "v"(zero4), "n"(32 * t) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aa), "v"(zero4), "n"(kBOff + 32 * t) : "memory");
+      }
     };
     auto landed = [&](Oct& o, bool more_behind) {  // o's reads are complete (LDS returns in order)
       if (more_behind) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(kLdOps) : "memory");
@@ -124,6 +137,9 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
       }
     };
     __syncthreads();  // (the producers' set-up barrier)
+#ifdef FBK_V_CPRIO
+    __builtin_amdgcn_s_setprio(FBK_V_CPRIO);
+#endif
     for (uint32_t it = 0; it <= n_stage; ++it) {
       stamp(it, 0);
       if (it >= 1 && !(ablate & 1u)) {
@@ -396,14 +412,33 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
     const FxProg& T = tabs[par];
     const uint32_t nbm = fx_uniform(T.nbm);
     l_nrun = fx_uniform(T.nrun);
+#ifndef FBK_V_SERIAL_ENTER
+    // LANE k looks up the wave's k-th row (list entry, then the row's address): two LDS round trips for the whole slot.  Row by row —
+    // each entry and each address made wave-uniform before the next is asked for — it was twelve, one after the other: 3 000 cycles
+    // of the stage that crosses a slot boundary, in which the bitmap waves arrived last (profiles/r06_fused_cycle_stamps_*.txt).
+    uint32_t row_l = 0, lo_l = 0, hi_l = 0;
+    {
+      const uint32_t e_l = bw + (uint32_t)kFqNB * (uint32_t)lane;
+      if (lane < kFqBP && e_l < nbm) {
+        row_l = T.bml[e_l];
+        const uint4 rt = T.row[row_l][0];
+        lo_l = rt.x, hi_l = rt.y;
+      }
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < kFqBP; ++k) {
       const uint32_t e = bw + (uint32_t)kFqNB * k;
       uint32_t off = ~0u;
       if (e < nbm) {
+#ifndef FBK_V_SERIAL_ENTER
+        bm_lo[k] = (uint32_t)__builtin_amdgcn_readlane((int)lo_l, k), bm_hi[k] = (uint32_t)__builtin_amdgcn_readlane((int)hi_l, k);
+        off = (uint32_t)__builtin_amdgcn_readlane((int)row_l, k) * (uint32_t)kFxStride;
+#else
         const uint32_t row = fx_uniform(T.bml[e]);
         const uint4 rt = T.row[row][0];
         bm_lo[k] = fx_uniform(rt.x), bm_hi[k] = fx_uniform(rt.y), off = row * (uint32_t)kFxStride;
+#endif
       }
       if (par) bmo1[k] = off;
       else bmo0[k] = off;

@@ -53,6 +53,16 @@ for i, r in enumerate(rows):
             print("   %-60s start +%10.1f us  dur %10.1f us" % (q["Kernel_Name"][:60], (int(q["Start_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3, (int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) / 1e3))
 PY
   rm -rf $O/fresh_trace ;;
+libab)  # k_count_matrix_fusedq of several library builds (LIBS: names under build_variants/, or "product"), alternating, rows generated once
+  timeout 600 python scripts/fused_lib_ab.py gen ${S3:-256} ${S4:-1024} > $O/libab_gen.log 2>&1; echo "gen rc $?"
+  for round in 1 2 3; do for L in ${LIBS:-product}; do
+    if [ $L = product ]; then timeout 300 python scripts/fused_lib_ab.py run $LIBAB_OPTS >> $O/libab.jsonl 2>> $O/libab.err
+    else FBK_LIB_PATH=$R/build_variants/$L/libfbk.so timeout 300 python scripts/fused_lib_ab.py run $LIBAB_OPTS >> $O/libab.jsonl 2>> $O/libab.err; fi
+  done; done
+  python scripts/fused_lib_ab.py rm; cut -c1-400 $O/libab.jsonl ;;
+fprof)  # cycle stamps of one block of k_count_matrix_fusedq (the -DFBK_EXPERIMENTS build), config 3 and config 4
+  timeout 400 python scripts/fused_prof.py 256 0 0 3 2> $O/fprof_c3.txt > /dev/null; python scripts/fused_prof_summary.py $O/fprof_c3.txt 24 > $O/fprof_c3_summary.txt; head -12 $O/fprof_c3_summary.txt | cut -c1-300
+  timeout 600 python scripts/fused_prof.py 1024 0 0 4 2> $O/fprof_c4.txt > /dev/null; python scripts/fused_prof_summary.py $O/fprof_c4.txt 24 > $O/fprof_c4_summary.txt; head -12 $O/fprof_c4_summary.txt | cut -c1-300 ;;
 *) echo "unknown: $what" ;;
 esac
 done
