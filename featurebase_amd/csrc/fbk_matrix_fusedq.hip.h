@@ -92,12 +92,11 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
     struct Oct {
       mm_u4 a, b, f;
     };
-#ifdef FBK_V_NOZB  // (timing variant, WRONG results: nothing is cleaned behind the reads)
-    constexpr int kZb = 0;
-#else
-    constexpr int kZb = 2;
-#endif
-    constexpr int kLdOps = (HAS_F ? 3 : 2) + kZb;  // LDS instructions of one octet's loads: the reads and the two clean-up writes behind them
+    // LDS instructions of one octet's loads: the reads and the two clean-up writes behind them.  (Round 6, profiles/r06_fused_lib_ab_prio_nozb.jsonl:
+    // a build WITHOUT the clean-up writes — wrong counts — is 2.5-4 % faster, which bounds what type-aware or producer-side zeroing could
+    // bring; a ds_write_b128 costs the same 14.7 cycles whatever lanes are enabled (profiles/r06_mfma_valu_overlap.txt), so masking the
+    // lanes of bitmap rows buys nothing; s_setprio 1 / 3 on these waves: +-0.5 %.)
+    constexpr int kLdOps = (HAS_F ? 3 : 2) + 2;
     constexpr int kBOff = 32 * kFxStride;        // (33 280: the offset field of a DS instruction is 16 bits)
     auto issue = [&](Oct& o, uint32_t bufoff, int t) {
       const uint32_t aa = addrA + bufoff, ff = addrF + bufoff;
@@ -105,10 +104,8 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o.b) : "v"(aa), "n"(kBOff + 32 * t));
       if (HAS_F) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o.f) : "v"(ff), "n"(32 * t));
       // clean behind the read (LDS operations of one wave execute in order): the producers get the buffer back zeroed
-      if (kZb) {
-        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aa), "v"(zero4), "n"(32 * t) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aa), "v"(zero4), "n"(kBOff + 32 * t) : "memory");
-      }
+      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aa), "v"(zero4), "n"(32 * t) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aa), "v"(zero4), "n"(kBOff + 32 * t) : "memory");
     };
     auto landed = [&](Oct& o, bool more_behind) {  // o's reads are complete (LDS returns in order)
       if (more_behind) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(kLdOps) : "memory");
@@ -137,9 +134,6 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
       }
     };
     __syncthreads();  // (the producers' set-up barrier)
-#ifdef FBK_V_CPRIO
-    __builtin_amdgcn_s_setprio(FBK_V_CPRIO);
-#endif
     for (uint32_t it = 0; it <= n_stage; ++it) {
       stamp(it, 0);
       if (it >= 1 && !(ablate & 1u)) {
@@ -412,10 +406,10 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
     const FxProg& T = tabs[par];
     const uint32_t nbm = fx_uniform(T.nbm);
     l_nrun = fx_uniform(T.nrun);
-#ifndef FBK_V_SERIAL_ENTER
     // LANE k looks up the wave's k-th row (list entry, then the row's address): two LDS round trips for the whole slot.  Row by row —
     // each entry and each address made wave-uniform before the next is asked for — it was twelve, one after the other: 3 000 cycles
-    // of the stage that crosses a slot boundary, in which the bitmap waves arrived last (profiles/r06_fused_cycle_stamps_*.txt).
+    // of the stage that crosses a slot boundary in the INSTRUMENTED build (profiles/r06_fused_cycle_stamps_*.txt).  The product
+    // build is bound elsewhere: same counts, +-1 % against the row-by-row form (profiles/r06_fused_lib_ab_roles_enter.jsonl).
     uint32_t row_l = 0, lo_l = 0, hi_l = 0;
     {
       const uint32_t e_l = bw + (uint32_t)kFqNB * (uint32_t)lane;
@@ -425,20 +419,13 @@ __global__ void __launch_bounds__(kFxWaves * 64) k_count_matrix_fusedq(const FxP
         lo_l = rt.x, hi_l = rt.y;
       }
     }
-#endif
 #pragma unroll
     for (int k = 0; k < kFqBP; ++k) {
       const uint32_t e = bw + (uint32_t)kFqNB * k;
       uint32_t off = ~0u;
       if (e < nbm) {
-#ifndef FBK_V_SERIAL_ENTER
         bm_lo[k] = (uint32_t)__builtin_amdgcn_readlane((int)lo_l, k), bm_hi[k] = (uint32_t)__builtin_amdgcn_readlane((int)hi_l, k);
         off = (uint32_t)__builtin_amdgcn_readlane((int)row_l, k) * (uint32_t)kFxStride;
-#else
-        const uint32_t row = fx_uniform(T.bml[e]);
-        const uint4 rt = T.row[row][0];
-        bm_lo[k] = fx_uniform(rt.x), bm_hi[k] = fx_uniform(rt.y), off = row * (uint32_t)kFxStride;
-#endif
       }
       if (par) bmo1[k] = off;
       else bmo0[k] = off;

@@ -267,6 +267,29 @@ def library_comm_init(ctx) -> bool:
         if ok:
             ctx.comm_close()
         return False
+    # Pre-flight: ONE all-reduce through the new communicator, checked on every rank against the closed form.  The library's
+    # collectives have never run over more than one device; a wrong sum here sends every rank back to torch's collectives
+    # instead of failing the run's parity assert later.
+    good = 1
+    try:
+        probe = torch.tensor([rank + 1], dtype=torch.int64, device=dev)
+        if dev is not None:
+            torch.cuda.synchronize()
+        ctx.comm_all_reduce(probe.data_ptr(), 1)
+        ctx.comm_fence()
+        if dev is not None:
+            torch.cuda.synchronize()
+        if int(probe.item()) != world * (world + 1) // 2:
+            print(f"[fbk dist] rank {rank}: the library's all-reduce returned {int(probe.item())}, expected {world * (world + 1) // 2}", file=sys.stderr, flush=True)
+            good = 0
+    except Exception as e:  # noqa: BLE001
+        print(f"[fbk dist] rank {rank}: the library's all-reduce failed: {e}", file=sys.stderr, flush=True)
+        good = 0
+    t = torch.tensor([good], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t.item()) == 0:
+        ctx.comm_close()
+        return False
     return True
 
 

@@ -418,3 +418,35 @@ def test_library_communicator_one_rank(gpu_ctx):
         gpu_ctx.comm_fence()  # no communicator any more
     plan.free()
     A.free()
+
+
+def test_library_comm_init_through_torch_one_rank():
+    """dist.library_comm_init as bench.py --gpus N calls it, on a one-rank `nccl` process group (the hardware this box has): the
+    unique id travels through torch, every rank enters ncclCommInitRank, and the PRE-FLIGHT all-reduce through the new
+    communicator is checked against the closed form before the caller is told to use it.  In a process of its own: a process
+    group is global state."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from featurebase_amd import dist as fd\n"
+        "from featurebase_amd.roaring import Context\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "ctx = Context(0)\n"
+        "ok = fd.library_comm_init(ctx)\n"
+        "assert ok, 'library_comm_init fell back to torch on one rank'\n"
+        "red = fd.LibraryPerQueryReducer(ctx, 1, 4, torch.device('cuda:0'))\n"
+        "red.buf.fill_(7); torch.cuda.synchronize()\n"
+        "red.reduce(); red.flush(); ctx.synchronize()\n"
+        "assert int(red.buf[0, 0].item()) == 7\n"
+        "ctx.comm_close(); ctx.close(); dist.destroy_process_group()\n"
+        "print('library_comm_init ok')\n"
+    )
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "library_comm_init ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
