@@ -189,6 +189,9 @@ def compact_line(full: dict, detail_name: str = "bench_detail.json") -> dict:
     c = full.get("roofline_l3_cold")
     if c:
         out["roofline_l3_cold"] = {"working_set_MiB": c.get("working_set_MiB"), "kernel_us": _r(c.get("kernel_us"), 2), "frac": _r(c.get("frac"))}
+    t2 = full.get("two_contexts")
+    if t2 and "error" not in t2:
+        out["two_contexts"] = {k: _r(t2.get(k), 5) for k in ("ms_per_step", "set_ops_per_s", "frac_of_8TBps")}
     tb = full.get("throughput_mode_bucketed")
     if tb:
         out["throughput_mode_bucketed"] = {k: _r(tb.get(k)) for k in ("ms_per_step", "set_ops_per_s", "steps_per_collective")}
@@ -214,7 +217,7 @@ def dumps_line(full: dict, detail_name: str = "bench_detail.json") -> str:
     """The line itself; shrinks in steps (never past the contract keys) if a future entry pushes it over the limit."""
     c = compact_line(full, detail_name)
     s = json.dumps(c, separators=(",", ":"))
-    for drop in ("group_api", "materialized", "roofline_l3_cold", "ms_per_step_distribution", "note"):
+    for drop in ("group_api", "two_contexts", "materialized", "roofline_l3_cold", "ms_per_step_distribution", "note"):
         if len(s.encode()) <= LINE_TARGET:
             break
         c.pop(drop, None)
