@@ -627,6 +627,39 @@ def test_count_matrix_dense_by_ticket_vs_numpy(gpu_ctx):
     F.free()
 
 
+@pytest.mark.parametrize("n_shards", [256, 257, 383, 512, 513, 777, 1025])
+def test_count_matrix_dense_ticket_tiers_at_their_edges(gpu_ctx, n_shards):
+    """The tiers of the ticketed launch (mm_ticket_plan) at shard counts around the places where the plan changes: the first size with
+    a plan at 2 slots per unit (256), odd sizes, the first with a plan at 4 slots (512), one past a power of two.  1 x 2 rows + filter,
+    per-shard counts against numpy popcounts, units by ticket and by block id, library-chosen and forced slots per unit."""
+    n_a, n_b = 1, 2
+    wa = D.dense_rows(n_shards * n_a, 0.5, 3100 + n_shards)
+    wb = D.dense_rows(n_shards * n_b, 0.5, 3200 + n_shards)
+    wf = D.dense_rows(n_shards, 0.5, 3300 + n_shards)
+    A, Bt, F = gpu_ctx.upload_dense(wa), gpu_ctx.upload_dense(wb), gpu_ctx.upload_dense(wf)
+    ra = np.arange(n_shards * n_a).reshape(n_shards, n_a)
+    rb = np.arange(n_shards * n_b).reshape(n_shards, n_b)
+    rf = np.arange(n_shards)
+    exp = np.zeros((n_shards, n_a, n_b), dtype=np.uint64)
+    x = wa & wf
+    for j in range(n_b):
+        exp[:, 0, j] = np.bitwise_count(x & wb[j::n_b]).sum(axis=(1, 2))
+    try:
+        for tickets, spb in ((1, 0), (1, 2), (1, 4), (1, 8), (0, 0)):
+            gpu_ctx.set_option("matrix_tickets", tickets)
+            gpu_ctx.set_option("matrix_spb", spb)
+            for rep in range(2):
+                tot, ps = gpu_ctx.count_matrix(A, ra, Bt, rb, F, rf, per_shard=True)
+                assert (ps == exp).all(), (n_shards, tickets, spb, rep)
+                assert (tot == exp.sum(axis=0)).all(), (n_shards, tickets, spb, rep)
+    finally:
+        gpu_ctx.set_option("matrix_tickets", 1)
+        gpu_ctx.set_option("matrix_spb", 0)
+    A.free()
+    Bt.free()
+    F.free()
+
+
 def test_rows_vs_filter_kernel_vs_oracle(gpu_ctx, oracle):
     """fbk_count_matrix with one B row per shard and no extra filter = doTopK / fragment.top:
     every encoding of the rows against every encoding of the filter, incl. full / empty / nil
