@@ -97,4 +97,7 @@ py = (base[:, None] + 18 + np.arange(16)[None, :]).astype(np.uint32)
 rec("fbk_bsi_add 16 + 16 planes (k_bsi_add)", pl * (32 + 17), lambda: ctx.bsi_add(bsi, px, bsi, py))
 small = ctx.upload_dense(w[:4, :18].reshape(-1))  # Distinct: 4 shards x (16 planes + exists + sign): 4 M values
 rec("fbk_bsi_distinct 4 shards x 16 planes (k_bsi_values + radix sort + unique)", 4 * 16 * 8192 * 18 + 4 * (1 << 20) * 8, lambda: ctx.bsi_distinct(small, np.arange(4, dtype=np.uint32) * 18, 16))
+if n5 >= 32:  # the same kernel where the launch is not most of it: 32 shards = 32 M values (344 MB: 75 read + 268 written)
+    mid = ctx.upload_dense(w[:32, :18].reshape(-1))
+    rec("fbk_bsi_distinct 32 shards x 16 planes (k_bsi_values + radix sort + unique)", 32 * 16 * 8192 * 18 + 32 * (1 << 20) * 8, lambda: ctx.bsi_distinct(mid, np.arange(32, dtype=np.uint32) * 18, 16))
 print(json.dumps(out))
