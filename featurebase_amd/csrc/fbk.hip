@@ -1484,9 +1484,20 @@ void launch_setop(bool dense, fbk_plan* p, hipStream_t st, bool want_runs, const
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
                        want_runs ? p->d_runs : nullptr, direct2, (const Slot*)nullptr);
   else if (use_pair_kernels2(p->ctx, p->a, p->b, OP == 0 ? FBK_OP_AND : OP == 1 ? FBK_OP_OR : OP == 2 ? FBK_OP_XOR : FBK_OP_ANDNOT))
-    hipLaunchKernelGGL((fbk::k_setop2<OP, 1>), dim3(uint32_t(p->n_pairs * fbk::kSlots)), dim3(64), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
-                       p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
-                       want_runs ? p->d_runs : nullptr, direct2, items);
+  {
+    // Intersect / Difference with optimize(): most results come from the probe paths — the register-lean instance (18 instead of 16 waves per CU;
+    // setop_direct_encode = 0 / 1 run the common instance + the separate re-encode pass: the byte-for-byte cross-check).  Union / Xor with
+    // optimize() send every item down the general path: there the lean instance loses 3 % (509 -> 524 us, profiles/r06_setop2_occupancy.txt)
+    constexpr bool kHasProbe = OP == 0 || OP == 3;
+    if (kHasProbe && direct == 2u)
+      hipLaunchKernelGGL((fbk::k_setop2<OP, 1, kHasProbe>), dim3(uint32_t(p->n_pairs * fbk::kSlots)), dim3(64), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
+                         p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
+                         want_runs ? p->d_runs : nullptr, direct2, items);
+    else
+      hipLaunchKernelGGL((fbk::k_setop2<OP, 1>), dim3(uint32_t(p->n_pairs * fbk::kSlots)), dim3(64), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
+                         p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,
+                         want_runs ? p->d_runs : nullptr, direct2, items);
+  }
   else
     hipLaunchKernelGGL(fbk::k_setop<OP>, dim3(blocks), dim3(256), 0, st, p->a->d_slots, p->a->d_arena, p->d_rows_a,
                        p->b->d_slots, p->b->d_arena, p->d_rows_b, p->n_pairs, p->out->d_arena, p->out->d_slots,

@@ -1081,8 +1081,12 @@ __device__ __forceinline__ void array_vs_run_emit(const uint8_t* __restrict__ pr
 
 // Materialising A <op> B, one wave per (pair, slot): k_setop's outputs and right-sized array paths
 // (fbk_kernels.hip.h) behind the pair loader above.
-template <int OP, int WPB>
-__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4))) k_setop2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
+// LEAN (round 6): the instance for calls whose results are mostly written by the probe paths (Intersect / Difference with optimize()).
+// The kernel's time follows its occupancy (profiles/r06_setop2_occupancy.txt: 16 / 14 / 12 waves per CU = 231 / 269 / 318 us) and 102
+// registers hold it at 4 waves per SIMD where the LDS allows 4.5: this instance is compiled for 5 (96 registers), its general path
+// — the minority of the items there — decodes one operand after the other (frag_load, the round-2 loader).
+template <int OP, int WPB, bool LEAN = false>
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LEAN ? 5 : 4))) k_setop2(const Slot* __restrict__ slotsA, const uint8_t* __restrict__ arenaA,
                                                     const uint32_t* __restrict__ rowsA, const Slot* __restrict__ slotsB,
                                                     const uint8_t* __restrict__ arenaB, const uint32_t* __restrict__ rowsB, uint64_t n_pairs,
                                                     uint8_t* __restrict__ arenaO, Slot* __restrict__ outSlots, uint32_t* __restrict__ outRuns,
@@ -1236,7 +1240,14 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4
     return;
   }
   u64 wa[kWordsPerLane], wb[kWordsPerLane];
-  frag_load_pair(sa, arenaA, sb, arenaB, lane, lds[wv], mini[wv], wa, wb);
+  if (LEAN) {  // one operand after the other through the table (the round-2 loader): the first one's temporaries are dead when the second starts
+    if (na) frag_load(sa, arenaA, lane, lds[wv], wa);
+    else frag_zero(wa);
+    if (nb) frag_load(sb, arenaB, lane, lds[wv], wb);
+    else frag_zero(wb);
+  } else {
+    frag_load_pair(sa, arenaA, sb, arenaB, lane, lds[wv], mini[wv], wa, wb);
+  }
 #pragma unroll
   for (int i = 0; i < kWordsPerLane; ++i) {
     wa[i] = apply_op<OP>(wa[i], wb[i]);

@@ -64,7 +64,8 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     res = {"shards": args.shards, "pairs": int(n_pairs), "encoded_bytes": int(rows.bytes), "type_pairs (n nil, a array, b bitmap, r run)": mix, "variants": {}}
     ops = [("intersectionCount", None), ("intersect", L.OP_AND), ("union", L.OP_OR), ("difference", L.OP_ANDNOT), ("xor", L.OP_XOR),
-           ("intersect + optimize()", (L.OP_AND, L.SETOP_OPTIMIZE)), ("difference + optimize()", (L.OP_ANDNOT, L.SETOP_OPTIMIZE))]
+           ("intersect + optimize()", (L.OP_AND, L.SETOP_OPTIMIZE)), ("difference + optimize()", (L.OP_ANDNOT, L.SETOP_OPTIMIZE)),
+           ("union + optimize()", (L.OP_OR, L.SETOP_OPTIMIZE)), ("xor + optimize()", (L.OP_XOR, L.SETOP_OPTIMIZE))]
     if args.only_count:
         ops = ops[:1]
     if args.ops:
