@@ -933,7 +933,9 @@ def main():
         global_expected = int(ge.item())
         vals = torch.cat([b.reshape(-1) for b in reduced]).cpu().numpy()
         vals = vals[vals != 0]
-        assert vals.size > 0 and (vals == global_expected).all(), "reduced totals differ from the sum of the per-shard counts"
+        assert vals.size > 0 and (vals == global_expected).all(), (
+            f"reduced totals differ from the sum of the per-shard counts: expected {global_expected} (this rank {local_expected}), cells "
+            f"{[int(x) for x in torch.cat([b.reshape(-1) for b in reduced]).cpu().numpy()]}")
 
         # ---- distribution: the same timed region `repeats` more times (median / p10 / p90 of the step time)
         rep = []

@@ -109,6 +109,18 @@ def bsi_sum_reduce(psum: int, nsum: int, count: int, device: Optional[str] = Non
     return (s - (1 << 64) if s >= (1 << 63) else s), int(v[2])
 
 
+def _filled(t):
+    """`t` (a tensor just created by torch.zeros) with its fill COMPLETE.  The fill is a kernel on the stream that was current when
+    the tensor was made — usually torch's default stream —, while the cells are written on the fbk context's stream and read by
+    the collective: without this wait a late fill can wipe a cell between the count kernel and the all-reduce (seen once with
+    eight ranks sharing one GPU: every rank's reduced totals short by one rank's share)."""
+    if t.is_cuda:
+        import torch
+
+        torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
 class BucketedCountReducer:
     """Cross-GPU sum of per-step partial counts with ONE collective per `bucket` steps.
 
@@ -127,7 +139,7 @@ class BucketedCountReducer:
         import torch
 
         self.bucket = int(bucket)
-        self.buf = [torch.zeros(self.bucket, dtype=torch.int64, device=device) for _ in range(2)]
+        self.buf = [_filled(torch.zeros(self.bucket, dtype=torch.int64, device=device)) for _ in range(2)]
         self.work = [None, None]
         self.cur = 0  # bucket being filled
         self.fill = 0  # slots used in it
@@ -199,7 +211,7 @@ class PerQueryReducer:
         self.producer_stream = producer_stream
         self.always = bool(always)  # issue the collective even in a one-rank group (scripts/collective_host_cost.py: what a call costs the launching thread)
         self.width, self.depth = int(width), int(depth)
-        self.buf = torch.zeros((self.depth, self.width), dtype=torch.int64, device=device)
+        self.buf = _filled(torch.zeros((self.depth, self.width), dtype=torch.int64, device=device))
         self.work = [None] * self.depth
         self.k = 0
         self.collectives = 0
@@ -307,7 +319,7 @@ class LibraryPerQueryReducer:
         if int(width) < 1 or int(depth) < 1:
             raise ValueError("LibraryPerQueryReducer: width and depth must be >= 1")
         self.ctx, self.width, self.depth = ctx, int(width), int(depth)
-        self.buf = torch.zeros((self.depth, self.width), dtype=torch.int64, device=device)
+        self.buf = _filled(torch.zeros((self.depth, self.width), dtype=torch.int64, device=device))
         self.base = self.buf.data_ptr()
         self.k = 0
         self.collectives = 0
@@ -399,7 +411,7 @@ def strong_scaling_queries(run_local, width: int, n_queries: int, device, expect
     pinned = torch.zeros(width, dtype=torch.int64)
     if device is not None and torch.device(device).type == "cuda":
         pinned = pinned.pin_memory()
-    cell = torch.zeros(width, dtype=torch.int64, device=device)
+    cell = _filled(torch.zeros(width, dtype=torch.int64, device=device))
     hl = []
     for _ in range(n_queries):
         t1 = time.perf_counter()
