@@ -274,6 +274,7 @@ def test_fused_count_and_total_plan(gpu_ctx):
     assert (counts == exp).all() and total == int(exp.sum())
     # into a caller-owned device cell
     cell = torch.zeros(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()  # (the fill runs on torch's stream, the kernel on the context's)
     plan.intersection_count_total(cell.data_ptr())
     gpu_ctx.synchronize()
     assert int(cell.item()) == int(exp.sum())
